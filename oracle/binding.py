@@ -1,0 +1,160 @@
+"""ctypes binding of oracle/libacdsp_oracle.so (see acdsp_oracle.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libacdsp_oracle.so")
+
+Q_MODES = {"TRN": 0, "RND": 1, "TRN_ZERO": 2, "RND_ZERO": 3, "RND_INF": 4, "RND_MIN_INF": 5, "RND_CONV": 6,
+           "RND_CONV_ODD": 7}
+O_MODES = {"WRAP": 0, "SAT": 1, "SAT_ZERO": 2, "SAT_SYM": 3}
+FTYPES = {"SHIFT_REG": 0, "ROTATE_SHIFT": 1, "C_BUFF": 2, "FOLD_EVEN": 3, "FOLD_ODD": 4, "TRANSPOSED": 5,
+          "FOLD_EVEN_ANTI": 6, "FOLD_ODD_ANTI": 7}
+
+
+class Fmt(C.Structure):
+    """ac_fixed<W,I,S,Q,O> descriptor (same field order as orc_fmt_t / acdsp_fmt_t)."""
+    _fields_ = [("W", C.c_int32), ("I", C.c_int32), ("S", C.c_int32), ("Q", C.c_int32), ("O", C.c_int32)]
+
+    def __init__(self, W, I, S=True, Q="TRN", O="WRAP"):
+        super().__init__(W, I, int(bool(S)), Q_MODES[Q] if isinstance(Q, str) else Q,
+                         O_MODES[O] if isinstance(O, str) else O)
+
+    @property
+    def F(self):
+        return self.W - self.I
+
+    def __repr__(self):
+        return "Fmt(%d,%d,%d,%d,%d)" % (self.W, self.I, self.S, self.Q, self.O)
+
+
+def _build():
+    src = os.path.join(_HERE, "acdsp_oracle.c")
+    if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+_build()
+lib = C.CDLL(_SO)
+_i64p = C.POINTER(C.c_int64)
+lib.orc_requant.restype = C.c_int64
+lib.orc_requant.argtypes = [C.c_int64, C.c_int32, C.POINTER(Fmt)]
+lib.orc_requant128.restype = C.c_int64
+lib.orc_requant128.argtypes = [C.c_int64, C.c_uint64, C.c_int32, C.POINTER(Fmt)]
+lib.orc_from_double.restype = C.c_int64
+lib.orc_from_double.argtypes = [C.c_double, C.POINTER(Fmt)]
+lib.orc_fir_new.restype = C.c_void_p
+lib.orc_fir_new.argtypes = [C.c_int32, C.c_int32] + [C.POINTER(Fmt)] * 4
+lib.orc_fir_free.argtypes = [C.c_void_p]
+lib.orc_fir_reset.argtypes = [C.c_void_p]
+lib.orc_fir_run.restype = C.c_int32
+lib.orc_fir_run.argtypes = [C.c_void_p, _i64p, _i64p, C.c_int64, _i64p]
+lib.orc_cic_new.restype = C.c_void_p
+lib.orc_cic_new.argtypes = [C.c_int32] * 4 + [C.POINTER(Fmt)] * 2
+lib.orc_cic_free.argtypes = [C.c_void_p]
+lib.orc_cic_int_type.restype = C.c_int32
+lib.orc_cic_int_type.argtypes = [C.c_int32] * 4 + [C.POINTER(Fmt)] * 2
+lib.orc_cic_run.restype = C.c_int64
+lib.orc_cic_run.argtypes = [C.c_void_p, _i64p, C.c_int64, _i64p, C.c_int64]
+lib.orc_stimulus.restype = C.c_int64
+lib.orc_stimulus.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]
+lib.orc_splitmix64.restype = C.c_uint64
+lib.orc_splitmix64.argtypes = [C.c_uint64, C.c_uint64]
+
+
+def _p(a):
+    return a.ctypes.data_as(_i64p)
+
+
+def requant(x, f_src, fmt):
+    """Exact python-int x * 2^-f_src -> raw word of fmt."""
+    x = int(x)
+    lo = x & ((1 << 64) - 1)
+    hi = (x >> 64)
+    if hi >= (1 << 63):
+        hi -= (1 << 64)
+    return lib.orc_requant128(hi, lo, f_src, C.byref(fmt))
+
+
+def from_double(d, fmt):
+    return lib.orc_from_double(float(d), C.byref(fmt))
+
+
+def stimulus(seed, n_ch, n, bits, ch0=0, t0=0):
+    """[n_ch][n] int64 array of the shared counter-hash stimulus (vectorised numpy restatement)."""
+    ch = (np.arange(ch0, ch0 + n_ch, dtype=np.uint64)[:, None] << np.uint64(32))
+    t = (np.arange(t0, t0 + n, dtype=np.uint64)[None, :] & np.uint64(0xffffffff))
+    idx = ch | t
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (idx + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z.view(np.int64) >> np.int64(64 - bits)
+
+
+def cic_int_type(interp, R, M, N, fin):
+    it = Fmt(1, 1)
+    if lib.orc_cic_int_type(int(interp), R, M, N, C.byref(fin), C.byref(it)):
+        raise ValueError("CIC intermediate type not representable (reference would not compile)")
+    return it
+
+
+class OracleFir:
+    """One reference-style FIR object per channel; run() takes/returns [n_ch][n] int64 raw words."""
+
+    def __init__(self, n_taps, ftype, fin, fcoeff, facc, fout, n_ch=1):
+        self.n_taps, self.n_ch = n_taps, n_ch
+        ft = FTYPES[ftype] if isinstance(ftype, str) else ftype
+        self._h = [lib.orc_fir_new(n_taps, ft, C.byref(fin), C.byref(fcoeff), C.byref(facc), C.byref(fout))
+                   for _ in range(n_ch)]
+        if any(h is None for h in self._h):
+            raise ValueError("oracle: unsupported FIR configuration")
+
+    def run(self, coeffs, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int64)
+        y = np.empty_like(x)
+        for ch in range(self.n_ch):
+            c = coeffs[ch] if coeffs.ndim == 2 else coeffs
+            c = np.ascontiguousarray(c)
+            if lib.orc_fir_run(self._h[ch], _p(c), _p(x[ch]), x.shape[1], _p(y[ch])):
+                raise ValueError("oracle: ftype not handled by the reference run()")
+        return y
+
+    def reset(self):
+        for h in self._h:
+            lib.orc_fir_reset(h)
+
+    def __del__(self):
+        for h in getattr(self, "_h", []):
+            if h:
+                lib.orc_fir_free(h)
+
+
+class OracleCic:
+    def __init__(self, interp, R, M, N, fin, fout, n_ch=1):
+        self.interp, self.R, self.M, self.N, self.n_ch = int(interp), R, M, N, n_ch
+        self._h = [lib.orc_cic_new(int(interp), R, M, N, C.byref(fin), C.byref(fout)) for _ in range(n_ch)]
+        if any(h is None for h in self._h):
+            raise ValueError("oracle: unsupported CIC configuration")
+
+    def run(self, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64)
+        n = x.shape[1]
+        cap = (n + 2) * (self.R if self.interp else 1) + 8
+        outs = []
+        for ch in range(self.n_ch):
+            y = np.empty(cap, dtype=np.int64)
+            k = lib.orc_cic_run(self._h[ch], _p(x[ch]), n, _p(y), cap)
+            assert k >= 0
+            outs.append(y[:k].copy())
+        return np.stack(outs)
+
+    def __del__(self):
+        for h in getattr(self, "_h", []):
+            if h:
+                lib.orc_cic_free(h)
