@@ -1,0 +1,27 @@
+# Builds libacdsp.so (HIP engine, gfx950 only) in-tree and the CPU oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC = ac_dsp_amd/csrc
+OUT = ac_dsp_amd/lib/libacdsp.so
+SRCS = $(CSRC)/engine.hip $(CSRC)/fir_generic.hip $(CSRC)/fir_mfma.hip $(CSRC)/cic.hip
+HDRS = $(CSRC)/acdsp_dev.hpp $(CSRC)/fir_kernels.hpp $(CSRC)/cic_kernels.hpp include/acdsp.h
+OBJS = $(SRCS:.hip=.o)
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+
+all: $(OUT) oracle
+
+%.o: %.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT): $(OBJS)
+	@mkdir -p ac_dsp_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(OBJS) $(OUT)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

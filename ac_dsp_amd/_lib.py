@@ -1,0 +1,104 @@
+"""ctypes binding of libacdsp.so (include/acdsp.h).  No fallbacks: a missing library is an error."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libacdsp.so")
+
+Q_MODES = {"TRN": 0, "RND": 1, "TRN_ZERO": 2, "RND_ZERO": 3, "RND_INF": 4, "RND_MIN_INF": 5, "RND_CONV": 6,
+           "RND_CONV_ODD": 7}
+O_MODES = {"WRAP": 0, "SAT": 1, "SAT_ZERO": 2, "SAT_SYM": 3}
+FTYPES = {"SHIFT_REG": 0, "ROTATE_SHIFT": 1, "C_BUFF": 2, "FOLD_EVEN": 3, "FOLD_ODD": 4, "TRANSPOSED": 5,
+          "FOLD_EVEN_ANTI": 6, "FOLD_ODD_ANTI": 7}
+KINDS = {"const": 0, "load": 1, "prog": 2}
+PATHS = {0: "generic", 1: "lossless64", 2: "mfma_i8"}
+FLAG_FORCE_GENERIC = 1
+
+
+class AcdspError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("acdsp error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Fmt(C.Structure):
+    """ac_fixed<W,I,S,Q,O> descriptor == acdsp_fmt_t."""
+    _fields_ = [("W", C.c_int32), ("I", C.c_int32), ("S", C.c_int32), ("Q", C.c_int32), ("O", C.c_int32)]
+
+    def __init__(self, W=1, I=1, S=True, Q="TRN", O="WRAP"):
+        super().__init__(W, I, int(bool(S)), Q_MODES[Q] if isinstance(Q, str) else Q,
+                         O_MODES[O] if isinstance(O, str) else O)
+
+    @property
+    def F(self):
+        return self.W - self.I
+
+    def __repr__(self):
+        return "ac_fixed<%d,%d,%s,%d,%d>" % (self.W, self.I, bool(self.S), self.Q, self.O)
+
+
+class FirDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("ftype", C.c_int32), ("n_taps", C.c_int32), ("n_channels", C.c_int32),
+                ("coeffs_per_channel", C.c_int32), ("fin", Fmt), ("fcoeff", Fmt), ("facc", Fmt), ("fout", Fmt),
+                ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+class CicDesc(C.Structure):
+    _fields_ = [("interp", C.c_int32), ("R", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
+                ("n_channels", C.c_int32), ("fin", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "ac_dsp_amd: %s is missing -- build it with `make` (or __graft_entry__.build()); there is no CPU "
+        "fallback for the HIP engine" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+_vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
+
+# every symbol include/acdsp.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "acdsp_abi_version": (_i32, []),
+    "acdsp_last_error": (C.c_char_p, []),
+    "acdsp_device_count": (_i32, []),
+    "acdsp_elem_bytes": (_i32, [_i32]),
+    "acdsp_dev_alloc": (_i32, [_i32, C.c_uint64, C.POINTER(_vp)]),
+    "acdsp_dev_free": (_i32, [_i32, _vp]),
+    "acdsp_copy_h2d": (_i32, [_i32, _vp, _vp, C.c_uint64]),
+    "acdsp_copy_d2h": (_i32, [_i32, _vp, _vp, C.c_uint64]),
+    "acdsp_sync": (_i32, [_i32, _vp]),
+    "acdsp_fill_stimulus": (_i32, [_i32, _vp, _i32, _i64, _i64, _i64, C.c_uint64, _i32, C.c_uint64, C.c_uint64, _vp]),
+    "acdsp_fir_create": (_i32, [C.POINTER(FirDesc), C.POINTER(_vp)]),
+    "acdsp_fir_destroy": (_i32, [_vp]),
+    "acdsp_fir_clone": (_i32, [_vp, C.POINTER(_vp)]),
+    "acdsp_fir_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
+    "acdsp_fir_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "acdsp_fir_run_host": (_i32, [_vp, _vp, _i64, _vp]),
+    "acdsp_fir_reset": (_i32, [_vp]),
+    "acdsp_fir_path": (_i32, [_vp]),
+    "acdsp_fir_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
+    "acdsp_fir_kernel_stats": (_i32, [_vp, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "acdsp_cic_create": (_i32, [C.POINTER(CicDesc), C.POINTER(_vp)]),
+    "acdsp_cic_destroy": (_i32, [_vp]),
+    "acdsp_cic_clone": (_i32, [_vp, C.POINTER(_vp)]),
+    "acdsp_cic_int_type": (_i32, [C.POINTER(CicDesc), C.POINTER(Fmt)]),
+    "acdsp_cic_out_count": (_i64, [_vp, _i64]),
+    "acdsp_cic_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64), _vp]),
+    "acdsp_cic_run_host": (_i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "acdsp_cic_reset": (_i32, [_vp]),
+    "acdsp_cic_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
+    "acdsp_cic_kernel_stats": (_i32, [_vp, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+}
+for _name, (_res, _args) in SYMBOLS.items():
+    _f = getattr(lib, _name)  # AttributeError here == the library does not export what the header declares
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def check(rc):
+    if rc != 0:
+        raise AcdspError(rc, lib.acdsp_last_error().decode())
+
+
+def elem_bytes(W):
+    return lib.acdsp_elem_bytes(W)

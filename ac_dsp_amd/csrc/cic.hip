@@ -1,0 +1,219 @@
+// cic.hip -- many-channel CIC decimator / interpolator kernels for gfx950.
+//
+// What they replace: ac_cic_full_core_intg::intStage / decIntgCore / intrIntgCore
+// (reference include/ac_dsp/ac_cic_full_core.h:80-160) and
+// ac_cic_full_core_diff::comb / diffStage (:228-255), driven by
+// ac_cic_dec_full::run (ac_cic_dec_full.h:163-222) and ac_cic_intr_full::run
+// (ac_cic_intr_full.h:150-215).
+//
+// Arithmetic.  The reference computes in INT_TYPE = ac_fixed<outW,..,true>
+// with the default AC_TRN/AC_WRAP, i.e. every add/sub is exact modulo 2^outW.
+// Reduction mod 2^outW is a ring homomorphism, so the kernels add/subtract in
+// uint64 (outW <= 64) and wrap to outW bits once, just before the OUT_TYPE
+// conversion.  The integrators are the reference's *pipelined* form (stage i
+// adds the previous value of stage i-1, :82-85).  The comb delay line keeps
+// the reference's behaviour exactly: its shift loop runs ascending (:249-254),
+// which makes the differential delay min(M, 2) -- see `me`.
+//
+// Parallelisation.  One lane = one channel (the recurrences are serial in
+// time, independent across channels); one wave = 64 channels x one time chunk.
+// Inputs are [channel][time]: a tile of 64 channels x 64 samples is fetched
+// with 16-byte coalesced row loads, transposed through a padded LDS tile
+// (conflict-free ds_write_b128 / ds_read_b128), and each lane then walks its
+// own row.  A chunk does not need the integrator state of the chunk before it:
+// the decimator (and interpolator) is an FIR system overall,
+//   H(z) = z^-(N-1) * (1 + z^-1 + ... + z^-(R*me-1))^N      (dec, at the input rate),
+// so simulating from zero state `warm_tiles` tiles earlier reproduces every
+// output of the chunk exactly (mod 2^outW).  The same argument replaces the
+// reference's carried registers by a short input history between run() calls.
+#include "cic_kernels.hpp"
+
+namespace acdsp {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <typename TIN> struct Vec16 {
+  union { v4i v; TIN e[16 / sizeof(TIN)]; };
+};
+
+template <int N, typename TIN, bool INTERP>
+__global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
+  constexpr int VE = 16 / (int)sizeof(TIN);             // elements per 16-byte vector
+  constexpr int LPR = kCicTile / VE;                    // lanes that cover one tile row
+  constexpr int RPI = 64 / LPR;                         // rows fetched per load instruction
+  constexpr int ROWB = kCicTile * (int)sizeof(TIN) + 16;  // padded LDS row (bytes)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[64 * ROWB];
+
+  const int lane = threadIdx.x;
+  const int ch0 = blockIdx.y * 64;
+  const int ch = ch0 + lane;
+  const bool ch_ok = ch < p.n_ch;
+  const int64_t c_start = (int64_t)blockIdx.x * p.chunk;
+  const int64_t c_end = (c_start + p.chunk < p.n_in) ? c_start + p.chunk : p.n_in;
+  const int64_t s0 = c_start - (int64_t)p.warm_tiles * kCicTile;  // >= -hl
+  const int R = p.R;
+  const bool me2 = p.me == 2;
+
+  uint64_t r[N], d0[N], d1[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { r[i] = 0; d0[i] = 0; d1[i] = 0; }
+
+  // decimator bookkeeping
+  int cnt = 0;
+  int64_t j = 0;
+  if (!INTERP) {
+    int64_t m = ((int64_t)p.phase0 + s0) % R;
+    cnt = (int)(m < 0 ? m + R : m);
+    int64_t te0 = s0 + ((R - cnt) % R);
+    j = (te0 - p.first) / R;  // exact division
+  }
+  // interpolator emission window of this chunk, in global iteration numbers
+  int64_t qa = 0, qb = 0, q_base = 0;
+  if (INTERP) {
+    q_base = p.q_begin > p.q_skip ? p.q_begin : p.q_skip;
+    qa = (blockIdx.x == 0) ? p.q_begin : (p.t_prev + c_start) * R;
+    if (qa < q_base) { qa = q_base; }
+    qb = (p.t_prev + c_end) * R;
+    if (qb > p.q_end) { qb = p.q_end; }
+  }
+
+  for (int64_t ts = s0; ts < c_end; ts += kCicTile) {
+    // ---- stage the tile: 64 channel rows x 64 samples ----
+#pragma unroll
+    for (int li = 0; li < LPR; li++) {
+      const int row = li * RPI + lane / LPR;
+      const int col = (lane % LPR) * VE;
+      int chr = ch0 + row;
+      if (chr >= p.n_ch) { chr = p.n_ch - 1; }
+      const int64_t t = ts + col;
+      Vec16<TIN> v;
+      if (ts < 0) {
+        v.v = *(const v4i *)((const TIN *)p.hist + (int64_t)chr * p.hl + (p.hl + t));
+      } else {
+        const TIN *src = (const TIN *)p.x + (int64_t)chr * p.in_stride + t;
+        if (p.vec_ok && t + VE <= p.n_in) {
+          v.v = *(const v4i *)src;
+        } else {
+#pragma unroll
+          for (int e = 0; e < VE; e++) { v.e[e] = (t + e < p.n_in) ? src[e] : (TIN)0; }
+        }
+      }
+      *(v4i *)(lds + row * ROWB + col * (int)sizeof(TIN)) = v.v;
+    }
+    __syncthreads();
+
+    // ---- every lane walks its own channel row ----
+    for (int k = 0; k < kCicTile; k += VE) {
+      Vec16<TIN> v;
+      v.v = *(const v4i *)(lds + lane * ROWB + k * (int)sizeof(TIN));
+#pragma unroll
+      for (int e = 0; e < VE; e++) {
+        const int64_t t = ts + k + e;
+        if (t >= c_end) { break; }
+        // (OUT_TYPE) data_in : lossless cast into INT_TYPE, ac_cic_full_core.h:114,147,213
+        uint64_t x;
+        if (sizeof(TIN) == 8) { x = (uint64_t)v.e[e]; }
+        else if (p.in.S) { x = (uint64_t)(int64_t)v.e[e]; }
+        else if (sizeof(TIN) == 4) { x = (uint64_t)(uint32_t)v.e[e]; }
+        else { x = (uint64_t)(uint16_t)v.e[e]; }
+
+        if (!INTERP) {
+          // intStage, ac_cic_full_core.h:80-87
+#pragma unroll
+          for (int i = N - 1; i > 0; i--) { r[i] += r[i - 1]; }
+          r[0] += x;
+          if (cnt == 0) {  // valid = (rate_cnt == 0), :116-120
+            uint64_t val = r[N - 1];
+#pragma unroll
+            for (int s = 0; s < N; s++) {  // comb / diffStage, :228-255
+              uint64_t o = val - (me2 ? d1[s] : d0[s]);
+              d1[s] = d0[s];
+              d0[s] = val;
+              val = o;
+            }
+            if (t >= c_start && ch_ok) {
+              int64_t y = requant64(wrap64((int64_t)val, p.w_int, 1), p.in.F, p.out);
+              store_raw(p.y, (int64_t)ch * p.out_stride + j, p.out_eb, y);
+            }
+            j++;
+          }
+          cnt = (cnt + 1 == R) ? 0 : cnt + 1;  // :130-133
+        } else {
+          // intrDiffCore, :211-216
+          uint64_t val = x;
+#pragma unroll
+          for (int s = 0; s < N; s++) {
+            uint64_t o = val - (me2 ? d1[s] : d0[s]);
+            d1[s] = d0[s];
+            d0[s] = val;
+            val = o;
+          }
+          // intrIntgCore, :143-160: the sample, then R-1 stuffed zeros
+          const int64_t qbase = (p.t_prev + t) * R;
+          for (int ph = 0; ph < R; ph++) {
+#pragma unroll
+            for (int i = N - 1; i > 0; i--) { r[i] += r[i - 1]; }
+            r[0] += (ph == 0) ? val : (uint64_t)0;
+            const int64_t q = qbase + ph;
+            if (q >= qa && q < qb && ch_ok) {
+              int64_t y = requant64(wrap64((int64_t)r[N - 1], p.w_int, 1), p.in.F, p.out);
+              store_raw(p.y, (int64_t)ch * p.out_stride + (q - q_base), p.out_eb, y);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int N, typename TIN>
+static hipError_t launch_n_t(const CicParams &p, dim3 grid, hipStream_t s) {
+  if (p.interp) { hipLaunchKernelGGL((cic_kernel<N, TIN, true>), grid, dim3(64), 0, s, p); }
+  else { hipLaunchKernelGGL((cic_kernel<N, TIN, false>), grid, dim3(64), 0, s, p); }
+  return hipGetLastError();
+}
+
+template <int N>
+static hipError_t launch_n(const CicParams &p, dim3 grid, hipStream_t s) {
+  switch (p.in_eb) {
+    case 2: return launch_n_t<N, int16_t>(p, grid, s);
+    case 4: return launch_n_t<N, int32_t>(p, grid, s);
+    default: return launch_n_t<N, int64_t>(p, grid, s);
+  }
+}
+
+hipError_t launch_cic(const CicParams &p, hipStream_t s) {
+  if (p.n_in <= 0) { return hipSuccess; }
+  dim3 grid((unsigned)((p.n_in + p.chunk - 1) / p.chunk), (unsigned)((p.n_ch + 63) / 64));
+  switch (p.N) {
+    case 1: return launch_n<1>(p, grid, s);
+    case 2: return launch_n<2>(p, grid, s);
+    case 3: return launch_n<3>(p, grid, s);
+    case 4: return launch_n<4>(p, grid, s);
+    case 5: return launch_n<5>(p, grid, s);
+    case 6: return launch_n<6>(p, grid, s);
+    case 7: return launch_n<7>(p, grid, s);
+    case 8: return launch_n<8>(p, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+__global__ void cic_hist_update_kernel(CicParams p, void *hist_next) {
+  const int ch = blockIdx.y;
+  for (int jj = blockIdx.x * blockDim.x + threadIdx.x; jj < p.hl; jj += gridDim.x * blockDim.x) {
+    int64_t g = p.n_in - p.hl + jj;
+    int64_t v = (g >= 0) ? load_raw(p.x, (int64_t)ch * p.in_stride + g, p.in_eb, 1)
+                         : load_raw(p.hist, (int64_t)ch * p.hl + p.hl + g, p.in_eb, 1);
+    store_raw(hist_next, (int64_t)ch * p.hl + jj, p.in_eb, v);
+  }
+}
+
+hipError_t launch_cic_hist_update(const CicParams &p, void *hist_next, hipStream_t s) {
+  if (p.n_in <= 0) { return hipSuccess; }
+  dim3 grid((unsigned)((p.hl + 255) / 256), (unsigned)p.n_ch);
+  hipLaunchKernelGGL(cic_hist_update_kernel, grid, dim3(256), 0, s, p, hist_next);
+  return hipGetLastError();
+}
+
+}  // namespace acdsp

@@ -1,0 +1,34 @@
+// cic_kernels.hpp -- launch interface between engine.hip and the CIC kernels.
+#pragma once
+#include "acdsp_dev.hpp"
+
+namespace acdsp {
+
+constexpr int kCicTile = 64;    // input samples per LDS tile (per channel)
+constexpr int kCicMaxN = 8;
+
+struct CicParams {
+  int32_t interp, R, me, N, n_ch;  // me = effective comb delay = min(M, 2) (see cic.hip)
+  int32_t w_int;                   // width of the reference's INT_TYPE (wrap arithmetic)
+  DFmt in, out;                    // in: only F and S are used
+  int32_t in_eb, out_eb;
+  int32_t hl;                      // history inputs kept per channel (multiple of kCicTile)
+  int32_t warm_tiles;              // tiles simulated before a chunk to rebuild the filter memory
+  int32_t vec_ok;                  // 16-byte aligned rows: vector loads allowed
+  int64_t in_stride, out_stride, n_in;
+  int64_t chunk;                   // inputs per wave chunk (multiple of kCicTile)
+  const void *x;                   // inputs  [n_ch][in_stride]
+  void *y;                         // outputs [n_ch][out_stride]
+  const void *hist;                // [n_ch][hl]: the hl inputs before local t = 0
+  // decimator: global phase of local t = 0 and local time of the first emitted sample
+  int32_t phase0;
+  int64_t first;
+  // interpolator: iteration window [q_begin, q_end) of this call in global iteration numbers,
+  // inputs consumed by earlier calls, and the number of start-up iterations that are never emitted
+  int64_t q_begin, q_end, t_prev, q_skip;
+};
+
+hipError_t launch_cic(const CicParams &p, hipStream_t s);
+hipError_t launch_cic_hist_update(const CicParams &p, void *hist_next, hipStream_t s);
+
+}  // namespace acdsp

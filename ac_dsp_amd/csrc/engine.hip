@@ -1,0 +1,713 @@
+// engine.hip -- the C ABI of libacdsp.so (declared in include/acdsp.h).
+//
+// Host-side object model: one handle = n_channels independent reference filter
+// objects (reference: one ac_fir_* / ac_cic_* instance each) whose state lives
+// in HBM and carries across run() calls.  There is no CPU compute path here:
+// every run() launches HIP kernels, and creation fails without a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cic_kernels.hpp"
+#include "fir_kernels.hpp"
+
+using namespace acdsp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) { return fail(ACDSP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
+  } while (0)
+
+int check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { return fail(ACDSP_ENODEVICE, "no HIP device visible"); }
+  if (device < 0 || device >= n) { return fail(ACDSP_EINVAL, "device %d out of range (%d devices)", device, n); }
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    return fail(ACDSP_ENODEVICE, "device %d is %s; this engine is built for gfx950 only", device, prop.gcnArchName);
+  }
+  HIP_TRY(hipSetDevice(device));
+  return ACDSP_OK;
+}
+
+int check_fmt(const acdsp_fmt_t &f, const char *name) {
+  if (f.W < 1 || f.W > 64) { return fail(ACDSP_EUNSUPPORTED, "%s: W=%d outside 1..64", name, f.W); }
+  if (!f.S && f.W > 63) { return fail(ACDSP_EUNSUPPORTED, "%s: unsigned W=64 not supported", name); }
+  if (f.Q < 0 || f.Q > ACDSP_RND_CONV_ODD) { return fail(ACDSP_EINVAL, "%s: bad Q mode %d", name, f.Q); }
+  if (f.O < 0 || f.O > ACDSP_SAT_SYM) { return fail(ACDSP_EINVAL, "%s: bad O mode %d", name, f.O); }
+  if (f.S != 0 && f.S != 1) { return fail(ACDSP_EINVAL, "%s: S must be 0 or 1", name); }
+  return ACDSP_OK;
+}
+
+int elem_bytes(int W) { return W <= 16 ? 2 : (W <= 32 ? 4 : 8); }
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// HIP-event timing of the main kernel of each run(), recorded on the launch stream.
+// A ring of event pairs so that a whole timed region can be read back afterwards.
+struct Timer {
+  static const int kRing = 64;
+  hipEvent_t e0[kRing], e1[kRing];
+  int64_t count = 0;  // runs recorded so far
+  bool ok = false;
+  int init() {
+    for (int i = 0; i < kRing; i++) { e0[i] = nullptr; e1[i] = nullptr; }
+    for (int i = 0; i < kRing; i++) {
+      HIP_TRY(hipEventCreate(&e0[i]));
+      HIP_TRY(hipEventCreate(&e1[i]));
+    }
+    ok = true;
+    return ACDSP_OK;
+  }
+  void destroy() {
+    if (!ok) { return; }
+    for (int i = 0; i < kRing; i++) {
+      if (e0[i]) { (void)hipEventDestroy(e0[i]); }
+      if (e1[i]) { (void)hipEventDestroy(e1[i]); }
+    }
+  }
+  hipEvent_t start() { return e0[count % kRing]; }
+  hipEvent_t stop() { return e1[count % kRing]; }
+  void commit() { count++; }
+  // average / minimum over the last k runs
+  int stats(int k, float *avg, float *mn) {
+    if (count == 0) { return fail(ACDSP_ESTATE, "no run() recorded yet"); }
+    if (k < 1) { k = 1; }
+    if (k > kRing) { k = kRing; }
+    if (k > count) { k = (int)count; }
+    double sum = 0;
+    float lo = 1e30f;
+    for (int i = 0; i < k; i++) {
+      const int64_t idx = (count - 1 - i) % kRing;
+      float ms = 0;
+      HIP_TRY(hipEventSynchronize(e1[idx]));
+      HIP_TRY(hipEventElapsedTime(&ms, e0[idx], e1[idx]));
+      sum += ms;
+      if (ms < lo) { lo = ms; }
+    }
+    if (avg) { *avg = (float)(sum / k); }
+    if (mn) { *mn = lo; }
+    return ACDSP_OK;
+  }
+};
+
+struct Staging {
+  void *d_in = nullptr, *d_out = nullptr;
+  size_t cap_in = 0, cap_out = 0;
+  int ensure(size_t bin, size_t bout) {
+    if (bin > cap_in) {
+      if (d_in) { (void)hipFree(d_in); }
+      HIP_TRY(hipMalloc(&d_in, bin));
+      cap_in = bin;
+    }
+    if (bout > cap_out) {
+      if (d_out) { (void)hipFree(d_out); }
+      HIP_TRY(hipMalloc(&d_out, bout));
+      cap_out = bout;
+    }
+    return ACDSP_OK;
+  }
+  void destroy() {
+    if (d_in) { (void)hipFree(d_in); }
+    if (d_out) { (void)hipFree(d_out); }
+  }
+};
+
+}  // namespace
+
+struct acdsp_fir {
+  acdsp_fir_desc_t d;
+  int in_eb, out_eb, hl;
+  bool use_rt, lossless, coeffs_set;
+  int path;
+  void *d_hist[2] = {nullptr, nullptr};
+  int64_t *d_rt[2] = {nullptr, nullptr};
+  int cur = 0;
+  int64_t *d_coeffs = nullptr;
+  uint32_t *d_frag = nullptr;
+  FirMfmaPlan plan;
+  bool mfma_ok = false;
+  std::vector<int64_t> h_coeffs;  // last coefficient set (for clone)
+  Timer tm;
+  Staging st;
+};
+
+struct acdsp_cic {
+  acdsp_cic_desc_t d;
+  acdsp_fmt_t it;
+  int in_eb, out_eb, hl, me;
+  int64_t t_total = 0;  // inputs consumed so far (all calls)
+  void *d_hist[2] = {nullptr, nullptr};
+  int cur = 0;
+  Timer tm;
+  Staging st;
+};
+
+extern "C" {
+
+int32_t acdsp_abi_version(void) { return ACDSP_ABI_VERSION; }
+const char *acdsp_last_error(void) { return g_err.c_str(); }
+int32_t acdsp_elem_bytes(int32_t W) { return elem_bytes(W); }
+
+int32_t acdsp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { return 0; }
+  int k = 0;
+  for (int i = 0; i < n; i++) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) { k++; }
+  }
+  return k;
+}
+
+int32_t acdsp_dev_alloc(int32_t device, uint64_t bytes, void **d_ptr) {
+  if (!d_ptr) { return fail(ACDSP_EINVAL, "null output pointer"); }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 16));
+  return ACDSP_OK;
+}
+int32_t acdsp_dev_free(int32_t device, void *d_ptr) {
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  HIP_TRY(hipFree(d_ptr));
+  return ACDSP_OK;
+}
+int32_t acdsp_copy_h2d(int32_t device, void *d_dst, const void *h_src, uint64_t bytes) {
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return ACDSP_OK;
+}
+int32_t acdsp_copy_d2h(int32_t device, void *h_dst, const void *d_src, uint64_t bytes) {
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return ACDSP_OK;
+}
+int32_t acdsp_sync(int32_t device, void *stream) {
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return ACDSP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// stimulus generator
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void fill_stimulus_kernel(void *d, int eb, int64_t n, int64_t stride, uint64_t seed, int bits, uint64_t ch0,
+                                     uint64_t t0) {
+  const int64_t ch = blockIdx.y;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t idx = ((ch0 + (uint64_t)ch) << 32) | ((t0 + (uint64_t)t) & 0xffffffffull);
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    store_raw(d, ch * stride + t, eb, ((int64_t)z) >> (64 - bits));
+  }
+}
+}  // namespace
+
+extern "C" int32_t acdsp_fill_stimulus(int32_t device, void *d_ptr, int32_t eb, int64_t n_ch, int64_t n, int64_t stride,
+                                       uint64_t seed, int32_t bits, uint64_t ch0, uint64_t t0, void *stream) {
+  if (!d_ptr || (eb != 2 && eb != 4 && eb != 8) || n_ch < 1 || n < 0 || stride < n || bits < 1 || bits > 8 * eb) {
+    return fail(ACDSP_EINVAL, "fill_stimulus: bad arguments");
+  }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  if (n == 0) { return ACDSP_OK; }
+  unsigned gx = (unsigned)((n + 255) / 256);
+  if (gx > 4096) { gx = 4096; }
+  for (int64_t c0 = 0; c0 < n_ch; c0 += 65535) {
+    int64_t nc = n_ch - c0 < 65535 ? n_ch - c0 : 65535;
+    hipLaunchKernelGGL(fill_stimulus_kernel, dim3(gx, (unsigned)nc), dim3(256), 0, (hipStream_t)stream,
+                       (char *)d_ptr + c0 * stride * eb, eb, n, stride, seed, bits, ch0 + (uint64_t)c0, t0);
+  }
+  HIP_TRY(hipGetLastError());
+  return ACDSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FIR
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// Effective direct-form coefficients of the folded architectures (lossless paths only):
+// FOLD_EVEN uses c[0..N/2-1] on both halves (ac_fir_const_coeffs.h:248-251), FOLD_ODD uses
+// c[0..mid] with the centre tap alone (:265-273).  Taps the reference never reads become 0.
+std::vector<int64_t> effective_coeffs(const int64_t *c, int N, int ftype) {
+  std::vector<int64_t> e(N, 0);
+  if (ftype == ACDSP_FOLD_EVEN) {
+    for (int i = 0; i < N / 2; i++) { e[i] += c[i]; e[N - 1 - i] += c[i]; }
+  } else if (ftype == ACDSP_FOLD_ODD) {
+    int mid = (N - 1) / 2;
+    for (int i = 0; i < mid; i++) { e[i] += c[i]; e[N - 1 - i] += c[i]; }
+    e[mid] += c[mid];
+  } else {
+    for (int i = 0; i < N; i++) { e[i] = c[i]; }
+  }
+  return e;
+}
+
+int fir_validate(const acdsp_fir_desc_t &d) {
+  if (d.ftype == ACDSP_FOLD_EVEN_ANTI || d.ftype == ACDSP_FOLD_ODD_ANTI) {
+    return fail(ACDSP_EUNSUPPORTED,
+                "FOLD_*_ANTI: the reference run() has no branch for these (output is an unassigned value)");
+  }
+  if (d.ftype < 0 || d.ftype > ACDSP_FOLD_ODD_ANTI) { return fail(ACDSP_EINVAL, "bad ftype %d", d.ftype); }
+  if (d.n_taps < 1 || d.n_taps > 2048) { return fail(ACDSP_EUNSUPPORTED, "n_taps=%d outside 1..2048", d.n_taps); }
+  if (d.n_channels < 1 || d.n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", d.n_channels); }
+  int rc;
+  if ((rc = check_fmt(d.in, "IN_TYPE")) || (rc = check_fmt(d.coeff, "COEFF_TYPE")) || (rc = check_fmt(d.acc, "ACC_TYPE")) ||
+      (rc = check_fmt(d.out, "OUT_TYPE"))) {
+    return rc;
+  }
+  // 128-bit exact intermediates must hold: product, aligned sum.
+  int fi = d.in.W - d.in.I, fc = d.coeff.W - d.coeff.I, fa = d.acc.W - d.acc.I;
+  int wp = d.in.W + d.coeff.W + 2, fp = fi + fc;
+  if (d.ftype == ACDSP_FOLD_ODD) { wp = d.acc.W + d.coeff.W + 1; fp = fa + fc; }
+  int f = fp > fa ? fp : fa;
+  if (wp + (f - fp) > 125 || d.acc.W + (f - fa) > 125) {
+    return fail(ACDSP_EUNSUPPORTED, "type combination needs more than 128-bit intermediates");
+  }
+  return ACDSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
+  if (!desc || !out) { return fail(ACDSP_EINVAL, "null argument"); }
+  int rc = fir_validate(*desc);
+  if (rc) { return rc; }
+  if ((rc = check_device(desc->device))) { return rc; }
+  acdsp_fir *h = new acdsp_fir();
+  h->d = *desc;
+  h->in_eb = elem_bytes(desc->in.W);
+  h->out_eb = elem_bytes(desc->out.W);
+  h->hl = round_up(desc->n_taps - 1 > 0 ? desc->n_taps - 1 : 1, 32);
+  // reg_trans[] carries partial sums computed with the coefficients of their own time; only
+  // the const-coefficient class may trade it for an input history.
+  h->use_rt = desc->ftype == ACDSP_TRANSPOSED && desc->kind != ACDSP_FIR_CONST;
+  const int fi = desc->in.W - desc->in.I, fc = desc->coeff.W - desc->coeff.I, fa = desc->acc.W - desc->acc.I;
+  bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && !h->use_rt;
+  if (desc->ftype == ACDSP_FOLD_ODD) {
+    // the ACC_TYPE `fold` variable must hold x[i] + x[N-1-i] without wrapping
+    int need_i = desc->in.I + 1 + ((desc->acc.S && !desc->in.S) ? 1 : 0);
+    lossless = lossless && desc->acc.I >= need_i && (desc->acc.S || !desc->in.S);
+  }
+  h->lossless = lossless;
+  h->coeffs_set = false;
+  h->path = ACDSP_PATH_GENERIC;
+  const size_t hist_bytes = (size_t)desc->n_channels * h->hl * h->in_eb;
+  const size_t n_sets = desc->coeffs_per_channel ? (size_t)desc->n_channels : 1;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    e = hipMalloc(&h->d_hist[i], hist_bytes);
+    if (e == hipSuccess) { e = hipMemset(h->d_hist[i], 0, hist_bytes); }
+    if (e == hipSuccess && h->use_rt) {
+      size_t rb = (size_t)desc->n_channels * desc->n_taps * sizeof(int64_t);
+      e = hipMalloc((void **)&h->d_rt[i], rb);
+      if (e == hipSuccess) { e = hipMemset(h->d_rt[i], 0, rb); }
+    }
+  }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_coeffs, n_sets * desc->n_taps * sizeof(int64_t)); }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_frag, sizeof(uint32_t) * 2 * (size_t)fir_mfma_max_blocks() * 64 * 4); }
+  if (e != hipSuccess || h->tm.init() != ACDSP_OK) {
+    acdsp_fir_destroy(h);
+    return fail(ACDSP_EHIP, "FIR state allocation failed: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_fir_destroy(acdsp_fir_t h) {
+  if (!h) { return ACDSP_OK; }
+  (void)hipSetDevice(h->d.device);
+  for (int i = 0; i < 2; i++) {
+    if (h->d_hist[i]) { (void)hipFree(h->d_hist[i]); }
+    if (h->d_rt[i]) { (void)hipFree(h->d_rt[i]); }
+  }
+  if (h->d_coeffs) { (void)hipFree(h->d_coeffs); }
+  if (h->d_frag) { (void)hipFree(h->d_frag); }
+  h->tm.destroy();
+  h->st.destroy();
+  delete h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
+  if (!h || !coeffs) { return fail(ACDSP_EINVAL, "null argument"); }
+  const acdsp_fir_desc_t &d = h->d;
+  if (d.kind == ACDSP_FIR_CONST && h->coeffs_set && d.ftype == ACDSP_TRANSPOSED) {
+    return fail(ACDSP_ESTATE, "const-coefficient TRANSPOSED filter: coefficients are bound once");
+  }
+  int rc = check_device(d.device);
+  if (rc) { return rc; }
+  const size_t n_sets = d.coeffs_per_channel ? (size_t)d.n_channels : 1;
+  const acdsp::DFmt cf = make_dfmt(d.coeff);
+  for (size_t i = 0; i < n_sets * d.n_taps; i++) {
+    if (coeffs[i] < cf.lo || coeffs[i] > cf.hi) {
+      return fail(ACDSP_EINVAL, "coefficient %zu = %lld is not a COEFF_TYPE raw word", i, (long long)coeffs[i]);
+    }
+  }
+  // Kernels of earlier run() calls may still be reading d_coeffs / d_frag.
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, n_sets * d.n_taps * sizeof(int64_t), hipMemcpyHostToDevice));
+  h->mfma_ok = false;
+  const bool i16_in = d.in.S ? d.in.W <= 16 : d.in.W <= 15;
+  const bool i16_cf = d.coeff.S ? d.coeff.W <= 16 : d.coeff.W <= 15;
+  if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && !d.coeffs_per_channel && i16_in && i16_cf && d.in.S &&
+      h->in_eb == 2 && (d.n_taps - 1 + 31) / 32 + 1 <= fir_mfma_max_blocks()) {
+    std::vector<int64_t> eff = effective_coeffs(coeffs, d.n_taps, d.ftype);
+    std::vector<uint32_t> frag((size_t)2 * fir_mfma_max_blocks() * 64 * 4, 0u);
+    if (fir_mfma_build_fragments(eff.data(), d.n_taps, &h->plan, frag.data())) {
+      HIP_TRY(hipMemcpy(h->d_frag, frag.data(), frag.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      h->mfma_ok = true;
+    }
+  }
+  h->path = h->mfma_ok ? ACDSP_PATH_MFMA_I8
+                       : ((h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC)) ? ACDSP_PATH_LOSSLESS64 : ACDSP_PATH_GENERIC);
+  h->coeffs_set = true;
+  h->h_coeffs.assign(coeffs, coeffs + n_sets * d.n_taps);
+  return ACDSP_OK;
+}
+
+int32_t acdsp_fir_clone(acdsp_fir_t h, acdsp_fir_t *out) {
+  if (!h || !out) { return fail(ACDSP_EINVAL, "null argument"); }
+  acdsp_fir_t c = nullptr;
+  int rc = acdsp_fir_create(&h->d, &c);
+  if (rc) { return rc; }
+  if (h->coeffs_set && (rc = acdsp_fir_set_coeffs(c, h->h_coeffs.data()))) { acdsp_fir_destroy(c); return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(c->d_hist[0], h->d_hist[h->cur], (size_t)h->d.n_channels * h->hl * h->in_eb, hipMemcpyDeviceToDevice));
+  if (h->use_rt) {
+    HIP_TRY(hipMemcpy(c->d_rt[0], h->d_rt[h->cur], (size_t)h->d.n_channels * h->d.n_taps * sizeof(int64_t), hipMemcpyDeviceToDevice));
+  }
+  c->cur = 0;
+  *out = c;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_fir_path(acdsp_fir_t h) { return h ? h->path : -1; }
+
+int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_t n, void *d_out, int64_t out_stride,
+                      void *stream) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  if (n < 0 || (n > 0 && (!d_in || !d_out || in_stride < n || out_stride < n))) {
+    return fail(ACDSP_EINVAL, "fir_run: bad buffer arguments");
+  }
+  if (!h->coeffs_set) { return fail(ACDSP_ESTATE, "fir_run before acdsp_fir_set_coeffs"); }
+  if (n == 0) { return ACDSP_OK; }
+  const acdsp_fir_desc_t &d = h->d;
+  int rc = check_device(d.device);
+  if (rc) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  FirParams k;
+  k.n_taps = d.n_taps; k.ftype = d.ftype; k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
+  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+  k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl; k.use_rt = h->use_rt ? 1 : 0;
+  k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
+  k.in_stride = in_stride; k.out_stride = out_stride; k.n = n;
+  k.x = d_in; k.y = d_out;
+  k.hist = h->d_hist[h->cur]; k.coeffs = h->d_coeffs; k.rt = h->d_rt[h->cur];
+
+  int path = h->path;
+  if (path == ACDSP_PATH_MFMA_I8) {
+    const bool aligned = ((uintptr_t)d_in % 16 == 0) && (in_stride % 8 == 0);
+    if (!aligned) { path = ACDSP_PATH_LOSSLESS64; }
+  }
+  HIP_TRY(hipEventRecord(h->tm.start(), s));
+  hipError_t e;
+  if (path == ACDSP_PATH_MFMA_I8) { e = launch_fir_mfma(k, h->plan, h->d_frag, s); }
+  else if (path == ACDSP_PATH_LOSSLESS64) { e = launch_fir_lossless64(k, s); }
+  else { e = launch_fir_generic(k, s); }
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR kernel launch failed: %s", hipGetErrorString(e)); }
+  HIP_TRY(hipEventRecord(h->tm.stop(), s));
+  h->tm.commit();
+  // state carry into the other buffer, then flip
+  if (h->use_rt) {
+    e = launch_fir_rt_update(k, h->d_rt[h->cur ^ 1], s);
+  } else {
+    e = launch_fir_hist_update(k, h->d_hist[h->cur ^ 1], s);
+  }
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR state kernel launch failed: %s", hipGetErrorString(e)); }
+  h->cur ^= 1;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_fir_run_host(acdsp_fir_t h, const void *h_in, int64_t n, void *h_out) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  if (n < 0 || (n > 0 && (!h_in || !h_out))) { return fail(ACDSP_EINVAL, "fir_run_host: bad arguments"); }
+  if (n == 0) { return ACDSP_OK; }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  const int64_t stride = (n + 7) / 8 * 8;  // keeps rows 16-byte aligned for every container
+  const size_t bin = (size_t)h->d.n_channels * stride * h->in_eb, bout = (size_t)h->d.n_channels * stride * h->out_eb;
+  if ((rc = h->st.ensure(bin, bout))) { return rc; }
+  HIP_TRY(hipMemcpy2D(h->st.d_in, (size_t)stride * h->in_eb, h_in, (size_t)n * h->in_eb, (size_t)n * h->in_eb,
+                      (size_t)h->d.n_channels, hipMemcpyHostToDevice));
+  if ((rc = acdsp_fir_run(h, h->st.d_in, stride, n, h->st.d_out, stride, nullptr))) { return rc; }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipMemcpy2D(h_out, (size_t)n * h->out_eb, h->st.d_out, (size_t)stride * h->out_eb, (size_t)n * h->out_eb,
+                      (size_t)h->d.n_channels, hipMemcpyDeviceToHost));
+  return ACDSP_OK;
+}
+
+int32_t acdsp_fir_reset(acdsp_fir_t h) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(hipMemset(h->d_hist[i], 0, (size_t)h->d.n_channels * h->hl * h->in_eb));
+    if (h->d_rt[i]) { HIP_TRY(hipMemset(h->d_rt[i], 0, (size_t)h->d.n_channels * h->d.n_taps * sizeof(int64_t))); }
+  }
+  return ACDSP_OK;
+}
+
+int32_t acdsp_fir_last_kernel_ms(acdsp_fir_t h, float *ms) {
+  if (!h || !ms) { return fail(ACDSP_EINVAL, "null argument"); }
+  return h->tm.stats(1, ms, nullptr);
+}
+
+int32_t acdsp_fir_kernel_stats(acdsp_fir_t h, int32_t last_k, float *avg_ms, float *min_ms) {
+  if (!h) { return fail(ACDSP_EINVAL, "null argument"); }
+  return h->tm.stats(last_k, avg_ms, min_ms);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// CIC
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+int log2_ceil_u64(uint64_t x) {
+  int lf = 63;
+  while (lf > 0 && !((x >> lf) & 1)) { lf--; }
+  return (x == (1ull << lf)) ? lf : lf + 1;
+}
+
+// find_inter_type_cic_dec / _intr: reference ac_cic_dec_full.h:116-137, ac_cic_intr_full.h:107-127.
+// power<> is an `int` enum there, so parameter sets whose product reaches 2^31 do not compile in
+// the reference; they are rejected here.
+int cic_int_type(const acdsp_cic_desc_t &d, acdsp_fmt_t *it) {
+  if (d.R < 1 || d.M < 1 || d.N < 1) { return fail(ACDSP_EINVAL, "CIC: R, M, N must be >= 1"); }
+  uint64_t pr = 1, pm = 1;
+  const int er = d.interp ? d.N - 1 : d.N;
+  for (int i = 0; i < er; i++) { pr *= (uint64_t)d.R; if (pr >= (1ull << 31)) { return fail(ACDSP_EUNSUPPORTED, "CIC: R^N overflows the reference's int power<>"); } }
+  for (int i = 0; i < d.N; i++) { pm *= (uint64_t)d.M; if (pm >= (1ull << 31)) { return fail(ACDSP_EUNSUPPORTED, "CIC: M^N overflows the reference's int power<>"); } }
+  if (pr * pm >= (1ull << 31)) { return fail(ACDSP_EUNSUPPORTED, "CIC: (R*M)^N overflows the reference's int power<>"); }
+  const int outF = d.in.W - d.in.I;
+  const int outW = log2_ceil_u64(pr * pm) + d.in.W + (d.in.S ? 0 : 1);
+  it->W = outW; it->I = outW - outF; it->S = 1; it->Q = ACDSP_TRN; it->O = ACDSP_WRAP;
+  return ACDSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t acdsp_cic_int_type(const acdsp_cic_desc_t *desc, acdsp_fmt_t *it) {
+  if (!desc || !it) { return fail(ACDSP_EINVAL, "null argument"); }
+  return cic_int_type(*desc, it);
+}
+
+int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
+  if (!desc || !out) { return fail(ACDSP_EINVAL, "null argument"); }
+  int rc;
+  if ((rc = check_fmt(desc->in, "IN_TYPE")) || (rc = check_fmt(desc->out, "OUT_TYPE"))) { return rc; }
+  acdsp_fmt_t it;
+  if ((rc = cic_int_type(*desc, &it))) { return rc; }
+  if (it.W > 64) { return fail(ACDSP_EUNSUPPORTED, "CIC: intermediate type needs %d bits (> 64)", it.W); }
+  if (desc->N > kCicMaxN) { return fail(ACDSP_EUNSUPPORTED, "CIC: N=%d > %d", desc->N, kCicMaxN); }
+  // rate counters are ac_int<8,false> in the reference (ac_cic_full_core.h:72-73)
+  if (desc->R > 256) { return fail(ACDSP_EUNSUPPORTED, "CIC: R=%d > 256 (8-bit rate counter in the reference)", desc->R); }
+  if (desc->interp && desc->R < 2) { return fail(ACDSP_EUNSUPPORTED, "CIC interpolator: R=1 never re-arms in the reference (ac_cic_full_core.h:146-158)"); }
+  if (desc->interp && desc->N > 255) { return fail(ACDSP_EUNSUPPORTED, "CIC: N too large"); }
+  if (desc->n_channels < 1) { return fail(ACDSP_EINVAL, "CIC: n_channels must be >= 1"); }
+  if ((rc = check_device(desc->device))) { return rc; }
+  acdsp_cic *h = new acdsp_cic();
+  h->d = *desc;
+  h->it = it;
+  h->in_eb = elem_bytes(desc->in.W);
+  h->out_eb = elem_bytes(desc->out.W);
+  h->me = desc->M < 2 ? desc->M : 2;  // effective comb delay of the reference's delay line, see cic.hip
+  const int64_t mem = desc->interp ? (int64_t)desc->N * h->me + 1 : (int64_t)desc->N * desc->R * h->me - 1;
+  h->hl = round_up((int)(mem > 1 ? mem : 1), kCicTile);
+  const size_t hb = (size_t)desc->n_channels * h->hl * h->in_eb;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    e = hipMalloc(&h->d_hist[i], hb);
+    if (e == hipSuccess) { e = hipMemset(h->d_hist[i], 0, hb); }
+  }
+  if (e != hipSuccess || h->tm.init() != ACDSP_OK) {
+    acdsp_cic_destroy(h);
+    return fail(ACDSP_EHIP, "CIC state allocation failed: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_cic_destroy(acdsp_cic_t h) {
+  if (!h) { return ACDSP_OK; }
+  (void)hipSetDevice(h->d.device);
+  for (int i = 0; i < 2; i++) {
+    if (h->d_hist[i]) { (void)hipFree(h->d_hist[i]); }
+  }
+  h->tm.destroy();
+  h->st.destroy();
+  delete h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_cic_clone(acdsp_cic_t h, acdsp_cic_t *out) {
+  if (!h || !out) { return fail(ACDSP_EINVAL, "null argument"); }
+  acdsp_cic_t c = nullptr;
+  int rc = acdsp_cic_create(&h->d, &c);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(c->d_hist[0], h->d_hist[h->cur], (size_t)h->d.n_channels * h->hl * h->in_eb, hipMemcpyDeviceToDevice));
+  c->cur = 0;
+  c->t_total = h->t_total;
+  *out = c;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_cic_reset(acdsp_cic_t h) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < 2; i++) { HIP_TRY(hipMemset(h->d_hist[i], 0, (size_t)h->d.n_channels * h->hl * h->in_eb)); }
+  h->t_total = 0;
+  return ACDSP_OK;
+}
+
+static void cic_window(const acdsp_cic *h, int64_t n_in, CicParams *p) {
+  const int R = h->d.R;
+  p->t_prev = h->t_total;
+  if (!h->d.interp) {
+    // decIntgCore emits when rate_cnt == 0, i.e. at global input indices 0, R, 2R, ... (ac_cic_full_core.h:116-133)
+    p->phase0 = (int)(h->t_total % R);
+    p->first = (R - p->phase0) % R;
+    p->q_begin = p->q_end = p->q_skip = 0;
+  } else {
+    // intrIntg: the call that consumes inputs T..T+K-1 runs iterations [(T-1)R+1, (T+K-1)R+1)
+    // (first call starts at 0); the first N-1 iterations ever are dropped (ac_cic_intr_full.h:200-213)
+    p->phase0 = 0; p->first = 0;
+    p->q_begin = h->t_total == 0 ? 0 : (h->t_total - 1) * R + 1;
+    p->q_end = n_in > 0 ? (h->t_total + n_in - 1) * R + 1 : p->q_begin;
+    p->q_skip = h->d.N - 1;
+  }
+}
+
+int64_t acdsp_cic_out_count(acdsp_cic_t h, int64_t n_in) {
+  if (!h || n_in < 0) { return -1; }
+  if (n_in == 0) { return 0; }
+  CicParams p;
+  cic_window(h, n_in, &p);
+  if (!h->d.interp) { return n_in > p.first ? (n_in - p.first + h->d.R - 1) / h->d.R : 0; }
+  int64_t lo = p.q_begin > p.q_skip ? p.q_begin : p.q_skip;
+  return p.q_end > lo ? p.q_end - lo : 0;
+}
+
+int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_t n_in, void *d_out, int64_t out_stride,
+                      int64_t *n_out, void *stream) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  if (n_in < 0 || (n_in > 0 && (!d_in || in_stride < n_in))) { return fail(ACDSP_EINVAL, "cic_run: bad input arguments"); }
+  const int64_t no = acdsp_cic_out_count(h, n_in);
+  if (n_out) { *n_out = no; }
+  if (n_in == 0) { return ACDSP_OK; }
+  if (no > 0 && (!d_out || out_stride < no)) { return fail(ACDSP_EINVAL, "cic_run: output buffer too small for %lld outputs", (long long)no); }
+  const acdsp_cic_desc_t &d = h->d;
+  int rc = check_device(d.device);
+  if (rc) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  CicParams p;
+  cic_window(h, n_in, &p);
+  p.interp = d.interp; p.R = d.R; p.me = h->me; p.N = d.N; p.n_ch = d.n_channels;
+  p.w_int = h->it.W;
+  p.in = make_dfmt(d.in); p.out = make_dfmt(d.out);
+  p.in_eb = h->in_eb; p.out_eb = h->out_eb;
+  p.hl = h->hl; p.warm_tiles = h->hl / kCicTile;
+  p.vec_ok = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0);
+  p.in_stride = in_stride; p.out_stride = out_stride; p.n_in = n_in;
+  p.x = d_in; p.y = d_out; p.hist = h->d_hist[h->cur];
+  // chunking: aim at >= 4096 waves, keep the warm-up below ~6 % of a chunk
+  const int64_t groups = (d.n_channels + 63) / 64;
+  int64_t chunk = (n_in * groups + 4095) / 4096;
+  const int64_t floor_chunk = (int64_t)16 * h->hl > 1024 ? (int64_t)16 * h->hl : 1024;
+  if (chunk < floor_chunk) { chunk = floor_chunk; }
+  p.chunk = (chunk + kCicTile - 1) / kCicTile * kCicTile;
+  HIP_TRY(hipEventRecord(h->tm.start(), s));
+  hipError_t e = launch_cic(p, s);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "CIC kernel launch failed: %s", hipGetErrorString(e)); }
+  HIP_TRY(hipEventRecord(h->tm.stop(), s));
+  h->tm.commit();
+  e = launch_cic_hist_update(p, h->d_hist[h->cur ^ 1], s);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "CIC state kernel launch failed: %s", hipGetErrorString(e)); }
+  h->cur ^= 1;
+  h->t_total += n_in;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_cic_run_host(acdsp_cic_t h, const void *h_in, int64_t n_in, void *h_out, int64_t out_cap, int64_t *n_out) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  if (n_in < 0 || (n_in > 0 && !h_in)) { return fail(ACDSP_EINVAL, "cic_run_host: bad arguments"); }
+  const int64_t no = acdsp_cic_out_count(h, n_in);
+  if (n_out) { *n_out = no; }
+  if (n_in == 0) { return ACDSP_OK; }
+  if (no > out_cap || (no > 0 && !h_out)) { return fail(ACDSP_EINVAL, "cic_run_host: output capacity %lld < %lld", (long long)out_cap, (long long)no); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  const int64_t si = (n_in + 7) / 8 * 8, so = (no + 7) / 8 * 8 + 8;
+  if ((rc = h->st.ensure((size_t)h->d.n_channels * si * h->in_eb, (size_t)h->d.n_channels * so * h->out_eb))) { return rc; }
+  HIP_TRY(hipMemcpy2D(h->st.d_in, (size_t)si * h->in_eb, h_in, (size_t)n_in * h->in_eb, (size_t)n_in * h->in_eb,
+                      (size_t)h->d.n_channels, hipMemcpyHostToDevice));
+  int64_t no2 = 0;
+  if ((rc = acdsp_cic_run(h, h->st.d_in, si, n_in, h->st.d_out, so, &no2, nullptr))) { return rc; }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  if (no > 0) {
+    HIP_TRY(hipMemcpy2D(h_out, (size_t)no * h->out_eb, h->st.d_out, (size_t)so * h->out_eb, (size_t)no * h->out_eb,
+                        (size_t)h->d.n_channels, hipMemcpyDeviceToHost));
+  }
+  return ACDSP_OK;
+}
+
+int32_t acdsp_cic_last_kernel_ms(acdsp_cic_t h, float *ms) {
+  if (!h || !ms) { return fail(ACDSP_EINVAL, "null argument"); }
+  return h->tm.stats(1, ms, nullptr);
+}
+
+int32_t acdsp_cic_kernel_stats(acdsp_cic_t h, int32_t last_k, float *avg_ms, float *min_ms) {
+  if (!h) { return fail(ACDSP_EINVAL, "null argument"); }
+  return h->tm.stats(last_k, avg_ms, min_ms);
+}
+
+}  // extern "C"

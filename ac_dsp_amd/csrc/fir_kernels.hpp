@@ -1,0 +1,46 @@
+// fir_kernels.hpp -- launch interface between the C-ABI layer (engine.hip) and the FIR kernels.
+#pragma once
+#include "acdsp_dev.hpp"
+
+namespace acdsp {
+
+// Everything a FIR launch needs; passed by value as the kernel argument.
+struct FirParams {
+  int32_t n_taps, ftype, n_ch, coeffs_per_channel;
+  DFmt in, cf, acc, out;
+  int32_t in_eb, out_eb;       // container bytes of IN / OUT
+  int32_t hl;                  // history samples kept per channel (>= n_taps-1, multiple of 32)
+  int32_t use_rt;              // TRANSPOSED with carried partial sums (reg_trans state)
+  int32_t lossless_shift;      // F_acc - F_in - F_coeff (>= 0 on the lossless paths)
+  int64_t in_stride, out_stride, n;
+  const void *x;               // input samples  [n_ch][in_stride]  (IN containers)
+  void *y;                     // output samples [n_ch][out_stride] (OUT containers)
+  const void *hist;            // [n_ch][hl] IN containers: the hl samples before t = 0
+  const int64_t *coeffs;       // [n_sets][n_taps] raw words
+  const int64_t *rt;           // [n_ch][n_taps] ACC raw words (use_rt)
+};
+
+// Exact per-tap emulation in the reference's loop order (any Q/O, any widths <= 64).
+hipError_t launch_fir_generic(const FirParams &p, hipStream_t s);
+// Lossless accumulator + AC_WRAP: integer dot product mod 2^64, one requant at the end.
+hipError_t launch_fir_lossless64(const FirParams &p, hipStream_t s);
+// State carry: history ring (all ftypes but TRANSPOSED-with-rt) and reg_trans partial sums.
+hipError_t launch_fir_hist_update(const FirParams &p, void *hist_next, hipStream_t s);
+hipError_t launch_fir_rt_update(const FirParams &p, int64_t *rt_next, hipStream_t s);
+
+// int8-split MFMA Toeplitz path (fir_mfma.hip)
+struct FirMfmaPlan {
+  int32_t nb;                  // 32-sample K blocks per output block = ceil((n_taps-1)/32) + 1
+  uint32_t hi_mask, lo_mask;   // bit b set: Toeplitz block b of the hi / lo coefficient plane is non-zero
+  int64_t corr;                // 128 * sum(c): undoes the signed re-bias of the low input byte
+  int64_t sum_abs;             // sum |c|            (bounds |y|  <= 32768 * sum_abs)
+  int64_t sum_abs_hi;          // sum |high byte|    (bounds |S(ch,.)| <= 128 * sum_abs_hi)
+  int64_t sum_abs_lo;          // sum |low byte|
+};
+// Builds the per-lane A fragments (host side) into frag[2][nb][64][4] dwords; returns false if the
+// coefficient set cannot be split into two signed bytes per tap.
+bool fir_mfma_build_fragments(const int64_t *coeffs, int n_taps, FirMfmaPlan *plan, uint32_t *frag /* host */);
+hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, const uint32_t *d_frag, hipStream_t s);
+int fir_mfma_max_blocks();
+
+}  // namespace acdsp

@@ -1,0 +1,283 @@
+// fir_mfma.hip -- many-channel 16-bit FIR on the gfx950 matrix cores (exact integer arithmetic).
+//
+// Replaces the tap-MAC loops of the reference cores (`acc += reg[i] * coeffs[i]`,
+// reference include/ac_dsp/ac_fir_const_coeffs.h:190-199 and the load_/prog_ twins) for the
+// arithmetic class in which that loop is an exact integer dot product: accumulator with at least
+// F_in + F_coeff fractional bits and AC_WRAP overflow (DESIGN.md "arithmetic classes").  The
+// folded architectures (:244-275) enter through their effective direct-form coefficients.
+//
+// Why MFMA at all: a 255-tap int16 FIR carries 255 MAC per 4 algorithmic bytes; the VALU
+// (v_dot2_i32_i16) tops out near 15 % of the HBM roofline, the int8 matrix pipe does not.
+//
+// Formulation.  For one block of 32 consecutive outputs of one channel,
+//     y[T0+i] = sum_k c[k] x[T0+i-k]        i = 0..31
+// is a [32 x 32*NB] Toeplitz matrix (built from c, the same for every output block and every
+// channel) times the [32*NB] input samples ending at T0+31, NB = ceil((N-1)/32)+1.  Stacking 32
+// channels as the columns of B gives NB dense 32x32x32 MFMA tiles per output block:
+//     D[i][ch] += A_b[i][k] * X_b[k][ch],   A_b[i][k] = c[i - k + 32*(NB-1-b)].
+// MFMA has no int16 operand type, so both operands are split into two signed bytes:
+//     c = 256*ch + cl            (cl = sign-extended low byte, ch = (c - cl)/256, both int8)
+//     x = 256*xh + xl + 128      (xh = high byte, xl = low byte re-biased to signed)
+//     y = 65536*S(ch,xh) + 256*(S(ch,xl) + S(cl,xh)) + S(cl,xl) + 128*sum(c)
+// Each S is an int32 MFMA accumulation (|S| <= 32*NB*2^14 < 2^31).  The result is the exact
+// integer dot product; rounding/saturation into OUT_TYPE happens once, in the epilogue.
+//
+// Data movement.  The 2*NB A fragments (4 VGPRs each) stay in registers for the whole kernel.
+// Every input block is read from HBM exactly once per chunk (16-byte loads, two per lane), split
+// into hi/lo byte planes with v_perm_b32 and kept in a rotating register window that is reused
+// by the NB output blocks it overlaps -- no LDS, no re-reads except the NB-1 halo blocks at a
+// chunk start.  One wave = 32 channels x one time chunk.
+#include <vector>
+
+#include "fir_kernels.hpp"
+
+namespace acdsp {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxNB = 9;  // register-resident Toeplitz fragments: up to 32*8+1 = 257 taps
+
+int fir_mfma_max_blocks() { return kMaxNB; }
+
+// Host: build frag[plane][b][lane][4 dwords]; plane 0 = high bytes, 1 = low bytes.
+// Lane l holds row i = l & 31 and the 16 K-positions k = 16*(l>>5) + j, j = 0..15 (the same
+// (lane-group, byte) -> k map is used for the data operand, so any K permutation inside the
+// instruction cancels).
+bool fir_mfma_build_fragments(const int64_t *c, int n_taps, FirMfmaPlan *plan, uint32_t *frag) {
+  const int nb = (n_taps - 1 + 31) / 32 + 1;
+  if (nb > kMaxNB) { return false; }
+  std::vector<int8_t> chi(n_taps), clo(n_taps);
+  int64_t sum = 0, sa = 0, sah = 0, sal = 0;
+  for (int k = 0; k < n_taps; k++) {
+    int64_t v = c[k];
+    if (v < -32768 || v > 32767) { return false; }
+    int64_t lo = ((v + 128) & 0xff) - 128;
+    int64_t hi = (v - lo) / 256;
+    if (hi < -128 || hi > 127) { return false; }  // c >= 32640: not representable as two signed bytes
+    chi[k] = (int8_t)hi; clo[k] = (int8_t)lo;
+    sum += v;
+    sa += v < 0 ? -v : v; sah += hi < 0 ? -hi : hi; sal += lo < 0 ? -lo : lo;
+  }
+  plan->nb = nb;
+  plan->sum_abs = sa; plan->sum_abs_hi = sah; plan->sum_abs_lo = sal;
+  plan->corr = 128 * sum;
+  plan->hi_mask = plan->lo_mask = 0;
+  for (int pl = 0; pl < 2; pl++) {
+    const int8_t *src = pl == 0 ? chi.data() : clo.data();
+    for (int b = 0; b < nb; b++) {
+      bool any = false;
+      for (int lane = 0; lane < 64; lane++) {
+        const int i = lane & 31, h = lane >> 5;
+        for (int dw = 0; dw < 4; dw++) {
+          uint32_t word = 0;
+          for (int bj = 0; bj < 4; bj++) {
+            const int k = 16 * h + 4 * dw + bj;
+            const int tap = i - k + 32 * (nb - 1 - b);
+            int8_t val = (tap >= 0 && tap < n_taps) ? src[tap] : (int8_t)0;
+            any = any || val != 0;
+            word |= (uint32_t)(uint8_t)val << (8 * bj);
+          }
+          frag[(((size_t)pl * nb + b) * 64 + lane) * 4 + dw] = word;
+        }
+      }
+      if (any) { (pl == 0 ? plan->hi_mask : plan->lo_mask) |= 1u << b; }
+    }
+  }
+  return true;
+}
+
+struct MfmaArgs {
+  int64_t chunk_blocks;  // 32-sample output blocks per wave
+  int64_t n_blocks;      // ceil(n / 32)
+  int32_t out_vec_ok;    // output rows aligned for 4-element vector stores
+};
+
+__device__ inline void split_planes(const v4i &ra, const v4i &rb, v4i &xh, v4i &xl) {
+  // ra/rb: 16 int16 samples (2 per dword).  High bytes -> xh, low bytes (re-biased) -> xl.
+  xh.x = (int)__builtin_amdgcn_perm((unsigned)ra.y, (unsigned)ra.x, 0x07050301u);
+  xh.y = (int)__builtin_amdgcn_perm((unsigned)ra.w, (unsigned)ra.z, 0x07050301u);
+  xh.z = (int)__builtin_amdgcn_perm((unsigned)rb.y, (unsigned)rb.x, 0x07050301u);
+  xh.w = (int)__builtin_amdgcn_perm((unsigned)rb.w, (unsigned)rb.z, 0x07050301u);
+  xl.x = (int)(__builtin_amdgcn_perm((unsigned)ra.y, (unsigned)ra.x, 0x06040200u) ^ 0x80808080u);
+  xl.y = (int)(__builtin_amdgcn_perm((unsigned)ra.w, (unsigned)ra.z, 0x06040200u) ^ 0x80808080u);
+  xl.z = (int)(__builtin_amdgcn_perm((unsigned)rb.y, (unsigned)rb.x, 0x06040200u) ^ 0x80808080u);
+  xl.w = (int)(__builtin_amdgcn_perm((unsigned)rb.w, (unsigned)rb.z, 0x06040200u) ^ 0x80808080u);
+}
+
+// EPI 0: any OUT_TYPE / ACC width through requant64.
+// EPI 1: OUT container int16, Q in {TRN, RND}, O in {WRAP, SAT}, no accumulator wrap possible,
+//        right shift >= 8: all-32-bit epilogue.
+template <int NB, int EPI>
+__global__ void __launch_bounds__(64, 2)
+fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, MfmaArgs a) {
+  const int lane = threadIdx.x;
+  const int n_col = lane & 31, h = lane >> 5;
+  const int ch = blockIdx.y * 32 + n_col;
+  const bool ch_ok = ch < p.n_ch;
+  const int chl = ch_ok ? ch : p.n_ch - 1;
+
+  v4i Ah[NB], Al[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    Ah[b] = frag[(0 * NB + b) * 64 + lane];
+    Al[b] = frag[(1 * NB + b) * 64 + lane];
+  }
+
+  const int16_t *xrow = (const int16_t *)p.x + (int64_t)chl * p.in_stride;
+  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)chl * p.hl + p.hl;  // hrow[t], t < 0
+  const int64_t ob0 = (int64_t)blockIdx.x * a.chunk_blocks;
+  const int64_t ob1 = (ob0 + a.chunk_blocks < a.n_blocks) ? ob0 + a.chunk_blocks : a.n_blocks;
+  const int nsteps = (int)(ob1 - ob0);
+
+  auto load_block = [&](int64_t ib, v4i &ra, v4i &rb) {
+    const int64_t t = ib * 32 + h * 16;
+    if (ib < 0) {
+      const v4i *s = (const v4i *)(hrow + t);
+      ra = s[0]; rb = s[1];
+    } else if (t + 16 <= p.n) {
+      const v4i *s = (const v4i *)(xrow + t);
+      ra = s[0]; rb = s[1];
+    } else {
+      union { v4i v[2]; int16_t e[16]; } u;
+#pragma unroll
+      for (int e = 0; e < 16; e++) { u.e[e] = (t + e < p.n) ? xrow[t + e] : (int16_t)0; }
+      ra = u.v[0]; rb = u.v[1];
+    }
+  };
+
+  // rotating window: input block ib lives in slot (ib - ob0) mod NB
+  v4i Xh[NB], Xl[NB];
+#pragma unroll
+  for (int b = 0; b < NB - 1; b++) {
+    v4i ra, rb;
+    load_block(ob0 - (NB - 1) + b, ra, rb);
+    split_planes(ra, rb, Xh[b + 1], Xl[b + 1]);
+  }
+  v4i na, nb_;  // raw samples of the next input block (software prefetch, one step ahead)
+  load_block(ob0, na, nb_);
+
+  // epilogue constants
+  const int rs = p.in.F + p.cf.F - p.out.F;  // net right shift of the raw dot product (EPI 1)
+  const int64_t corr = plan.corr;
+  const int64_t corr_t = corr + ((EPI == 1 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
+  const int cA = (int)(corr_t >> 8);          // added to hh*256 + mid
+  const int cB = (int)(corr_t & 0xff);        // added to ll
+  const int sat_lo = (int)p.out.lo, sat_hi = (int)p.out.hi;
+  const bool do_sat = p.out.O == ACDSP_SAT;
+
+  for (int s_base = 0; s_base < nsteps; s_base += NB) {
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      const int s = s_base + u;
+      if (s < nsteps) {
+      const int64_t ob = ob0 + s;
+      split_planes(na, nb_, Xh[u], Xl[u]);
+      if (s + 1 < nsteps) { load_block(ob + 1, na, nb_); }
+
+      v16i hh = {0}, mid = {0}, ll = {0};
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const int slot = (u + 1 + b) % NB;
+        hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xh[slot], hh, 0, 0, 0);
+        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xl[slot], mid, 0, 0, 0);
+        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[slot], mid, 0, 0, 0);
+        ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xl[slot], ll, 0, 0, 0);
+      }
+
+      // D layout (32x32): lane holds column n_col, rows (r&3) + 8*(r>>2) + 4*h
+      const int64_t tb = ob * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int64_t t0 = tb + 8 * g;
+        if (EPI == 1) {
+          int o[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int r = 4 * g + rr;
+            int A = hh[r] * 256 + mid[r] + cA;
+            int B = (ll[r] + cB) >> 8;
+            int q = (A + B) >> (rs - 8);
+            if (do_sat) { q = q < sat_lo ? sat_lo : (q > sat_hi ? sat_hi : q); }
+            o[rr] = q;
+          }
+          int16_t *dst = (int16_t *)p.y + (int64_t)ch * p.out_stride + t0;
+          if (ch_ok) {
+            if (a.out_vec_ok && t0 + 4 <= p.n) {
+              v4s pk = {(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+              *(v4s *)dst = pk;
+            } else {
+#pragma unroll
+              for (int rr = 0; rr < 4; rr++) {
+                if (t0 + rr < p.n) { dst[rr] = (int16_t)o[rr]; }
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int r = 4 * g + rr;
+            int64_t v = ((int64_t)hh[r] << 16) + ((int64_t)mid[r] << 8) + (int64_t)ll[r] + corr;
+            int64_t acc = wrap64((int64_t)((uint64_t)v << p.lossless_shift), p.acc.W, p.acc.S);
+            int64_t y = requant64(acc, p.acc.F, p.out);
+            if (ch_ok && t0 + rr < p.n) { store_raw(p.y, (int64_t)ch * p.out_stride + t0 + rr, p.out_eb, y); }
+          }
+        }
+      }
+      }  // s < nsteps
+    }
+  }
+}
+
+template <int NB>
+static hipError_t launch_nb(const FirParams &p, const FirMfmaPlan &plan, const uint32_t *d_frag, const MfmaArgs &a, int epi,
+                            dim3 grid, hipStream_t s) {
+  if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1>), grid, dim3(64), 0, s, p, plan, (const v4i *)d_frag, a); }
+  else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 0>), grid, dim3(64), 0, s, p, plan, (const v4i *)d_frag, a); }
+  return hipGetLastError();
+}
+
+hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, const uint32_t *d_frag, hipStream_t s) {
+  if (p.n <= 0) { return hipSuccess; }
+  MfmaArgs a;
+  a.n_blocks = (p.n + 31) / 32;
+  const int64_t groups = (p.n_ch + 31) / 32;
+  // >= 4096 waves when the problem allows it (2 waves/SIMD x 1024 SIMDs, two rounds); a chunk
+  // re-reads NB-1 halo blocks, so keep it >= 32 blocks.
+  int64_t cb = (a.n_blocks * groups + 4095) / 4096;
+  if (cb < 32) { cb = 32; }
+  a.chunk_blocks = cb;
+  const int oeb = p.out_eb;
+  a.out_vec_ok = ((uintptr_t)p.y % (4 * oeb) == 0) && ((p.out_stride * oeb) % (4 * oeb) == 0);
+  // all-32-bit epilogue: int16 container, TRN/RND, WRAP/SAT, shift >= 8, no accumulator wrap,
+  // and hh*256 + mid + corr/256 provably inside int32
+  const int rs = p.in.F + p.cf.F - p.out.F;
+  // |y| <= 32768 * sum|c| must fit the accumulator (no AC_WRAP event possible) ...
+  const int acc_bits = p.acc.W - (p.acc.S ? 1 : 0) - p.lossless_shift;
+  const bool acc_wide = acc_bits >= 63 || plan.sum_abs * 32768 < (int64_t(1) << (acc_bits > 0 ? acc_bits : 0));
+  // ... and hh*256 + mid + corr/256 + carry must fit int32
+  const int64_t hh_max = 128 * plan.sum_abs_hi, mid_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo), ll_max = 128 * plan.sum_abs_lo;
+  const int64_t corr_abs = (plan.corr < 0 ? -plan.corr : plan.corr) + (int64_t(1) << 38);
+  const bool small = hh_max * 256 + mid_max + corr_abs / 256 + (ll_max + 255) / 256 + 2 < (int64_t(1) << 31);
+  int epi = 0;
+  if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
+      rs >= 8 && rs <= 38 && acc_wide && small && p.out.W == 16) {
+    epi = 1;
+  }
+  dim3 grid((unsigned)((a.n_blocks + a.chunk_blocks - 1) / a.chunk_blocks), (unsigned)groups);
+  switch (plan.nb) {
+    case 1: return launch_nb<1>(p, plan, d_frag, a, epi, grid, s);
+    case 2: return launch_nb<2>(p, plan, d_frag, a, epi, grid, s);
+    case 3: return launch_nb<3>(p, plan, d_frag, a, epi, grid, s);
+    case 4: return launch_nb<4>(p, plan, d_frag, a, epi, grid, s);
+    case 5: return launch_nb<5>(p, plan, d_frag, a, epi, grid, s);
+    case 6: return launch_nb<6>(p, plan, d_frag, a, epi, grid, s);
+    case 7: return launch_nb<7>(p, plan, d_frag, a, epi, grid, s);
+    case 8: return launch_nb<8>(p, plan, d_frag, a, epi, grid, s);
+    case 9: return launch_nb<9>(p, plan, d_frag, a, epi, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace acdsp

@@ -1,0 +1,166 @@
+"""Thin object wrappers over the C ABI for tests and bench.py (torch tensors as device buffers)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, Fmt, FirDesc, CicDesc, FTYPES, KINDS, PATHS
+
+
+def device_count():
+    return lib.acdsp_device_count()
+
+
+def torch_dtype_for(fmt):
+    return {2: torch.int16, 4: torch.int32, 8: torch.int64}[lib.acdsp_elem_bytes(fmt.W)]
+
+
+def _np_dtype_for(fmt):
+    return {2: np.int16, 4: np.int32, 8: np.int64}[lib.acdsp_elem_bytes(fmt.W)]
+
+
+def _stream_ptr(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev_index(dev):
+    d = torch.device(dev)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def fill_stimulus(out, seed, bits, ch0=0, t0=0):
+    """Fill a [n_ch][n] device tensor with the counter-hash stimulus (bit-identical to oracle.stimulus)."""
+    assert out.is_cuda and out.dim() == 2 and out.stride(1) == 1
+    check(lib.acdsp_fill_stimulus(_dev_index(out.device), C.c_void_p(out.data_ptr()), out.element_size(), out.shape[0],
+                                  out.shape[1], out.stride(0), seed, bits, ch0, t0, _stream_ptr(out)))
+    return out
+
+
+class Fir:
+    """n_channels independent reference FIR objects (ac_fir_{const,load,prog}_coeffs) behind one handle."""
+
+    def __init__(self, n_taps, ftype, fin, fcoeff, facc, fout, n_channels=1, kind="load", coeffs_per_channel=False,
+                 device=0, force_generic=False):
+        self.fin, self.fcoeff, self.facc, self.fout = fin, fcoeff, facc, fout
+        self.n_taps, self.n_channels, self.device = n_taps, n_channels, device
+        self.coeffs_per_channel = bool(coeffs_per_channel)
+        d = FirDesc(KINDS[kind] if isinstance(kind, str) else kind, FTYPES[ftype] if isinstance(ftype, str) else ftype,
+                    n_taps, n_channels, int(self.coeffs_per_channel), fin, fcoeff, facc, fout, device,
+                    _lib.FLAG_FORCE_GENERIC if force_generic else 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_fir_create(C.byref(d), C.byref(self._h)))
+
+    def set_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        want = (self.n_channels, self.n_taps) if self.coeffs_per_channel else (self.n_taps,)
+        assert c.shape == want, (c.shape, want)
+        check(lib.acdsp_fir_set_coeffs(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    @property
+    def path(self):
+        return PATHS[lib.acdsp_fir_path(self._h)]
+
+    def run(self, x, out=None):
+        """x: [n_channels][n] device tensor of IN containers -> [n_channels][n] OUT containers."""
+        assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1
+        assert x.dtype == torch_dtype_for(self.fin), (x.dtype, self.fin)
+        n = x.shape[1]
+        if out is None:
+            out = torch.empty((self.n_channels, n), dtype=torch_dtype_for(self.fout), device=x.device)
+        assert out.dtype == torch_dtype_for(self.fout) and out.stride(1) == 1 and out.shape[1] >= n
+        check(lib.acdsp_fir_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), n, C.c_void_p(out.data_ptr()),
+                                out.stride(0), _stream_ptr(x)))
+        return out
+
+    def run_host(self, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=_np_dtype_for(self.fin))
+        assert x.shape[0] == self.n_channels
+        y = np.empty(x.shape, dtype=_np_dtype_for(self.fout))
+        check(lib.acdsp_fir_run_host(self._h, x.ctypes.data_as(C.c_void_p), x.shape[1], y.ctypes.data_as(C.c_void_p)))
+        return y
+
+    def reset(self):
+        check(lib.acdsp_fir_reset(self._h))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(lib.acdsp_fir_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def kernel_stats(self, last_k):
+        """(avg_ms, min_ms) of the main kernel over the last_k run() calls (HIP events on the launch stream)."""
+        a, m = C.c_float(), C.c_float()
+        check(lib.acdsp_fir_kernel_stats(self._h, last_k, C.byref(a), C.byref(m)))
+        return a.value, m.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.acdsp_fir_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Cic:
+    """n_channels independent ac_cic_dec_full (interp=False) / ac_cic_intr_full (interp=True) objects."""
+
+    def __init__(self, interp, R, M, N, fin, fout, n_channels=1, device=0):
+        self.interp, self.R, self.M, self.N = bool(interp), R, M, N
+        self.fin, self.fout, self.n_channels, self.device = fin, fout, n_channels, device
+        self._d = CicDesc(int(self.interp), R, M, N, n_channels, fin, fout, device, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_cic_create(C.byref(self._d), C.byref(self._h)))
+
+    @property
+    def int_type(self):
+        it = Fmt()
+        check(lib.acdsp_cic_int_type(C.byref(self._d), C.byref(it)))
+        return it
+
+    def out_count(self, n_in):
+        return lib.acdsp_cic_out_count(self._h, n_in)
+
+    def run(self, x, out=None):
+        assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1
+        assert x.dtype == torch_dtype_for(self.fin), (x.dtype, self.fin)
+        n_in = x.shape[1]
+        no = self.out_count(n_in)
+        if out is None:
+            out = torch.empty((self.n_channels, max(no, 1)), dtype=torch_dtype_for(self.fout), device=x.device)
+        assert out.dtype == torch_dtype_for(self.fout) and out.stride(1) == 1 and out.shape[1] >= no
+        n_out = C.c_int64()
+        check(lib.acdsp_cic_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), n_in, C.c_void_p(out.data_ptr()),
+                                out.stride(0), C.byref(n_out), _stream_ptr(x)))
+        return out[:, :n_out.value]
+
+    def run_host(self, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=_np_dtype_for(self.fin))
+        no = self.out_count(x.shape[1])
+        y = np.empty((self.n_channels, max(no, 1)), dtype=_np_dtype_for(self.fout))
+        n_out = C.c_int64()
+        check(lib.acdsp_cic_run_host(self._h, x.ctypes.data_as(C.c_void_p), x.shape[1], y.ctypes.data_as(C.c_void_p),
+                                     y.shape[1], C.byref(n_out)))
+        return y[:, :n_out.value]
+
+    def reset(self):
+        check(lib.acdsp_cic_reset(self._h))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(lib.acdsp_cic_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def kernel_stats(self, last_k):
+        a, m = C.c_float(), C.c_float()
+        check(lib.acdsp_cic_kernel_stats(self._h, last_k, C.byref(a), C.byref(m)))
+        return a.value, m.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.acdsp_cic_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X fixed-point streaming-filter engine.
+
+Metric (BASELINE.json): Msamples/s of the 255-tap ac_fixed<16,2> FIR on 1024 channels (configs[1]:
+ac_fir_load_coeffs, 1024 channels x 2^20 samples per GPU), inputs resident in HBM.  One "step" = one
+pass of the FIR hot path over one [1024][2^20] block of the stream (filter state carries from step to
+step, like consecutive run() calls of the reference).  With N GPUs every rank filters its own slice of
+N*1024 independent channels: no data-path collective, weak scaling.
+
+Launch: `python bench.py` (1 GPU) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W`.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (2x the 2.5 PF bf16 dense peak)
+
+
+def shard(n_total, world, rank):
+    """Contiguous channel slice [lo, hi) of rank `rank` (independent filter objects: no exchange)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def windowed_sinc_raw(n_taps, cutoff, frac_bits):
+    m = (n_taps - 1) / 2.0
+    k = np.arange(n_taps) - m
+    h = np.sinc(2 * cutoff * k) * 2 * cutoff * (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(n_taps) / (n_taps - 1)))
+    h = h / h.sum()
+    raw = np.round(h * 2.0 ** frac_bits).astype(np.int64)
+    return (raw + raw[::-1]) // 2
+
+
+def cpu_baseline_fir(n_taps, coeffs, fin, fc, fa, fo, seed):
+    """Oracle ("port" of the reference's per-sample loop) timed on this host's cores, bounded sample."""
+    import threading
+    from oracle import OracleFir, Fmt as OFmt, stimulus
+    cores = os.cpu_count() or 1
+    n = 16384
+    of = [OFmt(f.W, f.I, f.S, f.Q, f.O) for f in (fin, fc, fa, fo)]
+    xs = stimulus(seed, cores, n, fin.W)
+    objs = [OracleFir(n_taps, "SHIFT_REG", *of) for _ in range(cores)]
+    reps = 1
+
+    def work(i):
+        for _ in range(reps):
+            objs[i].run(coeffs, xs[i:i + 1])
+
+    # calibrate to ~10 s of wall time on all cores
+    t0 = time.perf_counter()
+    work(0)
+    t1 = time.perf_counter() - t0
+    reps = max(1, int(10.0 / max(t1, 1e-3)))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = cores * n * reps
+    return {"value": total / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d channels x %d samples x %d passes of the same 255-tap workload, one oracle object per core "
+                      "(ctypes releases the GIL), %.1f s wall" % (cores, n, reps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "cic_dec"])
+    ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
+    ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the HIP engine)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch one process per GPU"
+
+    import ac_dsp_amd as A
+    dev = torch.device("cuda", local_rank)
+    seed = 0xACD5
+
+    if args.workload in ("fir255", "fir255_dense"):
+        n_taps = 255
+        ch_per_gpu = args.channels or 1024
+        n = args.samples or (1 << 20)
+        fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+        fo = A.Fmt(16, 2, True, "RND", "SAT")
+        if args.workload == "fir255":
+            coeffs = windowed_sinc_raw(n_taps, 0.1, fc.F)  # symmetric windowed sinc, sum|c| < 2
+        else:  # every Toeplitz byte-plane block populated
+            coeffs = np.random.default_rng(1).integers(-32768, 32640, size=n_taps, dtype=np.int64)
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        eng = A.Fir(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_channels=hi - lo, kind="load", device=local_rank)
+        eng.set_coeffs(coeffs)
+        x = torch.empty((hi - lo, n), dtype=torch.int16, device=dev)
+        A.fill_stimulus(x, seed, 16, ch0=lo)
+        y = torch.empty((hi - lo, n), dtype=torch.int16, device=dev)
+        bytes_per_sample = 4.0                   # 2 B read + 2 B written
+        macs_per_sample = 4.0 * 32 * eng_nb(n_taps)  # int8 MACs issued: 4 byte-plane products x padded band
+        name = "ac_fir_load_coeffs 255-tap ac_fixed<16,2> -> <16,2,RND,SAT>, ACC <40,12>, %d ch x %d samples per GPU " \
+               "(BASELINE configs[1])" % (ch_per_gpu, n)
+        dtype = "int16 (exact: int8-split MFMA, int32 accumulate)"
+
+        def step():
+            eng.run(x, y)
+        path = eng.path
+        samples_per_step = (hi - lo) * n
+    else:
+        ch_per_gpu = args.channels or 4096
+        n = args.samples or (1 << 22)
+        fin, fo = A.Fmt(32, 16), A.Fmt(47, 31)
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        eng = A.Cic(False, 8, 1, 5, fin, fo, n_channels=hi - lo, device=local_rank)
+        x = torch.empty((hi - lo, n), dtype=torch.int32, device=dev)
+        A.fill_stimulus(x, seed, 32, ch0=lo)
+        y = torch.empty((hi - lo, n // 8 + 1), dtype=torch.int64, device=dev)
+        bytes_per_sample = 5.0                   # 4 B read + 8 B / 8 written
+        macs_per_sample = 0.0
+        name = "ac_cic_dec_full N=5 R=8 M=1 ac_fixed<32,16> -> <47,31>, %d ch x %d samples per GPU (BASELINE configs[2])" % (ch_per_gpu, n)
+        dtype = "int64 (wrap arithmetic mod 2^47)"
+        coeffs = None
+
+        def step():
+            eng.run(x, y)
+        path = "cic_dec"
+        samples_per_step = (hi - lo) * n
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    k_avg, k_min = eng.kernel_stats(min(args.steps, 64))   # HIP events around the dominant kernel, launch stream
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([float(samples_per_step)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_samples_per_step = float(tot.item())
+    else:
+        total_samples_per_step = float(samples_per_step)
+
+    if rank == 0:
+        value = total_samples_per_step * args.steps / dt / 1e6
+        ach = bytes_per_sample * samples_per_step / (k_avg * 1e-3) / 1e9
+        out = {
+            "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic (on-device splitmix64 counter hash, seed 0xACD5)",
+            "config": {"workload": name, "kernel_path": path, "channels_per_gpu": ch_per_gpu, "samples_per_step": n,
+                       "parallelism": "channel-slice x%d, no collectives" % world},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
+                         "algorithmic_bytes_per_sample": bytes_per_sample},
+            "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
+        }
+        if macs_per_sample:
+            tops = 2.0 * macs_per_sample * samples_per_step / (k_avg * 1e-3) / 1e12
+            out["mfma_roofline"] = {"bound": "mfma", "achieved": tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8, issued)",
+                                    "frac": tops / I8_MFMA_PEAK_TOPS}
+        if world == 1 and not args.no_cpu_baseline and coeffs is not None:
+            out["cpu_baseline"] = cpu_baseline_fir(255, coeffs, fin, fc, fa, fo, seed)
+        elif world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_cic(fin, fo, seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def eng_nb(n_taps):
+    return (n_taps - 1 + 31) // 32 + 1
+
+
+def cpu_baseline_cic(fin, fo, seed):
+    import threading
+    from oracle import OracleCic, Fmt as OFmt, stimulus
+    cores = os.cpu_count() or 1
+    n = 1 << 18
+    xs = stimulus(seed, cores, n, fin.W)
+    objs = [OracleCic(0, 8, 1, 5, OFmt(fin.W, fin.I, fin.S, fin.Q, fin.O), OFmt(fo.W, fo.I, fo.S, fo.Q, fo.O)) for _ in range(cores)]
+    reps = 1
+
+    def work(i):
+        for _ in range(reps):
+            objs[i].run(xs[i:i + 1])
+    t0 = time.perf_counter()
+    work(0)
+    t1 = time.perf_counter() - t0
+    reps = max(1, int(10.0 / max(t1, 1e-3)))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": cores * n * reps / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d channels x %d samples x %d passes, one oracle object per core, %.1f s wall" % (cores, n, reps, dt)}
+
+
+if __name__ == "__main__":
+    main()

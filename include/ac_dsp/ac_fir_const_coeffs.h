@@ -1,0 +1,57 @@
+// ac_fir_const_coeffs.h -- drop-in for hlslibs/ac_dsp's constant-coefficient FIR, MI355X back end.
+//
+// Same class template, constructor and run() signature as the reference
+// (include/ac_dsp/ac_fir_const_coeffs.h:309-321); the per-sample cores
+// fir_const_coeffs_core::firConstCoeffs* (:190-296) are replaced by the batched HIP
+// kernels behind include/acdsp.h.  run() drains the input channel like the
+// reference's non-synthesis `while (data_in.available(1))` loop (:325), but
+// hands the whole burst to the GPU in one call.
+//
+// Behaviour kept from the reference:
+//  * the coefficient pointer is borrowed for the object's lifetime and read at
+//    run() time, not in the constructor (:122,:314) -- the shipped testbench
+//    passes a pointer to a derived-class member that is initialised *after*
+//    the base constructor (tests/rtest_ac_fir_const_coeffs.cpp:94-108);
+//  * filter state persists across run() calls and is copied with the object;
+//  * FOLD_EVEN_ANTI / FOLD_ODD_ANTI are not handled by run() (:330-352): the
+//    reference writes an unassigned value, this implementation aborts.
+#ifndef _INCLUDED_AC_FIR_CONST_COEFFS_H_
+#define _INCLUDED_AC_FIR_CONST_COEFFS_H_
+
+#include <ac_fixed.h>
+#include <ac_int.h>
+#include <ac_channel.h>
+
+// Make sure that this enum is only defined once, as different FIR designs use and define the same enum.
+#ifndef __FIR_FILTER_TYPES_ENUM_DEF__
+#define __FIR_FILTER_TYPES_ENUM_DEF__
+typedef enum { SHIFT_REG, ROTATE_SHIFT, C_BUFF, FOLD_EVEN, FOLD_ODD, TRANSPOSED, FOLD_EVEN_ANTI, FOLD_ODD_ANTI } FTYPE;
+#endif
+
+#include <mc_scverify.h>
+#include <ac_dsp/acdsp_engine.h>
+
+template < class IN_TYPE, class OUT_TYPE, class COEFF_TYPE, class ACC_TYPE, unsigned N_TAPS, FTYPE ftype >
+class ac_fir_const_coeffs
+{
+public:
+  // constructor with pointer of const coeff array as an arg
+  ac_fir_const_coeffs(const COEFF_TYPE *const c_ptr) : coeffs(c_ptr), engine(ACDSP_FIR_CONST, (int)ftype, (int)N_TAPS) {}
+
+#pragma hls_design interface
+  void CCS_BLOCK(run)(ac_channel < IN_TYPE > &data_in, ac_channel < OUT_TYPE > &data_out) {
+    std::vector<IN_TYPE> burst;
+    while (data_in.available(1)) { burst.push_back(data_in.read()); }
+    if (burst.empty()) { return; }
+    engine.set_coeffs(coeffs);  // uploaded on first use / when the pointed-to values changed
+    std::vector<OUT_TYPE> result;
+    engine.run_values(burst, result);
+    for (size_t i = 0; i < result.size(); i++) { data_out.write(result[i]); }
+  }
+
+private:
+  const COEFF_TYPE *const coeffs;
+  acdsp::fir_engine<IN_TYPE, OUT_TYPE, COEFF_TYPE, ACC_TYPE> engine;
+};
+
+#endif

@@ -1,0 +1,245 @@
+// acdsp_engine.h -- C++ (header-only) front end of the MI355X filter engine.
+//
+// Maps ac_fixed template parameters onto the runtime descriptors of the C ABI
+// (include/acdsp.h) and owns the engine handles.  Two layers use it:
+//   * the drop-in class templates ac_fir_{const,load,prog}_coeffs and
+//     ac_cic_{dec,intr}_full (one channel, ac_channel I/O, same signatures as
+//     the reference's include/ac_dsp/*.h), and
+//   * the batched many-channel API acdsp::fir_engine / acdsp::cic_engine, which
+//     works on [channel][time] arrays of raw words (host or device memory).
+//
+// Only public AC Datatypes API is used on the ac_fixed side (width, i_width,
+// sign, q_mode, o_mode, slc, set_slc), so the headers work both with the
+// subset in include/ac_types/ and with a genuine hlslibs/ac_types install.
+//
+// Errors: the reference signals none (void run()).  Here every non-zero engine
+// status aborts with the engine's message -- never a silent wrong answer and
+// never a CPU fallback.
+#ifndef AC_DSP_AMD_ACDSP_ENGINE_H
+#define AC_DSP_AMD_ACDSP_ENGINE_H
+
+#include <ac_channel.h>
+#include <ac_fixed.h>
+#include <ac_int.h>
+#include <acdsp.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace acdsp {
+
+inline void check(int32_t rc, const char *what) {
+  if (rc != ACDSP_OK) {
+    fprintf(stderr, "ac_dsp_amd: %s failed (%d): %s\n", what, (int)rc, acdsp_last_error());
+    abort();
+  }
+}
+
+// Device used by objects that are constructed without an explicit one.
+inline int default_device() {
+  const char *e = getenv("ACDSP_DEVICE");
+  return e ? atoi(e) : 0;
+}
+
+inline int32_t q_code(ac_q_mode q) {
+  switch (q) {
+    case AC_TRN: return ACDSP_TRN;
+    case AC_RND: return ACDSP_RND;
+    case AC_TRN_ZERO: return ACDSP_TRN_ZERO;
+    case AC_RND_ZERO: return ACDSP_RND_ZERO;
+    case AC_RND_INF: return ACDSP_RND_INF;
+    case AC_RND_MIN_INF: return ACDSP_RND_MIN_INF;
+    case AC_RND_CONV: return ACDSP_RND_CONV;
+    case AC_RND_CONV_ODD: return ACDSP_RND_CONV_ODD;
+  }
+  return -1;
+}
+inline int32_t o_code(ac_o_mode o) {
+  switch (o) {
+    case AC_WRAP: return ACDSP_WRAP;
+    case AC_SAT: return ACDSP_SAT;
+    case AC_SAT_ZERO: return ACDSP_SAT_ZERO;
+    case AC_SAT_SYM: return ACDSP_SAT_SYM;
+  }
+  return -1;
+}
+
+// ac_fixed<W,I,S,Q,O>  ->  acdsp_fmt_t   (cf. reference ac_cic_dec_full.h:119-121 reading T::width etc.)
+template <class T> inline acdsp_fmt_t fmt_of() {
+  static_assert(T::width >= 1 && T::width <= 64, "ac_dsp_amd engine: ac_fixed widths up to 64 bits");
+  acdsp_fmt_t f;
+  f.W = T::width; f.I = T::i_width; f.S = T::sign ? 1 : 0;
+  f.Q = q_code(T::q_mode); f.O = o_code(T::o_mode);
+  return f;
+}
+
+template <class T> inline int64_t raw_of(const T &v) {
+  return (int64_t)v.template slc<T::width>(0).to_int64();  // ac_int<W,S>: already sign/zero extended
+}
+template <class T> inline T from_raw(int64_t r) {
+  T v;
+  v.set_slc(0, ac_int<T::width, T::sign>((long long)r));
+  return v;
+}
+
+// pack / unpack raw words into the engine's containers (int16 / int32 / int64 by width)
+inline void pack(const std::vector<int64_t> &src, int eb, std::vector<unsigned char> &dst) {
+  dst.resize(src.size() * (size_t)eb);
+  for (size_t i = 0; i < src.size(); i++) {
+    if (eb == 2) { int16_t t = (int16_t)src[i]; memcpy(&dst[i * 2], &t, 2); }
+    else if (eb == 4) { int32_t t = (int32_t)src[i]; memcpy(&dst[i * 4], &t, 4); }
+    else { memcpy(&dst[i * 8], &src[i], 8); }
+  }
+}
+inline int64_t unpack_one(const unsigned char *p, int eb, bool is_signed) {
+  if (eb == 2) { int16_t t; memcpy(&t, p, 2); return is_signed ? (int64_t)t : (int64_t)(uint16_t)t; }
+  if (eb == 4) { int32_t t; memcpy(&t, p, 4); return is_signed ? (int64_t)t : (int64_t)(uint32_t)t; }
+  int64_t t; memcpy(&t, p, 8); return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched FIR: n_channels independent filters behind one engine handle.
+// ---------------------------------------------------------------------------------------------
+template <class IN_TYPE, class OUT_TYPE, class COEFF_TYPE, class ACC_TYPE>
+class fir_engine {
+public:
+  fir_engine(int kind, int ftype, int n_taps, int n_channels = 1, bool coeffs_per_channel = false, int device = -1)
+      : h_(0), kind_(kind), ftype_(ftype), n_taps_(n_taps), n_ch_(n_channels), per_ch_(coeffs_per_channel),
+        device_(device < 0 ? default_device() : device) {}
+  ~fir_engine() { if (h_) { acdsp_fir_destroy(h_); } }
+  // The reference objects are plain aggregates: copying one copies its state.
+  fir_engine(const fir_engine &o)
+      : h_(0), kind_(o.kind_), ftype_(o.ftype_), n_taps_(o.n_taps_), n_ch_(o.n_ch_), per_ch_(o.per_ch_), device_(o.device_),
+        coeffs_(o.coeffs_) {
+    if (o.h_) { check(acdsp_fir_clone(o.h_, &h_), "acdsp_fir_clone"); }
+  }
+  fir_engine &operator=(const fir_engine &o) {
+    if (this != &o) {
+      if (h_) { acdsp_fir_destroy(h_); h_ = 0; }
+      kind_ = o.kind_; ftype_ = o.ftype_; n_taps_ = o.n_taps_; n_ch_ = o.n_ch_; per_ch_ = o.per_ch_; device_ = o.device_;
+      coeffs_ = o.coeffs_;
+      if (o.h_) { check(acdsp_fir_clone(o.h_, &h_), "acdsp_fir_clone"); }
+    }
+    return *this;
+  }
+
+  int n_channels() const { return n_ch_; }
+  int in_bytes() const { return acdsp_elem_bytes(IN_TYPE::width); }
+  int out_bytes() const { return acdsp_elem_bytes(OUT_TYPE::width); }
+  acdsp_fir_t handle() { ensure(); return h_; }
+
+  // raw coefficient words, [n_taps] or [n_channels][n_taps]; uploaded only when they changed
+  void set_coeffs_raw(const std::vector<int64_t> &c) {
+    ensure();
+    if (c == coeffs_) { return; }
+    check(acdsp_fir_set_coeffs(h_, c.data()), "acdsp_fir_set_coeffs");
+    coeffs_ = c;
+  }
+  void set_coeffs(const COEFF_TYPE *c) {
+    std::vector<int64_t> r((size_t)n_taps_ * (per_ch_ ? n_ch_ : 1));
+    for (size_t i = 0; i < r.size(); i++) { r[i] = raw_of(c[i]); }
+    set_coeffs_raw(r);
+  }
+  // device-resident streams (the hot path): containers of in_bytes()/out_bytes(), strides in elements
+  void run_device(const void *d_in, int64_t in_stride, int64_t n, void *d_out, int64_t out_stride, void *stream = 0) {
+    ensure();
+    check(acdsp_fir_run(h_, d_in, in_stride, n, d_out, out_stride, stream), "acdsp_fir_run");
+  }
+  // host-resident dense [n_channels][n] containers
+  void run_host(const void *h_in, int64_t n, void *h_out) {
+    ensure();
+    check(acdsp_fir_run_host(h_, h_in, n, h_out), "acdsp_fir_run_host");
+  }
+  // one channel of ac_fixed values in, ac_fixed values out (used by the drop-in run() bodies)
+  void run_values(const std::vector<IN_TYPE> &x, std::vector<OUT_TYPE> &y) {
+    std::vector<int64_t> r(x.size());
+    for (size_t i = 0; i < x.size(); i++) { r[i] = raw_of(x[i]); }
+    std::vector<unsigned char> bi, bo(x.size() * (size_t)out_bytes());
+    pack(r, in_bytes(), bi);
+    run_host(bi.data(), (int64_t)x.size(), bo.data());
+    y.resize(x.size());
+    for (size_t i = 0; i < x.size(); i++) { y[i] = from_raw<OUT_TYPE>(unpack_one(&bo[i * out_bytes()], out_bytes(), OUT_TYPE::sign)); }
+  }
+  void reset() { if (h_) { check(acdsp_fir_reset(h_), "acdsp_fir_reset"); } }
+
+private:
+  void ensure() {
+    if (h_) { return; }
+    acdsp_fir_desc_t d;
+    d.kind = kind_; d.ftype = ftype_; d.n_taps = n_taps_; d.n_channels = n_ch_; d.coeffs_per_channel = per_ch_ ? 1 : 0;
+    d.in = fmt_of<IN_TYPE>(); d.coeff = fmt_of<COEFF_TYPE>(); d.acc = fmt_of<ACC_TYPE>(); d.out = fmt_of<OUT_TYPE>();
+    d.device = device_; d.flags = 0;
+    check(acdsp_fir_create(&d, &h_), "acdsp_fir_create");
+  }
+  acdsp_fir_t h_;
+  int kind_, ftype_, n_taps_, n_ch_;
+  bool per_ch_;
+  int device_;
+  std::vector<int64_t> coeffs_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Batched CIC
+// ---------------------------------------------------------------------------------------------
+template <class IN_TYPE, class OUT_TYPE>
+class cic_engine {
+public:
+  cic_engine(bool interp, unsigned R, unsigned M, unsigned N, int n_channels = 1, int device = -1)
+      : h_(0), interp_(interp), R_(R), M_(M), N_(N), n_ch_(n_channels), device_(device < 0 ? default_device() : device) {}
+  ~cic_engine() { if (h_) { acdsp_cic_destroy(h_); } }
+  cic_engine(const cic_engine &o) : h_(0), interp_(o.interp_), R_(o.R_), M_(o.M_), N_(o.N_), n_ch_(o.n_ch_), device_(o.device_) {
+    if (o.h_) { check(acdsp_cic_clone(o.h_, &h_), "acdsp_cic_clone"); }
+  }
+  cic_engine &operator=(const cic_engine &o) {
+    if (this != &o) {
+      if (h_) { acdsp_cic_destroy(h_); h_ = 0; }
+      interp_ = o.interp_; R_ = o.R_; M_ = o.M_; N_ = o.N_; n_ch_ = o.n_ch_; device_ = o.device_;
+      if (o.h_) { check(acdsp_cic_clone(o.h_, &h_), "acdsp_cic_clone"); }
+    }
+    return *this;
+  }
+
+  int in_bytes() const { return acdsp_elem_bytes(IN_TYPE::width); }
+  int out_bytes() const { return acdsp_elem_bytes(OUT_TYPE::width); }
+  acdsp_cic_t handle() { ensure(); return h_; }
+  int64_t out_count(int64_t n_in) { ensure(); return acdsp_cic_out_count(h_, n_in); }
+
+  void run_device(const void *d_in, int64_t in_stride, int64_t n_in, void *d_out, int64_t out_stride, int64_t *n_out, void *stream = 0) {
+    ensure();
+    check(acdsp_cic_run(h_, d_in, in_stride, n_in, d_out, out_stride, n_out, stream), "acdsp_cic_run");
+  }
+  void run_values(const std::vector<IN_TYPE> &x, std::vector<OUT_TYPE> &y) {
+    ensure();
+    y.clear();
+    if (x.empty()) { return; }
+    std::vector<int64_t> r(x.size());
+    for (size_t i = 0; i < x.size(); i++) { r[i] = raw_of(x[i]); }
+    std::vector<unsigned char> bi;
+    pack(r, in_bytes(), bi);
+    const int64_t cap = out_count((int64_t)x.size());
+    std::vector<unsigned char> bo((size_t)(cap > 0 ? cap : 1) * (size_t)out_bytes());
+    int64_t n_out = 0;
+    check(acdsp_cic_run_host(h_, bi.data(), (int64_t)x.size(), bo.data(), cap, &n_out), "acdsp_cic_run_host");
+    y.resize((size_t)n_out);
+    for (int64_t i = 0; i < n_out; i++) { y[(size_t)i] = from_raw<OUT_TYPE>(unpack_one(&bo[(size_t)i * out_bytes()], out_bytes(), OUT_TYPE::sign)); }
+  }
+
+private:
+  void ensure() {
+    if (h_) { return; }
+    acdsp_cic_desc_t d;
+    d.interp = interp_ ? 1 : 0; d.R = (int32_t)R_; d.M = (int32_t)M_; d.N = (int32_t)N_; d.n_channels = n_ch_;
+    d.in = fmt_of<IN_TYPE>(); d.out = fmt_of<OUT_TYPE>(); d.device = device_; d.flags = 0;
+    check(acdsp_cic_create(&d, &h_), "acdsp_cic_create");
+  }
+  acdsp_cic_t h_;
+  bool interp_;
+  unsigned R_, M_, N_;
+  int n_ch_, device_;
+};
+
+}  // namespace acdsp
+
+#endif

@@ -1,0 +1,147 @@
+/* acdsp.h -- C ABI of the MI355X fixed-point streaming-filter engine (libacdsp.so).
+ *
+ * hlslibs/ac_dsp has no FFI/plugin layer: its boundary is the C++ class-template
+ * API (`ac_fir_*_coeffs::run`, `ac_cic_*_full::run`).  The drop-in headers in
+ * include/ac_dsp/ keep those templates and call the entry points below, which
+ * replace the reference's per-sample core loops:
+ *
+ *   acdsp_fir_*   <- fir_{const,load,prog}_coeffs_core member functions
+ *                    reference include/ac_dsp/ac_fir_const_coeffs.h:153-296,
+ *                    ac_fir_load_coeffs.h:145-278, ac_fir_prog_coeffs.h:110-247
+ *                    driven by run(): ac_fir_const_coeffs.h:321-355,
+ *                    ac_fir_load_coeffs.h:320-365, ac_fir_prog_coeffs.h:277-303
+ *   acdsp_cic_*   <- ac_cic_full_core_intg / _diff, ac_cic_full_core.h:80-160,198-255
+ *                    driven by run(): ac_cic_dec_full.h:163-222, ac_cic_intr_full.h:150-215
+ *
+ * Data model: every sample is the raw W-bit two's-complement word of an
+ * ac_fixed<W,I,S,Q,O> value (value = raw * 2^-(W-I)), stored sign-/zero-extended
+ * in the smallest of int16/int32/int64 that holds W bits (acdsp_elem_bytes).
+ * Streams are laid out [channel][time]: sample t of channel c is element
+ * c*stride + t.  Channels are independent filter objects (one reference object
+ * each); all filter state lives in the handle and carries across run() calls
+ * exactly like the reference's object members.
+ *
+ * There is no CPU fallback: every entry point runs HIP kernels on gfx950 and
+ * fails with ACDSP_ENODEVICE / ACDSP_EHIP otherwise.
+ */
+#ifndef ACDSP_H
+#define ACDSP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACDSP_ABI_VERSION 1
+
+/* ac_fixed<W,I,S,Q,O> */
+typedef struct { int32_t W, I, S, Q, O; } acdsp_fmt_t;
+
+enum { ACDSP_TRN = 0, ACDSP_RND, ACDSP_TRN_ZERO, ACDSP_RND_ZERO, ACDSP_RND_INF, ACDSP_RND_MIN_INF, ACDSP_RND_CONV, ACDSP_RND_CONV_ODD };
+enum { ACDSP_WRAP = 0, ACDSP_SAT, ACDSP_SAT_ZERO, ACDSP_SAT_SYM };
+/* FTYPE, reference ac_fir_const_coeffs.h:96.  The *_ANTI values are rejected:
+ * the reference run() has no branch for them and writes an unassigned value. */
+enum { ACDSP_SHIFT_REG = 0, ACDSP_ROTATE_SHIFT, ACDSP_C_BUFF, ACDSP_FOLD_EVEN, ACDSP_FOLD_ODD, ACDSP_TRANSPOSED, ACDSP_FOLD_EVEN_ANTI, ACDSP_FOLD_ODD_ANTI };
+enum { ACDSP_FIR_CONST = 0, ACDSP_FIR_LOAD = 1, ACDSP_FIR_PROG = 2 };
+
+enum {
+  ACDSP_OK = 0,
+  ACDSP_EINVAL = 1,       /* bad argument / descriptor */
+  ACDSP_EUNSUPPORTED = 2, /* valid in the reference but outside this engine's limits */
+  ACDSP_EHIP = 3,         /* a HIP call failed */
+  ACDSP_ENODEVICE = 4,    /* no gfx950 device */
+  ACDSP_ESTATE = 5        /* call sequence error (e.g. run before coefficients are set) */
+};
+
+/* flags */
+#define ACDSP_FLAG_FORCE_GENERIC 1 /* never pick the MFMA / fast kernels (parity tests) */
+
+/* which kernel family a FIR handle resolved to (acdsp_fir_path) */
+enum { ACDSP_PATH_GENERIC = 0, ACDSP_PATH_LOSSLESS64 = 1, ACDSP_PATH_MFMA_I8 = 2 };
+
+typedef struct {
+  int32_t kind;               /* ACDSP_FIR_*: which reference class this mirrors (informational) */
+  int32_t ftype;              /* ACDSP_SHIFT_REG ... */
+  int32_t n_taps;
+  int32_t n_channels;
+  int32_t coeffs_per_channel; /* 0: one coefficient set shared by all channels, 1: one set per channel */
+  acdsp_fmt_t in, coeff, acc, out;
+  int32_t device;             /* HIP device ordinal */
+  int32_t flags;
+} acdsp_fir_desc_t;
+
+typedef struct {
+  int32_t interp;             /* 0: ac_cic_dec_full, 1: ac_cic_intr_full */
+  int32_t R, M, N;
+  int32_t n_channels;
+  acdsp_fmt_t in, out;
+  int32_t device;
+  int32_t flags;
+} acdsp_cic_desc_t;
+
+typedef struct acdsp_fir *acdsp_fir_t;
+typedef struct acdsp_cic *acdsp_cic_t;
+
+/* ---- general ---- */
+int32_t acdsp_abi_version(void);
+const char *acdsp_last_error(void);            /* message for the last failing call on this thread */
+int32_t acdsp_device_count(void);              /* number of gfx950 devices, 0 if none */
+int32_t acdsp_elem_bytes(int32_t W);           /* 2, 4 or 8 */
+
+/* device-memory helpers so that pure C/C++ callers need no HIP headers */
+int32_t acdsp_dev_alloc(int32_t device, uint64_t bytes, void **d_ptr);
+int32_t acdsp_dev_free(int32_t device, void *d_ptr);
+int32_t acdsp_copy_h2d(int32_t device, void *d_dst, const void *h_src, uint64_t bytes);
+int32_t acdsp_copy_d2h(int32_t device, void *h_dst, const void *d_src, uint64_t bytes);
+int32_t acdsp_sync(int32_t device, void *stream);
+
+/* Counter-hash stimulus written straight into HBM (bench/test inputs too big to
+ * ship over PCIe).  Element (c,t) = top `bits` bits of splitmix64(seed, ((ch0+c)<<32)|(t0+t)),
+ * sign-extended, stored in an elem_bytes-wide integer. */
+int32_t acdsp_fill_stimulus(int32_t device, void *d_ptr, int32_t elem_bytes, int64_t n_ch, int64_t n, int64_t stride,
+                            uint64_t seed, int32_t bits, uint64_t ch0, uint64_t t0, void *stream);
+
+/* ---- FIR ---- */
+int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out);
+int32_t acdsp_fir_destroy(acdsp_fir_t h);
+/* Deep copy, state included (the reference objects are plain aggregates: copying one copies its
+ * shift register / reg_trans / coefficients). */
+int32_t acdsp_fir_clone(acdsp_fir_t h, acdsp_fir_t *out);
+/* Raw coefficient words from host memory: [n_taps] or [n_channels][n_taps].
+ * const_coeffs: call once (the reference borrows the pointer for the object's
+ * life); load_coeffs: the coefficient-load phase of run(); prog_coeffs: before
+ * every run().  Takes effect for samples processed by later run() calls. */
+int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs);
+/* Filter n_samples per channel.  d_in / d_out are device pointers to IN / OUT
+ * containers, strides in elements.  Asynchronous on `stream` (a hipStream_t, or
+ * NULL for the default stream). */
+int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_t n_samples, void *d_out,
+                      int64_t out_stride, void *stream);
+/* Same, host buffers, dense [n_channels][n_samples]; synchronous. */
+int32_t acdsp_fir_run_host(acdsp_fir_t h, const void *h_in, int64_t n_samples, void *h_out);
+int32_t acdsp_fir_reset(acdsp_fir_t h);        /* back to the freshly constructed state (coefficients kept) */
+int32_t acdsp_fir_path(acdsp_fir_t h);         /* ACDSP_PATH_* chosen for the current coefficients */
+/* Duration of the main kernel of the most recent run(), from HIP events
+ * recorded on the launch stream (blocks until that kernel has finished). */
+int32_t acdsp_fir_last_kernel_ms(acdsp_fir_t h, float *ms);
+/* Average / minimum main-kernel duration over the last `last_k` (<= 64) run() calls. */
+int32_t acdsp_fir_kernel_stats(acdsp_fir_t h, int32_t last_k, float *avg_ms, float *min_ms);
+
+/* ---- CIC ---- */
+int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out);
+int32_t acdsp_cic_destroy(acdsp_cic_t h);
+int32_t acdsp_cic_clone(acdsp_cic_t h, acdsp_cic_t *out);
+int32_t acdsp_cic_int_type(const acdsp_cic_desc_t *desc, acdsp_fmt_t *it); /* the reference's lossless INT_TYPE */
+int64_t acdsp_cic_out_count(acdsp_cic_t h, int64_t n_in); /* outputs per channel the next run(n_in) produces */
+int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_t n_in, void *d_out, int64_t out_stride,
+                      int64_t *n_out, void *stream);
+int32_t acdsp_cic_run_host(acdsp_cic_t h, const void *h_in, int64_t n_in, void *h_out, int64_t out_cap, int64_t *n_out);
+int32_t acdsp_cic_reset(acdsp_cic_t h);
+int32_t acdsp_cic_last_kernel_ms(acdsp_cic_t h, float *ms);
+int32_t acdsp_cic_kernel_stats(acdsp_cic_t h, int32_t last_k, float *avg_ms, float *min_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports everything include/acdsp.h
+declares, and refuses to compute without a gfx950 device (no fallback path)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "acdsp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(acdsp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ac_dsp_amd._lib as L
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L.lib, n), "libacdsp.so does not export %s" % n
+    assert set(names) == set(L.SYMBOLS), set(names) ^ set(L.SYMBOLS)
+    assert L.lib.acdsp_abi_version() == 1
+
+
+def test_descriptor_layout_matches_header():
+    import ac_dsp_amd._lib as L
+    assert C.sizeof(L.Fmt) == 20
+    assert C.sizeof(L.FirDesc) == 5 * 4 + 4 * 20 + 2 * 4
+    assert C.sizeof(L.CicDesc) == 5 * 4 + 2 * 20 + 2 * 4
+    assert [L.lib.acdsp_elem_bytes(w) for w in (1, 16, 17, 32, 33, 64)] == [2, 2, 4, 4, 8, 8]
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ac_dsp_amd as A
+    assert A.device_count() == 0
+    with pytest.raises(A.AcdspError) as e:
+        A.Fir(27, "FOLD_ODD", A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2))
+    assert e.value.code == 4  # ACDSP_ENODEVICE
+    with pytest.raises(A.AcdspError):
+        A.Cic(False, 8, 1, 5, A.Fmt(32, 16), A.Fmt(47, 31))
+
+
+def test_argument_validation_happens_before_device_use():
+    import ac_dsp_amd as A
+    with pytest.raises(A.AcdspError) as e:
+        A.Fir(8, "FOLD_ODD_ANTI", A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2))
+    assert e.value.code == 2  # ACDSP_EUNSUPPORTED, like the reference's unassigned output
+    with pytest.raises(A.AcdspError) as e:
+        A.Fir(8, "SHIFT_REG", A.Fmt(80, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2))
+    assert e.value.code == 2
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base in ("ac_dsp_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"^\s*(from|import)\s+oracle|#include\s*[<\"].*oracle|libacdsp_oracle", txt, flags=re.M):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

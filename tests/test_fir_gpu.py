@@ -1,0 +1,236 @@
+"""GPU parity tests, FIR: the HIP engine (through the C ABI) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import ac_dsp_amd as A
+from oracle import OracleFir, stimulus
+from helpers import ofmt, two_tone, read_fracs, sqnr_db, windowed_sinc
+from oracle import from_double
+
+pytestmark = pytest.mark.gpu
+
+FTYPES6 = ["SHIFT_REG", "ROTATE_SHIFT", "C_BUFF", "FOLD_EVEN", "FOLD_ODD", "TRANSPOSED"]
+
+
+def rand_raw(rng, fmt, shape):
+    lo = -(1 << (fmt.W - 1)) if fmt.S else 0
+    hi = (1 << (fmt.W - 1)) - 1 if fmt.S else (1 << fmt.W) - 1
+    return rng.integers(lo, hi + 1, size=shape, dtype=np.int64)
+
+
+def run_engine(fir, x, splits=None):
+    """x: [n_ch][n] int64 raw -> int64 raw, through device tensors; optional call splitting."""
+    dt = A.torch_dtype_for(fir.fin)
+    outs = []
+    bounds = [0] + list(splits or []) + [x.shape[1]]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b == a:
+            continue
+        xd = torch.from_numpy(x[:, a:b].copy()).to(dt).cuda()
+        outs.append(fir.run(xd).cpu().numpy().astype(np.int64))
+    return np.concatenate(outs, axis=1)
+
+
+def check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=700, kind="load", per_channel=False, splits=None, seed=0,
+               force_generic=False, coeffs=None, expect_path=None):
+    rng = np.random.default_rng(seed)
+    x = rand_raw(rng, fin, (n_ch, n))
+    if coeffs is None:
+        coeffs = rand_raw(rng, fc, (n_ch, n_taps) if per_channel else (n_taps,))
+    fir = A.Fir(n_taps, ftype, fin, fc, fa, fo, n_channels=n_ch, kind=kind, coeffs_per_channel=per_channel,
+                force_generic=force_generic)
+    fir.set_coeffs(coeffs)
+    if expect_path:
+        assert fir.path == expect_path, fir.path
+    y = run_engine(fir, x, splits)
+    orc = OracleFir(n_taps, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    yo = orc.run(coeffs, x)
+    bad = np.argwhere(y != yo)
+    assert bad.size == 0, "%d mismatches, first at %s: got %d want %d (path %s)" % (
+        len(bad), bad[0], y[tuple(bad[0])], yo[tuple(bad[0])], fir.path)
+    return fir
+
+
+@pytest.mark.parametrize("ftype", FTYPES6)
+def test_reference_test_types_all_ftypes(ftype):
+    # types of tests/rtest_ac_fir_load_coeffs.cpp:50-74 (lossless 64-bit accumulator)
+    check_case(27, ftype, A.Fmt(32, 16), A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(64, 32), splits=[100, 113, 400])
+
+
+@pytest.mark.parametrize("ftype", FTYPES6)
+def test_prog_test_types_lossy_acc(ftype):
+    # tests/rtest_ac_fir_prog_coeffs.cpp:47-54: F_in+F_c = 38 > F_acc = 32 -> per-tap truncation
+    check_case(27, ftype, A.Fmt(28, 6), A.Fmt(23, 7), A.Fmt(64, 32), A.Fmt(64, 32), kind="prog", splits=[1, 2, 30])
+
+
+@pytest.mark.parametrize("q", list(A.Q_MODES))
+@pytest.mark.parametrize("o", list(A.O_MODES))
+def test_all_q_o_modes_in_accumulator_and_output(q, o):
+    # sign/parity dependent rounding and saturation make the tap order observable
+    for ftype in ("SHIFT_REG", "C_BUFF", "FOLD_ODD", "TRANSPOSED"):
+        check_case(9, ftype, A.Fmt(12, 4), A.Fmt(10, 2), A.Fmt(18, 7, True, q, o), A.Fmt(9, 5, True, q, o), n=300,
+                   seed=hash((q, o)) % 1000, splits=[5])
+
+
+def test_unsigned_types():
+    check_case(8, "FOLD_EVEN", A.Fmt(10, 3, False), A.Fmt(9, 1, False), A.Fmt(24, 8, False), A.Fmt(12, 6, False, "RND", "SAT"))
+    check_case(8, "SHIFT_REG", A.Fmt(10, 3, False), A.Fmt(9, 1, True), A.Fmt(24, 8, True), A.Fmt(12, 6, False, "RND", "SAT"))
+
+
+@pytest.mark.parametrize("ftype", ["FOLD_EVEN", "FOLD_ODD"])
+@pytest.mark.parametrize("n_taps", [4, 5, 6, 7])
+def test_fold_parity_quirks(ftype, n_taps):
+    # FOLD_EVEN on an odd tap count drops the centre tap, FOLD_ODD on an even one ignores reg[N/2]
+    check_case(n_taps, ftype, A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT"))
+
+
+def test_per_channel_coefficients():
+    check_case(33, "SHIFT_REG", A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(40, 12), n_ch=5, per_channel=True)
+    check_case(12, "FOLD_EVEN", A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(20, 4), A.Fmt(16, 2), n_ch=5, per_channel=True)
+
+
+def test_transposed_coefficient_reload_mid_stream():
+    # reg_trans[] keeps partial sums made with the coefficients of their time (ac_fir_load_coeffs.h:265-278)
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(24, 5, True, "RND_CONV", "SAT"), A.Fmt(16, 3)
+    rng = np.random.default_rng(5)
+    n_ch, N = 2, 13
+    fir = A.Fir(N, "TRANSPOSED", fin, fc, fa, fo, n_channels=n_ch, kind="load")
+    orc = OracleFir(N, "TRANSPOSED", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    for n in (40, 3, 1, 25):
+        c = rand_raw(rng, fc, (N,))
+        x = rand_raw(rng, fin, (n_ch, n))
+        fir.set_coeffs(c)
+        y = run_engine(fir, x)
+        assert np.array_equal(y, orc.run(c, x))
+
+
+@pytest.mark.parametrize("n_taps", [1, 2, 31, 32, 33, 63, 64, 65, 127, 255, 257])
+def test_mfma_path_tap_counts(n_taps):
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
+    # raw coefficients >= 32640 cannot be split into two signed bytes (covered by the fallback test below)
+    c = np.minimum(rand_raw(np.random.default_rng(1000 + n_taps), fc, (n_taps,)), 32639)
+    check_case(n_taps, "SHIFT_REG", fin, fc, fa, A.Fmt(16, 2, True, "RND", "SAT"), n_ch=37, n=1000 + n_taps,
+               splits=[77, 512], expect_path="mfma_i8", seed=n_taps, coeffs=c)
+
+
+@pytest.mark.parametrize("ftype", FTYPES6)
+def test_mfma_path_ftypes_and_wide_output(ftype):
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    c = windowed_sinc(63, 0.11, fc)
+    check_case(63, ftype, fin, fc, fa, fa, n_ch=33, n=900, kind="const", coeffs=c, expect_path="mfma_i8", splits=[64])
+    check_case(63, ftype, fin, fc, fa, A.Fmt(16, 2, True, "TRN", "WRAP"), n_ch=64, n=900, kind="const", coeffs=c,
+               expect_path="mfma_i8")
+
+
+def test_mfma_extreme_values_and_fallback():
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+    N, n_ch, n = 255, 32, 2048
+    c = np.full(N, -32768, dtype=np.int64)
+    x = np.full((n_ch, n), -32768, dtype=np.int64)
+    x[1::2] = 32767
+    fir = A.Fir(N, "SHIFT_REG", fin, fc, fa, fo, n_channels=n_ch)
+    fir.set_coeffs(c)
+    assert fir.path == "mfma_i8"
+    orc = OracleFir(N, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    assert np.array_equal(run_engine(fir, x), orc.run(c, x))
+    # +32767 cannot be written as two signed bytes -> the engine must leave the MFMA path, not mis-compute
+    c2 = np.full(N, 32767, dtype=np.int64)
+    fir.reset()
+    fir.set_coeffs(c2)
+    assert fir.path == "lossless64"
+    orc = OracleFir(N, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    assert np.array_equal(run_engine(fir, x[:, :300]), orc.run(c2, x[:, :300]))
+
+
+def test_generic_equals_fast_paths():
+    # same configuration through all three kernel families
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+    for force in (False, True):
+        check_case(95, "FOLD_ODD", fin, fc, fa, fo, n_ch=40, n=640, force_generic=force,
+                   coeffs=windowed_sinc(95, 0.2, fc), expect_path="generic" if force else "mfma_i8")
+
+
+def test_reference_fir_testbench_vectors():
+    # the three shipped FIR tests (SQNR >= 60 dB against the MATLAB double reference)
+    cases = (("const", 29, A.Fmt(16, 8), A.Fmt(32, 16), 84.24), ("load", 27, A.Fmt(32, 16), A.Fmt(32, 16), 89.56),
+             ("prog", 27, A.Fmt(28, 6), A.Fmt(23, 7), 89.56))
+    for name, taps, fi, fc, want in cases:
+        fa = A.Fmt(64, 32)
+        c = np.array([from_double(float(v), ofmt(fc)) for v in read_fracs("ac_fir_%s_coeffs_cfg.txt" % name)], dtype=np.int64)
+        x = two_tone(ofmt(fi))[None, :]
+        fir = A.Fir(taps, "FOLD_ODD", fi, fc, fa, fa, kind=name)
+        fir.set_coeffs(c)
+        y = fir.run_host(x)[0].astype(np.int64)
+        got = sqnr_db(y, 32, read_fracs("ac_fir_%s_coeffs_ref.txt" % name)[:1024])
+        assert got >= 60.0 and abs(got - want) < 0.01, (name, got)
+        assert np.array_equal(y, OracleFir(taps, "FOLD_ODD", ofmt(fi), ofmt(fc), ofmt(fa), ofmt(fa)).run(c, x)[0])
+
+
+def test_ragged_and_empty_inputs():
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+    fir = check_case(40, "SHIFT_REG", fin, fc, fa, fo, n_ch=1, n=1)            # single sample
+    check_case(40, "SHIFT_REG", fin, fc, fa, fo, n_ch=65, n=33, splits=[0, 1])  # odd channel count, tiny calls
+    import ctypes as C
+    assert A.lib.acdsp_fir_run(fir._h, None, 0, 0, None, 0, None) == 0           # n = 0 is a no-op
+
+
+def test_unaligned_rows_take_a_correct_path():
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+    rng = np.random.default_rng(11)
+    n_ch, n, N = 4, 333, 50
+    c = rand_raw(rng, fc, (N,))
+    x = rand_raw(rng, fin, (n_ch, n))
+    fir = A.Fir(N, "SHIFT_REG", fin, fc, fa, fo, n_channels=n_ch)
+    fir.set_coeffs(c)
+    big = torch.zeros((n_ch, n + 5), dtype=torch.int16, device="cuda")
+    big[:, 3:3 + n] = torch.from_numpy(x).to(torch.int16).cuda()
+    y = fir.run(big[:, 3:3 + n]).cpu().numpy().astype(np.int64)   # row start not 16-byte aligned, odd stride
+    assert np.array_equal(y, OracleFir(N, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch).run(c, x))
+
+
+def test_anti_ftypes_are_rejected():
+    with pytest.raises(A.AcdspError):
+        A.Fir(8, "FOLD_EVEN_ANTI", A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2))
+
+
+def test_device_stimulus_matches_oracle():
+    t = torch.empty((5, 1000), dtype=torch.int16, device="cuda")
+    A.fill_stimulus(t, 0xACD5, 16, ch0=3, t0=17)
+    assert np.array_equal(t.cpu().numpy().astype(np.int64), stimulus(0xACD5, 5, 1000, 16, ch0=3, t0=17))
+    t = torch.empty((2, 77), dtype=torch.int32, device="cuda")
+    A.fill_stimulus(t, 7, 32)
+    assert np.array_equal(t.cpu().numpy().astype(np.int64), stimulus(7, 2, 77, 32))
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 at full size: 255 taps, 1024 channels x 2^20 samples, <16,2> in/out.
+    Checked by (a) oracle on sampled channels/windows and (b) linearity y(x1+x2) = y(x1)+y(x2) in the
+    wide (lossless) output, a size-independent property of the exact integer FIR."""
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    fo = A.Fmt(16, 2, True, "RND", "SAT")
+    N, n_ch, n = 255, 1024, 1 << 20
+    c = windowed_sinc(N, 0.1, fc)
+    x = torch.empty((n_ch, n), dtype=torch.int16, device="cuda")
+    A.fill_stimulus(x, 0xACD5, 16)
+    fir = A.Fir(N, "SHIFT_REG", fin, fc, fa, fo, n_channels=n_ch)
+    fir.set_coeffs(c)
+    assert fir.path == "mfma_i8"
+    y = fir.run(x)
+    torch.cuda.synchronize()
+    for ch, t0 in ((0, 0), (1, 5000), (517, 600000), (1023, n - 4096)):
+        w = 4096
+        xs = stimulus(0xACD5, 1, w + N - 1, 16, ch0=ch, t0=max(t0 - (N - 1), 0))
+        if t0 == 0:
+            xs = np.concatenate([np.zeros((1, N - 1), dtype=np.int64), xs[:, :w]], axis=1)
+        yo = OracleFir(N, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo)).run(c, xs)[0][N - 1:]
+        assert np.array_equal(y[ch, t0:t0 + w].cpu().numpy().astype(np.int64), yo), (ch, t0)
+    # linearity on a 64-channel slice with the wide output
+    firw = A.Fir(N, "SHIFT_REG", fin, fc, fa, fa, n_channels=64)
+    firw.set_coeffs(c)
+    x1 = (x[:64] >> 1)
+    x2 = (x[64:128] >> 1)
+    y1 = firw.run(x1); firw.reset()
+    y2 = firw.run(x2); firw.reset()
+    y12 = firw.run(x1 + x2)
+    assert torch.equal(y12, y1 + y2)
