@@ -48,29 +48,21 @@ def cpu_baseline_fir(n_taps, coeffs, fin, fc, fa, fo, seed):
     """Oracle ("port" of the reference's per-sample loop) timed on this host's cores, bounded sample."""
     import threading
     from oracle import OracleFir, Fmt as OFmt, stimulus
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n = 16384
     of = [OFmt(f.W, f.I, f.S, f.Q, f.O) for f in (fin, fc, fa, fo)]
     xs = stimulus(seed, cores, n, fin.W)
     objs = [OracleFir(n_taps, "SHIFT_REG", *of) for _ in range(cores)]
-    reps = 1
+    state = {"reps": 1}
+
+    def set_reps(r):
+        state["reps"] = r
 
     def work(i):
-        for _ in range(reps):
+        for _ in range(state["reps"]):
             objs[i].run(coeffs, xs[i:i + 1])
 
-    # calibrate to ~10 s of wall time on all cores
-    t0 = time.perf_counter()
-    work(0)
-    t1 = time.perf_counter() - t0
-    reps = max(1, int(10.0 / max(t1, 1e-3)))
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
+    reps, dt = timed_threads(work, cores, lambda r: set_reps(r))
     total = cores * n * reps
     return {"value": total / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": "%d channels x %d samples x %d passes of the same 255-tap workload, one oracle object per core "
@@ -86,6 +78,7 @@ def main():
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pad", type=int, default=0, help="extra elements per row (row stride = samples + pad)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,9 +109,9 @@ def main():
         lo, hi = shard(ch_per_gpu * world, world, rank)
         eng = A.Fir(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_channels=hi - lo, kind="load", device=local_rank)
         eng.set_coeffs(coeffs)
-        x = torch.empty((hi - lo, n), dtype=torch.int16, device=dev)
+        x = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
         A.fill_stimulus(x, seed, 16, ch0=lo)
-        y = torch.empty((hi - lo, n), dtype=torch.int16, device=dev)
+        y = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
         bytes_per_sample = 4.0                   # 2 B read + 2 B written
         macs_per_sample = 4.0 * 32 * eng_nb(n_taps)  # int8 MACs issued: 4 byte-plane products x padded band
         name = "ac_fir_load_coeffs 255-tap ac_fixed<16,2> -> <16,2,RND,SAT>, ACC <40,12>, %d ch x %d samples per GPU " \
@@ -135,9 +128,9 @@ def main():
         fin, fo = A.Fmt(32, 16), A.Fmt(47, 31)
         lo, hi = shard(ch_per_gpu * world, world, rank)
         eng = A.Cic(False, 8, 1, 5, fin, fo, n_channels=hi - lo, device=local_rank)
-        x = torch.empty((hi - lo, n), dtype=torch.int32, device=dev)
+        x = torch.empty((hi - lo, n + args.pad), dtype=torch.int32, device=dev)[:, :n]
         A.fill_stimulus(x, seed, 32, ch0=lo)
-        y = torch.empty((hi - lo, n // 8 + 1), dtype=torch.int64, device=dev)
+        y = torch.empty((hi - lo, n // 8 + 8 + args.pad), dtype=torch.int64, device=dev)
         bytes_per_sample = 5.0                   # 4 B read + 8 B / 8 written
         macs_per_sample = 0.0
         name = "ac_cic_dec_full N=5 R=8 M=1 ac_fixed<32,16> -> <47,31>, %d ch x %d samples per GPU (BASELINE configs[2])" % (ch_per_gpu, n)
@@ -205,33 +198,49 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """Cores this process may actually run on (the box can expose fewer than os.cpu_count())."""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def timed_threads(work, cores, set_reps):
+    """Run work(i) on `cores` threads: one all-core calibration pass, then ~10 s of wall time."""
+    import threading
+
+    def go():
+        th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+    set_reps(1)
+    t1 = go()
+    reps = max(1, min(1000, int(10.0 / max(t1, 1e-3))))
+    set_reps(reps)
+    return reps, go()
+
+
 def eng_nb(n_taps):
     return (n_taps - 1 + 31) // 32 + 1
 
 
 def cpu_baseline_cic(fin, fo, seed):
-    import threading
     from oracle import OracleCic, Fmt as OFmt, stimulus
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n = 1 << 18
     xs = stimulus(seed, cores, n, fin.W)
     objs = [OracleCic(0, 8, 1, 5, OFmt(fin.W, fin.I, fin.S, fin.Q, fin.O), OFmt(fo.W, fo.I, fo.S, fo.Q, fo.O)) for _ in range(cores)]
-    reps = 1
+    state = {"reps": 1}
 
     def work(i):
-        for _ in range(reps):
+        for _ in range(state["reps"]):
             objs[i].run(xs[i:i + 1])
-    t0 = time.perf_counter()
-    work(0)
-    t1 = time.perf_counter() - t0
-    reps = max(1, int(10.0 / max(t1, 1e-3)))
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
+    reps, dt = timed_threads(work, cores, lambda r: state.__setitem__("reps", r))
     return {"value": cores * n * reps / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": "%d channels x %d samples x %d passes, one oracle object per core, %.1f s wall" % (cores, n, reps, dt)}
 
