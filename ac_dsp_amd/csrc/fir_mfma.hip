@@ -107,11 +107,17 @@ __device__ inline void split_planes(const v4i &ra, const v4i &rb, v4i &xh, v4i &
 }
 
 // EPI 0: any OUT_TYPE / ACC width through requant64.
-// EPI 1: OUT container int16, Q in {TRN, RND}, O in {WRAP, SAT}, no accumulator wrap possible,
-//        right shift >= 8: all-32-bit epilogue.
-template <int NB, int EPI>
-__global__ void __launch_bounds__(64, 2)
-fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, MfmaArgs a) {
+// EPI 1: OUT container int16, Q in {TRN, RND}, O = WRAP, no accumulator wrap possible, right shift >= 8:
+//        all-32-bit epilogue.   EPI 2: the same with O = SAT (clamp).
+//
+// FAST: the wave's whole chunk is interior -- every block it loads or stores is a full 32-sample block,
+// all 32 channels exist and the output rows are vector-aligned.  The loop body is then free of
+// divergent branches, so the compiler can count outstanding memory operations exactly and waits for
+// the prefetched block with s_waitcnt vmcnt(4) (the 4 younger stores stay in flight) instead of
+// draining the store queue every step.
+template <int NB, int EPI, bool FAST>
+__device__ __forceinline__ void fir_mfma_body(const FirParams &p, const FirMfmaPlan &plan, const v4i *__restrict__ frag,
+                                              const MfmaArgs &a) {
   const int lane = threadIdx.x;
   const int n_col = lane & 31, h = lane >> 5;
   const int ch = blockIdx.y * 32 + n_col;
@@ -125,25 +131,33 @@ fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, Mfm
     Al[b] = frag[(1 * NB + b) * 64 + lane];
   }
 
-  const int16_t *xrow = (const int16_t *)p.x + (int64_t)chl * p.in_stride;
-  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)chl * p.hl + p.hl;  // hrow[t], t < 0
+  const int16_t *xrow = (const int16_t *)p.x + (int64_t)chl * p.in_stride + h * 16;
+  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)chl * p.hl + p.hl + h * 16;  // hrow[t], t < 0
   const int64_t ob0 = (int64_t)blockIdx.x * a.chunk_blocks;
   const int64_t ob1 = (ob0 + a.chunk_blocks < a.n_blocks) ? ob0 + a.chunk_blocks : a.n_blocks;
   const int nsteps = (int)(ob1 - ob0);
+  const int64_t last_full = p.n / 32 - 1;  // FAST: index of the last full input block (>= ob1 - 1)
 
   auto load_block = [&](int64_t ib, v4i &ra, v4i &rb) {
-    const int64_t t = ib * 32 + h * 16;
-    if (ib < 0) {
-      const v4i *s = (const v4i *)(hrow + t);
-      ra = s[0]; rb = s[1];
-    } else if (t + 16 <= p.n) {
-      const v4i *s = (const v4i *)(xrow + t);
+    if (FAST) {
+      if (ib > last_full) { ib = last_full; }            // harmless re-read instead of a branch
+      const int16_t *base = (ib < 0) ? hrow : xrow;      // wave-uniform select
+      const v4i *s = (const v4i *)(base + ib * 32);
       ra = s[0]; rb = s[1];
     } else {
-      union { v4i v[2]; int16_t e[16]; } u;
+      const int64_t t = ib * 32 + h * 16;
+      if (ib < 0) {
+        const v4i *s = (const v4i *)(hrow + ib * 32);
+        ra = s[0]; rb = s[1];
+      } else if (t + 16 <= p.n) {
+        const v4i *s = (const v4i *)(xrow + ib * 32);
+        ra = s[0]; rb = s[1];
+      } else {
+        union { v4i v[2]; int16_t e[16]; } u;
 #pragma unroll
-      for (int e = 0; e < 16; e++) { u.e[e] = (t + e < p.n) ? xrow[t + e] : (int16_t)0; }
-      ra = u.v[0]; rb = u.v[1];
+        for (int e = 0; e < 16; e++) { u.e[e] = (t + e < p.n) ? xrow[ib * 32 + e] : (int16_t)0; }
+        ra = u.v[0]; rb = u.v[1];
+      }
     }
   };
 
@@ -159,13 +173,14 @@ fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, Mfm
   load_block(ob0, na, nb_);
 
   // epilogue constants
-  const int rs = p.in.F + p.cf.F - p.out.F;  // net right shift of the raw dot product (EPI 1)
+  const int rs = p.in.F + p.cf.F - p.out.F;  // net right shift of the raw dot product (EPI 1/2)
   const int64_t corr = plan.corr;
-  const int64_t corr_t = corr + ((EPI == 1 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
+  const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
   const int cA = (int)(corr_t >> 8);          // added to hh*256 + mid
   const int cB = (int)(corr_t & 0xff);        // added to ll
   const int sat_lo = (int)p.out.lo, sat_hi = (int)p.out.hi;
-  const bool do_sat = p.out.O == ACDSP_SAT;
+  const int rs8 = rs - 8;
+  int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 4 * h;   // EPI 1/2 only
 
   for (int s_base = 0; s_base < nsteps; s_base += NB) {
 #pragma unroll
@@ -174,7 +189,7 @@ fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, Mfm
       if (s < nsteps) {
       const int64_t ob = ob0 + s;
       split_planes(na, nb_, Xh[u], Xl[u]);
-      if (s + 1 < nsteps) { load_block(ob + 1, na, nb_); }
+      if (FAST || s + 1 < nsteps) { load_block(ob + 1, na, nb_); }
 
       v16i hh = {0}, mid = {0}, ll = {0};
 #pragma unroll
@@ -182,8 +197,8 @@ fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, Mfm
         const int slot = (u + 1 + b) % NB;
         hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xh[slot], hh, 0, 0, 0);
         mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xl[slot], mid, 0, 0, 0);
-        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[slot], mid, 0, 0, 0);
         ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xl[slot], ll, 0, 0, 0);
+        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[slot], mid, 0, 0, 0);
       }
 
       // D layout (32x32): lane holds column n_col, rows (r&3) + 8*(r>>2) + 4*h
@@ -191,21 +206,23 @@ fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, Mfm
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const int64_t t0 = tb + 8 * g;
-        if (EPI == 1) {
+        if (EPI != 0) {
           int o[4];
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
             const int r = 4 * g + rr;
-            int A = hh[r] * 256 + mid[r] + cA;
-            int B = (ll[r] + cB) >> 8;
-            int q = (A + B) >> (rs - 8);
-            if (do_sat) { q = q < sat_lo ? sat_lo : (q > sat_hi ? sat_hi : q); }
+            const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid[r]);
+            const int B = (ll[r] + cB) >> 8;
+            int q = (A + cA + B) >> rs8;
+            if (EPI == 2) { q = max(sat_lo, min(q, sat_hi)); }
             o[rr] = q;
           }
-          int16_t *dst = (int16_t *)p.y + (int64_t)ch * p.out_stride + t0;
-          if (ch_ok) {
+          v4s pk = {(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+          if (FAST) {
+            *(v4s *)(yrow + ob * 32 + 8 * g) = pk;
+          } else if (ch_ok) {
+            int16_t *dst = yrow + ob * 32 + 8 * g;
             if (a.out_vec_ok && t0 + 4 <= p.n) {
-              v4s pk = {(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
               *(v4s *)dst = pk;
             } else {
 #pragma unroll
@@ -230,10 +247,21 @@ fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, Mfm
   }
 }
 
+template <int NB, int EPI>
+__global__ void __launch_bounds__(64, 2)
+fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, MfmaArgs a) {
+  const int64_t ob0 = (int64_t)blockIdx.x * a.chunk_blocks;
+  const int64_t ob1 = (ob0 + a.chunk_blocks < a.n_blocks) ? ob0 + a.chunk_blocks : a.n_blocks;
+  const bool interior = EPI != 0 && a.out_vec_ok && ob1 * 32 <= p.n && (int)(blockIdx.y + 1) * 32 <= p.n_ch;
+  if (interior) { fir_mfma_body<NB, EPI, true>(p, plan, frag, a); }
+  else { fir_mfma_body<NB, EPI, false>(p, plan, frag, a); }
+}
+
 template <int NB>
 static hipError_t launch_nb(const FirParams &p, const FirMfmaPlan &plan, const uint32_t *d_frag, const MfmaArgs &a, int epi,
                             dim3 grid, hipStream_t s) {
   if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1>), grid, dim3(64), 0, s, p, plan, (const v4i *)d_frag, a); }
+  else if (epi == 2) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2>), grid, dim3(64), 0, s, p, plan, (const v4i *)d_frag, a); }
   else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 0>), grid, dim3(64), 0, s, p, plan, (const v4i *)d_frag, a); }
   return hipGetLastError();
 }
@@ -249,7 +277,8 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, const ui
   if (cb < 32) { cb = 32; }
   a.chunk_blocks = cb;
   const int oeb = p.out_eb;
-  a.out_vec_ok = ((uintptr_t)p.y % (4 * oeb) == 0) && ((p.out_stride * oeb) % (4 * oeb) == 0);
+  a.out_vec_ok = ((uintptr_t)p.y % (4 * oeb) == 0) && ((p.out_stride * oeb) % (4 * oeb) == 0) && ((uintptr_t)p.x % 16 == 0) &&
+                 ((p.in_stride * 2) % 16 == 0);
   // all-32-bit epilogue: int16 container, TRN/RND, WRAP/SAT, shift >= 8, no accumulator wrap,
   // and hh*256 + mid + corr/256 provably inside int32
   const int rs = p.in.F + p.cf.F - p.out.F;
@@ -263,7 +292,7 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, const ui
   int epi = 0;
   if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
       rs >= 8 && rs <= 38 && acc_wide && small && p.out.W == 16) {
-    epi = 1;
+    epi = p.out.O == ACDSP_SAT ? 2 : 1;
   }
   dim3 grid((unsigned)((a.n_blocks + a.chunk_blocks - 1) / a.chunk_blocks), (unsigned)groups);
   switch (plan.nb) {

@@ -1,0 +1,141 @@
+// mfma_probe.hip -- micro-benchmarks used while tuning fir_mfma.hip (not part of the product).
+// Measures the int8 32x32x32 MFMA issue rate of one SIMD under the FIR kernel's instruction mix:
+//   mode 0: NB*4 MFMAs per step on 3 accumulators, nothing else
+//   mode 1: + the 32-bit epilogue VALU work (16 outputs/lane/step)
+//   mode 2: + v_perm byte-plane split of a fresh operand each step
+//   mode 3: + global loads (prefetch) and stores, FIR-like addressing (HBM-sized footprint: 32 channel groups)
+//   mode 4: mode 3 without the stores     mode 5: mode 3 without the loads
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int NB, int MODE, int WPS, int KPF>
+__global__ void __launch_bounds__(64, WPS) probe(const v4i *__restrict__ frag, const short *__restrict__ x, short *__restrict__ y,
+                                                 int steps, long stride) {
+  const int lane = threadIdx.x;
+  v4i Ah[NB], Al[NB], Xh[NB], Xl[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    Ah[b] = frag[b * 64 + lane]; Al[b] = frag[(NB + b) * 64 + lane];
+    Xh[b] = frag[(2 * NB + b) * 64 + lane]; Xl[b] = frag[(3 * NB + b) * 64 + lane];
+  }
+  const long grp = blockIdx.x % 32, chunk = blockIdx.x / 32;
+  const short *xr = x + (grp * 32 + (lane & 31)) * stride + (lane >> 5) * 16 + chunk * 32L * steps;
+  short *yr = y + (grp * 32 + (lane & 31)) * stride + (lane >> 5) * 4 + chunk * 32L * steps;
+  v4i na = {0, 0, 0, 0}, nb = {0, 0, 0, 0};
+  v4i pa[KPF], pb[KPF];   // raw prefetch group: KPF consecutive blocks of this lane's row half
+#pragma unroll
+  for (int k = 0; k < KPF; k++) { pa[k] = na; pb[k] = nb; }
+  if (MODE == 3 || MODE == 4) {
+#pragma unroll
+    for (int k = 0; k < KPF; k++) { pa[k] = *(const v4i *)(xr + k * 32); pb[k] = *(const v4i *)(xr + k * 32 + 8); }
+  }
+  int sink = 0;
+  for (int s0 = 0; s0 < steps; s0 += NB) {
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      if (MODE >= 2) {
+        Xh[u].x = __builtin_amdgcn_perm(na.y, na.x, 0x07050301u); Xh[u].y = __builtin_amdgcn_perm(na.w, na.z, 0x07050301u);
+        Xh[u].z = __builtin_amdgcn_perm(nb.y, nb.x, 0x07050301u); Xh[u].w = __builtin_amdgcn_perm(nb.w, nb.z, 0x07050301u);
+        Xl[u].x = __builtin_amdgcn_perm(na.y, na.x, 0x06040200u) ^ 0x80808080u; Xl[u].y = __builtin_amdgcn_perm(na.w, na.z, 0x06040200u) ^ 0x80808080u;
+        Xl[u].z = __builtin_amdgcn_perm(nb.y, nb.x, 0x06040200u) ^ 0x80808080u; Xl[u].w = __builtin_amdgcn_perm(nb.w, nb.z, 0x06040200u) ^ 0x80808080u;
+        if (MODE == 2 || MODE == 5) { na.x += 0x01010101; nb.y ^= na.x; }
+      }
+      if (MODE == 3 || MODE == 4) {
+        na = pa[u % KPF]; nb = pb[u % KPF];
+        if (u % KPF == KPF - 1) {   // group consumed: fetch the next KPF blocks back to back
+          const short *src = xr + (long)(s0 + u + 1) * 32;
+#pragma unroll
+          for (int k = 0; k < KPF; k++) { pa[k] = *(const v4i *)(src + k * 32); pb[k] = *(const v4i *)(src + k * 32 + 8); }
+        }
+      }
+      v16i hh = {0}, mid = {0}, ll = {0};
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const int slot = (u + 1 + b) % NB;
+        hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xh[slot], hh, 0, 0, 0);
+        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xl[slot], mid, 0, 0, 0);
+        ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xl[slot], ll, 0, 0, 0);
+        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[slot], mid, 0, 0, 0);
+      }
+      if (MODE == 0) {
+        sink += hh[0] + mid[5] + ll[15];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          int o[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int r = 4 * g + rr;
+            const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid[r]);
+            const int B = (ll[r] + 77) >> 8;
+            int q = (A + 1234 + B) >> 6;
+            q = max(-32768, min(q, 32767));
+            o[rr] = q;
+          }
+          if (MODE == 3 || MODE == 5) {
+            v4s pk = {(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+            *(v4s *)(yr + (long)(s0 + u) * 32 + 8 * g) = pk;
+          } else {
+            sink += o[0] ^ o[1] ^ o[2] ^ o[3];
+          }
+        }
+      }
+    }
+  }
+  if (sink == 0x7fffffff) { y[lane] = (short)sink; }
+}
+
+template <int NB, int MODE, int WPS, int KPF = 1>
+static void run(const char *name, int waves, int steps, const v4i *frag, const short *x, short *y, long stride) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int it = 0; it < 2; it++) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((probe<NB, MODE, WPS, KPF>), dim3(waves), dim3(64), 0, 0, frag, x, y, steps, stride);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+  }
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  double mfma = (double)waves * steps * NB * 4;
+  double cyc_per_mfma_per_simd = ms * 1e-3 * 2.4e9 / (mfma / 1024.0);
+  printf("%-34s waves %5d steps %4d  %.3f ms  %.1f TOPS  %.1f cyc/MFMA/SIMD@2.4GHz\n", name, waves, steps, ms,
+         mfma * 2 * 32768 / (ms * 1e-3) / 1e12, cyc_per_mfma_per_simd);
+}
+
+int main() {
+  const int NB = 9;
+  std::vector<int> hf(4 * NB * 64 * 4);
+  for (size_t i = 0; i < hf.size(); i++) { hf[i] = (int)(i * 2654435761u); }
+  v4i *frag; CK(hipMalloc(&frag, hf.size() * 4)); CK(hipMemcpy(frag, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+  const long stride = (1 << 20) + 64;
+  short *x, *y;
+  CK(hipMalloc(&x, 1025 * stride * 2)); CK(hipMalloc(&y, 1025 * stride * 2));
+  {
+    std::vector<short> hx(1 << 24);
+    for (size_t i = 0; i < hx.size(); i++) { hx[i] = (short)((i * 2654435761u) >> 11); }
+    for (long off = 0; off + (long)hx.size() <= 1025 * stride; off += hx.size()) { CK(hipMemcpy(x + off, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); }
+  }
+  run<9, 0, 2>("mfma only, 2 waves/SIMD", 2048, 512, frag, x, y, stride);
+  run<9, 0, 1>("mfma only, 1 wave/SIMD", 1024, 512, frag, x, y, stride);
+  run<9, 1, 2>("mfma+epilogue, 2 w/SIMD", 2048, 512, frag, x, y, stride);
+  run<9, 1, 1>("mfma+epilogue, 1 w/SIMD", 1024, 512, frag, x, y, stride);
+  run<9, 2, 2>("mfma+epi+split, 2 w/SIMD", 2048, 512, frag, x, y, stride);
+  run<9, 2, 1>("mfma+epi+split, 1 w/SIMD", 1024, 512, frag, x, y, stride);
+  run<9, 3, 2>("full mix, 2 w/SIMD, 4096 waves", 4096, 256, frag, x, y, stride);
+  run<9, 4, 2>("loads only, 4096 waves", 4096, 256, frag, x, y, stride);
+  run<9, 5, 2>("stores only, 4096 waves", 4096, 256, frag, x, y, stride);
+  run<9, 3, 1>("full mix, 1 w/SIMD, 4096 waves", 4096, 256, frag, x, y, stride);
+  run<9, 4, 1, 3>("loads only, 1w, group of 3 blocks", 4096, 256, frag, x, y, stride);
+  run<9, 4, 1, 9>("loads only, 1w, group of 9 blocks", 4096, 256, frag, x, y, stride);
+  run<9, 3, 1, 9>("full mix, 1w, group of 9 blocks", 4096, 256, frag, x, y, stride);
+  return 0;
+}
