@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libacdsp.so")
+LIB_PATH = os.environ.get("ACDSP_LIB") or os.path.join(_HERE, "lib", "libacdsp.so")  # ACDSP_LIB: A/B testing of builds
 
 Q_MODES = {"TRN": 0, "RND": 1, "TRN_ZERO": 2, "RND_ZERO": 3, "RND_INF": 4, "RND_MIN_INF": 5, "RND_CONV": 6,
            "RND_CONV_ODD": 7}

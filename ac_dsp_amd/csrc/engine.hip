@@ -143,8 +143,9 @@ struct acdsp_fir {
   int64_t *d_rt[2] = {nullptr, nullptr};
   int cur = 0;
   int64_t *d_coeffs = nullptr;
-  uint32_t *d_frag = nullptr;
-  FirMfmaPlan plan;
+  uint32_t *d_frag = nullptr;   // [n_sets][2][nb][64][4] Toeplitz byte-plane fragments
+  int64_t *d_corr = nullptr;    // [n_sets] 128 * sum(c)
+  FirMfmaPlan plan;             // worst case over the coefficient sets (bounds for the epilogue choice)
   bool mfma_ok = false;
   std::vector<int64_t> h_coeffs;  // last coefficient set (for clone)
   Timer tm;
@@ -336,7 +337,8 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
     }
   }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_coeffs, n_sets * desc->n_taps * sizeof(int64_t)); }
-  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_frag, sizeof(uint32_t) * 2 * (size_t)fir_mfma_max_blocks() * 64 * 4); }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_frag, n_sets * sizeof(uint32_t) * 2 * (size_t)fir_mfma_max_blocks() * 64 * 4); }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_corr, n_sets * sizeof(int64_t)); }
   if (e != hipSuccess || h->tm.init() != ACDSP_OK) {
     acdsp_fir_destroy(h);
     return fail(ACDSP_EHIP, "FIR state allocation failed: %s", hipGetErrorString(e));
@@ -354,6 +356,7 @@ int32_t acdsp_fir_destroy(acdsp_fir_t h) {
   }
   if (h->d_coeffs) { (void)hipFree(h->d_coeffs); }
   if (h->d_frag) { (void)hipFree(h->d_frag); }
+  if (h->d_corr) { (void)hipFree(h->d_corr); }
   h->tm.destroy();
   h->st.destroy();
   delete h;
@@ -381,12 +384,33 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   h->mfma_ok = false;
   const bool i16_in = d.in.S ? d.in.W <= 16 : d.in.W <= 15;
   const bool i16_cf = d.coeff.S ? d.coeff.W <= 16 : d.coeff.W <= 15;
-  if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && !d.coeffs_per_channel && i16_in && i16_cf && d.in.S &&
-      h->in_eb == 2 && (d.n_taps - 1 + 31) / 32 + 1 <= fir_mfma_max_blocks()) {
-    std::vector<int64_t> eff = effective_coeffs(coeffs, d.n_taps, d.ftype);
-    std::vector<uint32_t> frag((size_t)2 * fir_mfma_max_blocks() * 64 * 4, 0u);
-    if (fir_mfma_build_fragments(eff.data(), d.n_taps, &h->plan, frag.data())) {
+  if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && i16_in && i16_cf && d.in.S && h->in_eb == 2 &&
+      (d.n_taps - 1 + 31) / 32 + 1 <= fir_mfma_max_blocks()) {
+    const int nb = (d.n_taps - 1 + 31) / 32 + 1;
+    const size_t per_set = (size_t)2 * nb * 64 * 4;
+    std::vector<uint32_t> frag(n_sets * per_set, 0u);
+    std::vector<int64_t> corr(n_sets, 0);
+    FirMfmaPlan worst;
+    memset(&worst, 0, sizeof worst);
+    bool ok = true;
+    for (size_t st = 0; st < n_sets && ok; st++) {
+      std::vector<int64_t> eff = effective_coeffs(coeffs + st * d.n_taps, d.n_taps, d.ftype);
+      FirMfmaPlan pl;
+      ok = fir_mfma_build_fragments(eff.data(), d.n_taps, &pl, frag.data() + st * per_set);
+      if (!ok) { break; }
+      corr[st] = pl.corr;
+      worst.nb = pl.nb;
+      worst.hi_mask |= pl.hi_mask; worst.lo_mask |= pl.lo_mask;
+      if (pl.sum_abs > worst.sum_abs) { worst.sum_abs = pl.sum_abs; }
+      if (pl.sum_abs_hi > worst.sum_abs_hi) { worst.sum_abs_hi = pl.sum_abs_hi; }
+      if (pl.sum_abs_lo > worst.sum_abs_lo) { worst.sum_abs_lo = pl.sum_abs_lo; }
+      const int64_t ca = pl.corr < 0 ? -pl.corr : pl.corr, wa = worst.corr < 0 ? -worst.corr : worst.corr;
+      if (st == 0 || ca > wa) { worst.corr = pl.corr; }
+    }
+    if (ok) {
       HIP_TRY(hipMemcpy(h->d_frag, frag.data(), frag.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(h->d_corr, corr.data(), corr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+      h->plan = worst;
       h->mfma_ok = true;
     }
   }
@@ -443,7 +467,11 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   }
   HIP_TRY(hipEventRecord(h->tm.start(), s));
   hipError_t e;
-  if (path == ACDSP_PATH_MFMA_I8) { e = launch_fir_mfma(k, h->plan, h->d_frag, s); }
+  if (path == ACDSP_PATH_MFMA_I8) {
+    static const bool use_v1 = getenv("ACDSP_MFMA_V1") != nullptr;  // A/B switch for the older 32-channel mapping
+    if (use_v1 && !d.coeffs_per_channel) { e = launch_fir_mfma(k, h->plan, h->d_frag, s); }
+    else { e = launch_fir_mfma2(k, h->plan, fir_mfma_epilogue_class(k, h->plan), d.coeffs_per_channel, h->d_frag, h->d_corr, s); }
+  }
   else if (path == ACDSP_PATH_LOSSLESS64) { e = launch_fir_lossless64(k, s); }
   else { e = launch_fir_generic(k, s); }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR kernel launch failed: %s", hipGetErrorString(e)); }

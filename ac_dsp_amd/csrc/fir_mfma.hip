@@ -266,6 +266,306 @@ static hipError_t launch_nb(const FirParams &p, const FirMfmaPlan &plan, const u
   return hipGetLastError();
 }
 
+// =============================================================================================
+// v2: one wave = ONE channel; the 32 MFMA columns are 32 CONSECUTIVE 32-sample output blocks.
+//
+//     D[i][n] = y[T0 + 32n + i],   B_b[k][n] = x[T0 - 32(NB-1) + 32(n+b) + k]
+//
+// so one step produces 1024 consecutive outputs of one channel from one contiguous
+// (32+NB-1)*64-byte stretch of its row: every HBM visit of a row moves 2+ KB (the v1 mapping
+// touched 32 rows x 64 B per step, i.e. ~130k interleaved DRAM streams, and stalled near 2 TB/s).
+// Column n of K-block b is "input chunk n+b": the B fragments of the NB K-blocks are lane-shifted
+// copies of each other.  The shift is done by LDS addressing: the step's chunks are split into
+// byte planes once, staged in LDS (2.5 KB per wave), and each K-block's fragment is a contiguous,
+// conflict-free ds_read_b128 at offset 16*(n+b).  The Toeplitz fragments are per channel (pointer
+// offset), so per-channel coefficient sets cost nothing extra.
+// =============================================================================================
+struct Mfma2Args {
+  int64_t steps_per_wave;  // 1024-sample steps per wave
+  int64_t n_steps;         // ceil(n / 1024)
+  int64_t n8;              // n rounded up to a multiple of 8 (rows are readable that far)
+  int32_t out_vec_ok;
+  int32_t frag_per_channel;
+  uint32_t hi_mask, lo_mask;  // bit b: K-block b of the hi / lo coefficient plane has a non-zero entry (any set)
+  const int64_t *corr;     // [n_sets] 128 * sum(c) per coefficient set
+};
+
+template <int NB, int EPI, int HS, bool FAST>
+__device__ __forceinline__ void fir_mfma2_body(const FirParams &p, const v4i *__restrict__ frag, const Mfma2Args &a,
+                                               unsigned char *lds) {
+  constexpr int HB = NB - 1;          // halo chunks
+  constexpr int NC = 32 + HB;         // chunks staged per step
+  constexpr int NP = 4 * NC;          // 16-byte raw pieces per step
+  constexpr int JN = (NP + 63) / 64;  // raw loads per lane per step
+  constexpr int ARR = NC * 16;        // bytes of one [plane][half] array
+  const int lane = threadIdx.x;
+  const int n_col = lane & 31, h = lane >> 5;
+  const int ch = blockIdx.y;
+  const int set = a.frag_per_channel ? ch : 0;
+
+  v4i Ah[NB], Al[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    Ah[b] = frag[((int64_t)set * 2 * NB + 0 * NB + b) * 64 + lane];
+    Al[b] = frag[((int64_t)set * 2 * NB + 1 * NB + b) * 64 + lane];
+  }
+
+  const int16_t *xrow = (const int16_t *)p.x + (int64_t)ch * p.in_stride;
+  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)ch * p.hl + p.hl;  // hrow[t], t < 0
+  const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
+  const int nsteps = (int)(s1 - s0);
+
+  // raw 16-byte pieces of this lane: piece l + 64 j covers samples T0 - 32 HB + 8 (l + 64 j) ...
+  v4i R[JN];
+  auto issue_loads = [&](int64_t T0) {
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      // every lane loads (surplus lanes repeat the last piece): no divergent branch around VMEM, so the
+      // compiler can count outstanding operations exactly (s_waitcnt vmcnt(k) instead of vmcnt(0))
+      const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
+      int64_t t = T0 - 32 * HB + 8 * pc;
+      const int16_t *src = (t < 0) ? hrow + t : xrow + ((t < a.n8) ? t : 0);  // beyond n: any valid address
+      R[j] = *(const v4i *)src;
+    }
+  };
+  // split into byte planes and stage: arrays [plane][half][chunk] of 16 bytes
+  auto stage = [&](unsigned char *buf) {
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      const int pc = lane + 64 * j;
+      if (JN * 64 == NP || pc < NP) {
+        const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
+        unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
+        unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
+        unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
+        unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        *(v2u *)(buf + (0 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){hi0, hi1};
+        *(v2u *)(buf + (1 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){lo0, lo1};
+      }
+    }
+  };
+
+  // epilogue constants
+  const int rs = p.in.F + p.cf.F - p.out.F;
+  const int64_t corr = a.corr[set];
+  // EPI 1/2: the re-bias correction and the rounding constant ride in as the initial value of the
+  // low-plane accumulator (|corr_t| + |S(cl,xl)| < 2^31 is checked on the host), so the epilogue is
+  //   q = ((hh << 8) + mid + (ll >> 8)) >> (rs - 8)      -- 4 VALU ops per output, then a packing
+  // v_cvt_pk_i16_i32 that also performs the AC_SAT clamp for the 16-bit OUT_TYPE.
+  const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
+#ifdef ACDSP_X_NO_LLINIT
+  const int c_ll = 0;
+#else
+  const int c_ll = (EPI != 0) ? (int)corr_t : 0;
+#endif
+  const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
+  const int rs8 = rs - 8;
+  int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 32 * n_col + 4 * h;  // EPI 1/2
+
+  // The Toeplitz fragments must have landed before the loop: otherwise the compiler keeps
+  // "s_waitcnt vmcnt(k)" for them inside the loop body, where in steady state they drain the
+  // prefetch loads and the previous step's stores (simm16: vmcnt 0, expcnt/lgkmcnt untouched).
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_sched_barrier(0);
+  issue_loads(s0 * 1024);
+  for (int s = 0; s < nsteps; s++) {
+    const int64_t T0 = (s0 + s) * 1024;
+    unsigned char *buf = lds + (s & 1) * (4 * ARR);
+    stage(buf);
+    if (FAST || s + 1 < nsteps) { issue_loads(T0 + 1024); }  // FAST: the extra fetch after the last step is clamped, harmless
+    __syncthreads();  // single-wave workgroup: orders the LDS writes before the fragment reads
+
+    v16i hh = {0}, mid = {0}, ll = ll_init;
+    const unsigned char *fh = buf + (0 * 2 + h) * ARR + n_col * 16;
+    const unsigned char *fl = buf + (1 * 2 + h) * ARR + n_col * 16;
+    // Fragment reads (conflict-free ds_read_b128) run one group of GS K-blocks ahead of the MFMAs that
+    // consume them; sched_barrier(0) pins the "reads of group g+1, then MFMAs of group g" order, which
+    // the scheduler would otherwise re-serialise into read-wait-MFMA per block.
+    // A Toeplitz block whose high-byte plane is all zero contributes nothing to hh / mid: kernels are
+    // instantiated for a few centred bands [HS, NB-1-HS] of non-zero high-byte blocks (typical low-pass
+    // sets have |c| < 128 LSB outside the centre taps) and the host picks the widest one that is exact.
+#ifdef ACDSP_X_UPFRONT
+    constexpr int GS = NB, NG = 1;
+#else
+    constexpr int GS = 3, NG = (NB + GS - 1) / GS;
+#endif
+    v4i Bh[2][GS], Bl[2][GS];
+    auto read_group = [&](int g, v4i (&dh)[GS], v4i (&dl)[GS]) {
+#pragma unroll
+      for (int i = 0; i < GS; i++) {
+        const int b = g * GS + i;
+        if (b < NB) {
+          dh[i] = *(const v4i *)(fh + 16 * b);
+          dl[i] = *(const v4i *)(fl + 16 * b);
+        }
+      }
+    };
+    read_group(0, Bh[0], Bl[0]);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < NG) { read_group(g + 1, Bh[(g + 1) & 1], Bl[(g + 1) & 1]); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < GS; i++) {
+        const int b = g * GS + i;
+        if (b < NB) {
+          if (HS == 0 || (b >= HS && b <= NB - 1 - HS)) {   // compile-time band of non-zero high-byte blocks
+            hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bh[g & 1][i], hh, 0, 0, 0);
+            mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[g & 1][i], mid, 0, 0, 0);
+          }
+          ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bl[g & 1][i], ll, 0, 0, 0);
+          mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[g & 1][i], mid, 0, 0, 0);
+        }
+      }
+    }
+
+    // D layout: lane (n_col, h), register r: sample T0 + 32 n_col + (r&3) + 8 (r>>2) + 4 h
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int64_t t0 = T0 + 32 * n_col + 8 * g + 4 * h;
+      if (EPI != 0) {
+        int o[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int r = 4 * g + rr;
+          const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid[r]);
+#ifdef ACDSP_X_NO_LLINIT
+          o[rr] = (A + (int)(corr_t >> 8) + ((ll[r] + (int)(corr_t & 0xff)) >> 8)) >> rs8;
+#else
+          o[rr] = (A + (ll[r] >> 8)) >> rs8;
+#endif
+        }
+        v4s pk;
+#ifdef ACDSP_X_NO_CVTPK
+        if (EPI == 2) { for (int rr = 0; rr < 4; rr++) { o[rr] = max(-32768, min(o[rr], 32767)); } }
+        if (false) {
+#else
+        if (EPI == 2) {  // OUT_TYPE is a signed 16-bit AC_SAT type: clamp and pack in one instruction
+#endif
+          typedef short v2s __attribute__((ext_vector_type(2)));
+          const v2s p0 = __builtin_amdgcn_cvt_pk_i16(o[0], o[1]), p1 = __builtin_amdgcn_cvt_pk_i16(o[2], o[3]);
+          pk = (v4s){p0.x, p0.y, p1.x, p1.y};
+        } else {
+          pk = (v4s){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+        }
+        int16_t *dst = yrow + T0 + 8 * g;
+        if (FAST) {
+          *(v4s *)dst = pk;
+        } else if (a.out_vec_ok && t0 + 4 <= p.n) {
+          *(v4s *)dst = pk;
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            if (t0 + rr < p.n) { dst[rr] = (int16_t)o[rr]; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int r = 4 * g + rr;
+          int64_t v = ((int64_t)hh[r] << 16) + ((int64_t)mid[r] << 8) + (int64_t)ll[r] + corr;
+          int64_t acc = wrap64((int64_t)((uint64_t)v << p.lossless_shift), p.acc.W, p.acc.S);
+          int64_t y = requant64(acc, p.acc.F, p.out);
+          if (t0 + rr < p.n) { store_raw(p.y, (int64_t)ch * p.out_stride + t0 + rr, p.out_eb, y); }
+        }
+      }
+    }
+  }
+}
+
+template <int NB, int EPI, int HS>
+__global__ void __launch_bounds__(64, 2)
+fir_mfma2_kernel(FirParams p, const v4i *__restrict__ frag, Mfma2Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 4 * (32 + NB - 1) * 16];
+  const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
+  const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n;
+  if (interior) { fir_mfma2_body<NB, EPI, HS, true>(p, frag, a, lds); }
+  else { fir_mfma2_body<NB, EPI, HS, false>(p, frag, a, lds); }
+}
+
+template <int NB, int HS>
+static hipError_t launch2_nb_hs(const FirParams &p, const uint32_t *d_frag, const Mfma2Args &a, int epi, dim3 grid, hipStream_t s) {
+  if (epi == 1) { hipLaunchKernelGGL((fir_mfma2_kernel<NB, 1, HS>), grid, dim3(64), 0, s, p, (const v4i *)d_frag, a); }
+  else if (epi == 2) { hipLaunchKernelGGL((fir_mfma2_kernel<NB, 2, HS>), grid, dim3(64), 0, s, p, (const v4i *)d_frag, a); }
+  else { hipLaunchKernelGGL((fir_mfma2_kernel<NB, 0, 0>), grid, dim3(64), 0, s, p, (const v4i *)d_frag, a); }
+  return hipGetLastError();
+}
+
+// Largest instantiated band skip hs (0, 2 or 3) such that every non-zero high-byte block lies in [hs, NB-1-hs].
+static int pick_hs(int nb, uint32_t hi_mask) {
+  const int cand[2] = {3, 2};
+  for (int hs : cand) {
+    if (2 * hs >= nb) { continue; }
+    uint32_t band = 0;
+    for (int b = hs; b <= nb - 1 - hs; b++) { band |= 1u << b; }
+    if ((hi_mask & ~band) == 0) { return hs; }
+  }
+  return 0;
+}
+
+template <int NB>
+static hipError_t launch2_nb(const FirParams &p, const uint32_t *d_frag, const Mfma2Args &a, int epi, dim3 grid, hipStream_t s) {
+  const int hs = epi ? pick_hs(NB, a.hi_mask) : 0;
+  if (NB >= 7 && hs == 3) { return launch2_nb_hs<NB, (NB >= 7 ? 3 : 0)>(p, d_frag, a, epi, grid, s); }
+  if (NB >= 5 && hs == 2) { return launch2_nb_hs<NB, (NB >= 5 ? 2 : 0)>(p, d_frag, a, epi, grid, s); }
+  return launch2_nb_hs<NB, 0>(p, d_frag, a, epi, grid, s);
+}
+
+// Can the all-32-bit epilogue be used for this plan / type combination?  0: no, 1: WRAP, 2: SAT
+int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
+  const int rs = p.in.F + p.cf.F - p.out.F;
+  // |y| <= 32768 * sum|c| must fit the accumulator (no AC_WRAP event possible) ...
+  const int acc_bits = p.acc.W - (p.acc.S ? 1 : 0) - p.lossless_shift;
+  const bool acc_wide = acc_bits >= 63 || plan.sum_abs * 32768 < (int64_t(1) << (acc_bits > 0 ? acc_bits : 0));
+  // ... and hh*256 + mid + corr/256 + carry must fit int32
+  const int64_t hh_max = 128 * plan.sum_abs_hi, mid_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo), ll_max = 128 * plan.sum_abs_lo;
+  const int64_t rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs <= 38) ? (int64_t(1) << (rs - 1)) : 0;  // rounding constant added with corr
+  const int64_t corr_abs = (plan.corr < 0 ? -plan.corr : plan.corr) + rnd;
+  const bool small = hh_max * 256 + mid_max + corr_abs / 256 + (ll_max + 255) / 256 + 2 < (int64_t(1) << 31) &&
+                     ll_max + corr_abs + 2 < (int64_t(1) << 31);  // v2: corr + rounding constant preloaded into the ll accumulator
+  if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
+      rs >= 8 && rs <= 38 && acc_wide && small && p.out.W == 16) {
+    return p.out.O == ACDSP_SAT ? 2 : 1;
+  }
+  return 0;
+}
+
+hipError_t launch_fir_mfma2(const FirParams &p, const FirMfmaPlan &plan, int epi, int frag_per_channel, const uint32_t *d_frag,
+                            const int64_t *d_corr, hipStream_t s) {
+  const int nb = plan.nb;
+  if (p.n <= 0) { return hipSuccess; }
+  Mfma2Args a;
+  a.n_steps = (p.n + 1023) / 1024;
+  a.n8 = (p.n + 7) / 8 * 8;
+  int64_t spw = (a.n_steps * p.n_ch + 16383) / 16384;
+  if (spw < 8) { spw = 8; }
+  a.steps_per_wave = spw;
+  const int oeb = p.out_eb;
+  a.out_vec_ok = ((uintptr_t)p.y % (4 * oeb) == 0) && ((p.out_stride * oeb) % (4 * oeb) == 0);
+  a.frag_per_channel = frag_per_channel;
+  a.hi_mask = plan.hi_mask;
+  a.lo_mask = plan.lo_mask;
+  a.corr = d_corr;
+  dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)p.n_ch);
+  switch (nb) {
+    case 1: return launch2_nb<1>(p, d_frag, a, epi, grid, s);
+    case 2: return launch2_nb<2>(p, d_frag, a, epi, grid, s);
+    case 3: return launch2_nb<3>(p, d_frag, a, epi, grid, s);
+    case 4: return launch2_nb<4>(p, d_frag, a, epi, grid, s);
+    case 5: return launch2_nb<5>(p, d_frag, a, epi, grid, s);
+    case 6: return launch2_nb<6>(p, d_frag, a, epi, grid, s);
+    case 7: return launch2_nb<7>(p, d_frag, a, epi, grid, s);
+    case 8: return launch2_nb<8>(p, d_frag, a, epi, grid, s);
+    case 9: return launch2_nb<9>(p, d_frag, a, epi, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, const uint32_t *d_frag, hipStream_t s) {
   if (p.n <= 0) { return hipSuccess; }
   MfmaArgs a;
@@ -287,8 +587,10 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, const ui
   const bool acc_wide = acc_bits >= 63 || plan.sum_abs * 32768 < (int64_t(1) << (acc_bits > 0 ? acc_bits : 0));
   // ... and hh*256 + mid + corr/256 + carry must fit int32
   const int64_t hh_max = 128 * plan.sum_abs_hi, mid_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo), ll_max = 128 * plan.sum_abs_lo;
-  const int64_t corr_abs = (plan.corr < 0 ? -plan.corr : plan.corr) + (int64_t(1) << 38);
-  const bool small = hh_max * 256 + mid_max + corr_abs / 256 + (ll_max + 255) / 256 + 2 < (int64_t(1) << 31);
+  const int64_t rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs <= 38) ? (int64_t(1) << (rs - 1)) : 0;  // rounding constant added with corr
+  const int64_t corr_abs = (plan.corr < 0 ? -plan.corr : plan.corr) + rnd;
+  const bool small = hh_max * 256 + mid_max + corr_abs / 256 + (ll_max + 255) / 256 + 2 < (int64_t(1) << 31) &&
+                     ll_max + corr_abs + 2 < (int64_t(1) << 31);  // v2: corr + rounding constant preloaded into the ll accumulator
   int epi = 0;
   if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
       rs >= 8 && rs <= 38 && acc_wide && small && p.out.W == 16) {

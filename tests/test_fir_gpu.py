@@ -90,6 +90,15 @@ def test_per_channel_coefficients():
     check_case(12, "FOLD_EVEN", A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(20, 4), A.Fmt(16, 2), n_ch=5, per_channel=True)
 
 
+def test_per_channel_coefficients_on_the_mfma_path():
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    rng = np.random.default_rng(77)
+    c = np.minimum(rand_raw(rng, fc, (9, 200)), 32639)
+    check_case(200, "SHIFT_REG", fin, fc, fa, A.Fmt(16, 2, True, "RND", "SAT"), n_ch=9, n=3000, per_channel=True, coeffs=c,
+               expect_path="mfma_i8", splits=[1000, 1024, 2047])
+    check_case(200, "C_BUFF", fin, fc, fa, fa, n_ch=9, n=1500, per_channel=True, coeffs=c, expect_path="mfma_i8")
+
+
 def test_transposed_coefficient_reload_mid_stream():
     # reg_trans[] keeps partial sums made with the coefficients of their time (ac_fir_load_coeffs.h:265-278)
     fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(24, 5, True, "RND_CONV", "SAT"), A.Fmt(16, 3)
@@ -121,6 +130,27 @@ def test_mfma_path_ftypes_and_wide_output(ftype):
     check_case(63, ftype, fin, fc, fa, fa, n_ch=33, n=900, kind="const", coeffs=c, expect_path="mfma_i8", splits=[64])
     check_case(63, ftype, fin, fc, fa, A.Fmt(16, 2, True, "TRN", "WRAP"), n_ch=64, n=900, kind="const", coeffs=c,
                expect_path="mfma_i8")
+
+
+@pytest.mark.parametrize("pattern", ["small_only", "big_multiples_of_256", "single_tap", "all_zero", "two_islands"])
+def test_mfma_zero_block_skipping(pattern):
+    # Toeplitz blocks whose hi or lo byte plane is entirely zero are skipped: exercise every mask shape
+    N = 255
+    rng = np.random.default_rng(3)
+    c = np.zeros(N, dtype=np.int64)
+    if pattern == "small_only":
+        c[:] = rng.integers(-128, 128, size=N)            # hi plane all zero
+    elif pattern == "big_multiples_of_256":
+        c[:] = 256 * rng.integers(-100, 100, size=N)      # lo plane all zero
+    elif pattern == "single_tap":
+        c[200] = -12345
+    elif pattern == "two_islands":
+        c[10:20] = rng.integers(-30000, 30000, size=10)
+        c[230:240] = rng.integers(-100, 100, size=10)
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    check_case(N, "SHIFT_REG", fin, fc, fa, A.Fmt(16, 2, True, "RND", "SAT"), n_ch=3, n=2500, coeffs=c, expect_path="mfma_i8",
+               splits=[1024])
+    check_case(N, "SHIFT_REG", fin, fc, fa, fa, n_ch=2, n=1100, coeffs=c, expect_path="mfma_i8")
 
 
 def test_mfma_extreme_values_and_fallback():
