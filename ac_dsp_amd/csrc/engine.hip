@@ -467,11 +467,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   }
   HIP_TRY(hipEventRecord(h->tm.start(), s));
   hipError_t e;
-  if (path == ACDSP_PATH_MFMA_I8) {
-    static const bool use_v1 = getenv("ACDSP_MFMA_V1") != nullptr;  // A/B switch for the older 32-channel mapping
-    if (use_v1 && !d.coeffs_per_channel) { e = launch_fir_mfma(k, h->plan, h->d_frag, s); }
-    else { e = launch_fir_mfma2(k, h->plan, fir_mfma_epilogue_class(k, h->plan), d.coeffs_per_channel, h->d_frag, h->d_corr, s); }
-  }
+  if (path == ACDSP_PATH_MFMA_I8) { e = launch_fir_mfma(k, h->plan, d.coeffs_per_channel, h->d_frag, h->d_corr, s); }
   else if (path == ACDSP_PATH_LOSSLESS64) { e = launch_fir_lossless64(k, s); }
   else { e = launch_fir_generic(k, s); }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR kernel launch failed: %s", hipGetErrorString(e)); }

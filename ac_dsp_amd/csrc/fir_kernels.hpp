@@ -40,12 +40,10 @@ struct FirMfmaPlan {
 // Builds the per-lane A fragments (host side) into frag[2][nb][64][4] dwords; returns false if the
 // coefficient set cannot be split into two signed bytes per tap.
 bool fir_mfma_build_fragments(const int64_t *coeffs, int n_taps, FirMfmaPlan *plan, uint32_t *frag /* host */);
-hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, const uint32_t *d_frag, hipStream_t s);
 int fir_mfma_max_blocks();
-// v2 mapping (one channel per wave, 32 consecutive output blocks as the MFMA columns); fragments and
-// corr are per coefficient set: d_frag[n_sets][2][nb][64][4], d_corr[n_sets].
-int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan);
-hipError_t launch_fir_mfma2(const FirParams &p, const FirMfmaPlan &plan, int epi, int frag_per_channel, const uint32_t *d_frag,
-                            const int64_t *d_corr, hipStream_t s);
+// One wave = one channel x a time chunk; fragments and corr are per coefficient set:
+// d_frag[n_sets][2][nb][64][4], d_corr[n_sets]; `plan` carries the worst-case bounds over all sets.
+hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag_per_channel, const uint32_t *d_frag,
+                           const int64_t *d_corr, hipStream_t s);
 
 }  // namespace acdsp

@@ -11,10 +11,13 @@
 //
 // Formulation.  For one block of 32 consecutive outputs of one channel,
 //     y[T0+i] = sum_k c[k] x[T0+i-k]        i = 0..31
-// is a [32 x 32*NB] Toeplitz matrix (built from c, the same for every output block and every
-// channel) times the [32*NB] input samples ending at T0+31, NB = ceil((N-1)/32)+1.  Stacking 32
-// channels as the columns of B gives NB dense 32x32x32 MFMA tiles per output block:
-//     D[i][ch] += A_b[i][k] * X_b[k][ch],   A_b[i][k] = c[i - k + 32*(NB-1-b)].
+// is a [32 x 32*NB] Toeplitz matrix (built from c, the same for every output block of the
+// channel) times the [32*NB] input samples ending at T0+31, NB = ceil((N-1)/32)+1.  The 32 MFMA
+// columns are 32 CONSECUTIVE output blocks of the same channel:
+//     D[i][n] = y[T0 + 32n + i] = sum_b sum_k A_b[i][k] * X_b[k][n],
+//     A_b[i][k] = c[i - k + 32*(NB-1-b)],     X_b[k][n] = x[T0 - 32(NB-1) + 32(n+b) + k],
+// so one step (4*NB MFMA 32x32x32) produces 1024 consecutive outputs of one channel from one
+// contiguous (32+NB-1)*64-byte stretch of its row.
 // MFMA has no int16 operand type, so both operands are split into two signed bytes:
 //     c = 256*ch + cl            (cl = sign-extended low byte, ch = (c - cl)/256, both int8)
 //     x = 256*xh + xl + 128      (xh = high byte, xl = low byte re-biased to signed)
@@ -23,10 +26,23 @@
 // integer dot product; rounding/saturation into OUT_TYPE happens once, in the epilogue.
 //
 // Data movement.  The 2*NB A fragments (4 VGPRs each) stay in registers for the whole kernel.
-// Every input block is read from HBM exactly once per chunk (16-byte loads, two per lane), split
-// into hi/lo byte planes with v_perm_b32 and kept in a rotating register window that is reused
-// by the NB output blocks it overlaps -- no LDS, no re-reads except the NB-1 halo blocks at a
-// chunk start.  One wave = 32 channels x one time chunk.
+// Column n of K-block b is "input chunk n+b": the X fragments of the NB K-blocks are lane-shifted
+// copies of each other.  The shift is done by LDS addressing: a step's chunks are fetched with fully
+// coalesced 16-byte loads (every HBM visit of a row moves 2+ KB -- a first version that put 32
+// channels in the columns touched 32 rows x 64 B per step, ~130k interleaved DRAM streams, and
+// stalled near 2 TB/s), split into byte planes with v_perm_b32, staged in LDS (2.5 KB per wave) and
+// each K-block's fragment is a contiguous, conflict-free ds_read_b128 at offset 16*(n+b).
+// One wave = one channel x one time chunk; the Toeplitz fragments are per coefficient set, so
+// per-channel coefficients cost nothing extra.
+//
+// Scheduling.  VALU and MFMA instructions share one issue port per SIMD: an MFMA owns it for 4 of
+// its 32 cycles, so ~7 other instructions can hide behind each MFMA -- but only if they come from
+// the partner wave while this one is inside its MFMA run.  Two identical waves drift into the same
+// phase and then total = MFMA time + VALU time.  The kernel therefore runs 8-wave workgroups (two
+// waves per SIMD) in ping-pong: waves 0-3 execute their MFMA run while waves 4-7 execute their
+// epilogue / stores / staging, and an s_barrier swaps the roles (two barriers per step).
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "fir_kernels.hpp"
@@ -89,198 +105,6 @@ bool fir_mfma_build_fragments(const int64_t *c, int n_taps, FirMfmaPlan *plan, u
 }
 
 struct MfmaArgs {
-  int64_t chunk_blocks;  // 32-sample output blocks per wave
-  int64_t n_blocks;      // ceil(n / 32)
-  int32_t out_vec_ok;    // output rows aligned for 4-element vector stores
-};
-
-__device__ inline void split_planes(const v4i &ra, const v4i &rb, v4i &xh, v4i &xl) {
-  // ra/rb: 16 int16 samples (2 per dword).  High bytes -> xh, low bytes (re-biased) -> xl.
-  xh.x = (int)__builtin_amdgcn_perm((unsigned)ra.y, (unsigned)ra.x, 0x07050301u);
-  xh.y = (int)__builtin_amdgcn_perm((unsigned)ra.w, (unsigned)ra.z, 0x07050301u);
-  xh.z = (int)__builtin_amdgcn_perm((unsigned)rb.y, (unsigned)rb.x, 0x07050301u);
-  xh.w = (int)__builtin_amdgcn_perm((unsigned)rb.w, (unsigned)rb.z, 0x07050301u);
-  xl.x = (int)(__builtin_amdgcn_perm((unsigned)ra.y, (unsigned)ra.x, 0x06040200u) ^ 0x80808080u);
-  xl.y = (int)(__builtin_amdgcn_perm((unsigned)ra.w, (unsigned)ra.z, 0x06040200u) ^ 0x80808080u);
-  xl.z = (int)(__builtin_amdgcn_perm((unsigned)rb.y, (unsigned)rb.x, 0x06040200u) ^ 0x80808080u);
-  xl.w = (int)(__builtin_amdgcn_perm((unsigned)rb.w, (unsigned)rb.z, 0x06040200u) ^ 0x80808080u);
-}
-
-// EPI 0: any OUT_TYPE / ACC width through requant64.
-// EPI 1: OUT container int16, Q in {TRN, RND}, O = WRAP, no accumulator wrap possible, right shift >= 8:
-//        all-32-bit epilogue.   EPI 2: the same with O = SAT (clamp).
-//
-// FAST: the wave's whole chunk is interior -- every block it loads or stores is a full 32-sample block,
-// all 32 channels exist and the output rows are vector-aligned.  The loop body is then free of
-// divergent branches, so the compiler can count outstanding memory operations exactly and waits for
-// the prefetched block with s_waitcnt vmcnt(4) (the 4 younger stores stay in flight) instead of
-// draining the store queue every step.
-template <int NB, int EPI, bool FAST>
-__device__ __forceinline__ void fir_mfma_body(const FirParams &p, const FirMfmaPlan &plan, const v4i *__restrict__ frag,
-                                              const MfmaArgs &a) {
-  const int lane = threadIdx.x;
-  const int n_col = lane & 31, h = lane >> 5;
-  const int ch = blockIdx.y * 32 + n_col;
-  const bool ch_ok = ch < p.n_ch;
-  const int chl = ch_ok ? ch : p.n_ch - 1;
-
-  v4i Ah[NB], Al[NB];
-#pragma unroll
-  for (int b = 0; b < NB; b++) {
-    Ah[b] = frag[(0 * NB + b) * 64 + lane];
-    Al[b] = frag[(1 * NB + b) * 64 + lane];
-  }
-
-  const int16_t *xrow = (const int16_t *)p.x + (int64_t)chl * p.in_stride + h * 16;
-  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)chl * p.hl + p.hl + h * 16;  // hrow[t], t < 0
-  const int64_t ob0 = (int64_t)blockIdx.x * a.chunk_blocks;
-  const int64_t ob1 = (ob0 + a.chunk_blocks < a.n_blocks) ? ob0 + a.chunk_blocks : a.n_blocks;
-  const int nsteps = (int)(ob1 - ob0);
-  const int64_t last_full = p.n / 32 - 1;  // FAST: index of the last full input block (>= ob1 - 1)
-
-  auto load_block = [&](int64_t ib, v4i &ra, v4i &rb) {
-    if (FAST) {
-      if (ib > last_full) { ib = last_full; }            // harmless re-read instead of a branch
-      const int16_t *base = (ib < 0) ? hrow : xrow;      // wave-uniform select
-      const v4i *s = (const v4i *)(base + ib * 32);
-      ra = s[0]; rb = s[1];
-    } else {
-      const int64_t t = ib * 32 + h * 16;
-      if (ib < 0) {
-        const v4i *s = (const v4i *)(hrow + ib * 32);
-        ra = s[0]; rb = s[1];
-      } else if (t + 16 <= p.n) {
-        const v4i *s = (const v4i *)(xrow + ib * 32);
-        ra = s[0]; rb = s[1];
-      } else {
-        union { v4i v[2]; int16_t e[16]; } u;
-#pragma unroll
-        for (int e = 0; e < 16; e++) { u.e[e] = (t + e < p.n) ? xrow[ib * 32 + e] : (int16_t)0; }
-        ra = u.v[0]; rb = u.v[1];
-      }
-    }
-  };
-
-  // rotating window: input block ib lives in slot (ib - ob0) mod NB
-  v4i Xh[NB], Xl[NB];
-#pragma unroll
-  for (int b = 0; b < NB - 1; b++) {
-    v4i ra, rb;
-    load_block(ob0 - (NB - 1) + b, ra, rb);
-    split_planes(ra, rb, Xh[b + 1], Xl[b + 1]);
-  }
-  v4i na, nb_;  // raw samples of the next input block (software prefetch, one step ahead)
-  load_block(ob0, na, nb_);
-
-  // epilogue constants
-  const int rs = p.in.F + p.cf.F - p.out.F;  // net right shift of the raw dot product (EPI 1/2)
-  const int64_t corr = plan.corr;
-  const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
-  const int cA = (int)(corr_t >> 8);          // added to hh*256 + mid
-  const int cB = (int)(corr_t & 0xff);        // added to ll
-  const int sat_lo = (int)p.out.lo, sat_hi = (int)p.out.hi;
-  const int rs8 = rs - 8;
-  int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 4 * h;   // EPI 1/2 only
-
-  for (int s_base = 0; s_base < nsteps; s_base += NB) {
-#pragma unroll
-    for (int u = 0; u < NB; u++) {
-      const int s = s_base + u;
-      if (s < nsteps) {
-      const int64_t ob = ob0 + s;
-      split_planes(na, nb_, Xh[u], Xl[u]);
-      if (FAST || s + 1 < nsteps) { load_block(ob + 1, na, nb_); }
-
-      v16i hh = {0}, mid = {0}, ll = {0};
-#pragma unroll
-      for (int b = 0; b < NB; b++) {
-        const int slot = (u + 1 + b) % NB;
-        hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xh[slot], hh, 0, 0, 0);
-        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xl[slot], mid, 0, 0, 0);
-        ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xl[slot], ll, 0, 0, 0);
-        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[slot], mid, 0, 0, 0);
-      }
-
-      // D layout (32x32): lane holds column n_col, rows (r&3) + 8*(r>>2) + 4*h
-      const int64_t tb = ob * 32 + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int64_t t0 = tb + 8 * g;
-        if (EPI != 0) {
-          int o[4];
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const int r = 4 * g + rr;
-            const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid[r]);
-            const int B = (ll[r] + cB) >> 8;
-            int q = (A + cA + B) >> rs8;
-            if (EPI == 2) { q = max(sat_lo, min(q, sat_hi)); }
-            o[rr] = q;
-          }
-          v4s pk = {(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
-          if (FAST) {
-            *(v4s *)(yrow + ob * 32 + 8 * g) = pk;
-          } else if (ch_ok) {
-            int16_t *dst = yrow + ob * 32 + 8 * g;
-            if (a.out_vec_ok && t0 + 4 <= p.n) {
-              *(v4s *)dst = pk;
-            } else {
-#pragma unroll
-              for (int rr = 0; rr < 4; rr++) {
-                if (t0 + rr < p.n) { dst[rr] = (int16_t)o[rr]; }
-              }
-            }
-          }
-        } else {
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const int r = 4 * g + rr;
-            int64_t v = ((int64_t)hh[r] << 16) + ((int64_t)mid[r] << 8) + (int64_t)ll[r] + corr;
-            int64_t acc = wrap64((int64_t)((uint64_t)v << p.lossless_shift), p.acc.W, p.acc.S);
-            int64_t y = requant64(acc, p.acc.F, p.out);
-            if (ch_ok && t0 + rr < p.n) { store_raw(p.y, (int64_t)ch * p.out_stride + t0 + rr, p.out_eb, y); }
-          }
-        }
-      }
-      }  // s < nsteps
-    }
-  }
-}
-
-template <int NB, int EPI>
-__global__ void __launch_bounds__(64, 2)
-fir_mfma_kernel(FirParams p, FirMfmaPlan plan, const v4i *__restrict__ frag, MfmaArgs a) {
-  const int64_t ob0 = (int64_t)blockIdx.x * a.chunk_blocks;
-  const int64_t ob1 = (ob0 + a.chunk_blocks < a.n_blocks) ? ob0 + a.chunk_blocks : a.n_blocks;
-  const bool interior = EPI != 0 && a.out_vec_ok && ob1 * 32 <= p.n && (int)(blockIdx.y + 1) * 32 <= p.n_ch;
-  if (interior) { fir_mfma_body<NB, EPI, true>(p, plan, frag, a); }
-  else { fir_mfma_body<NB, EPI, false>(p, plan, frag, a); }
-}
-
-template <int NB>
-static hipError_t launch_nb(const FirParams &p, const FirMfmaPlan &plan, const uint32_t *d_frag, const MfmaArgs &a, int epi,
-                            dim3 grid, hipStream_t s) {
-  if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1>), grid, dim3(64), 0, s, p, plan, (const v4i *)d_frag, a); }
-  else if (epi == 2) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2>), grid, dim3(64), 0, s, p, plan, (const v4i *)d_frag, a); }
-  else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 0>), grid, dim3(64), 0, s, p, plan, (const v4i *)d_frag, a); }
-  return hipGetLastError();
-}
-
-// =============================================================================================
-// v2: one wave = ONE channel; the 32 MFMA columns are 32 CONSECUTIVE 32-sample output blocks.
-//
-//     D[i][n] = y[T0 + 32n + i],   B_b[k][n] = x[T0 - 32(NB-1) + 32(n+b) + k]
-//
-// so one step produces 1024 consecutive outputs of one channel from one contiguous
-// (32+NB-1)*64-byte stretch of its row: every HBM visit of a row moves 2+ KB (the v1 mapping
-// touched 32 rows x 64 B per step, i.e. ~130k interleaved DRAM streams, and stalled near 2 TB/s).
-// Column n of K-block b is "input chunk n+b": the B fragments of the NB K-blocks are lane-shifted
-// copies of each other.  The shift is done by LDS addressing: the step's chunks are split into
-// byte planes once, staged in LDS (2.5 KB per wave), and each K-block's fragment is a contiguous,
-// conflict-free ds_read_b128 at offset 16*(n+b).  The Toeplitz fragments are per channel (pointer
-// offset), so per-channel coefficient sets cost nothing extra.
-// =============================================================================================
-struct Mfma2Args {
   int64_t steps_per_wave;  // 1024-sample steps per wave
   int64_t n_steps;         // ceil(n / 1024)
   int64_t n8;              // n rounded up to a multiple of 8 (rows are readable that far)
@@ -288,20 +112,31 @@ struct Mfma2Args {
   int32_t frag_per_channel;
   uint32_t hi_mask, lo_mask;  // bit b: K-block b of the hi / lo coefficient plane has a non-zero entry (any set)
   const int64_t *corr;     // [n_sets] 128 * sum(c) per coefficient set
+  int64_t *dbg;            // optional: per-wave {shader-clock ticks, 100 MHz real-time ticks} (ACDSP_DEBUG_CLOCK)
 };
 
-template <int NB, int EPI, int HS, bool FAST>
-__device__ __forceinline__ void fir_mfma2_body(const FirParams &p, const v4i *__restrict__ frag, const Mfma2Args &a,
-                                               unsigned char *lds) {
+// EPI 0: any OUT_TYPE / ACC width through requant64.
+// EPI 1: OUT container int16, Q in {TRN, RND}, O = WRAP, no accumulator wrap possible, right shift >= 8:
+//        all-32-bit epilogue.   EPI 2: the same with O = SAT (v_cvt_pk_i16_i32 clamps and packs).
+// HS:    compile-time band [HS, NB-1-HS] of K-blocks whose high-byte Toeplitz plane is non-zero.
+// WAVES: 8 = ping-pong workgroup (see header), 1 = single-wave workgroup.
+// FAST:  the chunk is interior: all loads/stores are full vectors, so the loop has no divergent branch
+//        around VMEM and the compiler counts outstanding operations exactly (vmcnt(k), not vmcnt(0)).
+template <int NB, int EPI, int HS, int WAVES, bool FAST>
+__device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
+                                              unsigned char *lds_all) {
   constexpr int HB = NB - 1;          // halo chunks
   constexpr int NC = 32 + HB;         // chunks staged per step
   constexpr int NP = 4 * NC;          // 16-byte raw pieces per step
   constexpr int JN = (NP + 63) / 64;  // raw loads per lane per step
   constexpr int ARR = NC * 16;        // bytes of one [plane][half] array
-  const int lane = threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = (WAVES == 8) ? (wave >> 2) : 0;  // waves w and w+4 share a SIMD
   const int n_col = lane & 31, h = lane >> 5;
-  const int ch = blockIdx.y;
+  int ch = blockIdx.y * WAVES + wave;
+  if (ch >= p.n_ch) { ch = p.n_ch - 1; }  // surplus waves redo the last channel (identical stores): barriers stay uniform
   const int set = a.frag_per_channel ? ch : 0;
+  unsigned char *lds = lds_all + wave * (2 * 4 * ARR);
 
   v4i Ah[NB], Al[NB];
 #pragma unroll
@@ -321,8 +156,7 @@ __device__ __forceinline__ void fir_mfma2_body(const FirParams &p, const v4i *__
   auto issue_loads = [&](int64_t T0) {
 #pragma unroll
     for (int j = 0; j < JN; j++) {
-      // every lane loads (surplus lanes repeat the last piece): no divergent branch around VMEM, so the
-      // compiler can count outstanding operations exactly (s_waitcnt vmcnt(k) instead of vmcnt(0))
+      // every lane loads (surplus lanes repeat the last piece): no divergent branch around VMEM
       const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
       int64_t t = T0 - 32 * HB + 8 * pc;
       const int16_t *src = (t < 0) ? hrow + t : xrow + ((t < a.n8) ? t : 0);  // beyond n: any valid address
@@ -355,43 +189,35 @@ __device__ __forceinline__ void fir_mfma2_body(const FirParams &p, const v4i *__
   //   q = ((hh << 8) + mid + (ll >> 8)) >> (rs - 8)      -- 4 VALU ops per output, then a packing
   // v_cvt_pk_i16_i32 that also performs the AC_SAT clamp for the 16-bit OUT_TYPE.
   const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
-#ifdef ACDSP_X_NO_LLINIT
-  const int c_ll = 0;
-#else
   const int c_ll = (EPI != 0) ? (int)corr_t : 0;
-#endif
   const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
   const int rs8 = rs - 8;
   int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 32 * n_col + 4 * h;  // EPI 1/2
 
   // The Toeplitz fragments must have landed before the loop: otherwise the compiler keeps
-  // "s_waitcnt vmcnt(k)" for them inside the loop body, where in steady state they drain the
-  // prefetch loads and the previous step's stores (simm16: vmcnt 0, expcnt/lgkmcnt untouched).
+  // "s_waitcnt vmcnt(k)" for them inside the loop body (simm16: vmcnt 0, expcnt/lgkmcnt untouched).
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __builtin_amdgcn_sched_barrier(0);
+
+  // software pipeline: loads run two steps ahead of the MFMAs, staging one step ahead
   issue_loads(s0 * 1024);
+  stage(lds);
+  if (FAST || nsteps > 1) { issue_loads((s0 + 1) * 1024); }
+  if (WAVES == 8 && grp == 1) { __builtin_amdgcn_s_barrier(); }  // second half starts one phase later
+
   for (int s = 0; s < nsteps; s++) {
     const int64_t T0 = (s0 + s) * 1024;
     unsigned char *buf = lds + (s & 1) * (4 * ARR);
-    stage(buf);
-    if (FAST || s + 1 < nsteps) { issue_loads(T0 + 1024); }  // FAST: the extra fetch after the last step is clamped, harmless
-    __syncthreads();  // single-wave workgroup: orders the LDS writes before the fragment reads
 
+    // ---------------- phase M: fragment reads + MFMA run ----------------
     v16i hh = {0}, mid = {0}, ll = ll_init;
     const unsigned char *fh = buf + (0 * 2 + h) * ARR + n_col * 16;
     const unsigned char *fl = buf + (1 * 2 + h) * ARR + n_col * 16;
     // Fragment reads (conflict-free ds_read_b128) run one group of GS K-blocks ahead of the MFMAs that
     // consume them; sched_barrier(0) pins the "reads of group g+1, then MFMAs of group g" order, which
     // the scheduler would otherwise re-serialise into read-wait-MFMA per block.
-    // A Toeplitz block whose high-byte plane is all zero contributes nothing to hh / mid: kernels are
-    // instantiated for a few centred bands [HS, NB-1-HS] of non-zero high-byte blocks (typical low-pass
-    // sets have |c| < 128 LSB outside the centre taps) and the host picks the widest one that is exact.
-#ifdef ACDSP_X_UPFRONT
-    constexpr int GS = NB, NG = 1;
-#else
     constexpr int GS = 3, NG = (NB + GS - 1) / GS;
-#endif
     v4i Bh[2][GS], Bl[2][GS];
     auto read_group = [&](int g, v4i (&dh)[GS], v4i (&dl)[GS]) {
 #pragma unroll
@@ -413,7 +239,8 @@ __device__ __forceinline__ void fir_mfma2_body(const FirParams &p, const v4i *__
       for (int i = 0; i < GS; i++) {
         const int b = g * GS + i;
         if (b < NB) {
-          if (HS == 0 || (b >= HS && b <= NB - 1 - HS)) {   // compile-time band of non-zero high-byte blocks
+          // a Toeplitz block whose high-byte plane is all zero contributes nothing to hh / mid
+          if (HS == 0 || (b >= HS && b <= NB - 1 - HS)) {
             hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bh[g & 1][i], hh, 0, 0, 0);
             mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[g & 1][i], mid, 0, 0, 0);
           }
@@ -422,7 +249,10 @@ __device__ __forceinline__ void fir_mfma2_body(const FirParams &p, const v4i *__
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (WAVES == 8) { __builtin_amdgcn_s_barrier(); }
 
+    // ---------------- phase O: epilogue, stores, staging of the next step, prefetch ----------------
     // D layout: lane (n_col, h), register r: sample T0 + 32 n_col + (r&3) + 8 (r>>2) + 4 h
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -433,19 +263,10 @@ __device__ __forceinline__ void fir_mfma2_body(const FirParams &p, const v4i *__
         for (int rr = 0; rr < 4; rr++) {
           const int r = 4 * g + rr;
           const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid[r]);
-#ifdef ACDSP_X_NO_LLINIT
-          o[rr] = (A + (int)(corr_t >> 8) + ((ll[r] + (int)(corr_t & 0xff)) >> 8)) >> rs8;
-#else
           o[rr] = (A + (ll[r] >> 8)) >> rs8;
-#endif
         }
         v4s pk;
-#ifdef ACDSP_X_NO_CVTPK
-        if (EPI == 2) { for (int rr = 0; rr < 4; rr++) { o[rr] = max(-32768, min(o[rr], 32767)); } }
-        if (false) {
-#else
         if (EPI == 2) {  // OUT_TYPE is a signed 16-bit AC_SAT type: clamp and pack in one instruction
-#endif
           typedef short v2s __attribute__((ext_vector_type(2)));
           const v2s p0 = __builtin_amdgcn_cvt_pk_i16(o[0], o[1]), p1 = __builtin_amdgcn_cvt_pk_i16(o[2], o[3]);
           pk = (v4s){p0.x, p0.y, p1.x, p1.y};
@@ -474,25 +295,37 @@ __device__ __forceinline__ void fir_mfma2_body(const FirParams &p, const v4i *__
         }
       }
     }
+    if (s + 1 < nsteps) {
+      stage(lds + ((s + 1) & 1) * (4 * ARR));                           // consumes the loads of step s+1
+      if (FAST || s + 2 < nsteps) { issue_loads(T0 + 2048); }           // FAST: a fetch past the chunk is clamped, harmless
+    }
+    if (WAVES == 8 && (grp == 0 || s + 1 < nsteps)) { __builtin_amdgcn_s_barrier(); }
   }
 }
 
-template <int NB, int EPI, int HS>
-__global__ void __launch_bounds__(64, 2)
-fir_mfma2_kernel(FirParams p, const v4i *__restrict__ frag, Mfma2Args a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 4 * (32 + NB - 1) * 16];
+template <int NB, int EPI, int HS, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 2)
+fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * 2 * 4 * (32 + NB - 1) * 16];
   const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
   const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n;
-  if (interior) { fir_mfma2_body<NB, EPI, HS, true>(p, frag, a, lds); }
-  else { fir_mfma2_body<NB, EPI, HS, false>(p, frag, a, lds); }
+  const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  if (interior) { fir_mfma_body<NB, EPI, HS, WAVES, true>(p, frag, a, lds); }
+  else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
+  if (a.dbg && (threadIdx.x & 63) == 0) {
+    const int64_t w = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6);
+    a.dbg[2 * w] = (int64_t)(__builtin_readcyclecounter() - c0);
+    a.dbg[2 * w + 1] = (int64_t)(__builtin_amdgcn_s_memrealtime() - r0);
+  }
 }
 
-template <int NB, int HS>
-static hipError_t launch2_nb_hs(const FirParams &p, const uint32_t *d_frag, const Mfma2Args &a, int epi, dim3 grid, hipStream_t s) {
-  if (epi == 1) { hipLaunchKernelGGL((fir_mfma2_kernel<NB, 1, HS>), grid, dim3(64), 0, s, p, (const v4i *)d_frag, a); }
-  else if (epi == 2) { hipLaunchKernelGGL((fir_mfma2_kernel<NB, 2, HS>), grid, dim3(64), 0, s, p, (const v4i *)d_frag, a); }
-  else { hipLaunchKernelGGL((fir_mfma2_kernel<NB, 0, 0>), grid, dim3(64), 0, s, p, (const v4i *)d_frag, a); }
+template <int NB, int HS, int WAVES>
+static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  const dim3 blk(64 * WAVES);
+  if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
+  else if (epi == 2) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
+  else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 0, 0, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   return hipGetLastError();
 }
 
@@ -509,11 +342,11 @@ static int pick_hs(int nb, uint32_t hi_mask) {
 }
 
 template <int NB>
-static hipError_t launch2_nb(const FirParams &p, const uint32_t *d_frag, const Mfma2Args &a, int epi, dim3 grid, hipStream_t s) {
+static hipError_t launch_nb(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   const int hs = epi ? pick_hs(NB, a.hi_mask) : 0;
-  if (NB >= 7 && hs == 3) { return launch2_nb_hs<NB, (NB >= 7 ? 3 : 0)>(p, d_frag, a, epi, grid, s); }
-  if (NB >= 5 && hs == 2) { return launch2_nb_hs<NB, (NB >= 5 ? 2 : 0)>(p, d_frag, a, epi, grid, s); }
-  return launch2_nb_hs<NB, 0>(p, d_frag, a, epi, grid, s);
+  if (NB >= 7 && hs == 3) { return launch_nb_hs<NB, (NB >= 7 ? 3 : 0), 8>(p, d_frag, a, epi, grid, s); }
+  if (NB >= 5 && hs == 2) { return launch_nb_hs<NB, (NB >= 5 ? 2 : 0), 8>(p, d_frag, a, epi, grid, s); }
+  return launch_nb_hs<NB, 0, 8>(p, d_frag, a, epi, grid, s);
 }
 
 // Can the all-32-bit epilogue be used for this plan / type combination?  0: no, 1: WRAP, 2: SAT
@@ -522,12 +355,12 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   // |y| <= 32768 * sum|c| must fit the accumulator (no AC_WRAP event possible) ...
   const int acc_bits = p.acc.W - (p.acc.S ? 1 : 0) - p.lossless_shift;
   const bool acc_wide = acc_bits >= 63 || plan.sum_abs * 32768 < (int64_t(1) << (acc_bits > 0 ? acc_bits : 0));
-  // ... and hh*256 + mid + corr/256 + carry must fit int32
+  // ... hh*256 + mid + carry must fit int32, and so must the low plane with corr + rounding constant preloaded
   const int64_t hh_max = 128 * plan.sum_abs_hi, mid_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo), ll_max = 128 * plan.sum_abs_lo;
-  const int64_t rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs <= 38) ? (int64_t(1) << (rs - 1)) : 0;  // rounding constant added with corr
+  const int64_t rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs <= 38) ? (int64_t(1) << (rs - 1)) : 0;
   const int64_t corr_abs = (plan.corr < 0 ? -plan.corr : plan.corr) + rnd;
-  const bool small = hh_max * 256 + mid_max + corr_abs / 256 + (ll_max + 255) / 256 + 2 < (int64_t(1) << 31) &&
-                     ll_max + corr_abs + 2 < (int64_t(1) << 31);  // v2: corr + rounding constant preloaded into the ll accumulator
+  const bool small = hh_max * 256 + mid_max + (ll_max + corr_abs + 255) / 256 + 2 < (int64_t(1) << 31) &&
+                     ll_max + corr_abs + 2 < (int64_t(1) << 31);
   if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
       rs >= 8 && rs <= 38 && acc_wide && small && p.out.W == 16) {
     return p.out.O == ACDSP_SAT ? 2 : 1;
@@ -535,13 +368,16 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   return 0;
 }
 
-hipError_t launch_fir_mfma2(const FirParams &p, const FirMfmaPlan &plan, int epi, int frag_per_channel, const uint32_t *d_frag,
-                            const int64_t *d_corr, hipStream_t s) {
-  const int nb = plan.nb;
+static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s);
+
+hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag_per_channel, const uint32_t *d_frag,
+                           const int64_t *d_corr, hipStream_t s) {
   if (p.n <= 0) { return hipSuccess; }
-  Mfma2Args a;
+  const int epi = fir_mfma_epilogue_class(p, plan);
+  MfmaArgs a;
   a.n_steps = (p.n + 1023) / 1024;
   a.n8 = (p.n + 7) / 8 * 8;
+  // >= 16384 waves when the problem allows it; a chunk re-reads NB-1 halo blocks per step anyway
   int64_t spw = (a.n_steps * p.n_ch + 16383) / 16384;
   if (spw < 8) { spw = 8; }
   a.steps_per_wave = spw;
@@ -551,62 +387,36 @@ hipError_t launch_fir_mfma2(const FirParams &p, const FirMfmaPlan &plan, int epi
   a.hi_mask = plan.hi_mask;
   a.lo_mask = plan.lo_mask;
   a.corr = d_corr;
-  dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)p.n_ch);
-  switch (nb) {
-    case 1: return launch2_nb<1>(p, d_frag, a, epi, grid, s);
-    case 2: return launch2_nb<2>(p, d_frag, a, epi, grid, s);
-    case 3: return launch2_nb<3>(p, d_frag, a, epi, grid, s);
-    case 4: return launch2_nb<4>(p, d_frag, a, epi, grid, s);
-    case 5: return launch2_nb<5>(p, d_frag, a, epi, grid, s);
-    case 6: return launch2_nb<6>(p, d_frag, a, epi, grid, s);
-    case 7: return launch2_nb<7>(p, d_frag, a, epi, grid, s);
-    case 8: return launch2_nb<8>(p, d_frag, a, epi, grid, s);
-    case 9: return launch2_nb<9>(p, d_frag, a, epi, grid, s);
-    default: return hipErrorInvalidValue;
+  dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)((p.n_ch + 7) / 8));
+  a.dbg = nullptr;
+  static const bool dbg_clock = getenv("ACDSP_DEBUG_CLOCK") != nullptr;
+  const size_t n_waves = (size_t)grid.x * grid.y * 8;
+  if (dbg_clock) { if (hipMalloc((void **)&a.dbg, n_waves * 16) != hipSuccess) { a.dbg = nullptr; } }
+  hipError_t rc = launch_switch(p, plan.nb, d_frag, a, epi, grid, s);
+  if (a.dbg) {
+    std::vector<int64_t> hd(2 * n_waves);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(hd.data(), a.dbg, n_waves * 16, hipMemcpyDeviceToHost);
+    (void)hipFree(a.dbg);
+    double sc = 0, sr = 0;
+    for (size_t i = 0; i < n_waves; i++) { sc += (double)hd[2 * i]; sr += (double)hd[2 * i + 1]; }
+    fprintf(stderr, "[acdsp] fir_mfma: %zu waves, mean wave life %.1f us, shader clock %.3f GHz (spw %lld)\n", n_waves,
+            sr / n_waves / 100.0, sc / sr * 0.1, (long long)spw);
   }
+  return rc;
 }
 
-hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, const uint32_t *d_frag, hipStream_t s) {
-  if (p.n <= 0) { return hipSuccess; }
-  MfmaArgs a;
-  a.n_blocks = (p.n + 31) / 32;
-  const int64_t groups = (p.n_ch + 31) / 32;
-  // >= 4096 waves when the problem allows it (2 waves/SIMD x 1024 SIMDs, two rounds); a chunk
-  // re-reads NB-1 halo blocks, so keep it >= 32 blocks.
-  int64_t cb = (a.n_blocks * groups + 4095) / 4096;
-  if (cb < 32) { cb = 32; }
-  a.chunk_blocks = cb;
-  const int oeb = p.out_eb;
-  a.out_vec_ok = ((uintptr_t)p.y % (4 * oeb) == 0) && ((p.out_stride * oeb) % (4 * oeb) == 0) && ((uintptr_t)p.x % 16 == 0) &&
-                 ((p.in_stride * 2) % 16 == 0);
-  // all-32-bit epilogue: int16 container, TRN/RND, WRAP/SAT, shift >= 8, no accumulator wrap,
-  // and hh*256 + mid + corr/256 provably inside int32
-  const int rs = p.in.F + p.cf.F - p.out.F;
-  // |y| <= 32768 * sum|c| must fit the accumulator (no AC_WRAP event possible) ...
-  const int acc_bits = p.acc.W - (p.acc.S ? 1 : 0) - p.lossless_shift;
-  const bool acc_wide = acc_bits >= 63 || plan.sum_abs * 32768 < (int64_t(1) << (acc_bits > 0 ? acc_bits : 0));
-  // ... and hh*256 + mid + corr/256 + carry must fit int32
-  const int64_t hh_max = 128 * plan.sum_abs_hi, mid_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo), ll_max = 128 * plan.sum_abs_lo;
-  const int64_t rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs <= 38) ? (int64_t(1) << (rs - 1)) : 0;  // rounding constant added with corr
-  const int64_t corr_abs = (plan.corr < 0 ? -plan.corr : plan.corr) + rnd;
-  const bool small = hh_max * 256 + mid_max + corr_abs / 256 + (ll_max + 255) / 256 + 2 < (int64_t(1) << 31) &&
-                     ll_max + corr_abs + 2 < (int64_t(1) << 31);  // v2: corr + rounding constant preloaded into the ll accumulator
-  int epi = 0;
-  if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
-      rs >= 8 && rs <= 38 && acc_wide && small && p.out.W == 16) {
-    epi = p.out.O == ACDSP_SAT ? 2 : 1;
-  }
-  dim3 grid((unsigned)((a.n_blocks + a.chunk_blocks - 1) / a.chunk_blocks), (unsigned)groups);
-  switch (plan.nb) {
-    case 1: return launch_nb<1>(p, plan, d_frag, a, epi, grid, s);
-    case 2: return launch_nb<2>(p, plan, d_frag, a, epi, grid, s);
-    case 3: return launch_nb<3>(p, plan, d_frag, a, epi, grid, s);
-    case 4: return launch_nb<4>(p, plan, d_frag, a, epi, grid, s);
-    case 5: return launch_nb<5>(p, plan, d_frag, a, epi, grid, s);
-    case 6: return launch_nb<6>(p, plan, d_frag, a, epi, grid, s);
-    case 7: return launch_nb<7>(p, plan, d_frag, a, epi, grid, s);
-    case 8: return launch_nb<8>(p, plan, d_frag, a, epi, grid, s);
-    case 9: return launch_nb<9>(p, plan, d_frag, a, epi, grid, s);
+static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  switch (nb) {
+    case 1: return launch_nb<1>(p, d_frag, a, epi, grid, s);
+    case 2: return launch_nb<2>(p, d_frag, a, epi, grid, s);
+    case 3: return launch_nb<3>(p, d_frag, a, epi, grid, s);
+    case 4: return launch_nb<4>(p, d_frag, a, epi, grid, s);
+    case 5: return launch_nb<5>(p, d_frag, a, epi, grid, s);
+    case 6: return launch_nb<6>(p, d_frag, a, epi, grid, s);
+    case 7: return launch_nb<7>(p, d_frag, a, epi, grid, s);
+    case 8: return launch_nb<8>(p, d_frag, a, epi, grid, s);
+    case 9: return launch_nb<9>(p, d_frag, a, epi, grid, s);
     default: return hipErrorInvalidValue;
   }
 }
