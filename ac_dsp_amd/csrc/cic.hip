@@ -39,10 +39,13 @@ template <typename TIN> struct Vec16 {
 template <int N, typename TIN, bool INTERP>
 __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
   constexpr int VE = 16 / (int)sizeof(TIN);             // elements per 16-byte vector
-  constexpr int LPR = kCicTile / VE;                    // lanes that cover one tile row
+  constexpr int LPR = kCicTile / VE;                    // lanes that cover one tile row = load instructions per tile
   constexpr int RPI = 64 / LPR;                         // rows fetched per load instruction
   constexpr int ROWB = kCicTile * (int)sizeof(TIN) + 16;  // padded LDS row (bytes)
+  constexpr int OB = 16;                                // decimator: outputs staged per row before a flush
+  constexpr int OPITCH = OB + 1;                        // int64 words per staged row (conflict-free ds_write_b64)
   __shared__ __attribute__((aligned(16))) unsigned char lds[64 * ROWB];
+  __shared__ int64_t obuf[INTERP ? 1 : 64 * OPITCH];
 
   const int lane = threadIdx.x;
   const int ch0 = blockIdx.y * 64;
@@ -60,7 +63,9 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
 
   // decimator bookkeeping
   int cnt = 0;
-  int64_t j = 0;
+  int64_t j = 0;       // output index of the next emission
+  int ocnt = 0;        // outputs staged since the last flush (same for every lane)
+  int64_t jbase = 0;   // output index of staged slot 0
   if (!INTERP) {
     int64_t m = ((int64_t)p.phase0 + s0) % R;
     cnt = (int)(m < 0 ? m + R : m);
@@ -77,8 +82,22 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
     if (qb > p.q_end) { qb = p.q_end; }
   }
 
-  for (int64_t ts = s0; ts < c_end; ts += kCicTile) {
-    // ---- stage the tile: 64 channel rows x 64 samples ----
+  // Row-coalesced write-out of the staged outputs: 64 consecutive lanes cover 64/OB rows x OB outputs.
+  auto flush = [&](int n_valid) {
+    __syncthreads();
+    for (int idx = lane; idx < 64 * OB; idx += 64) {
+      const int row = idx / OB, col = idx % OB;
+      if (col < n_valid && ch0 + row < p.n_ch) {
+        store_raw(p.y, (int64_t)(ch0 + row) * p.out_stride + jbase + col, p.out_eb, obuf[row * OPITCH + col]);
+      }
+    }
+    __syncthreads();
+  };
+
+  // The tile of step ts is fetched one tile ahead into registers (16-byte coalesced row loads), so
+  // its HBM latency overlaps the serial walk through the previous tile.
+  Vec16<TIN> pre[LPR];
+  auto fetch = [&](int64_t ts) {
 #pragma unroll
     for (int li = 0; li < LPR; li++) {
       const int row = li * RPI + lane / LPR;
@@ -86,85 +105,118 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
       int chr = ch0 + row;
       if (chr >= p.n_ch) { chr = p.n_ch - 1; }
       const int64_t t = ts + col;
-      Vec16<TIN> v;
       if (ts < 0) {
-        v.v = *(const v4i *)((const TIN *)p.hist + (int64_t)chr * p.hl + (p.hl + t));
+        pre[li].v = *(const v4i *)((const TIN *)p.hist + (int64_t)chr * p.hl + (p.hl + t));
       } else {
         const TIN *src = (const TIN *)p.x + (int64_t)chr * p.in_stride + t;
         if (p.vec_ok && t + VE <= p.n_in) {
-          v.v = *(const v4i *)src;
+          pre[li].v = *(const v4i *)src;
         } else {
 #pragma unroll
-          for (int e = 0; e < VE; e++) { v.e[e] = (t + e < p.n_in) ? src[e] : (TIN)0; }
+          for (int e = 0; e < VE; e++) { pre[li].e[e] = (t + e < p.n_in) ? src[e] : (TIN)0; }
         }
       }
-      *(v4i *)(lds + row * ROWB + col * (int)sizeof(TIN)) = v.v;
+    }
+  };
+
+  fetch(s0);
+  for (int64_t ts = s0; ts < c_end; ts += kCicTile) {
+    // ---- stage the tile: 64 channel rows x 64 samples (transposition through padded LDS) ----
+#pragma unroll
+    for (int li = 0; li < LPR; li++) {
+      const int row = li * RPI + lane / LPR;
+      const int col = (lane % LPR) * VE;
+      *(v4i *)(lds + row * ROWB + col * (int)sizeof(TIN)) = pre[li].v;
     }
     __syncthreads();
+    if (ts + kCicTile < c_end) { fetch(ts + kCicTile); }
 
     // ---- every lane walks its own channel row ----
-    for (int k = 0; k < kCicTile; k += VE) {
-      Vec16<TIN> v;
-      v.v = *(const v4i *)(lds + lane * ROWB + k * (int)sizeof(TIN));
+    // Tile-local integer bounds keep the per-sample control flow scalar and cheap:
+    // samples [0, nv) of the tile exist, emissions count from sample index e0 on.
+    const int nv = (c_end - ts < kCicTile) ? (int)(c_end - ts) : kCicTile;
+    const int e0 = (c_start > ts) ? ((c_start - ts < kCicTile) ? (int)(c_start - ts) : kCicTile) : 0;
+    auto sample = [&](TIN raw, int idx) {
+      // (OUT_TYPE) data_in : lossless cast into INT_TYPE, ac_cic_full_core.h:114,147,213
+      uint64_t x;
+      if (sizeof(TIN) == 8) { x = (uint64_t)raw; }
+      else if (p.in.S) { x = (uint64_t)(int64_t)raw; }
+      else if (sizeof(TIN) == 4) { x = (uint64_t)(uint32_t)raw; }
+      else { x = (uint64_t)(uint16_t)raw; }
+      if (!INTERP) {
+        // intStage, ac_cic_full_core.h:80-87
 #pragma unroll
-      for (int e = 0; e < VE; e++) {
-        const int64_t t = ts + k + e;
-        if (t >= c_end) { break; }
-        // (OUT_TYPE) data_in : lossless cast into INT_TYPE, ac_cic_full_core.h:114,147,213
-        uint64_t x;
-        if (sizeof(TIN) == 8) { x = (uint64_t)v.e[e]; }
-        else if (p.in.S) { x = (uint64_t)(int64_t)v.e[e]; }
-        else if (sizeof(TIN) == 4) { x = (uint64_t)(uint32_t)v.e[e]; }
-        else { x = (uint64_t)(uint16_t)v.e[e]; }
-
-        if (!INTERP) {
-          // intStage, ac_cic_full_core.h:80-87
+        for (int i = N - 1; i > 0; i--) { r[i] += r[i - 1]; }
+        r[0] += x;
+        if (cnt == 0) {  // valid = (rate_cnt == 0), :116-120
+          uint64_t val = r[N - 1];
+          if (me2) {  // comb / diffStage, :228-255 (differential delay 2 ...
 #pragma unroll
-          for (int i = N - 1; i > 0; i--) { r[i] += r[i - 1]; }
-          r[0] += x;
-          if (cnt == 0) {  // valid = (rate_cnt == 0), :116-120
-            uint64_t val = r[N - 1];
-#pragma unroll
-            for (int s = 0; s < N; s++) {  // comb / diffStage, :228-255
-              uint64_t o = val - (me2 ? d1[s] : d0[s]);
-              d1[s] = d0[s];
-              d0[s] = val;
+            for (int st = 0; st < N; st++) {
+              uint64_t o = val - d1[st];
+              d1[st] = d0[st];
+              d0[st] = val;
               val = o;
             }
-            if (t >= c_start && ch_ok) {
-              int64_t y = requant64(wrap64((int64_t)val, p.w_int, 1), p.in.F, p.out);
-              store_raw(p.y, (int64_t)ch * p.out_stride + j, p.out_eb, y);
-            }
-            j++;
-          }
-          cnt = (cnt + 1 == R) ? 0 : cnt + 1;  // :130-133
-        } else {
-          // intrDiffCore, :211-216
-          uint64_t val = x;
+          } else {    // ... or 1: wave-uniform, so the delay registers are never selected per lane)
 #pragma unroll
-          for (int s = 0; s < N; s++) {
-            uint64_t o = val - (me2 ? d1[s] : d0[s]);
-            d1[s] = d0[s];
-            d0[s] = val;
-            val = o;
-          }
-          // intrIntgCore, :143-160: the sample, then R-1 stuffed zeros
-          const int64_t qbase = (p.t_prev + t) * R;
-          for (int ph = 0; ph < R; ph++) {
-#pragma unroll
-            for (int i = N - 1; i > 0; i--) { r[i] += r[i - 1]; }
-            r[0] += (ph == 0) ? val : (uint64_t)0;
-            const int64_t q = qbase + ph;
-            if (q >= qa && q < qb && ch_ok) {
-              int64_t y = requant64(wrap64((int64_t)r[N - 1], p.w_int, 1), p.in.F, p.out);
-              store_raw(p.y, (int64_t)ch * p.out_stride + (q - q_base), p.out_eb, y);
+            for (int st = 0; st < N; st++) {
+              uint64_t o = val - d0[st];
+              d0[st] = val;
+              val = o;
             }
+          }
+          if (idx >= e0) {
+            if (ocnt == 0) { jbase = j; }
+            int64_t y;
+            if (p.out_simple == 2) { y = wrap64((int64_t)val, p.w_int, 1); }                               // OUT holds INT_TYPE
+            else if (p.out_simple) { y = wrap64(wrap64((int64_t)val, p.w_int, 1), p.out.W, p.out.S); }  // same F, AC_WRAP
+            else { y = requant64(wrap64((int64_t)val, p.w_int, 1), p.in.F, p.out); }
+            obuf[lane * OPITCH + ocnt] = y;
+            if (++ocnt == OB) { flush(OB); ocnt = 0; }
+          }
+          j++;
+        }
+        cnt = (cnt + 1 == R) ? 0 : cnt + 1;  // :130-133
+      } else {
+        // intrDiffCore, :211-216
+        uint64_t val = x;
+#pragma unroll
+        for (int st = 0; st < N; st++) {
+          uint64_t o = val - (me2 ? d1[st] : d0[st]);
+          d1[st] = d0[st];
+          d0[st] = val;
+          val = o;
+        }
+        // intrIntgCore, :143-160: the sample, then R-1 stuffed zeros
+        const int64_t qbase = (p.t_prev + ts + idx) * R;
+        for (int ph = 0; ph < R; ph++) {
+#pragma unroll
+          for (int i = N - 1; i > 0; i--) { r[i] += r[i - 1]; }
+          r[0] += (ph == 0) ? val : (uint64_t)0;
+          const int64_t q = qbase + ph;
+          if (q >= qa && q < qb && ch_ok) {
+            int64_t y;
+            if (p.out_simple) { y = wrap64(wrap64((int64_t)r[N - 1], p.w_int, 1), p.out.W, p.out.S); }
+            else { y = requant64(wrap64((int64_t)r[N - 1], p.w_int, 1), p.in.F, p.out); }
+            store_raw(p.y, (int64_t)ch * p.out_stride + (q - q_base), p.out_eb, y);
           }
         }
       }
+    };
+    if (nv == kCicTile) {
+      for (int k = 0; k < kCicTile; k += VE) {
+        Vec16<TIN> v;
+        v.v = *(const v4i *)(lds + lane * ROWB + k * (int)sizeof(TIN));
+#pragma unroll
+        for (int e = 0; e < VE; e++) { sample(v.e[e], k + e); }
+      }
+    } else {
+      for (int k = 0; k < nv; k++) { sample(*(const TIN *)(lds + lane * ROWB + k * (int)sizeof(TIN)), k); }
     }
     __syncthreads();
   }
+  if (!INTERP && ocnt > 0) { flush(ocnt); }
 }
 
 template <int N, typename TIN>

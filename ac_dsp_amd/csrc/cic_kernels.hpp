@@ -15,6 +15,7 @@ struct CicParams {
   int32_t hl;                      // history inputs kept per channel (multiple of kCicTile)
   int32_t warm_tiles;              // tiles simulated before a chunk to rebuild the filter memory
   int32_t vec_ok;                  // 16-byte aligned rows: vector loads allowed
+  int32_t out_simple;              // OUT_TYPE has INT_TYPE's fraction and AC_WRAP: conversion is a bit-field wrap
   int64_t in_stride, out_stride, n_in;
   int64_t chunk;                   // inputs per wave chunk (multiple of kCicTile)
   const void *x;                   // inputs  [n_ch][in_stride]

@@ -681,6 +681,7 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
   p.in_eb = h->in_eb; p.out_eb = h->out_eb;
   p.hl = h->hl; p.warm_tiles = h->hl / kCicTile;
   p.vec_ok = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0);
+  p.out_simple = (p.out.F == p.in.F && p.out.O == ACDSP_WRAP) ? ((p.out.S && p.out.W >= h->it.W) ? 2 : 1) : 0;
   p.in_stride = in_stride; p.out_stride = out_stride; p.n_in = n_in;
   p.x = d_in; p.y = d_out; p.hist = h->d_hist[h->cur];
   // chunking: aim at >= 4096 waves, keep the warm-up below ~6 % of a chunk

@@ -181,13 +181,16 @@ def main():
             "config": {"workload": name, "kernel_path": path, "channels_per_gpu": ch_per_gpu, "samples_per_step": n,
                        "parallelism": "channel-slice x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
+                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "cic_dec": "r1_cic_dec"}[args.workload]),
+                         "algorithmic_bytes_per_launch": bytes_per_sample * samples_per_step, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
                          "algorithmic_bytes_per_sample": bytes_per_sample},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
         }
         if macs_per_sample:
             tops = 2.0 * macs_per_sample * samples_per_step / (k_avg * 1e-3) / 1e12
-            out["mfma_roofline"] = {"bound": "mfma", "achieved": tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8, issued)",
+            out["mfma_roofline"] = {"bound": "mfma", "achieved": tops, "peak": I8_MFMA_PEAK_TOPS,
+                                    "unit": "TOP/s (int8 ops of the dense 4-byte-plane Toeplitz formulation; all-zero high-byte "
+                                            "blocks of the coefficient set are skipped, so fewer are issued)",
                                     "frac": tops / I8_MFMA_PEAK_TOPS}
         if world == 1 and not args.no_cpu_baseline and coeffs is not None:
             out["cpu_baseline"] = cpu_baseline_fir(255, coeffs, fin, fc, fa, fo, seed)
@@ -199,11 +202,46 @@ def main():
 
 
 def host_cores():
-    """Cores this process may actually run on (the box can expose fewer than os.cpu_count())."""
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of the same
+    command (profiles/<tag>_rocprof.txt): FETCH_SIZE (KB, x2 on gfx950 for 16-byte streaming reads, see
+    MI355X_MICROARCH.md) + WRITE_SIZE (KB).  None when no summary has been committed for this workload."""
+    path = os.path.join(ROOT, "profiles", tag + "_rocprof.txt")
+    try:
+        vals = {}
+        kernel = None
+        for line in open(path):
+            if line.startswith("void ") or line.startswith("acdsp::"):
+                kernel = line.strip()
+            f = line.split()
+            if len(f) == 3 and f[0] in ("FETCH_SIZE", "WRITE_SIZE") and kernel and ("fir_mfma" in kernel or "cic_kernel" in kernel):
+                vals[f[0]] = float(f[2])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except OSError:
+        pass
+    return None
 
 
 def timed_threads(work, cores, set_reps):
