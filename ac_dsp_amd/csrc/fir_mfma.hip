@@ -136,7 +136,8 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   int ch = blockIdx.y * WAVES + wave;
   if (ch >= p.n_ch) { ch = p.n_ch - 1; }  // surplus waves redo the last channel (identical stores): barriers stay uniform
   const int set = a.frag_per_channel ? ch : 0;
-  unsigned char *lds = lds_all + wave * (2 * 4 * ARR);
+  unsigned char *lds = lds_all + wave * (2 * 4 * ARR + 2048);
+  unsigned char *obuf = lds + 2 * 4 * ARR;  // 2 KB output tile (FAST path)
 
   v4i Ah[NB], Al[NB];
 #pragma unroll
@@ -184,13 +185,12 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   // epilogue constants
   const int rs = p.in.F + p.cf.F - p.out.F;
   const int64_t corr = a.corr[set];
-  // EPI 1/2: the re-bias correction and the rounding constant ride in as the initial value of the
-  // low-plane accumulator (|corr_t| + |S(cl,xl)| < 2^31 is checked on the host), so the epilogue is
-  //   q = ((hh << 8) + mid + (ll >> 8)) >> (rs - 8)      -- 4 VALU ops per output, then a packing
-  // v_cvt_pk_i16_i32 that also performs the AC_SAT clamp for the 16-bit OUT_TYPE.
+  // EPI 1/2: with C = 128*sum(c) + rounding constant (|C| + |S(cl,xl)| < 2^31 is checked on the host)
+  //   q = ((hh << 8) + mid1 + mid2 + ((ll + C) >> 8)) >> (rs - 8)
+  // then a packing v_cvt_pk_i16_i32 that also performs the AC_SAT clamp for the 16-bit OUT_TYPE.
+  // The epilogue runs in the O phase, which has issue slack under the partner wave's MFMA run.
   const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
-  const int c_ll = (EPI != 0) ? (int)corr_t : 0;
-  const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
+  const int c_ll = (EPI != 0) ? (int)corr_t : 0;   // added to the low-plane sum in the epilogue (int32-safe, host-checked)
   const int rs8 = rs - 8;
   int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 32 * n_col + 4 * h;  // EPI 1/2
 
@@ -200,52 +200,55 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __builtin_amdgcn_sched_barrier(0);
 
+  // Fragment reads (conflict-free ds_read_b128) run one group of GS K-blocks ahead of the MFMAs that
+  // consume them; sched_barrier(0) pins the "reads of group g+1, then MFMAs of group g" order, which
+  // the scheduler would otherwise re-serialise into read-wait-MFMA per block.  Group 0 of a step is
+  // read at the end of the previous O phase, so its latency hides behind the barrier.
+  constexpr int GS = 3, NG = (NB + GS - 1) / GS;
+  v4i Bh[2][GS], Bl[2][GS];
+  auto read_group = [&](const unsigned char *buf, int g, v4i (&dh)[GS], v4i (&dl)[GS]) {
+    const unsigned char *fh = buf + (0 * 2 + h) * ARR + n_col * 16;
+    const unsigned char *fl = buf + (1 * 2 + h) * ARR + n_col * 16;
+#pragma unroll
+    for (int i = 0; i < GS; i++) {
+      const int b = g * GS + i;
+      if (b < NB) {
+        dh[i] = *(const v4i *)(fh + 16 * b);
+        dl[i] = *(const v4i *)(fl + 16 * b);
+      }
+    }
+  };
+
   // software pipeline: loads run two steps ahead of the MFMAs, staging one step ahead
   issue_loads(s0 * 1024);
   stage(lds);
   if (FAST || nsteps > 1) { issue_loads((s0 + 1) * 1024); }
+  read_group(lds, 0, Bh[0], Bl[0]);
   if (WAVES == 8 && grp == 1) { __builtin_amdgcn_s_barrier(); }  // second half starts one phase later
 
   for (int s = 0; s < nsteps; s++) {
     const int64_t T0 = (s0 + s) * 1024;
-    unsigned char *buf = lds + (s & 1) * (4 * ARR);
+    const unsigned char *buf = lds + (s & 1) * (4 * ARR);
 
-    // ---------------- phase M: fragment reads + MFMA run ----------------
-    v16i hh = {0}, mid = {0}, ll = ll_init;
-    const unsigned char *fh = buf + (0 * 2 + h) * ARR + n_col * 16;
-    const unsigned char *fl = buf + (1 * 2 + h) * ARR + n_col * 16;
-    // Fragment reads (conflict-free ds_read_b128) run one group of GS K-blocks ahead of the MFMAs that
-    // consume them; sched_barrier(0) pins the "reads of group g+1, then MFMAs of group g" order, which
-    // the scheduler would otherwise re-serialise into read-wait-MFMA per block.
-    constexpr int GS = 3, NG = (NB + GS - 1) / GS;
-    v4i Bh[2][GS], Bl[2][GS];
-    auto read_group = [&](int g, v4i (&dh)[GS], v4i (&dl)[GS]) {
-#pragma unroll
-      for (int i = 0; i < GS; i++) {
-        const int b = g * GS + i;
-        if (b < NB) {
-          dh[i] = *(const v4i *)(fh + 16 * b);
-          dl[i] = *(const v4i *)(fl + 16 * b);
-        }
-      }
-    };
-    read_group(0, Bh[0], Bl[0]);
+    // ---------------- phase M: MFMA run (four independent accumulators: every one is reused only
+    // every fourth MFMA, so a single wave keeps the matrix pipe at its 32-cycle issue rate) ----------------
+    v16i hh = {0}, mid1 = {0}, mid2 = {0}, ll = {0};
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       __builtin_amdgcn_sched_barrier(0);
-      if (g + 1 < NG) { read_group(g + 1, Bh[(g + 1) & 1], Bl[(g + 1) & 1]); }
+      if (g + 1 < NG) { read_group(buf, g + 1, Bh[(g + 1) & 1], Bl[(g + 1) & 1]); }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < GS; i++) {
         const int b = g * GS + i;
         if (b < NB) {
-          // a Toeplitz block whose high-byte plane is all zero contributes nothing to hh / mid
+          // a Toeplitz block whose high-byte plane is all zero contributes nothing to hh / mid1
           if (HS == 0 || (b >= HS && b <= NB - 1 - HS)) {
             hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bh[g & 1][i], hh, 0, 0, 0);
-            mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[g & 1][i], mid, 0, 0, 0);
+            mid1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[g & 1][i], mid1, 0, 0, 0);
           }
           ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bl[g & 1][i], ll, 0, 0, 0);
-          mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[g & 1][i], mid, 0, 0, 0);
+          mid2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[g & 1][i], mid2, 0, 0, 0);
         }
       }
     }
@@ -262,8 +265,8 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           const int r = 4 * g + rr;
-          const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid[r]);
-          o[rr] = (A + (ll[r] >> 8)) >> rs8;
+          const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid1[r]);
+          o[rr] = (A + mid2[r] + ((ll[r] + c_ll) >> 8)) >> rs8;
         }
         v4s pk;
         if (EPI == 2) {  // OUT_TYPE is a signed 16-bit AC_SAT type: clamp and pack in one instruction
@@ -275,7 +278,11 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
         }
         int16_t *dst = yrow + T0 + 8 * g;
         if (FAST) {
-          *(v4s *)dst = pk;
+          // stage the 8-byte piece for the row-contiguous write-out below: pair P = 4 n + g holds samples
+          // 32 n + 8 g .. +7; its slot is rotated by P >> 4 so that both the ds_write_b64 here and the
+          // ds_read_b128 there are bank-conflict free
+          const int P = 4 * n_col + g;
+          *(v4s *)(obuf + (((P & ~15) | ((P + (P >> 4)) & 15)) * 16 + 8 * h)) = pk;
         } else if (a.out_vec_ok && t0 + 4 <= p.n) {
           *(v4s *)dst = pk;
         } else {
@@ -288,16 +295,28 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           const int r = 4 * g + rr;
-          int64_t v = ((int64_t)hh[r] << 16) + ((int64_t)mid[r] << 8) + (int64_t)ll[r] + corr;
+          int64_t v = ((int64_t)hh[r] << 16) + (((int64_t)mid1[r] + (int64_t)mid2[r]) << 8) + (int64_t)ll[r] + corr;
           int64_t acc = wrap64((int64_t)((uint64_t)v << p.lossless_shift), p.acc.W, p.acc.S);
           int64_t y = requant64(acc, p.acc.F, p.out);
           if (t0 + rr < p.n) { store_raw(p.y, (int64_t)ch * p.out_stride + t0 + rr, p.out_eb, y); }
         }
       }
     }
+    if (FAST && EPI != 0) {
+      // 1024 outputs = 2 KB contiguous: two fully coalesced 16-byte-per-lane stores (8 whole 128-byte
+      // lines each) instead of four 8-byte scatters that L2 has to merge
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int P = 64 * half + lane;
+        const v4i val = *(const v4i *)(obuf + ((P & ~15) | ((P + (P >> 4)) & 15)) * 16);
+        *(v4i *)((int16_t *)p.y + (int64_t)ch * p.out_stride + T0 + 512 * half + 8 * lane) = val;
+      }
+    }
     if (s + 1 < nsteps) {
-      stage(lds + ((s + 1) & 1) * (4 * ARR));                           // consumes the loads of step s+1
+      unsigned char *nbuf = lds + ((s + 1) & 1) * (4 * ARR);
+      stage(nbuf);                                                      // consumes the loads of step s+1
       if (FAST || s + 2 < nsteps) { issue_loads(T0 + 2048); }           // FAST: a fetch past the chunk is clamped, harmless
+      read_group(nbuf, 0, Bh[0], Bl[0]);
     }
     if (WAVES == 8 && (grp == 0 || s + 1 < nsteps)) { __builtin_amdgcn_s_barrier(); }
   }
@@ -306,7 +325,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 template <int NB, int EPI, int HS, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES, 2)
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * 2 * 4 * (32 + NB - 1) * 16];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * (32 + NB - 1) * 16 + 2048)];
   const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
   const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n;

@@ -264,3 +264,39 @@ def test_config2_full_size_properties():
     y2 = firw.run(x2); firw.reset()
     y12 = firw.run(x1 + x2)
     assert torch.equal(y12, y1 + y2)
+
+
+def test_config4_shape_1023_taps_prog_coeffs():
+    """BASELINE config 4 shape (ac_fir_prog_coeffs, 1023 taps, <16,2>, ACC <42,14>) at a reduced size."""
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
+    c = windowed_sinc(1023, 0.05, fc)
+    check_case(1023, "SHIFT_REG", fin, fc, fa, A.Fmt(16, 2, True, "RND", "SAT"), n_ch=5, n=3000, kind="prog", coeffs=c,
+               splits=[1, 1500])
+    check_case(1023, "FOLD_ODD", fin, fc, fa, fa, n_ch=2, n=1200, kind="prog", coeffs=c)
+
+
+def test_config5_ddc_cascade_cic_then_fir():
+    """BASELINE config 5 shape: ac_cic_dec_full R=16 N=5 on <16,1> -> INT <36,21> -> 127-tap
+    ac_fir_const_coeffs with IN=<36,21>, COEFF=<16,1>; I and Q are two real streams (the CIC takes plain
+    ac_fixed only, ac_cic_dec_full.h:76).  The engine output of the cascade must equal the oracle cascade."""
+    from oracle import OracleCic
+    cin = A.Fmt(16, 1)
+    cic = A.Cic(False, 16, 1, 5, cin, cin, n_channels=6)
+    it = cic.int_type
+    assert (it.W, it.I) == (36, 21)
+    mid = A.Fmt(it.W, it.I)
+    fc, fa, fo = A.Fmt(16, 1), A.Fmt(60, 30), A.Fmt(24, 9, True, "RND", "SAT")
+    c = windowed_sinc(127, 0.2, fc)
+    n_ch, n = 6, 16 * 700            # 3 complex channels = 6 real streams
+    x = stimulus(0xDDC, n_ch, n, 16)
+    cic = A.Cic(False, 16, 1, 5, cin, mid, n_channels=n_ch)
+    fir = A.Fir(127, "SHIFT_REG", mid, fc, fa, fo, n_channels=n_ch, kind="const")
+    fir.set_coeffs(c)
+    oc = OracleCic(0, 16, 1, 5, ofmt(cin), ofmt(mid), n_ch=n_ch)
+    of = OracleFir(127, "SHIFT_REG", ofmt(mid), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    for a, b in ((0, 16 * 300), (16 * 300, n)):      # two bursts: both stages carry state
+        xd = torch.from_numpy(x[:, a:b].copy()).to(torch.int16).cuda()
+        u = cic.run(xd)                               # int64 containers (36-bit words)
+        y = fir.run(u.contiguous()).cpu().numpy().astype(np.int64)
+        yo = of.run(c, oc.run(x[:, a:b]))
+        assert np.array_equal(y, yo)

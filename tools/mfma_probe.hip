@@ -5,6 +5,7 @@
 //   mode 2: + v_perm byte-plane split of a fresh operand each step
 //   mode 3: + global loads (prefetch) and stores, FIR-like addressing (HBM-sized footprint: 32 channel groups)
 //   mode 4: mode 3 without the stores     mode 5: mode 3 without the loads
+//   mode 6: mode 0 with FOUR accumulators (the two middle products kept apart)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -56,17 +57,18 @@ __global__ void __launch_bounds__(64, WPS) probe(const v4i *__restrict__ frag, c
           for (int k = 0; k < KPF; k++) { pa[k] = *(const v4i *)(src + k * 32); pb[k] = *(const v4i *)(src + k * 32 + 8); }
         }
       }
-      v16i hh = {0}, mid = {0}, ll = {0};
+      v16i hh = {0}, mid = {0}, ll = {0}, mid2 = {0};
 #pragma unroll
       for (int b = 0; b < NB; b++) {
         const int slot = (u + 1 + b) % NB;
         hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xh[slot], hh, 0, 0, 0);
         mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xl[slot], mid, 0, 0, 0);
         ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xl[slot], ll, 0, 0, 0);
-        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[slot], mid, 0, 0, 0);
+        if (MODE == 6) { mid2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[slot], mid2, 0, 0, 0); }
+        else { mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[slot], mid, 0, 0, 0); }
       }
-      if (MODE == 0) {
-        sink += hh[0] + mid[5] + ll[15];
+      if (MODE == 0 || MODE == 6) {
+        sink += hh[0] + mid[5] + ll[15] + mid2[3];
       } else {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -124,18 +126,10 @@ int main() {
     for (size_t i = 0; i < hx.size(); i++) { hx[i] = (short)((i * 2654435761u) >> 11); }
     for (long off = 0; off + (long)hx.size() <= 1025 * stride; off += hx.size()) { CK(hipMemcpy(x + off, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); }
   }
-  run<9, 0, 2>("mfma only, 2 waves/SIMD", 2048, 512, frag, x, y, stride);
-  run<9, 0, 1>("mfma only, 1 wave/SIMD", 1024, 512, frag, x, y, stride);
-  run<9, 1, 2>("mfma+epilogue, 2 w/SIMD", 2048, 512, frag, x, y, stride);
+  run<9, 0, 2>("mfma only, 3 acc, 2 waves/SIMD", 2048, 512, frag, x, y, stride);
+  run<9, 0, 1>("mfma only, 3 acc, 1 wave/SIMD", 1024, 512, frag, x, y, stride);
+  run<9, 6, 2>("mfma only, 4 acc, 2 waves/SIMD", 2048, 512, frag, x, y, stride);
+  run<9, 6, 1>("mfma only, 4 acc, 1 wave/SIMD", 1024, 512, frag, x, y, stride);
   run<9, 1, 1>("mfma+epilogue, 1 w/SIMD", 1024, 512, frag, x, y, stride);
-  run<9, 2, 2>("mfma+epi+split, 2 w/SIMD", 2048, 512, frag, x, y, stride);
-  run<9, 2, 1>("mfma+epi+split, 1 w/SIMD", 1024, 512, frag, x, y, stride);
-  run<9, 3, 2>("full mix, 2 w/SIMD, 4096 waves", 4096, 256, frag, x, y, stride);
-  run<9, 4, 2>("loads only, 4096 waves", 4096, 256, frag, x, y, stride);
-  run<9, 5, 2>("stores only, 4096 waves", 4096, 256, frag, x, y, stride);
-  run<9, 3, 1>("full mix, 1 w/SIMD, 4096 waves", 4096, 256, frag, x, y, stride);
-  run<9, 4, 1, 3>("loads only, 1w, group of 3 blocks", 4096, 256, frag, x, y, stride);
-  run<9, 4, 1, 9>("loads only, 1w, group of 9 blocks", 4096, 256, frag, x, y, stride);
-  run<9, 3, 1, 9>("full mix, 1w, group of 9 blocks", 4096, 256, frag, x, y, stride);
   return 0;
 }
