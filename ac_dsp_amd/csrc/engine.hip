@@ -337,7 +337,10 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
     }
   }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_coeffs, n_sets * desc->n_taps * sizeof(int64_t)); }
-  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_frag, n_sets * sizeof(uint32_t) * 2 * (size_t)fir_mfma_max_blocks() * 64 * 4); }
+  {
+    const int nbk = (desc->n_taps - 1 + 31) / 32 + 1;
+    if (e == hipSuccess) { e = hipMalloc((void **)&h->d_frag, n_sets * sizeof(uint32_t) * 2 * (size_t)(nbk > 0 ? nbk : 1) * 64 * 4); }
+  }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_corr, n_sets * sizeof(int64_t)); }
   if (e != hipSuccess || h->tm.init() != ACDSP_OK) {
     acdsp_fir_destroy(h);
@@ -385,7 +388,7 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   const bool i16_in = d.in.S ? d.in.W <= 16 : d.in.W <= 15;
   const bool i16_cf = d.coeff.S ? d.coeff.W <= 16 : d.coeff.W <= 15;
   if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && i16_in && i16_cf && d.in.S && h->in_eb == 2 &&
-      (d.n_taps - 1 + 31) / 32 + 1 <= fir_mfma_max_blocks()) {
+      (d.n_taps - 1 + 31) / 32 + 1 <= (d.coeffs_per_channel ? fir_mfma_max_reg_blocks() : fir_mfma_max_blocks())) {
     const int nb = (d.n_taps - 1 + 31) / 32 + 1;
     const size_t per_set = (size_t)2 * nb * 64 * 4;
     std::vector<uint32_t> frag(n_sets * per_set, 0u);

@@ -31,7 +31,7 @@ hipError_t launch_fir_rt_update(const FirParams &p, int64_t *rt_next, hipStream_
 // int8-split MFMA Toeplitz path (fir_mfma.hip)
 struct FirMfmaPlan {
   int32_t nb;                  // 32-sample K blocks per output block = ceil((n_taps-1)/32) + 1
-  uint32_t hi_mask, lo_mask;   // bit b set: Toeplitz block b of the hi / lo coefficient plane is non-zero
+  uint64_t hi_mask, lo_mask;   // bit b set: Toeplitz block b of the hi / lo coefficient plane is non-zero
   int64_t corr;                // 128 * sum(c): undoes the signed re-bias of the low input byte
   int64_t sum_abs;             // sum |c|            (bounds |y|  <= 32768 * sum_abs)
   int64_t sum_abs_hi;          // sum |high byte|    (bounds |S(ch,.)| <= 128 * sum_abs_hi)
@@ -40,7 +40,8 @@ struct FirMfmaPlan {
 // Builds the per-lane A fragments (host side) into frag[2][nb][64][4] dwords; returns false if the
 // coefficient set cannot be split into two signed bytes per tap.
 bool fir_mfma_build_fragments(const int64_t *coeffs, int n_taps, FirMfmaPlan *plan, uint32_t *frag /* host */);
-int fir_mfma_max_blocks();
+int fir_mfma_max_blocks();       // K-blocks the MFMA path can take at all (A fragments in LDS): 33 -> 1025 taps
+int fir_mfma_max_reg_blocks();   // ... with the A fragments register-resident (needed for per-channel coefficient sets): 9
 // One wave = one channel x a time chunk; fragments and corr are per coefficient set:
 // d_frag[n_sets][2][nb][64][4], d_corr[n_sets]; `plan` carries the worst-case bounds over all sets.
 hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag_per_channel, const uint32_t *d_frag,

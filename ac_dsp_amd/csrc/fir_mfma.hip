@@ -53,9 +53,11 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 
-constexpr int kMaxNB = 9;  // register-resident Toeplitz fragments: up to 32*8+1 = 257 taps
+constexpr int kMaxRegNB = 9;  // register-resident Toeplitz fragments: up to 32*8+1 = 257 taps
+constexpr int kMaxNB = 33;    // Toeplitz fragments in LDS (shared coefficient set): up to 1025 taps
 
 int fir_mfma_max_blocks() { return kMaxNB; }
+int fir_mfma_max_reg_blocks() { return kMaxRegNB; }
 
 // Host: build frag[plane][b][lane][4 dwords]; plane 0 = high bytes, 1 = low bytes.
 // Lane l holds row i = l & 31 and the 16 K-positions k = 16*(l>>5) + j, j = 0..15 (the same
@@ -98,7 +100,7 @@ bool fir_mfma_build_fragments(const int64_t *c, int n_taps, FirMfmaPlan *plan, u
           frag[(((size_t)pl * nb + b) * 64 + lane) * 4 + dw] = word;
         }
       }
-      if (any) { (pl == 0 ? plan->hi_mask : plan->lo_mask) |= 1u << b; }
+      if (any) { (pl == 0 ? plan->hi_mask : plan->lo_mask) |= uint64_t(1) << b; }
     }
   }
   return true;
@@ -110,7 +112,8 @@ struct MfmaArgs {
   int64_t n8;              // n rounded up to a multiple of 8 (rows are readable that far)
   int32_t out_vec_ok;
   int32_t frag_per_channel;
-  uint32_t hi_mask, lo_mask;  // bit b: K-block b of the hi / lo coefficient plane has a non-zero entry (any set)
+  uint64_t hi_mask, lo_mask;  // bit b: K-block b of the hi / lo coefficient plane has a non-zero entry (any set)
+  int32_t nb, hb0, hb1;       // big-NB kernel: K-blocks, and the range [hb0, hb1] of non-zero high-byte blocks
   const int64_t *corr;     // [n_sets] 128 * sum(c) per coefficient set
   int64_t *dbg;            // optional: per-wave {shader-clock ticks, 100 MHz real-time ticks} (ACDSP_DEBUG_CLOCK)
 };
@@ -349,12 +352,12 @@ static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const
 }
 
 // Largest instantiated band skip hs (0, 2 or 3) such that every non-zero high-byte block lies in [hs, NB-1-hs].
-static int pick_hs(int nb, uint32_t hi_mask) {
+static int pick_hs(int nb, uint64_t hi_mask) {
   const int cand[2] = {3, 2};
   for (int hs : cand) {
     if (2 * hs >= nb) { continue; }
-    uint32_t band = 0;
-    for (int b = hs; b <= nb - 1 - hs; b++) { band |= 1u << b; }
+    uint64_t band = 0;
+    for (int b = hs; b <= nb - 1 - hs; b++) { band |= uint64_t(1) << b; }
     if ((hi_mask & ~band) == 0) { return hs; }
   }
   return 0;
@@ -366,6 +369,200 @@ static hipError_t launch_nb(const FirParams &p, const uint32_t *d_frag, const Mf
   if (NB >= 7 && hs == 3) { return launch_nb_hs<NB, (NB >= 7 ? 3 : 0), 8>(p, d_frag, a, epi, grid, s); }
   if (NB >= 5 && hs == 2) { return launch_nb_hs<NB, (NB >= 5 ? 2 : 0), 8>(p, d_frag, a, epi, grid, s); }
   return launch_nb_hs<NB, 0, 8>(p, d_frag, a, epi, grid, s);
+}
+
+
+// =============================================================================================
+// Large tap counts (NB = 10 .. 33, e.g. the 1023-tap configuration): the 2*NB Toeplitz fragments no
+// longer fit the register file, so they live in LDS (2 KB per K-block, one shared coefficient set per
+// launch) and are read next to the data fragments: four ds_read_b128 per four MFMAs, ~50 % of the LDS
+// bandwidth.  Same one-channel-per-wave mapping, same 8-wave ping-pong, run-time K loop.
+// =============================================================================================
+template <int EPI, bool FAST>
+__device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
+                                                  unsigned char *lds_all) {
+  const int NB = a.nb;
+  const int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, ARR = NC * 16;
+  constexpr int JN = 4;   // NP <= 256
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = wave >> 2;
+  const int n_col = lane & 31, h = lane >> 5;
+  int ch = blockIdx.y * 8 + wave;
+  if (ch >= p.n_ch) { ch = p.n_ch - 1; }
+  // LDS: [A fragments: 2 planes x NB x 1 KB][per wave: 2 x 4 arrays x ARR staging + 2 KB output tile]
+  v4i *ldsA = (v4i *)lds_all;
+  const int wave_bytes = 2 * 4 * ARR + 2048;
+  unsigned char *lds = lds_all + 2 * NB * 1024 + wave * wave_bytes;
+  unsigned char *obuf = lds + 2 * 4 * ARR;
+  for (int i = threadIdx.x; i < 2 * NB * 64; i += 512) { ldsA[i] = frag[i]; }
+
+  const int16_t *xrow = (const int16_t *)p.x + (int64_t)ch * p.in_stride;
+  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)ch * p.hl + p.hl;
+  const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
+  const int nsteps = (int)(s1 - s0);
+
+  v4i R[JN];
+  auto issue_loads = [&](int64_t T0) {
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
+      int64_t t = T0 - 32 * HB + 8 * pc;
+      const int16_t *src = (t < 0) ? hrow + t : xrow + ((t < a.n8) ? t : 0);
+      R[j] = *(const v4i *)src;
+    }
+  };
+  auto stage = [&](unsigned char *buf) {
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      const int pc = lane + 64 * j;
+      if (pc < NP) {
+        const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
+        unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
+        unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
+        unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
+        unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        *(v2u *)(buf + (0 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){hi0, hi1};
+        *(v2u *)(buf + (1 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){lo0, lo1};
+      }
+    }
+  };
+
+  const int rs = p.in.F + p.cf.F - p.out.F;
+  const int64_t corr = a.corr[0];
+  const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
+  const int c_ll = (EPI != 0) ? (int)corr_t : 0;
+  const int rs8 = rs - 8;
+  int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 32 * n_col + 4 * h;
+
+  issue_loads(s0 * 1024);
+  __syncthreads();          // A fragments visible to every wave (also drains the first loads: once per chunk)
+  stage(lds);
+  if (FAST || nsteps > 1) { issue_loads((s0 + 1) * 1024); }
+  if (grp == 1) { __builtin_amdgcn_s_barrier(); }
+
+  for (int s = 0; s < nsteps; s++) {
+    const int64_t T0 = (s0 + s) * 1024;
+    const unsigned char *buf = lds + (s & 1) * (4 * ARR);
+    const unsigned char *fh = buf + (0 * 2 + h) * ARR + n_col * 16;
+    const unsigned char *fl = buf + (1 * 2 + h) * ARR + n_col * 16;
+    const v4i *ah = ldsA + lane, *al = ldsA + NB * 64 + lane;
+
+    // ---------------- phase M ----------------
+    v16i hh = {0}, mid1 = {0}, mid2 = {0}, ll = {0};
+    v4i Ahc = ah[0], Alc = al[0], Bhc = *(const v4i *)fh, Blc = *(const v4i *)fl;
+    for (int b = 0; b < NB; b++) {
+      v4i Ahn = Ahc, Aln = Alc, Bhn = Bhc, Bln = Blc;
+      if (b + 1 < NB) {   // fragments of the next K-block are in flight while this one multiplies
+        Ahn = ah[(b + 1) * 64]; Aln = al[(b + 1) * 64];
+        Bhn = *(const v4i *)(fh + 16 * (b + 1)); Bln = *(const v4i *)(fl + 16 * (b + 1));
+      }
+      if (b >= a.hb0 && b <= a.hb1) {
+        hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bhc, hh, 0, 0, 0);
+        mid1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Blc, mid1, 0, 0, 0);
+      }
+      ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Blc, ll, 0, 0, 0);
+      mid2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bhc, mid2, 0, 0, 0);
+      Ahc = Ahn; Alc = Aln; Bhc = Bhn; Blc = Bln;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+
+    // ---------------- phase O ----------------
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int64_t t0 = T0 + 32 * n_col + 8 * g + 4 * h;
+      if (EPI != 0) {
+        int o[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int r = 4 * g + rr;
+          const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid1[r]);
+          o[rr] = (A + mid2[r] + ((ll[r] + c_ll) >> 8)) >> rs8;
+        }
+        v4s pk;
+        if (EPI == 2) {
+          typedef short v2s __attribute__((ext_vector_type(2)));
+          const v2s p0 = __builtin_amdgcn_cvt_pk_i16(o[0], o[1]), p1 = __builtin_amdgcn_cvt_pk_i16(o[2], o[3]);
+          pk = (v4s){p0.x, p0.y, p1.x, p1.y};
+        } else {
+          pk = (v4s){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+        }
+        int16_t *dst = yrow + T0 + 8 * g;
+        if (FAST) {
+          const int P = 4 * n_col + g;
+          *(v4s *)(obuf + (((P & ~15) | ((P + (P >> 4)) & 15)) * 16 + 8 * h)) = pk;
+        } else if (a.out_vec_ok && t0 + 4 <= p.n) {
+          *(v4s *)dst = pk;
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            if (t0 + rr < p.n) { dst[rr] = (int16_t)o[rr]; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int r = 4 * g + rr;
+          int64_t v = ((int64_t)hh[r] << 16) + (((int64_t)mid1[r] + (int64_t)mid2[r]) << 8) + (int64_t)ll[r] + corr;
+          int64_t acc = wrap64((int64_t)((uint64_t)v << p.lossless_shift), p.acc.W, p.acc.S);
+          int64_t y = requant64(acc, p.acc.F, p.out);
+          if (t0 + rr < p.n) { store_raw(p.y, (int64_t)ch * p.out_stride + t0 + rr, p.out_eb, y); }
+        }
+      }
+    }
+    if (FAST && EPI != 0) {
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int P = 64 * half + lane;
+        const v4i val = *(const v4i *)(obuf + ((P & ~15) | ((P + (P >> 4)) & 15)) * 16);
+        *(v4i *)((int16_t *)p.y + (int64_t)ch * p.out_stride + T0 + 512 * half + 8 * lane) = val;
+      }
+    }
+    if (s + 1 < nsteps) {
+      stage(lds + ((s + 1) & 1) * (4 * ARR));
+      if (FAST || s + 2 < nsteps) { issue_loads(T0 + 2048); }
+    }
+    if (grp == 0 || s + 1 < nsteps) { __builtin_amdgcn_s_barrier(); }
+  }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 2)
+fir_mfma_big_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+  const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
+  const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n;
+  if (interior) { fir_mfma_big_body<EPI, true>(p, frag, a, lds_dyn); }
+  else { fir_mfma_big_body<EPI, false>(p, frag, a, lds_dyn); }
+}
+
+static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArgs a, int epi, dim3 grid, hipStream_t s) {
+  const int nb = a.nb;
+  // contiguous range of non-zero high-byte blocks
+  a.hb0 = 0; a.hb1 = nb - 1;
+  if (epi) {
+    if (a.hi_mask == 0) { a.hb0 = 1; a.hb1 = 0; }
+    else {
+      while (!((a.hi_mask >> a.hb0) & 1)) { a.hb0++; }
+      while (!((a.hi_mask >> a.hb1) & 1)) { a.hb1--; }
+    }
+  }
+  const size_t lds_bytes = (size_t)2 * nb * 1024 + 8 * ((size_t)2 * 4 * (32 + nb - 1) * 16 + 2048);
+  hipError_t e = hipSuccess;
+  if (epi == 1) {
+    e = hipFuncSetAttribute((const void *)fir_mfma_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big_kernel<1>), grid, dim3(512), lds_bytes, s, p, (const v4i *)d_frag, a); }
+  } else if (epi == 2) {
+    e = hipFuncSetAttribute((const void *)fir_mfma_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big_kernel<2>), grid, dim3(512), lds_bytes, s, p, (const v4i *)d_frag, a); }
+  } else {
+    e = hipFuncSetAttribute((const void *)fir_mfma_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big_kernel<0>), grid, dim3(512), lds_bytes, s, p, (const v4i *)d_frag, a); }
+  }
+  return e != hipSuccess ? e : hipGetLastError();
 }
 
 // Can the all-32-bit epilogue be used for this plan / type combination?  0: no, 1: WRAP, 2: SAT
@@ -405,6 +602,7 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   a.frag_per_channel = frag_per_channel;
   a.hi_mask = plan.hi_mask;
   a.lo_mask = plan.lo_mask;
+  a.nb = plan.nb; a.hb0 = 0; a.hb1 = plan.nb - 1;
   a.corr = d_corr;
   dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)((p.n_ch + 7) / 8));
   a.dbg = nullptr;
@@ -426,6 +624,7 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
 }
 
 static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  if (nb > kMaxRegNB) { return launch_big(p, d_frag, a, epi, grid, s); }
   switch (nb) {
     case 1: return launch_nb<1>(p, d_frag, a, epi, grid, s);
     case 2: return launch_nb<2>(p, d_frag, a, epi, grid, s);

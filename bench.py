@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "cic_dec"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir1023", "cic_dec"])
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -96,13 +96,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     seed = 0xACD5
 
-    if args.workload in ("fir255", "fir255_dense"):
-        n_taps = 255
+    if args.workload in ("fir255", "fir255_dense", "fir1023"):
+        n_taps = 1023 if args.workload == "fir1023" else 255
         ch_per_gpu = args.channels or 1024
         n = args.samples or (1 << 20)
         fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
         fo = A.Fmt(16, 2, True, "RND", "SAT")
-        if args.workload == "fir255":
+        if args.workload == "fir1023":     # BASELINE configs[3]: ac_fir_prog_coeffs, 1023 taps, ACC <42,14>, 1024 ch per GPU
+            fa = A.Fmt(42, 14)
+            coeffs = windowed_sinc_raw(n_taps, 0.05, fc.F)
+        elif args.workload == "fir255":
             coeffs = windowed_sinc_raw(n_taps, 0.1, fc.F)  # symmetric windowed sinc, sum|c| < 2
         else:  # every Toeplitz byte-plane block populated
             coeffs = np.random.default_rng(1).integers(-32768, 32640, size=n_taps, dtype=np.int64)
@@ -116,6 +119,9 @@ def main():
         macs_per_sample = 4.0 * 32 * eng_nb(n_taps)  # int8 MACs issued: 4 byte-plane products x padded band
         name = "ac_fir_load_coeffs 255-tap ac_fixed<16,2> -> <16,2,RND,SAT>, ACC <40,12>, %d ch x %d samples per GPU " \
                "(BASELINE configs[1])" % (ch_per_gpu, n)
+        if args.workload == "fir1023":
+            name = "ac_fir_prog_coeffs 1023-tap ac_fixed<16,2> -> <16,2,RND,SAT>, ACC <42,14>, %d ch x %d samples per GPU " \
+                   "(BASELINE configs[3])" % (ch_per_gpu, n)
         dtype = "int16 (exact: int8-split MFMA, int32 accumulate)"
 
         def step():
@@ -181,7 +187,7 @@ def main():
             "config": {"workload": name, "kernel_path": path, "channels_per_gpu": ch_per_gpu, "samples_per_step": n,
                        "parallelism": "channel-slice x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "cic_dec": "r1_cic_dec"}[args.workload]),
+                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec"}[args.workload]),
                          "algorithmic_bytes_per_launch": bytes_per_sample * samples_per_step, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
                          "algorithmic_bytes_per_sample": bytes_per_sample},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
@@ -193,7 +199,7 @@ def main():
                                             "blocks of the coefficient set are skipped, so fewer are issued)",
                                     "frac": tops / I8_MFMA_PEAK_TOPS}
         if world == 1 and not args.no_cpu_baseline and coeffs is not None:
-            out["cpu_baseline"] = cpu_baseline_fir(255, coeffs, fin, fc, fa, fo, seed)
+            out["cpu_baseline"] = cpu_baseline_fir(n_taps, coeffs, fin, fc, fa, fo, seed)
         elif world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_cic(fin, fo, seed)
         print(json.dumps(out), flush=True)

@@ -266,12 +266,23 @@ def test_config2_full_size_properties():
     assert torch.equal(y12, y1 + y2)
 
 
+@pytest.mark.parametrize("n_taps", [258, 300, 511, 800, 1023, 1025])
+def test_mfma_path_large_tap_counts(n_taps):
+    # more than 257 taps: Toeplitz fragments live in LDS (shared coefficient set)
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16)
+    c = np.minimum(rand_raw(np.random.default_rng(n_taps), fc, (n_taps,)), 32639)
+    check_case(n_taps, "SHIFT_REG", fin, fc, fa, A.Fmt(16, 2, True, "RND", "SAT"), n_ch=11, n=2500 + n_taps, coeffs=c,
+               expect_path="mfma_i8", splits=[1024, 1500], seed=n_taps)
+    check_case(n_taps, "C_BUFF", fin, fc, fa, fa, n_ch=3, n=1100 + n_taps, coeffs=windowed_sinc(n_taps, 0.07, fc),
+               expect_path="mfma_i8")
+
+
 def test_config4_shape_1023_taps_prog_coeffs():
     """BASELINE config 4 shape (ac_fir_prog_coeffs, 1023 taps, <16,2>, ACC <42,14>) at a reduced size."""
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
     c = windowed_sinc(1023, 0.05, fc)
     check_case(1023, "SHIFT_REG", fin, fc, fa, A.Fmt(16, 2, True, "RND", "SAT"), n_ch=5, n=3000, kind="prog", coeffs=c,
-               splits=[1, 1500])
+               splits=[1, 1500], expect_path="mfma_i8")
     check_case(1023, "FOLD_ODD", fin, fc, fa, fa, n_ch=2, n=1200, kind="prog", coeffs=c)
 
 
