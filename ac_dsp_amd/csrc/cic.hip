@@ -36,13 +36,15 @@ template <typename TIN> struct Vec16 {
   union { v4i v; TIN e[16 / sizeof(TIN)]; };
 };
 
-template <int N, typename TIN, bool INTERP>
+template <int N, typename TIN, bool INTERP, int ME>
 __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
   constexpr int VE = 16 / (int)sizeof(TIN);             // elements per 16-byte vector
   constexpr int LPR = kCicTile / VE;                    // lanes that cover one tile row = load instructions per tile
   constexpr int RPI = 64 / LPR;                         // rows fetched per load instruction
-  constexpr int ROWB = kCicTile * (int)sizeof(TIN) + 16;  // padded LDS row (bytes)
-  constexpr int OB = 16;                                // decimator: outputs staged per row before a flush
+  // LDS tile [64 rows][64 samples] with a row pitch of 64*sizeof(TIN)+4 bytes (== 1 dword mod 32): the
+  // per-sample column read of lane c (row c) is bank-conflict free for every container width
+  constexpr int ROWB = kCicTile * (int)sizeof(TIN) + 4;
+  constexpr int OB = 16;                                // decimator: outputs staged per row before a flush (128-byte row segments; 8 and 32 measured slower)
   constexpr int OPITCH = OB + 1;                        // int64 words per staged row (conflict-free ds_write_b64)
   __shared__ __attribute__((aligned(16))) unsigned char lds[64 * ROWB];
   __shared__ int64_t obuf[INTERP ? 1 : 64 * OPITCH];
@@ -55,11 +57,12 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
   const int64_t c_end = (c_start + p.chunk < p.n_in) ? c_start + p.chunk : p.n_in;
   const int64_t s0 = c_start - (int64_t)p.warm_tiles * kCicTile;  // >= -hl
   const int R = p.R;
-  const bool me2 = p.me == 2;
 
-  uint64_t r[N], d0[N], d1[N];
+  uint64_t r[N], d0[N], d1[ME == 2 ? N : 1];
 #pragma unroll
-  for (int i = 0; i < N; i++) { r[i] = 0; d0[i] = 0; d1[i] = 0; }
+  for (int i = 0; i < N; i++) { r[i] = 0; d0[i] = 0; }
+#pragma unroll
+  for (int i = 0; i < (ME == 2 ? N : 1); i++) { d1[i] = 0; }
 
   // decimator bookkeeping
   int cnt = 0;
@@ -119,6 +122,32 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
     }
   };
 
+  // (OUT_TYPE) data_in : lossless cast of one staged sample into INT_TYPE, ac_cic_full_core.h:114,147,213
+  auto load_x = [&](int k) -> uint64_t {
+    const TIN raw = *(const TIN *)(lds + lane * ROWB + k * (int)sizeof(TIN));
+    if (sizeof(TIN) == 8) { return (uint64_t)raw; }
+    if (p.in.S) { return (uint64_t)(int64_t)raw; }
+    if (sizeof(TIN) == 4) { return (uint64_t)(uint32_t)raw; }
+    return (uint64_t)(uint16_t)raw;
+  };
+  auto out_word = [&](uint64_t val) -> int64_t {
+    if (p.out_simple == 2) { return wrap64((int64_t)val, p.w_int, 1); }                               // OUT holds INT_TYPE
+    if (p.out_simple) { return wrap64(wrap64((int64_t)val, p.w_int, 1), p.out.W, p.out.S); }         // same F, AC_WRAP
+    return requant64(wrap64((int64_t)val, p.w_int, 1), p.in.F, p.out);
+  };
+  // comb / diffStage, ac_cic_full_core.h:228-255, differential delay ME = min(M, 2)
+  auto comb = [&](uint64_t val) -> uint64_t {
+#pragma unroll
+    for (int st = 0; st < N; st++) {
+      uint64_t o;
+      if (ME == 2) { o = val - d1[st]; d1[st] = d0[st]; }
+      else { o = val - d0[st]; }
+      d0[st] = val;
+      val = o;
+    }
+    return val;
+  };
+
   fetch(s0);
   for (int64_t ts = s0; ts < c_end; ts += kCicTile) {
     // ---- stage the tile: 64 channel rows x 64 samples (transposition through padded LDS) ----
@@ -126,93 +155,71 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
     for (int li = 0; li < LPR; li++) {
       const int row = li * RPI + lane / LPR;
       const int col = (lane % LPR) * VE;
-      *(v4i *)(lds + row * ROWB + col * (int)sizeof(TIN)) = pre[li].v;
+      int *dst = (int *)(lds + row * ROWB + col * (int)sizeof(TIN));
+      dst[0] = pre[li].v.x; dst[1] = pre[li].v.y; dst[2] = pre[li].v.z; dst[3] = pre[li].v.w;
     }
     __syncthreads();
     if (ts + kCicTile < c_end) { fetch(ts + kCicTile); }
 
     // ---- every lane walks its own channel row ----
-    // Tile-local integer bounds keep the per-sample control flow scalar and cheap:
-    // samples [0, nv) of the tile exist, emissions count from sample index e0 on.
+    // samples [0, nv) of the tile exist; emissions are stored from sample index e0 on (warm-up before)
     const int nv = (c_end - ts < kCicTile) ? (int)(c_end - ts) : kCicTile;
     const int e0 = (c_start > ts) ? ((c_start - ts < kCicTile) ? (int)(c_start - ts) : kCicTile) : 0;
-    auto sample = [&](TIN raw, int idx) {
-      // (OUT_TYPE) data_in : lossless cast into INT_TYPE, ac_cic_full_core.h:114,147,213
-      uint64_t x;
-      if (sizeof(TIN) == 8) { x = (uint64_t)raw; }
-      else if (p.in.S) { x = (uint64_t)(int64_t)raw; }
-      else if (sizeof(TIN) == 4) { x = (uint64_t)(uint32_t)raw; }
-      else { x = (uint64_t)(uint16_t)raw; }
-      if (!INTERP) {
-        // intStage, ac_cic_full_core.h:80-87
+    if (!INTERP) {
+      // The walk is split into runs that end at an emitting sample, so the integrator loop body is
+      // branch-free: intStage (ac_cic_full_core.h:80-87) on every sample, comb + output only at run ends.
+      int k = 0;
+      while (k < nv) {
+        const int to_emit = (cnt == 0) ? 1 : R - cnt + 1;      // samples up to and including the next emitting one
+        const int run = (to_emit < nv - k) ? to_emit : nv - k;
+        int i = 0;
+        for (; i + 8 <= run; i += 8) {       // 8 LDS reads in flight, then 8 branch-free integrator steps
+          uint64_t xs[8];
 #pragma unroll
-        for (int i = N - 1; i > 0; i--) { r[i] += r[i - 1]; }
-        r[0] += x;
-        if (cnt == 0) {  // valid = (rate_cnt == 0), :116-120
-          uint64_t val = r[N - 1];
-          if (me2) {  // comb / diffStage, :228-255 (differential delay 2 ...
+          for (int u = 0; u < 8; u++) { xs[u] = load_x(k + i + u); }
 #pragma unroll
-            for (int st = 0; st < N; st++) {
-              uint64_t o = val - d1[st];
-              d1[st] = d0[st];
-              d0[st] = val;
-              val = o;
-            }
-          } else {    // ... or 1: wave-uniform, so the delay registers are never selected per lane)
+          for (int u = 0; u < 8; u++) {
 #pragma unroll
-            for (int st = 0; st < N; st++) {
-              uint64_t o = val - d0[st];
-              d0[st] = val;
-              val = o;
-            }
+            for (int q = N - 1; q > 0; q--) { r[q] += r[q - 1]; }
+            r[0] += xs[u];
           }
-          if (idx >= e0) {
+        }
+        for (; i < run; i++) {
+          const uint64_t x = load_x(k + i);
+#pragma unroll
+          for (int q = N - 1; q > 0; q--) { r[q] += r[q - 1]; }
+          r[0] += x;
+        }
+        k += run;
+        if (run == to_emit) {                                   // valid = (rate_cnt == 0), :116-120
+          const uint64_t val = comb(r[N - 1]);
+          if (k - 1 >= e0) {
             if (ocnt == 0) { jbase = j; }
-            int64_t y;
-            if (p.out_simple == 2) { y = wrap64((int64_t)val, p.w_int, 1); }                               // OUT holds INT_TYPE
-            else if (p.out_simple) { y = wrap64(wrap64((int64_t)val, p.w_int, 1), p.out.W, p.out.S); }  // same F, AC_WRAP
-            else { y = requant64(wrap64((int64_t)val, p.w_int, 1), p.in.F, p.out); }
-            obuf[lane * OPITCH + ocnt] = y;
+            obuf[lane * OPITCH + ocnt] = out_word(val);
             if (++ocnt == OB) { flush(OB); ocnt = 0; }
           }
           j++;
+          cnt = (R == 1) ? 0 : 1;                               // :130-133
+        } else {
+          cnt += run;
         }
-        cnt = (cnt + 1 == R) ? 0 : cnt + 1;  // :130-133
-      } else {
+      }
+    } else {
+      for (int k = 0; k < nv; k++) {
         // intrDiffCore, :211-216
-        uint64_t val = x;
-#pragma unroll
-        for (int st = 0; st < N; st++) {
-          uint64_t o = val - (me2 ? d1[st] : d0[st]);
-          d1[st] = d0[st];
-          d0[st] = val;
-          val = o;
-        }
+        const uint64_t val = comb(load_x(k));
         // intrIntgCore, :143-160: the sample, then R-1 stuffed zeros
-        const int64_t qbase = (p.t_prev + ts + idx) * R;
+        const int64_t qbase = (p.t_prev + ts + k) * R;
         for (int ph = 0; ph < R; ph++) {
 #pragma unroll
           for (int i = N - 1; i > 0; i--) { r[i] += r[i - 1]; }
           r[0] += (ph == 0) ? val : (uint64_t)0;
           const int64_t q = qbase + ph;
           if (q >= qa && q < qb && ch_ok) {
-            int64_t y;
-            if (p.out_simple) { y = wrap64(wrap64((int64_t)r[N - 1], p.w_int, 1), p.out.W, p.out.S); }
-            else { y = requant64(wrap64((int64_t)r[N - 1], p.w_int, 1), p.in.F, p.out); }
-            store_raw(p.y, (int64_t)ch * p.out_stride + (q - q_base), p.out_eb, y);
+            store_raw(p.y, (int64_t)ch * p.out_stride + (q - q_base), p.out_eb, out_word(r[N - 1]));
           }
         }
       }
-    };
-    if (nv == kCicTile) {
-      for (int k = 0; k < kCicTile; k += VE) {
-        Vec16<TIN> v;
-        v.v = *(const v4i *)(lds + lane * ROWB + k * (int)sizeof(TIN));
-#pragma unroll
-        for (int e = 0; e < VE; e++) { sample(v.e[e], k + e); }
-      }
-    } else {
-      for (int k = 0; k < nv; k++) { sample(*(const TIN *)(lds + lane * ROWB + k * (int)sizeof(TIN)), k); }
     }
     __syncthreads();
   }
@@ -221,8 +228,13 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
 
 template <int N, typename TIN>
 static hipError_t launch_n_t(const CicParams &p, dim3 grid, hipStream_t s) {
-  if (p.interp) { hipLaunchKernelGGL((cic_kernel<N, TIN, true>), grid, dim3(64), 0, s, p); }
-  else { hipLaunchKernelGGL((cic_kernel<N, TIN, false>), grid, dim3(64), 0, s, p); }
+  if (p.interp) {
+    if (p.me == 2) { hipLaunchKernelGGL((cic_kernel<N, TIN, true, 2>), grid, dim3(64), 0, s, p); }
+    else { hipLaunchKernelGGL((cic_kernel<N, TIN, true, 1>), grid, dim3(64), 0, s, p); }
+  } else {
+    if (p.me == 2) { hipLaunchKernelGGL((cic_kernel<N, TIN, false, 2>), grid, dim3(64), 0, s, p); }
+    else { hipLaunchKernelGGL((cic_kernel<N, TIN, false, 1>), grid, dim3(64), 0, s, p); }
+  }
   return hipGetLastError();
 }
 

@@ -74,11 +74,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir1023", "cic_dec"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir1023", "cic_dec", "ddc"])
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pad", type=int, default=0, help="extra elements per row (row stride = samples + pad)")
+    ap.add_argument("--stim-bits", type=int, default=0, help="diagnostic: amplitude of the FIR stimulus in bits (default: full 16)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,7 +114,7 @@ def main():
         eng = A.Fir(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_channels=hi - lo, kind="load", device=local_rank)
         eng.set_coeffs(coeffs)
         x = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
-        A.fill_stimulus(x, seed, 16, ch0=lo)
+        A.fill_stimulus(x, seed, args.stim_bits or 16, ch0=lo)
         y = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
         bytes_per_sample = 4.0                   # 2 B read + 2 B written
         macs_per_sample = 4.0 * 32 * eng_nb(n_taps)  # int8 MACs issued: 4 byte-plane products x padded band
@@ -128,6 +129,34 @@ def main():
             eng.run(x, y)
         path = eng.path
         samples_per_step = (hi - lo) * n
+    elif args.workload == "ddc":
+        # BASELINE configs[4]: CIC R=16 N=5 on ac_fixed<16,1> -> lossless INT <36,21> -> 127-tap FIR (IN <36,21>,
+        # COEFF <16,1>); I and Q are separate real streams, 2048 complex = 4096 real streams per GPU
+        ch_per_gpu = args.channels or 4096
+        n = args.samples or (1 << 20)
+        cin, mid = A.Fmt(16, 1), A.Fmt(36, 21)
+        fc, fa, fo = A.Fmt(16, 1), A.Fmt(60, 30), A.Fmt(24, 9, True, "RND", "SAT")
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        cic = A.Cic(False, 16, 1, 5, cin, mid, n_channels=hi - lo, device=local_rank)
+        eng = A.Fir(127, "SHIFT_REG", mid, fc, fa, fo, n_channels=hi - lo, kind="const", device=local_rank)
+        coeffs = windowed_sinc_raw(127, 0.2, fc.F)
+        eng.set_coeffs(coeffs)
+        x = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
+        A.fill_stimulus(x, seed, 16, ch0=lo)
+        u = torch.empty((hi - lo, n // 16 + 8), dtype=torch.int64, device=dev)
+        y = torch.empty((hi - lo, n // 16 + 8), dtype=torch.int32, device=dev)
+        bytes_per_sample = 2.0 + 4.0 / 16      # 2 B read per real input sample + 4 B written per 16 (intermediate stays on chip ideally)
+        macs_per_sample = 0.0
+        name = "DDC: ac_cic_dec_full R=16 N=5 <16,1> -> 127-tap ac_fir_const_coeffs IN <36,21>, %d real streams x %d samples per GPU " \
+               "(BASELINE configs[4])" % (ch_per_gpu, n)
+        dtype = "int64 (CIC wrap arithmetic, FIR exact dot product)"
+
+        def step():
+            uu = cic.run(x, u)
+            eng.run(uu, y)
+        path = "cic_dec + fir_" + eng.path
+        samples_per_step = (hi - lo) * n
+        coeffs = None
     else:
         ch_per_gpu = args.channels or 4096
         n = args.samples or (1 << 22)
@@ -167,6 +196,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     k_avg, k_min = eng.kernel_stats(min(args.steps, 64))   # HIP events around the dominant kernel, launch stream
+    if args.workload == "ddc":                              # two kernels per step: report their sum
+        c_avg, c_min = cic.kernel_stats(min(args.steps, 64))
+        k_avg, k_min = k_avg + c_avg, k_min + c_min
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -187,7 +219,7 @@ def main():
             "config": {"workload": name, "kernel_path": path, "channels_per_gpu": ch_per_gpu, "samples_per_step": n,
                        "parallelism": "channel-slice x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec"}[args.workload]),
+                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec", "ddc": "r1_ddc"}[args.workload]),
                          "algorithmic_bytes_per_launch": bytes_per_sample * samples_per_step, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
                          "algorithmic_bytes_per_sample": bytes_per_sample},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
@@ -200,7 +232,7 @@ def main():
                                     "frac": tops / I8_MFMA_PEAK_TOPS}
         if world == 1 and not args.no_cpu_baseline and coeffs is not None:
             out["cpu_baseline"] = cpu_baseline_fir(n_taps, coeffs, fin, fc, fa, fo, seed)
-        elif world == 1 and not args.no_cpu_baseline:
+        elif world == 1 and not args.no_cpu_baseline and args.workload == "cic_dec":
             out["cpu_baseline"] = cpu_baseline_cic(fin, fo, seed)
         print(json.dumps(out), flush=True)
     if world > 1:
