@@ -233,6 +233,9 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
     const int64_t T0 = (s0 + s) * 1024;
     const unsigned char *buf = lds + (s & 1) * (4 * ARR);
 
+#ifdef ACDSP_X_PHASES
+    const uint64_t tp0 = __builtin_readcyclecounter();
+#endif
     // ---------------- phase M: MFMA run (four independent accumulators: every one is reused only
     // every fourth MFMA, so a single wave keeps the matrix pipe at its 32-cycle issue rate) ----------------
     v16i hh = {0}, mid1 = {0}, mid2 = {0}, ll = {0};
@@ -256,7 +259,13 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef ACDSP_X_PHASES
+    const uint64_t tp1 = __builtin_readcyclecounter();
+#endif
     if (WAVES == 8) { __builtin_amdgcn_s_barrier(); }
+#ifdef ACDSP_X_PHASES
+    const uint64_t tp2 = __builtin_readcyclecounter();
+#endif
 
     // ---------------- phase O: epilogue, stores, staging of the next step, prefetch ----------------
     // D layout: lane (n_col, h), register r: sample T0 + 32 n_col + (r&3) + 8 (r>>2) + 4 h
@@ -321,7 +330,18 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
       if (FAST || s + 2 < nsteps) { issue_loads(T0 + 2048); }           // FAST: a fetch past the chunk is clamped, harmless
       read_group(nbuf, 0, Bh[0], Bl[0]);
     }
+#ifdef ACDSP_X_PHASES
+    const uint64_t tp3 = __builtin_readcyclecounter();
+#endif
     if (WAVES == 8 && (grp == 0 || s + 1 < nsteps)) { __builtin_amdgcn_s_barrier(); }
+#ifdef ACDSP_X_PHASES
+    if (a.dbg && lane == 0) {
+      const int64_t w = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave;
+      int64_t *d = a.dbg + 2 * (int64_t)gridDim.x * gridDim.y * WAVES + 4 * w;
+      d[0] += (int64_t)(tp1 - tp0); d[1] += (int64_t)(tp2 - tp1); d[2] += (int64_t)(tp3 - tp2);
+      d[3] += (int64_t)(__builtin_readcyclecounter() - tp3);
+    }
+#endif
   }
 }
 
@@ -608,17 +628,27 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   a.dbg = nullptr;
   static const bool dbg_clock = getenv("ACDSP_DEBUG_CLOCK") != nullptr;
   const size_t n_waves = (size_t)grid.x * grid.y * 8;
-  if (dbg_clock) { if (hipMalloc((void **)&a.dbg, n_waves * 16) != hipSuccess) { a.dbg = nullptr; } }
+  if (dbg_clock) { if (hipMalloc((void **)&a.dbg, n_waves * 48) != hipSuccess) { a.dbg = nullptr; } else { (void)hipMemsetAsync(a.dbg, 0, n_waves * 48, s); } }
   hipError_t rc = launch_switch(p, plan.nb, d_frag, a, epi, grid, s);
   if (a.dbg) {
     std::vector<int64_t> hd(2 * n_waves);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(hd.data(), a.dbg, n_waves * 16, hipMemcpyDeviceToHost);
-    (void)hipFree(a.dbg);
     double sc = 0, sr = 0;
     for (size_t i = 0; i < n_waves; i++) { sc += (double)hd[2 * i]; sr += (double)hd[2 * i + 1]; }
     fprintf(stderr, "[acdsp] fir_mfma: %zu waves, mean wave life %.1f us, shader clock %.3f GHz (spw %lld)\n", n_waves,
             sr / n_waves / 100.0, sc / sr * 0.1, (long long)spw);
+#ifdef ACDSP_X_PHASES
+    {
+      std::vector<int64_t> ph(4 * n_waves);
+      (void)hipMemcpy(ph.data(), a.dbg + 2 * n_waves, n_waves * 32, hipMemcpyDeviceToHost);
+      double t[4] = {0, 0, 0, 0};
+      for (size_t i = 0; i < n_waves; i++) { for (int q = 0; q < 4; q++) { t[q] += (double)ph[4 * i + q]; } }
+      const double steps = (double)n_waves * (double)spw;
+      fprintf(stderr, "[acdsp] cycles per step: M %.0f | barrier %.0f | O %.0f | barrier %.0f\n", t[0] / steps, t[1] / steps, t[2] / steps, t[3] / steps);
+    }
+#endif
+    (void)hipFree(a.dbg);
   }
   return rc;
 }

@@ -113,6 +113,70 @@ static void run(const char *name, int waves, int steps, const v4i *frag, const s
          mfma * 2 * 32768 / (ms * 1e-3) / 1e12, cyc_per_mfma_per_simd);
 }
 
+// mode P: software-pipelined: the epilogue VALU of step s-1 is interleaved with the MFMAs of step s
+// (sched_group_barrier: 1 MFMA, then VPM VALU), four accumulators, 1 wave per SIMD.
+template <int NB, int VPM, int WPS>
+__global__ void __launch_bounds__(64, WPS) probe_pipe(const v4i *__restrict__ frag, short *__restrict__ y, int steps) {
+  const int lane = threadIdx.x;
+  v4i Ah[NB], Al[NB], Xh[NB], Xl[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    Ah[b] = frag[b * 64 + lane]; Al[b] = frag[(NB + b) * 64 + lane];
+    Xh[b] = frag[(2 * NB + b) * 64 + lane]; Xl[b] = frag[(3 * NB + b) * 64 + lane];
+  }
+  v16i ph = {0}, pm1 = {0}, pm2 = {0}, pl = {0};   // accumulators of the previous step
+  int sink = 0;
+  for (int s = 0; s < steps; s++) {
+    v16i hh = {0}, m1 = {0}, m2 = {0}, ll = {0};
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xh[b], hh, 0, 0, 0);
+      m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xl[b], m1, 0, 0, 0);
+      ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xl[b], ll, 0, 0, 0);
+      m2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[b], m2, 0, 0, 0);
+    }
+    // epilogue of the previous step (independent of this step's MFMAs)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int A0 = (int)(((unsigned)ph[r] << 8) + (unsigned)pm1[r]);
+      const int A1 = (int)(((unsigned)ph[r + 1] << 8) + (unsigned)pm1[r + 1]);
+      const int q0 = (A0 + pm2[r] + ((pl[r] + 77) >> 8)) >> 6;
+      const int q1 = (A1 + pm2[r + 1] + ((pl[r + 1] + 77) >> 8)) >> 6;
+      typedef short v2s __attribute__((ext_vector_type(2)));
+      const v2s pk = __builtin_amdgcn_cvt_pk_i16(q0, q1);
+      sink += (int)pk.x ^ (int)pk.y;
+    }
+    if (VPM > 0) {
+#pragma unroll
+      for (int i = 0; i < 4 * NB; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);   // VPM VALU
+      }
+    }
+    ph = hh; pm1 = m1; pm2 = m2; pl = ll;
+    Xh[0].x += sink & 1;   // keep the loop honest
+  }
+  if (sink == 0x7fffffff) { y[lane] = (short)(sink + ph[0] + pm1[1] + pm2[2] + pl[3]); }
+  else if (lane == 77) { y[0] = (short)(ph[0] + pm1[1] + pm2[2] + pl[3]); }
+}
+
+template <int NB, int VPM, int WPS>
+static void run_pipe(const char *name, int waves, int steps, const v4i *frag, short *y) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int it = 0; it < 2; it++) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((probe_pipe<NB, VPM, WPS>), dim3(waves), dim3(64), 0, 0, frag, y, steps);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+  }
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  double mfma = (double)waves * steps * NB * 4;
+  printf("%-34s waves %5d steps %4d  %.3f ms  %.1f TOPS  %.1f cyc/MFMA/SIMD@2.4GHz\n", name, waves, steps, ms,
+         mfma * 2 * 32768 / (ms * 1e-3) / 1e12, ms * 1e-3 * 2.4e9 / (mfma / 1024.0));
+}
+
 int main() {
   const int NB = 9;
   std::vector<int> hf(4 * NB * 64 * 4);
@@ -126,10 +190,11 @@ int main() {
     for (size_t i = 0; i < hx.size(); i++) { hx[i] = (short)((i * 2654435761u) >> 11); }
     for (long off = 0; off + (long)hx.size() <= 1025 * stride; off += hx.size()) { CK(hipMemcpy(x + off, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); }
   }
-  run<9, 0, 2>("mfma only, 3 acc, 2 waves/SIMD", 2048, 512, frag, x, y, stride);
-  run<9, 0, 1>("mfma only, 3 acc, 1 wave/SIMD", 1024, 512, frag, x, y, stride);
-  run<9, 6, 2>("mfma only, 4 acc, 2 waves/SIMD", 2048, 512, frag, x, y, stride);
   run<9, 6, 1>("mfma only, 4 acc, 1 wave/SIMD", 1024, 512, frag, x, y, stride);
-  run<9, 1, 1>("mfma+epilogue, 1 w/SIMD", 1024, 512, frag, x, y, stride);
+  run<9, 6, 2>("mfma only, 4 acc, 2 waves/SIMD", 2048, 512, frag, x, y, stride);
+  run_pipe<9, 0, 1>("pipelined epi, no hints, 1 w/SIMD", 1024, 512, frag, y);
+  run_pipe<9, 3, 1>("pipelined epi, 1 MFMA : 3 VALU, 1w", 1024, 512, frag, y);
+  run_pipe<9, 4, 1>("pipelined epi, 1 MFMA : 4 VALU, 1w", 1024, 512, frag, y);
+  run_pipe<9, 4, 2>("pipelined epi, 1 MFMA : 4 VALU, 2w", 2048, 512, frag, y);
   return 0;
 }
