@@ -11,7 +11,7 @@ O_MODES = {"WRAP": 0, "SAT": 1, "SAT_ZERO": 2, "SAT_SYM": 3}
 FTYPES = {"SHIFT_REG": 0, "ROTATE_SHIFT": 1, "C_BUFF": 2, "FOLD_EVEN": 3, "FOLD_ODD": 4, "TRANSPOSED": 5,
           "FOLD_EVEN_ANTI": 6, "FOLD_ODD_ANTI": 7}
 KINDS = {"const": 0, "load": 1, "prog": 2}
-PATHS = {0: "generic", 1: "lossless64", 2: "mfma_i8"}
+PATHS = {0: "generic", 1: "lossless64", 2: "mfma_i8", 3: "mfma_gen"}
 FLAG_FORCE_GENERIC = 1
 
 
@@ -86,6 +86,7 @@ SYMBOLS = {
     "acdsp_cic_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64), _vp]),
     "acdsp_cic_run_host": (_i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "acdsp_cic_reset": (_i32, [_vp]),
+    "acdsp_cic_path": (_i32, [_vp]),
     "acdsp_cic_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "acdsp_cic_kernel_stats": (_i32, [_vp, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }

@@ -147,6 +147,9 @@ struct acdsp_fir {
   int64_t *d_corr = nullptr;    // [n_sets] 128 * sum(c)
   FirMfmaPlan plan;             // worst case over the coefficient sets (bounds for the epilogue choice)
   bool mfma_ok = false;
+  uint32_t *d_gfrag = nullptr;  // fragments of the generalised (wide-input) MFMA kernel
+  FirGenPlan gplan;
+  bool gen_ok = false;
   std::vector<int64_t> h_coeffs;  // last coefficient set (for clone)
   Timer tm;
   Staging st;
@@ -156,6 +159,13 @@ struct acdsp_cic {
   acdsp_cic_desc_t d;
   acdsp_fmt_t it;
   int in_eb, out_eb, hl, me;
+  // decimator through its FIR identity on the matrix cores (fir_gen.hip): taps, and per (first mod 16) plans / fragments
+  std::vector<int64_t> h_taps;
+  bool gen_ok = false;
+  bool gen_have[16] = {false};
+  FirGenPlan gen_plan[16];
+  uint32_t *d_gfrag = nullptr;   // [16][3*8*64*4]
+  int last_path = 0;
   int64_t t_total = 0;  // inputs consumed so far (all calls)
   void *d_hist[2] = {nullptr, nullptr};
   int cur = 0;
@@ -310,7 +320,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   h->d = *desc;
   h->in_eb = elem_bytes(desc->in.W);
   h->out_eb = elem_bytes(desc->out.W);
-  h->hl = round_up(desc->n_taps - 1 > 0 ? desc->n_taps - 1 : 1, 32);
+  h->hl = round_up(desc->n_taps + 15, 32);  // >= n_taps-1 for every kernel, >= n_taps+14 for the 16-aligned windows of fir_gen
   // reg_trans[] carries partial sums computed with the coefficients of their own time; only
   // the const-coefficient class may trade it for an input history.
   h->use_rt = desc->ftype == ACDSP_TRANSPOSED && desc->kind != ACDSP_FIR_CONST;
@@ -342,6 +352,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
     if (e == hipSuccess) { e = hipMalloc((void **)&h->d_frag, n_sets * sizeof(uint32_t) * 2 * (size_t)(nbk > 0 ? nbk : 1) * 64 * 4); }
   }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_corr, n_sets * sizeof(int64_t)); }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_gfrag, 3 * 8 * 64 * 4 * sizeof(uint32_t)); }
   if (e != hipSuccess || h->tm.init() != ACDSP_OK) {
     acdsp_fir_destroy(h);
     return fail(ACDSP_EHIP, "FIR state allocation failed: %s", hipGetErrorString(e));
@@ -360,6 +371,7 @@ int32_t acdsp_fir_destroy(acdsp_fir_t h) {
   if (h->d_coeffs) { (void)hipFree(h->d_coeffs); }
   if (h->d_frag) { (void)hipFree(h->d_frag); }
   if (h->d_corr) { (void)hipFree(h->d_corr); }
+  if (h->d_gfrag) { (void)hipFree(h->d_gfrag); }
   h->tm.destroy();
   h->st.destroy();
   delete h;
@@ -417,8 +429,21 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
       h->mfma_ok = true;
     }
   }
+  // wide inputs (more than 16 bits) / other misses of the int16 kernel: generalised multi-plane MFMA kernel
+  h->gen_ok = false;
+  static const bool no_gen = getenv("ACDSP_NO_GEN") != nullptr;
+  if (!h->mfma_ok && h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && !d.coeffs_per_channel && !no_gen &&
+      (d.in.W + (d.in.S ? 0 : 1) + 7) / 8 <= h->in_eb) {
+    std::vector<int64_t> eff = effective_coeffs(coeffs, d.n_taps, d.ftype);
+    std::vector<uint32_t> gfrag;
+    if (fir_gen_plan(eff.data(), d.n_taps, 1, 0, &h->gplan, &gfrag)) {
+      HIP_TRY(hipMemcpy(h->d_gfrag, gfrag.data(), gfrag.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      h->gen_ok = true;
+    }
+  }
   h->path = h->mfma_ok ? ACDSP_PATH_MFMA_I8
-                       : ((h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC)) ? ACDSP_PATH_LOSSLESS64 : ACDSP_PATH_GENERIC);
+            : h->gen_ok ? ACDSP_PATH_MFMA_GEN
+                        : ((h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC)) ? ACDSP_PATH_LOSSLESS64 : ACDSP_PATH_GENERIC);
   h->coeffs_set = true;
   h->h_coeffs.assign(coeffs, coeffs + n_sets * d.n_taps);
   return ACDSP_OK;
@@ -468,9 +493,14 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
     const bool aligned = ((uintptr_t)d_in % 16 == 0) && (in_stride % 8 == 0);
     if (!aligned) { path = ACDSP_PATH_LOSSLESS64; }
   }
+  if (path == ACDSP_PATH_MFMA_GEN) {   // 16-sample slots: rows must be 16-byte aligned and readable up to the next multiple of 16
+    const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0) && in_stride >= (n + 15) / 16 * 16;
+    if (!aligned) { path = ACDSP_PATH_LOSSLESS64; }
+  }
   HIP_TRY(hipEventRecord(h->tm.start(), s));
   hipError_t e;
   if (path == ACDSP_PATH_MFMA_I8) { e = launch_fir_mfma(k, h->plan, d.coeffs_per_channel, h->d_frag, h->d_corr, s); }
+  else if (path == ACDSP_PATH_MFMA_GEN) { e = launch_fir_gen(k, h->gplan, h->d_gfrag, 0, 0, 0, n, s); }
   else if (path == ACDSP_PATH_LOSSLESS64) { e = launch_fir_lossless64(k, s); }
   else { e = launch_fir_generic(k, s); }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR kernel launch failed: %s", hipGetErrorString(e)); }
@@ -493,7 +523,7 @@ int32_t acdsp_fir_run_host(acdsp_fir_t h, const void *h_in, int64_t n, void *h_o
   if (n == 0) { return ACDSP_OK; }
   int rc = check_device(h->d.device);
   if (rc) { return rc; }
-  const int64_t stride = (n + 7) / 8 * 8;  // keeps rows 16-byte aligned for every container
+  const int64_t stride = (n + 15) / 16 * 16;  // rows 16-byte aligned and readable in whole 16-sample slots
   const size_t bin = (size_t)h->d.n_channels * stride * h->in_eb, bout = (size_t)h->d.n_channels * stride * h->out_eb;
   if ((rc = h->st.ensure(bin, bout))) { return rc; }
   HIP_TRY(hipMemcpy2D(h->st.d_in, (size_t)stride * h->in_eb, h_in, (size_t)n * h->in_eb, (size_t)n * h->in_eb,
@@ -586,12 +616,31 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
   h->out_eb = elem_bytes(desc->out.W);
   h->me = desc->M < 2 ? desc->M : 2;  // effective comb delay of the reference's delay line, see cic.hip
   const int64_t mem = desc->interp ? (int64_t)desc->N * h->me + 1 : (int64_t)desc->N * desc->R * h->me - 1;
-  h->hl = round_up((int)(mem > 1 ? mem : 1), kCicTile);
+  h->hl = round_up((int)(mem > 1 ? mem : 1) + 16, kCicTile);   // + 16: the 16-aligned input windows of fir_gen
   const size_t hb = (size_t)desc->n_channels * h->hl * h->in_eb;
   hipError_t e = hipSuccess;
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     e = hipMalloc(&h->d_hist[i], hb);
     if (e == hipSuccess) { e = hipMemset(h->d_hist[i], 0, hb); }
+  }
+  if (e == hipSuccess && !desc->interp) {
+    // FIR identity of the decimator: h = z^-(N-1) * boxcar(R*M')^N, all arithmetic mod 2^64 (then mod 2^outW)
+    const int L = desc->R * h->me;
+    std::vector<uint64_t> c(1, 1);
+    for (int st = 0; st < desc->N; st++) {
+      std::vector<uint64_t> nx(c.size() + L - 1, 0);
+      for (size_t i = 0; i < c.size(); i++) { for (int j = 0; j < L; j++) { nx[i + j] += c[i]; } }
+      c.swap(nx);
+    }
+    h->h_taps.assign((size_t)desc->N - 1, 0);
+    for (uint64_t v : c) { h->h_taps.push_back((int64_t)v); }
+    FirGenPlan probe;
+    std::vector<uint32_t> fr;
+    static const bool no_gen = getenv("ACDSP_NO_GEN") != nullptr;
+    h->gen_ok = !no_gen && (desc->in.W + (desc->in.S ? 0 : 1) + 7) / 8 <= h->in_eb &&
+                fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), desc->R, 15, &probe, &fr) &&   // worst-case window offset
+                fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), desc->R, 0, &probe, &fr);
+    if (h->gen_ok) { e = hipMalloc((void **)&h->d_gfrag, (size_t)16 * 3 * 8 * 64 * 4 * sizeof(uint32_t)); }
   }
   if (e != hipSuccess || h->tm.init() != ACDSP_OK) {
     acdsp_cic_destroy(h);
@@ -604,6 +653,7 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
 int32_t acdsp_cic_destroy(acdsp_cic_t h) {
   if (!h) { return ACDSP_OK; }
   (void)hipSetDevice(h->d.device);
+  if (h->d_gfrag) { (void)hipFree(h->d_gfrag); }
   for (int i = 0; i < 2; i++) {
     if (h->d_hist[i]) { (void)hipFree(h->d_hist[i]); }
   }
@@ -625,6 +675,8 @@ int32_t acdsp_cic_clone(acdsp_cic_t h, acdsp_cic_t *out) {
   *out = c;
   return ACDSP_OK;
 }
+
+int32_t acdsp_cic_path(acdsp_cic_t h) { return h ? h->last_path : -1; }
 
 int32_t acdsp_cic_reset(acdsp_cic_t h) {
   if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
@@ -693,8 +745,38 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
   const int64_t floor_chunk = (int64_t)16 * h->hl > 1024 ? (int64_t)16 * h->hl : 1024;
   if (chunk < floor_chunk) { chunk = floor_chunk; }
   p.chunk = (chunk + kCicTile - 1) / kCicTile * kCicTile;
+  // decimator on the matrix cores when the FIR identity fits and the rows are slot-aligned
+  bool use_gen = h->gen_ok && !d.interp && p.vec_ok && in_stride >= (n_in + 15) / 16 * 16;
+  const uint32_t *gfrag = nullptr;
+  FirGenPlan gpl;
+  if (use_gen) {
+    const int fm = (int)(p.first % 16);
+    if (!h->gen_have[fm]) {
+      std::vector<uint32_t> fr;
+      if (!fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), d.R, fm, &h->gen_plan[fm], &fr)) { use_gen = false; }
+      else {
+        HIP_TRY(hipMemcpyAsync(h->d_gfrag + (size_t)fm * 3 * 8 * 64 * 4, fr.data(), fr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));   // fr is a stack vector
+        h->gen_have[fm] = true;
+      }
+    }
+    if (use_gen) { gfrag = h->d_gfrag + (size_t)fm * 3 * 8 * 64 * 4; gpl = h->gen_plan[fm]; }
+  }
+  h->last_path = use_gen ? ACDSP_PATH_MFMA_GEN : 0;
   HIP_TRY(hipEventRecord(h->tm.start(), s));
-  hipError_t e = launch_cic(p, s);
+  hipError_t e;
+  if (use_gen) {
+    FirParams k;
+    memset(&k, 0, sizeof k);
+    k.n_ch = d.n_channels;
+    k.in = p.in; k.out = p.out; k.acc = p.out; k.cf = p.in;
+    k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl;
+    k.in_stride = in_stride; k.out_stride = out_stride; k.n = n_in;
+    k.x = d_in; k.y = d_out; k.hist = h->d_hist[h->cur];
+    e = launch_fir_gen(k, gpl, gfrag, 1, h->it.W, p.first, no, s);
+  } else {
+    e = launch_cic(p, s);
+  }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "CIC kernel launch failed: %s", hipGetErrorString(e)); }
   HIP_TRY(hipEventRecord(h->tm.stop(), s));
   h->tm.commit();
@@ -714,7 +796,7 @@ int32_t acdsp_cic_run_host(acdsp_cic_t h, const void *h_in, int64_t n_in, void *
   if (no > out_cap || (no > 0 && !h_out)) { return fail(ACDSP_EINVAL, "cic_run_host: output capacity %lld < %lld", (long long)out_cap, (long long)no); }
   int rc = check_device(h->d.device);
   if (rc) { return rc; }
-  const int64_t si = (n_in + 7) / 8 * 8, so = (no + 7) / 8 * 8 + 8;
+  const int64_t si = (n_in + 15) / 16 * 16, so = (no + 7) / 8 * 8 + 8;
   if ((rc = h->st.ensure((size_t)h->d.n_channels * si * h->in_eb, (size_t)h->d.n_channels * so * h->out_eb))) { return rc; }
   HIP_TRY(hipMemcpy2D(h->st.d_in, (size_t)si * h->in_eb, h_in, (size_t)n_in * h->in_eb, (size_t)n_in * h->in_eb,
                       (size_t)h->d.n_channels, hipMemcpyHostToDevice));

@@ -1,0 +1,272 @@
+// fir_gen.hip -- generalised exact FIR on the matrix cores: wide inputs, wide coefficients, decimation.
+//
+//     y[m] = sum_k h[k] * x[first + m*R - k]   (mod 2^64),   m = 0, 1, ...
+//
+// with x in 1..8 byte planes (16/32/64-bit containers), h in 1..4 balanced base-256 digit planes and an
+// integer decimation factor R.  It serves
+//   * the lossless FIR class for inputs wider than 16 bits (e.g. the 36-bit CIC output feeding the
+//     DDC's 127-tap ac_fir_const_coeffs: reference ac_fir_const_coeffs.h:190-199 with IN = <36,21>),
+//   * the CIC decimator through its FIR identity  H(z) = z^-(N-1) (1 + ... + z^-(R*M'-1))^N  taken
+//     mod 2^outW (reference ac_cic_full_core.h:80-135,198-255; identity checked in
+//     tests/test_oracle.py::test_cic_closed_form_fir_identity): the N wide adds per input sample of
+//     intStage become a handful of int8 MFMAs per 256 outputs.
+//
+// Mapping (v_mfma_i32_16x16x64_i8).  One wave = one channel x a chunk of steps; a step is 256 outputs:
+// column n = output block m0+16n .. +15, row i = output inside the block.  With W_n = the 16-aligned
+// start of column n's input window (W_n = W_0 + 16*R*n) and off = T_n - W_n (constant),
+//     D[i][n] = sum_kappa A[i][kappa] * X[kappa][n],   A[i][kappa] = h[off + i*R - kappa],
+//     X[kappa][n] = x[W_n + kappa],  kappa in [0, 64*NB).
+// Both operands are split into byte planes; plane products with equal weight p+q share one int32
+// accumulator (4 VGPRs); the 64-bit recombination, the re-bias correction of the unsigned input planes
+// and the OUT_TYPE conversion happen once per output in the epilogue.
+//
+// Data movement.  Lane <-> 16-sample slot: a lane loads its slot (16*sizeof(TIN) contiguous bytes),
+// builds one 16-byte vector per plane (v_perm_b32 byte gathers) and writes it to the plane array in
+// LDS; column n / K-group kg / block b then reads slot R*n + 4b + kg.  For even R the slot index is
+// padded by slot/R so that the 16 columns of a read hit 16 different 16-byte bank groups.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fir_kernels.hpp"
+
+namespace acdsp {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kGenMaxPX = 8, kGenMaxPC = 3, kGenMaxNB = 8, kGenMaxFrag = kGenMaxPC * kGenMaxNB;  // A fragments: [b][q], <= 96 VGPRs
+
+// ---------------------------------------------------------------------------------------------
+// host: coefficient planes and A fragments
+// ---------------------------------------------------------------------------------------------
+bool fir_gen_plan(const int64_t *h, int n_taps, int R, int first_mod16, FirGenPlan *pl, std::vector<uint32_t> *frag) {
+  // balanced base-256 digits of every tap
+  int pc = 1;
+  std::vector<std::vector<int8_t>> dig(kGenMaxPC, std::vector<int8_t>(n_taps, 0));
+  if (n_taps < 1 || R < 1 || R > 64) { return false; }
+  for (int k = 0; k < n_taps; k++) {
+    __int128 v = h[k];
+    for (int q = 0; q < kGenMaxPC; q++) {
+      int lo = (int)(((v % 256) + 256) % 256);
+      if (lo >= 128) { lo -= 256; }
+      dig[q][k] = (int8_t)lo;
+      v = (v - lo) / 256;
+      if (lo != 0 && q + 1 > pc) { pc = q + 1; }
+    }
+    if (v != 0) { return false; }  // needs more than kGenMaxPC digits (dig[][] has exactly kGenMaxPC rows)
+  }
+  // window geometry: T_n mod 16 == first mod 16; window start is the 16-aligned floor of T_n - (taps-1)
+  const int a = ((first_mod16 - (n_taps - 1)) % 16 + 16) % 16;
+  const int off = (n_taps - 1) + a;
+  const int nb = (off + 15 * R + 1 + 63) / 64;
+  if (nb > kGenMaxNB) { return false; }
+  pl->pc = pc; pl->nb = nb; pl->off = off; pl->R = R;
+  __int128 sum = 0;
+  for (int k = 0; k < n_taps; k++) { sum += (__int128)h[k]; }
+  pl->sum_h = (int64_t)(unsigned long long)sum;  // mod 2^64
+  frag->assign((size_t)pc * nb * 64 * 4, 0u);
+  for (int q = 0; q < pc; q++) {
+    for (int b = 0; b < nb; b++) {
+      for (int lane = 0; lane < 64; lane++) {
+        const int i = lane & 15, kg = lane >> 4;
+        for (int dw = 0; dw < 4; dw++) {
+          uint32_t word = 0;
+          for (int bj = 0; bj < 4; bj++) {
+            const int kappa = 64 * b + 16 * kg + 4 * dw + bj;
+            const int tap = off + i * R - kappa;
+            const int8_t val = (tap >= 0 && tap < n_taps) ? dig[q][tap] : (int8_t)0;
+            word |= (uint32_t)(uint8_t)val << (8 * bj);
+          }
+          (*frag)[(((size_t)q * nb + b) * 64 + lane) * 4 + dw] = word;
+        }
+      }
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------
+struct GenArgs {
+  FirGenPlan pl;
+  int32_t px;                 // input byte planes
+  int32_t pad;                // 1: slot index padded by slot / R (even R)
+  uint32_t rcp;               // ceil(2^32 / R) for the slot / R division
+  int32_t n_slots;            // slots staged per step
+  int32_t out_mode;           // 0: FIR class A (shift, ACC wrap, requant)   1: CIC (wrap to w_int, requant from F_in)
+  int32_t w_int;
+  int64_t corr;               // 128 * sum(h) * sum_{p < px-1} 256^p  (mod 2^64)
+  int64_t first;              // local input index of output 0
+  int64_t n_out;              // outputs per channel in this call
+  int64_t steps_per_wave, n_steps;
+  int64_t n16;                // n_in rounded up to 16: rows are readable that far
+};
+
+__device__ inline int phys_slot(int s, const GenArgs &a) {
+  return a.pad ? s + (int)__umulhi((unsigned)s, a.rcp) : s;   // s + s / R (exact for s < 2^16)
+}
+
+// gather byte `p` (0..3 of a dword) of four dwords into one dword
+__device__ inline unsigned gather4(unsigned d0, unsigned d1, unsigned d2, unsigned d3, int p) {
+  const unsigned sel = 0x0c0c0400u + 0x0101u * (unsigned)p;               // result bytes: [d0.p, d1.p, 0, 0]
+  const unsigned lo = __builtin_amdgcn_perm(d1, d0, sel);
+  const unsigned hi = __builtin_amdgcn_perm(d3, d2, sel);
+  return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+template <typename TIN, int PX>
+__global__ void __launch_bounds__(64, 2) fir_gen_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [PX][phys slots][16]
+  const int lane = threadIdx.x;
+  const int n_col = lane & 15, kg = lane >> 4;
+  const int ch = blockIdx.y;
+  const int NB = a.pl.nb, PC = a.pl.pc, R = a.pl.R;
+  const int plane_bytes = (phys_slot(a.n_slots, a) + 1) * 16;
+
+  v4i A[kGenMaxFrag];   // A[b * kGenMaxPC + q]; only the (b < NB, q < PC) entries are loaded and used
+#pragma unroll
+  for (int b = 0; b < kGenMaxNB; b++) {
+#pragma unroll
+    for (int q = 0; q < kGenMaxPC; q++) {
+      A[b * kGenMaxPC + q] = (b < NB && q < PC) ? frag[((size_t)q * NB + b) * 64 + lane] : (v4i){0, 0, 0, 0};
+    }
+  }
+
+  const TIN *xrow = (const TIN *)p.x + (int64_t)ch * p.in_stride;
+  const TIN *hrow = (const TIN *)p.hist + (int64_t)ch * p.hl + p.hl;
+  const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
+
+  for (int64_t st = s0; st < s1; st++) {
+    const int64_t m0 = st * 256;
+    // W_0: 16-aligned window start of column 0   (T_0 = first + m0*R, off = T_0 - W_0)
+    const int64_t W0 = a.first + m0 * R - a.pl.off;
+    __syncthreads();   // previous step's fragment reads are done
+    // ---- stage: lane <-> slot ----
+    for (int sl = lane; sl < a.n_slots; sl += 64) {
+      const int64_t t = W0 + 16 * (int64_t)sl;
+      union { v4i v[sizeof(TIN)]; TIN e[16]; unsigned d[4 * sizeof(TIN)]; } u;
+      const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
+#pragma unroll
+      for (int q = 0; q < (int)sizeof(TIN); q++) { u.v[q] = ((const v4i *)src)[q]; }
+      const int ps = phys_slot(sl, a);
+#pragma unroll
+      for (int pp = 0; pp < PX; pp++) {
+        v4i o;
+        if (sizeof(TIN) == 2) {        // 16 samples = 8 dwords, plane pp = byte pp of each 16-bit sample
+          const unsigned sel = pp == 0 ? 0x06040200u : 0x07050301u;
+          o.x = (int)__builtin_amdgcn_perm(u.d[1], u.d[0], sel); o.y = (int)__builtin_amdgcn_perm(u.d[3], u.d[2], sel);
+          o.z = (int)__builtin_amdgcn_perm(u.d[5], u.d[4], sel); o.w = (int)__builtin_amdgcn_perm(u.d[7], u.d[6], sel);
+        } else if (sizeof(TIN) == 4) { // 16 samples = 16 dwords
+          o.x = (int)gather4(u.d[0], u.d[1], u.d[2], u.d[3], pp); o.y = (int)gather4(u.d[4], u.d[5], u.d[6], u.d[7], pp);
+          o.z = (int)gather4(u.d[8], u.d[9], u.d[10], u.d[11], pp); o.w = (int)gather4(u.d[12], u.d[13], u.d[14], u.d[15], pp);
+        } else {                       // 16 samples = 32 dwords; byte pp of sample e lives in dword 2e + pp/4
+          const int hi = pp >> 2, bp = pp & 3;
+          o.x = (int)gather4(u.d[0 + hi], u.d[2 + hi], u.d[4 + hi], u.d[6 + hi], bp);
+          o.y = (int)gather4(u.d[8 + hi], u.d[10 + hi], u.d[12 + hi], u.d[14 + hi], bp);
+          o.z = (int)gather4(u.d[16 + hi], u.d[18 + hi], u.d[20 + hi], u.d[22 + hi], bp);
+          o.w = (int)gather4(u.d[24 + hi], u.d[26 + hi], u.d[28 + hi], u.d[30 + hi], bp);
+        }
+        if (pp < PX - 1) { o ^= (v4i){(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u}; }  // unsigned plane -> signed
+        *(v4i *)(lds + pp * plane_bytes + ps * 16) = o;
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA: plane products of equal weight share an accumulator ----
+    v4i acc[kGenMaxPX + kGenMaxPC - 1];
+#pragma unroll
+    for (int w = 0; w < kGenMaxPX + kGenMaxPC - 1; w++) { acc[w] = (v4i){0, 0, 0, 0}; }
+#pragma unroll
+    for (int b = 0; b < kGenMaxNB; b++) {
+      if (b < NB) {   // wave-uniform
+        const int ps = phys_slot(R * n_col + 4 * b + kg, a);
+        v4i X[PX];
+#pragma unroll
+        for (int pp = 0; pp < PX; pp++) { X[pp] = *(const v4i *)(lds + pp * plane_bytes + ps * 16); }
+#pragma unroll
+        for (int q = 0; q < kGenMaxPC; q++) {
+          if (q < PC) {
+#pragma unroll
+            for (int pp = 0; pp < PX; pp++) {
+              acc[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b * kGenMaxPC + q], X[pp], acc[pp + q], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: lane (n_col, kg) holds outputs m0 + 16 n_col + 4 kg + r ----
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int64_t m = m0 + 16 * n_col + 4 * kg + r;
+      uint64_t y = (uint64_t)a.corr;
+#pragma unroll
+      for (int w = 0; w < PX + kGenMaxPC - 1; w++) {
+        if (w < PX + PC - 1 && w < 8) { y += (uint64_t)(int64_t)acc[w][r] << (8 * w); }
+      }
+      if (m < a.n_out) {
+        int64_t o;
+        if (a.out_mode == 1) {
+          o = requant64(wrap64((int64_t)y, a.w_int, 1), p.in.F, p.out);
+        } else {
+          const int64_t accv = wrap64((int64_t)(y << p.lossless_shift), p.acc.W, p.acc.S);
+          o = requant64(accv, p.acc.F, p.out);
+        }
+        store_raw(p.y, (int64_t)ch * p.out_stride + m, p.out_eb, o);
+      }
+    }
+  }
+}
+
+template <typename TIN>
+static hipError_t launch_px(int px, dim3 grid, size_t lds_bytes, hipStream_t s, const FirParams &p, const v4i *frag, const GenArgs &a) {
+#define ACDSP_GEN_CASE(PXV)                                                                                         \
+  case PXV: {                                                                                                       \
+    hipError_t e = hipFuncSetAttribute((const void *)fir_gen_kernel<TIN, PXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+    if (e != hipSuccess) { return e; }                                                                              \
+    hipLaunchKernelGGL((fir_gen_kernel<TIN, PXV>), grid, dim3(64), lds_bytes, s, p, frag, a);                     \
+    return hipGetLastError();                                                                                       \
+  }
+  switch (px) {
+    ACDSP_GEN_CASE(1) ACDSP_GEN_CASE(2) ACDSP_GEN_CASE(3) ACDSP_GEN_CASE(4)
+    ACDSP_GEN_CASE(5) ACDSP_GEN_CASE(6) ACDSP_GEN_CASE(7) ACDSP_GEN_CASE(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef ACDSP_GEN_CASE
+}
+
+// p.n = inputs of this call; outputs m with first + m*R < n.  hist must hold >= off + 16 samples.
+hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32_t *d_frag, int out_mode, int w_int,
+                          int64_t first, int64_t n_out, hipStream_t s) {
+  if (n_out <= 0) { return hipSuccess; }
+  GenArgs a;
+  a.pl = pl;
+  const int in_bits = p.in.W + (p.in.S ? 0 : 1);
+  a.px = (in_bits + 7) / 8;
+  if (a.px > p.in_eb) { return hipErrorInvalidValue; }
+  a.pad = (pl.R % 2 == 0 && pl.R > 1) ? 1 : 0;
+  a.rcp = (uint32_t)((0x100000000ull + pl.R - 1) / pl.R);
+  a.n_slots = 15 * pl.R + 4 * pl.nb;
+  a.out_mode = out_mode; a.w_int = w_int;
+  unsigned __int128 bias = 0;
+  for (int q = 0; q < a.px - 1; q++) { bias += (unsigned __int128)1 << (8 * q); }
+  a.corr = (int64_t)(unsigned long long)((unsigned __int128)128 * bias * (unsigned long long)pl.sum_h);
+  a.first = first; a.n_out = n_out;
+  a.n_steps = (n_out + 255) / 256;
+  int64_t spw = (a.n_steps * p.n_ch + 16383) / 16384;
+  if (spw < 4) { spw = 4; }
+  a.steps_per_wave = spw;
+  a.n16 = (p.n + 15) / 16 * 16;
+  const int phys = a.pad ? a.n_slots + a.n_slots / pl.R : a.n_slots;
+  const size_t lds_bytes = (size_t)a.px * (phys + 1) * 16;
+  dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)p.n_ch);
+  switch (p.in_eb) {
+    case 2: return launch_px<int16_t>(a.px, grid, lds_bytes, s, p, (const v4i *)d_frag, a);
+    case 4: return launch_px<int32_t>(a.px, grid, lds_bytes, s, p, (const v4i *)d_frag, a);
+    default: return launch_px<int64_t>(a.px, grid, lds_bytes, s, p, (const v4i *)d_frag, a);
+  }
+}
+
+}  // namespace acdsp

@@ -1,5 +1,7 @@
 // fir_kernels.hpp -- launch interface between the C-ABI layer (engine.hip) and the FIR kernels.
 #pragma once
+#include <vector>
+
 #include "acdsp_dev.hpp"
 
 namespace acdsp {
@@ -46,5 +48,18 @@ int fir_mfma_max_reg_blocks();   // ... with the A fragments register-resident (
 // d_frag[n_sets][2][nb][64][4], d_corr[n_sets]; `plan` carries the worst-case bounds over all sets.
 hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag_per_channel, const uint32_t *d_frag,
                            const int64_t *d_corr, hipStream_t s);
+
+// Generalised exact FIR on the matrix cores (fir_gen.hip): wide inputs / coefficients, decimation.
+struct FirGenPlan {
+  int32_t pc, nb, off, R;   // coefficient byte planes, 64-sample K blocks, T_n - W_n, decimation
+  int64_t sum_h;            // sum of the taps mod 2^64 (re-bias correction)
+};
+// y[m] = sum_k h[k] x[first + m R - k] mod 2^64.  Builds the A fragments for first % 16 == first_mod16;
+// false if the taps need more than 3 byte planes or more than 8 K blocks.
+bool fir_gen_plan(const int64_t *h, int n_taps, int R, int first_mod16, FirGenPlan *pl, std::vector<uint32_t> *frag);
+// out_mode 0: FIR class A epilogue (p.lossless_shift, p.acc wrap, requant to p.out);
+// out_mode 1: CIC epilogue (wrap to w_int, requant from p.in.F to p.out).  p.n = inputs, p.hist holds >= off samples.
+hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32_t *d_frag, int out_mode, int w_int,
+                          int64_t first, int64_t n_out, hipStream_t s);
 
 }  // namespace acdsp

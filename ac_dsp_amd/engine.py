@@ -122,6 +122,10 @@ class Cic:
     def out_count(self, n_in):
         return lib.acdsp_cic_out_count(self._h, n_in)
 
+    @property
+    def path(self):
+        return {0: "recurrence", 3: "mfma_gen"}[lib.acdsp_cic_path(self._h)]
+
     def run(self, x, out=None):
         assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1
         assert x.dtype == torch_dtype_for(self.fin), (x.dtype, self.fin)

@@ -58,7 +58,7 @@ enum {
 #define ACDSP_FLAG_FORCE_GENERIC 1 /* never pick the MFMA / fast kernels (parity tests) */
 
 /* which kernel family a FIR handle resolved to (acdsp_fir_path) */
-enum { ACDSP_PATH_GENERIC = 0, ACDSP_PATH_LOSSLESS64 = 1, ACDSP_PATH_MFMA_I8 = 2 };
+enum { ACDSP_PATH_GENERIC = 0, ACDSP_PATH_LOSSLESS64 = 1, ACDSP_PATH_MFMA_I8 = 2, ACDSP_PATH_MFMA_GEN = 3 };
 
 typedef struct {
   int32_t kind;               /* ACDSP_FIR_*: which reference class this mirrors (informational) */
@@ -138,6 +138,7 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
                       int64_t *n_out, void *stream);
 int32_t acdsp_cic_run_host(acdsp_cic_t h, const void *h_in, int64_t n_in, void *h_out, int64_t out_cap, int64_t *n_out);
 int32_t acdsp_cic_reset(acdsp_cic_t h);
+int32_t acdsp_cic_path(acdsp_cic_t h);         /* 0: recurrence kernel, 3: FIR-identity MFMA kernel (ACDSP_PATH_MFMA_GEN) */
 int32_t acdsp_cic_last_kernel_ms(acdsp_cic_t h, float *ms);
 int32_t acdsp_cic_kernel_stats(acdsp_cic_t h, int32_t last_k, float *avg_ms, float *min_ms);
 

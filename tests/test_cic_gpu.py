@@ -132,8 +132,28 @@ def test_config3_sampled_full_rate():
     n_ch, n = 4096, 1 << 16
     x = torch.empty((n_ch, n), dtype=torch.int32, device="cuda")
     A.fill_stimulus(x, 0xACD5, 32)
-    y = A.Cic(False, 8, 1, 5, fin, fout, n_channels=n_ch).run(x)
+    cic = A.Cic(False, 8, 1, 5, fin, fout, n_channels=n_ch)
+    y = cic.run(x)
+    assert cic.path == "mfma_gen"        # decimator through its FIR identity on the matrix cores
     assert y.shape == (n_ch, n // 8)
     for ch in (0, 63, 64, 2049, 4095):
         yo = run_oracle(False, 8, 1, 5, fin, fout, stimulus(0xACD5, 1, n, 32, ch0=ch))
         assert np.array_equal(y[ch].cpu().numpy().astype(np.int64), yo[0]), ch
+
+
+def test_recurrence_and_mfma_kernels_agree(monkeypatch):
+    """Both decimator kernels (integrator/comb recurrences, FIR identity on MFMA) on the same stream: the
+    unaligned view forces the recurrence kernel, the aligned one takes the MFMA kernel."""
+    fin, fout = A.Fmt(32, 16), A.Fmt(47, 31)
+    x = stimulus(21, 5, 8000, 32)
+    big = torch.zeros((5, 8016), dtype=torch.int32, device="cuda")
+    big[:, 1:8001] = torch.from_numpy(x).to(torch.int32).cuda()
+    c1 = A.Cic(False, 8, 1, 5, fin, fout, n_channels=5)
+    y1 = c1.run(big[:, 1:8001]).cpu().numpy()
+    assert c1.path == "recurrence"
+    c2 = A.Cic(False, 8, 1, 5, fin, fout, n_channels=5)
+    xa = torch.zeros((5, 8000), dtype=torch.int32, device="cuda")
+    xa.copy_(torch.from_numpy(x).to(torch.int32))
+    y2 = c2.run(xa).cpu().numpy()
+    assert c2.path == "mfma_gen"
+    assert np.array_equal(y1, y2)

@@ -164,11 +164,12 @@ def test_mfma_extreme_values_and_fallback():
     assert fir.path == "mfma_i8"
     orc = OracleFir(N, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
     assert np.array_equal(run_engine(fir, x), orc.run(c, x))
-    # +32767 cannot be written as two signed bytes -> the engine must leave the MFMA path, not mis-compute
+    # +32767 cannot be written as two signed bytes -> the engine must leave the int16 MFMA kernel (the
+    # generalised kernel takes it with a third coefficient digit), not mis-compute
     c2 = np.full(N, 32767, dtype=np.int64)
     fir.reset()
     fir.set_coeffs(c2)
-    assert fir.path == "lossless64"
+    assert fir.path == "mfma_gen"
     orc = OracleFir(N, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
     assert np.array_equal(run_engine(fir, x[:, :300]), orc.run(c2, x[:, :300]))
 
@@ -303,6 +304,7 @@ def test_config5_ddc_cascade_cic_then_fir():
     cic = A.Cic(False, 16, 1, 5, cin, mid, n_channels=n_ch)
     fir = A.Fir(127, "SHIFT_REG", mid, fc, fa, fo, n_channels=n_ch, kind="const")
     fir.set_coeffs(c)
+    assert fir.path == "mfma_gen"            # 36-bit input: five byte planes on the matrix cores
     oc = OracleCic(0, 16, 1, 5, ofmt(cin), ofmt(mid), n_ch=n_ch)
     of = OracleFir(127, "SHIFT_REG", ofmt(mid), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
     for a, b in ((0, 16 * 300), (16 * 300, n)):      # two bursts: both stages carry state
@@ -311,3 +313,16 @@ def test_config5_ddc_cascade_cic_then_fir():
         y = fir.run(u.contiguous()).cpu().numpy().astype(np.int64)
         yo = of.run(c, oc.run(x[:, a:b]))
         assert np.array_equal(y, yo)
+
+
+@pytest.mark.parametrize("fin,fc,n_taps", [(A.Fmt(24, 8), A.Fmt(16, 2), 63), (A.Fmt(32, 16), A.Fmt(18, 2), 100),
+                                           (A.Fmt(36, 21), A.Fmt(16, 1), 127), (A.Fmt(48, 20), A.Fmt(12, 2), 33),
+                                           (A.Fmt(16, 2), A.Fmt(24, 4), 40), (A.Fmt(20, 4, False), A.Fmt(10, 1), 17)])
+def test_generalised_mfma_kernel_wide_types(fin, fc, n_taps):
+    """Inputs / coefficients wider than 16 bits: multi-plane int8 MFMA, exact mod 2^64 then ACC wrap."""
+    fa = A.Fmt(64, 64 - (fin.F + fc.F))
+    rng = np.random.default_rng(n_taps)
+    c = rand_raw(rng, fc, (n_taps,))
+    for ftype, fo in (("SHIFT_REG", fa), ("FOLD_ODD", A.Fmt(30, 12, True, "RND_CONV", "SAT")), ("C_BUFF", A.Fmt(64, 40))):
+        check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=1200, coeffs=c, expect_path="mfma_gen", splits=[16, 500],
+                   seed=n_taps + 1)
