@@ -95,6 +95,7 @@ struct GenArgs {
   uint32_t rcp;               // ceil(2^32 / R) for the slot / R division
   int32_t n_slots;            // slots staged per step
   int32_t out_mode;           // 0: FIR class A (shift, ACC wrap, requant)   1: CIC (wrap to w_int, requant from F_in)
+  int32_t out_simple;         // CIC: 2 = OUT holds INT_TYPE (one wrap), 1 = same fraction + AC_WRAP (two wraps), 0 = general
   int32_t w_int;
   int64_t corr;               // 128 * sum(h) * sum_{p < px-1} 256^p  (mod 2^64)
   int64_t first;              // local input index of output 0
@@ -138,41 +139,78 @@ __global__ void __launch_bounds__(64, 2) fir_gen_kernel(FirParams p, const v4i *
   const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
 
+  // Slots of the next step are fetched into registers while the current step multiplies (when the
+  // per-lane slot count fits the register budget), so the HBM latency overlaps MFMA + epilogue.
+  constexpr int SPLMAX = 16 / (int)sizeof(TIN);            // 64 VGPRs of prefetch
+  const int spl = (a.n_slots + 63) / 64;
+  const bool prefetch = spl <= SPLMAX;
+  v4i pre[SPLMAX][sizeof(TIN)];
+  auto slot_src = [&](int64_t W0, int sl) -> const TIN * {
+    const int64_t t = W0 + 16 * (int64_t)sl;
+    return (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);   // beyond the data: any valid address (never used)
+  };
+  auto fetch = [&](int64_t st) {
+    const int64_t W0 = a.first + st * 256 * R - a.pl.off;
+#pragma unroll
+    for (int j = 0; j < SPLMAX; j++) {
+      if (j < spl) {
+        const int sl = (lane + 64 * j < a.n_slots) ? lane + 64 * j : a.n_slots - 1;
+        const TIN *src = slot_src(W0, sl);
+#pragma unroll
+        for (int q = 0; q < (int)sizeof(TIN); q++) { pre[j][q] = ((const v4i *)src)[q]; }
+      }
+    }
+  };
+  // split one slot (16 samples) into its byte planes and store them
+  auto stage_slot = [&](const v4i (&raw)[sizeof(TIN)], int sl) {
+    union { v4i v[sizeof(TIN)]; unsigned d[4 * sizeof(TIN)]; } u;
+#pragma unroll
+    for (int q = 0; q < (int)sizeof(TIN); q++) { u.v[q] = raw[q]; }
+    const int ps = phys_slot(sl, a);
+#pragma unroll
+    for (int pp = 0; pp < PX; pp++) {
+      v4i o;
+      if (sizeof(TIN) == 2) {        // 16 samples = 8 dwords, plane pp = byte pp of each 16-bit sample
+        const unsigned sel = pp == 0 ? 0x06040200u : 0x07050301u;
+        o.x = (int)__builtin_amdgcn_perm(u.d[1], u.d[0], sel); o.y = (int)__builtin_amdgcn_perm(u.d[3], u.d[2], sel);
+        o.z = (int)__builtin_amdgcn_perm(u.d[5], u.d[4], sel); o.w = (int)__builtin_amdgcn_perm(u.d[7], u.d[6], sel);
+      } else if (sizeof(TIN) == 4) { // 16 samples = 16 dwords
+        o.x = (int)gather4(u.d[0], u.d[1], u.d[2], u.d[3], pp); o.y = (int)gather4(u.d[4], u.d[5], u.d[6], u.d[7], pp);
+        o.z = (int)gather4(u.d[8], u.d[9], u.d[10], u.d[11], pp); o.w = (int)gather4(u.d[12], u.d[13], u.d[14], u.d[15], pp);
+      } else {                       // 16 samples = 32 dwords; byte pp of sample e lives in dword 2e + pp/4
+        const int hi = pp >> 2, bp = pp & 3;
+        o.x = (int)gather4(u.d[0 + hi], u.d[2 + hi], u.d[4 + hi], u.d[6 + hi], bp);
+        o.y = (int)gather4(u.d[8 + hi], u.d[10 + hi], u.d[12 + hi], u.d[14 + hi], bp);
+        o.z = (int)gather4(u.d[16 + hi], u.d[18 + hi], u.d[20 + hi], u.d[22 + hi], bp);
+        o.w = (int)gather4(u.d[24 + hi], u.d[26 + hi], u.d[28 + hi], u.d[30 + hi], bp);
+      }
+      if (pp < PX - 1) { o ^= (v4i){(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u}; }  // unsigned plane -> signed
+      *(v4i *)(lds + pp * plane_bytes + ps * 16) = o;
+    }
+  };
+
+  if (prefetch) { fetch(s0); }
   for (int64_t st = s0; st < s1; st++) {
     const int64_t m0 = st * 256;
-    // W_0: 16-aligned window start of column 0   (T_0 = first + m0*R, off = T_0 - W_0)
-    const int64_t W0 = a.first + m0 * R - a.pl.off;
     __syncthreads();   // previous step's fragment reads are done
-    // ---- stage: lane <-> slot ----
-    for (int sl = lane; sl < a.n_slots; sl += 64) {
-      const int64_t t = W0 + 16 * (int64_t)sl;
-      union { v4i v[sizeof(TIN)]; TIN e[16]; unsigned d[4 * sizeof(TIN)]; } u;
-      const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
+    if (prefetch) {
 #pragma unroll
-      for (int q = 0; q < (int)sizeof(TIN); q++) { u.v[q] = ((const v4i *)src)[q]; }
-      const int ps = phys_slot(sl, a);
+      for (int j = 0; j < SPLMAX; j++) {
+        if (j < spl && lane + 64 * j < a.n_slots) { stage_slot(pre[j], lane + 64 * j); }
+      }
+    } else {
+      // W_0: 16-aligned window start of column 0   (T_0 = first + m0*R, off = T_0 - W_0)
+      const int64_t W0 = a.first + m0 * R - a.pl.off;
+      for (int sl = lane; sl < a.n_slots; sl += 64) {
+        v4i raw[sizeof(TIN)];
+        const TIN *src = slot_src(W0, sl);
 #pragma unroll
-      for (int pp = 0; pp < PX; pp++) {
-        v4i o;
-        if (sizeof(TIN) == 2) {        // 16 samples = 8 dwords, plane pp = byte pp of each 16-bit sample
-          const unsigned sel = pp == 0 ? 0x06040200u : 0x07050301u;
-          o.x = (int)__builtin_amdgcn_perm(u.d[1], u.d[0], sel); o.y = (int)__builtin_amdgcn_perm(u.d[3], u.d[2], sel);
-          o.z = (int)__builtin_amdgcn_perm(u.d[5], u.d[4], sel); o.w = (int)__builtin_amdgcn_perm(u.d[7], u.d[6], sel);
-        } else if (sizeof(TIN) == 4) { // 16 samples = 16 dwords
-          o.x = (int)gather4(u.d[0], u.d[1], u.d[2], u.d[3], pp); o.y = (int)gather4(u.d[4], u.d[5], u.d[6], u.d[7], pp);
-          o.z = (int)gather4(u.d[8], u.d[9], u.d[10], u.d[11], pp); o.w = (int)gather4(u.d[12], u.d[13], u.d[14], u.d[15], pp);
-        } else {                       // 16 samples = 32 dwords; byte pp of sample e lives in dword 2e + pp/4
-          const int hi = pp >> 2, bp = pp & 3;
-          o.x = (int)gather4(u.d[0 + hi], u.d[2 + hi], u.d[4 + hi], u.d[6 + hi], bp);
-          o.y = (int)gather4(u.d[8 + hi], u.d[10 + hi], u.d[12 + hi], u.d[14 + hi], bp);
-          o.z = (int)gather4(u.d[16 + hi], u.d[18 + hi], u.d[20 + hi], u.d[22 + hi], bp);
-          o.w = (int)gather4(u.d[24 + hi], u.d[26 + hi], u.d[28 + hi], u.d[30 + hi], bp);
-        }
-        if (pp < PX - 1) { o ^= (v4i){(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u}; }  // unsigned plane -> signed
-        *(v4i *)(lds + pp * plane_bytes + ps * 16) = o;
+        for (int q = 0; q < (int)sizeof(TIN); q++) { raw[q] = ((const v4i *)src)[q]; }
+        stage_slot(raw, sl);
       }
     }
     __syncthreads();
+    if (prefetch && st + 1 < s1) { fetch(st + 1); }
 
     // ---- MFMA: plane products of equal weight share an accumulator ----
     v4i acc[kGenMaxPX + kGenMaxPC - 1];
@@ -209,7 +247,9 @@ __global__ void __launch_bounds__(64, 2) fir_gen_kernel(FirParams p, const v4i *
       if (m < a.n_out) {
         int64_t o;
         if (a.out_mode == 1) {
-          o = requant64(wrap64((int64_t)y, a.w_int, 1), p.in.F, p.out);
+          if (a.out_simple == 2) { o = wrap64((int64_t)y, a.w_int, 1); }
+          else if (a.out_simple == 1) { o = wrap64(wrap64((int64_t)y, a.w_int, 1), p.out.W, p.out.S); }
+          else { o = requant64(wrap64((int64_t)y, a.w_int, 1), p.in.F, p.out); }
         } else {
           const int64_t accv = wrap64((int64_t)(y << p.lossless_shift), p.acc.W, p.acc.S);
           o = requant64(accv, p.acc.F, p.out);
@@ -240,6 +280,8 @@ static hipError_t launch_px(int px, dim3 grid, size_t lds_bytes, hipStream_t s, 
 // p.n = inputs of this call; outputs m with first + m*R < n.  hist must hold >= off + 16 samples.
 hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32_t *d_frag, int out_mode, int w_int,
                           int64_t first, int64_t n_out, hipStream_t s) {
+  // (out_mode 1) OUT_TYPE with INT_TYPE's fraction and AC_WRAP converts by bit-field wraps only
+  const int out_simple = (out_mode == 1 && p.out.F == p.in.F && p.out.O == ACDSP_WRAP) ? ((p.out.S && p.out.W >= w_int) ? 2 : 1) : 0;
   if (n_out <= 0) { return hipSuccess; }
   GenArgs a;
   a.pl = pl;
@@ -249,7 +291,7 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   a.pad = (pl.R % 2 == 0 && pl.R > 1) ? 1 : 0;
   a.rcp = (uint32_t)((0x100000000ull + pl.R - 1) / pl.R);
   a.n_slots = 15 * pl.R + 4 * pl.nb;
-  a.out_mode = out_mode; a.w_int = w_int;
+  a.out_mode = out_mode; a.w_int = w_int; a.out_simple = out_simple;
   unsigned __int128 bias = 0;
   for (int q = 0; q < a.px - 1; q++) { bias += (unsigned __int128)1 << (8 * q); }
   a.corr = (int64_t)(unsigned long long)((unsigned __int128)128 * bias * (unsigned long long)pl.sum_h);
