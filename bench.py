@@ -267,15 +267,17 @@ def pmc_traffic(tag):
     MI355X_MICROARCH.md) + WRITE_SIZE (KB).  None when no summary has been committed for this workload."""
     path = os.path.join(ROOT, "profiles", tag + "_rocprof.txt")
     try:
-        vals = {}
+        vals = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+        seen = set()
         kernel = None
         for line in open(path):
             if line.startswith("void ") or line.startswith("acdsp::"):
                 kernel = line.strip()
             f = line.split()
-            if len(f) == 3 and f[0] in ("FETCH_SIZE", "WRITE_SIZE") and kernel and ("fir_mfma" in kernel or "cic_kernel" in kernel):
-                vals[f[0]] = float(f[2])
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            if len(f) == 3 and f[0] in vals and kernel and any(k in kernel for k in ("fir_mfma", "fir_gen", "cic_kernel<")):
+                vals[f[0]] += float(f[2])      # summed over the data-path kernels of one step (the DDC has two)
+                seen.add(f[0])
+        if len(seen) == 2:
             return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     except OSError:
         pass
