@@ -116,8 +116,11 @@ __device__ inline unsigned gather4(unsigned d0, unsigned d1, unsigned d2, unsign
   return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
-template <typename TIN, int PX>
-__global__ void __launch_bounds__(64, 2) fir_gen_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
+// SMALL: at most 3 K blocks x 2 coefficient digits (24 VGPRs of A fragments instead of 96): the common CIC /
+// DDC shapes then fit three or four waves per SIMD, which is what hides the HBM latency of this streaming kernel.
+template <typename TIN, int PX, bool SMALL>
+__global__ void __launch_bounds__(64, SMALL ? 3 : 2) fir_gen_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
+  constexpr int kMaxNB = SMALL ? 3 : kGenMaxNB, kMaxPC = SMALL ? 2 : kGenMaxPC;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [PX][phys slots][16]
   const int lane = threadIdx.x;
   const int n_col = lane & 15, kg = lane >> 4;
@@ -125,12 +128,12 @@ __global__ void __launch_bounds__(64, 2) fir_gen_kernel(FirParams p, const v4i *
   const int NB = a.pl.nb, PC = a.pl.pc, R = a.pl.R;
   const int plane_bytes = (phys_slot(a.n_slots, a) + 1) * 16;
 
-  v4i A[kGenMaxFrag];   // A[b * kGenMaxPC + q]; only the (b < NB, q < PC) entries are loaded and used
+  v4i A[kMaxNB * kMaxPC];   // A[b * kMaxPC + q]; only the (b < NB, q < PC) entries are loaded and used
 #pragma unroll
-  for (int b = 0; b < kGenMaxNB; b++) {
+  for (int b = 0; b < kMaxNB; b++) {
 #pragma unroll
-    for (int q = 0; q < kGenMaxPC; q++) {
-      A[b * kGenMaxPC + q] = (b < NB && q < PC) ? frag[((size_t)q * NB + b) * 64 + lane] : (v4i){0, 0, 0, 0};
+    for (int q = 0; q < kMaxPC; q++) {
+      A[b * kMaxPC + q] = (b < NB && q < PC) ? frag[((size_t)q * NB + b) * 64 + lane] : (v4i){0, 0, 0, 0};
     }
   }
 
@@ -217,18 +220,18 @@ __global__ void __launch_bounds__(64, 2) fir_gen_kernel(FirParams p, const v4i *
 #pragma unroll
     for (int w = 0; w < kGenMaxPX + kGenMaxPC - 1; w++) { acc[w] = (v4i){0, 0, 0, 0}; }
 #pragma unroll
-    for (int b = 0; b < kGenMaxNB; b++) {
+    for (int b = 0; b < kMaxNB; b++) {
       if (b < NB) {   // wave-uniform
         const int ps = phys_slot(R * n_col + 4 * b + kg, a);
         v4i X[PX];
 #pragma unroll
         for (int pp = 0; pp < PX; pp++) { X[pp] = *(const v4i *)(lds + pp * plane_bytes + ps * 16); }
 #pragma unroll
-        for (int q = 0; q < kGenMaxPC; q++) {
+        for (int q = 0; q < kMaxPC; q++) {
           if (q < PC) {
 #pragma unroll
             for (int pp = 0; pp < PX; pp++) {
-              acc[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b * kGenMaxPC + q], X[pp], acc[pp + q], 0, 0, 0);
+              acc[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b * kMaxPC + q], X[pp], acc[pp + q], 0, 0, 0);
             }
           }
         }
@@ -262,11 +265,18 @@ __global__ void __launch_bounds__(64, 2) fir_gen_kernel(FirParams p, const v4i *
 
 template <typename TIN>
 static hipError_t launch_px(int px, dim3 grid, size_t lds_bytes, hipStream_t s, const FirParams &p, const v4i *frag, const GenArgs &a) {
+  const bool small = a.pl.nb <= 3 && a.pl.pc <= 2;
 #define ACDSP_GEN_CASE(PXV)                                                                                         \
   case PXV: {                                                                                                       \
-    hipError_t e = hipFuncSetAttribute((const void *)fir_gen_kernel<TIN, PXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-    if (e != hipSuccess) { return e; }                                                                              \
-    hipLaunchKernelGGL((fir_gen_kernel<TIN, PXV>), grid, dim3(64), lds_bytes, s, p, frag, a);                     \
+    if (small) {                                                                                                    \
+      hipError_t e = hipFuncSetAttribute((const void *)fir_gen_kernel<TIN, PXV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+      if (e != hipSuccess) { return e; }                                                                            \
+      hipLaunchKernelGGL((fir_gen_kernel<TIN, PXV, true>), grid, dim3(64), lds_bytes, s, p, frag, a);             \
+    } else {                                                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void *)fir_gen_kernel<TIN, PXV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+      if (e != hipSuccess) { return e; }                                                                            \
+      hipLaunchKernelGGL((fir_gen_kernel<TIN, PXV, false>), grid, dim3(64), lds_bytes, s, p, frag, a);            \
+    }                                                                                                               \
     return hipGetLastError();                                                                                       \
   }
   switch (px) {
