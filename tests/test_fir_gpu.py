@@ -326,3 +326,57 @@ def test_generalised_mfma_kernel_wide_types(fin, fc, n_taps):
     for ftype, fo in (("SHIFT_REG", fa), ("FOLD_ODD", A.Fmt(30, 12, True, "RND_CONV", "SAT")), ("C_BUFF", A.Fmt(64, 40))):
         check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=1200, coeffs=c, expect_path="mfma_gen", splits=[16, 500],
                    seed=n_taps + 1)
+
+
+def test_scale_edges_long_stream_and_many_channels():
+    """One very long channel (2^24 samples, many chunks per channel) and many short channels (8192 x 2048)."""
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    fo = A.Fmt(16, 2, True, "RND", "SAT")
+    c = windowed_sinc(255, 0.1, fc)
+    # long stream: check three windows against the oracle
+    n = 1 << 24
+    x = torch.empty((1, n), dtype=torch.int16, device="cuda")
+    A.fill_stimulus(x, 5, 16)
+    fir = A.Fir(255, "SHIFT_REG", fin, fc, fa, fo, n_channels=1)
+    fir.set_coeffs(c)
+    y = fir.run(x)
+    for t0 in (0, 5_000_000, n - 3000):
+        w = 3000
+        xs = stimulus(5, 1, w + 254, 16, t0=max(t0 - 254, 0))
+        if t0 == 0:
+            xs = np.concatenate([np.zeros((1, 254), dtype=np.int64), xs[:, :w]], axis=1)
+        yo = OracleFir(255, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo)).run(c, xs)[0][254:]
+        assert np.array_equal(y[0, t0:t0 + w].cpu().numpy().astype(np.int64), yo), t0
+    # many channels
+    n_ch, n2 = 8192, 2048
+    x2 = torch.empty((n_ch, n2), dtype=torch.int16, device="cuda")
+    A.fill_stimulus(x2, 6, 16)
+    fir2 = A.Fir(255, "SHIFT_REG", fin, fc, fa, fo, n_channels=n_ch)
+    fir2.set_coeffs(c)
+    y2 = fir2.run(x2)
+    for ch in (0, 4097, 8191):
+        yo = OracleFir(255, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo)).run(c, stimulus(6, 1, n2, 16, ch0=ch))[0]
+        assert np.array_equal(y2[ch].cpu().numpy().astype(np.int64), yo), ch
+
+
+def test_two_handles_on_two_streams_are_independent():
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+    c1, c2 = windowed_sinc(127, 0.1, fc), windowed_sinc(127, 0.3, fc)
+    xs = [stimulus(70 + i, 8, 50000, 16) for i in range(2)]
+    firs = [A.Fir(127, "SHIFT_REG", fin, fc, fa, fo, n_channels=8) for _ in range(2)]
+    firs[0].set_coeffs(c1); firs[1].set_coeffs(c2)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    xd = [torch.from_numpy(x).to(torch.int16).cuda() for x in xs]
+    torch.cuda.synchronize()
+    outs = [None, None]
+    for rep in range(3):        # interleaved launches on two streams, state carried per handle
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                o = firs[i].run(xd[i])
+                outs[i] = o if rep == 2 else outs[i]
+    torch.cuda.synchronize()
+    for i, c in enumerate((c1, c2)):
+        orc = OracleFir(127, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=8)
+        for rep in range(3):
+            yo = orc.run(c, xs[i])
+        assert np.array_equal(outs[i].cpu().numpy().astype(np.int64), yo)
