@@ -43,6 +43,11 @@ class FirDesc(C.Structure):
                 ("device", C.c_int32), ("flags", C.c_int32)]
 
 
+class PolyDecDesc(C.Structure):
+    _fields_ = [("n_taps", C.c_int32), ("df", C.c_int32), ("n_channels", C.c_int32), ("fin", Fmt), ("fcoeff", Fmt),
+                ("facc", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
+
+
 class CicDesc(C.Structure):
     _fields_ = [("interp", C.c_int32), ("R", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("n_channels", C.c_int32), ("fin", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
@@ -89,6 +94,13 @@ SYMBOLS = {
     "acdsp_cic_path": (_i32, [_vp]),
     "acdsp_cic_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "acdsp_cic_kernel_stats": (_i32, [_vp, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "acdsp_polydec_create": (_i32, [C.POINTER(PolyDecDesc), C.POINTER(_vp)]),
+    "acdsp_polydec_destroy": (_i32, [_vp]),
+    "acdsp_polydec_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
+    "acdsp_polydec_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "acdsp_polydec_run_host": (_i32, [_vp, _vp, _i64, _vp]),
+    "acdsp_polydec_reset": (_i32, [_vp]),
+    "acdsp_polydec_path": (_i32, [_vp]),
 }
 for _name, (_res, _args) in SYMBOLS.items():
     _f = getattr(lib, _name)  # AttributeError here == the library does not export what the header declares

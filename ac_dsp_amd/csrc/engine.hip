@@ -821,3 +821,166 @@ int32_t acdsp_cic_kernel_stats(acdsp_cic_t h, int32_t last_k, float *avg_ms, flo
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// polyphase decimator
+// ---------------------------------------------------------------------------------------------
+struct acdsp_polydec {
+  acdsp_polydec_desc_t d;
+  int in_eb, out_eb, hl;
+  bool lossless = false, coeffs_set = false, gen_ok = false;
+  void *d_hist[2] = {nullptr, nullptr};
+  int cur = 0;
+  int64_t *d_coeffs = nullptr;
+  uint32_t *d_gfrag = nullptr;
+  FirGenPlan gplan;
+  int last_path = ACDSP_PATH_GENERIC;
+  Staging st;
+};
+
+extern "C" {
+
+int32_t acdsp_polydec_create(const acdsp_polydec_desc_t *desc, acdsp_polydec_t *out) {
+  if (!desc || !out) { return fail(ACDSP_EINVAL, "null argument"); }
+  if (desc->n_taps < 1 || desc->df < 1 || (int64_t)desc->n_taps * desc->df > 2048) {
+    return fail(ACDSP_EUNSUPPORTED, "poly_dec: NTAPS*DF = %lld outside 1..2048", (long long)desc->n_taps * desc->df);
+  }
+  if (desc->n_channels < 1 || desc->n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", desc->n_channels); }
+  int rc;
+  if ((rc = check_fmt(desc->in, "IN_TYPE")) || (rc = check_fmt(desc->coeff, "COEFF_TYPE")) || (rc = check_fmt(desc->acc, "ACC_TYPE")) ||
+      (rc = check_fmt(desc->out, "OUT_TYPE"))) {
+    return rc;
+  }
+  const int fi = desc->in.W - desc->in.I, fc = desc->coeff.W - desc->coeff.I, fa = desc->acc.W - desc->acc.I;
+  const int f = fi + fc > fa ? fi + fc : fa;
+  if (desc->in.W + desc->coeff.W + 2 + (f - fi - fc) > 125 || desc->acc.W + (f - fa) > 125) {
+    return fail(ACDSP_EUNSUPPORTED, "type combination needs more than 128-bit intermediates");
+  }
+  if ((rc = check_device(desc->device))) { return rc; }
+  acdsp_polydec *h = new acdsp_polydec();
+  h->d = *desc;
+  h->in_eb = elem_bytes(desc->in.W);
+  h->out_eb = elem_bytes(desc->out.W);
+  h->hl = round_up(desc->n_taps * desc->df + 15, 32);
+  h->lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc;
+  const size_t hb = (size_t)desc->n_channels * h->hl * h->in_eb;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    e = hipMalloc(&h->d_hist[i], hb);
+    if (e == hipSuccess) { e = hipMemset(h->d_hist[i], 0, hb); }
+  }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_coeffs, (size_t)desc->n_taps * desc->df * sizeof(int64_t)); }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_gfrag, 3 * 8 * 64 * 4 * sizeof(uint32_t)); }
+  if (e != hipSuccess) {
+    acdsp_polydec_destroy(h);
+    return fail(ACDSP_EHIP, "poly_dec state allocation failed: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_polydec_destroy(acdsp_polydec_t h) {
+  if (!h) { return ACDSP_OK; }
+  (void)hipSetDevice(h->d.device);
+  for (int i = 0; i < 2; i++) { if (h->d_hist[i]) { (void)hipFree(h->d_hist[i]); } }
+  if (h->d_coeffs) { (void)hipFree(h->d_coeffs); }
+  if (h->d_gfrag) { (void)hipFree(h->d_gfrag); }
+  h->st.destroy();
+  delete h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_polydec_set_coeffs(acdsp_polydec_t h, const int64_t *coeffs) {
+  if (!h || !coeffs) { return fail(ACDSP_EINVAL, "null argument"); }
+  const acdsp_polydec_desc_t &d = h->d;
+  int rc = check_device(d.device);
+  if (rc) { return rc; }
+  const int n = d.n_taps * d.df;
+  const acdsp::DFmt cf = make_dfmt(d.coeff);
+  for (int i = 0; i < n; i++) {
+    if (coeffs[i] < cf.lo || coeffs[i] > cf.hi) { return fail(ACDSP_EINVAL, "coefficient %d = %lld is not a COEFF_TYPE raw word", i, (long long)coeffs[i]); }
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+  h->gen_ok = false;
+  static const bool no_gen = getenv("ACDSP_NO_GEN") != nullptr;
+  if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && !no_gen && (d.in.W + (d.in.S ? 0 : 1) + 7) / 8 <= h->in_eb) {
+    // decimating FIR  y[g] = sum_k hh[k] x[g*DF + DF-1 - k],  hh[df + tp*DF] = c[tp + NTAPS*df]
+    std::vector<int64_t> hh((size_t)n, 0);
+    for (int df = 0; df < d.df; df++) { for (int tp = 0; tp < d.n_taps; tp++) { hh[df + tp * d.df] = coeffs[tp + d.n_taps * df]; } }
+    std::vector<uint32_t> fr;
+    if (fir_gen_plan(hh.data(), n, d.df, (d.df - 1) % 16, &h->gplan, &fr)) {
+      HIP_TRY(hipMemcpy(h->d_gfrag, fr.data(), fr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      h->gen_ok = true;
+    }
+  }
+  h->coeffs_set = true;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_polydec_path(acdsp_polydec_t h) { return h ? h->last_path : -1; }
+
+int32_t acdsp_polydec_run(acdsp_polydec_t h, const void *d_in, int64_t in_stride, int64_t n_in, void *d_out, int64_t out_stride,
+                          void *stream) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  const acdsp_polydec_desc_t &d = h->d;
+  if (n_in < 0 || n_in % d.df != 0) { return fail(ACDSP_EINVAL, "poly_dec: n_in = %lld is not a multiple of DF = %d", (long long)n_in, d.df); }
+  const int64_t n_out = n_in / d.df;
+  if (n_in > 0 && (!d_in || !d_out || in_stride < n_in || out_stride < n_out)) { return fail(ACDSP_EINVAL, "poly_dec: bad buffer arguments"); }
+  if (!h->coeffs_set) { return fail(ACDSP_ESTATE, "poly_dec run before set_coeffs"); }
+  if (n_in == 0) { return ACDSP_OK; }
+  int rc = check_device(d.device);
+  if (rc) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  FirParams k;
+  memset(&k, 0, sizeof k);
+  k.n_taps = d.n_taps * d.df; k.ftype = ACDSP_SHIFT_REG; k.n_ch = d.n_channels;
+  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+  k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl;
+  k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
+  k.in_stride = in_stride; k.out_stride = out_stride; k.n = n_in;
+  k.x = d_in; k.y = d_out; k.hist = h->d_hist[h->cur]; k.coeffs = h->d_coeffs;
+  const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0) && in_stride >= (n_in + 15) / 16 * 16;
+  hipError_t e;
+  if (h->gen_ok && aligned) {
+    h->last_path = ACDSP_PATH_MFMA_GEN;
+    e = launch_fir_gen(k, h->gplan, h->d_gfrag, 0, 0, d.df - 1, n_out, s);
+  } else {
+    h->last_path = ACDSP_PATH_GENERIC;
+    e = launch_polydec_generic(k, d.n_taps, d.df, n_out, s);
+  }
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_dec kernel launch failed: %s", hipGetErrorString(e)); }
+  e = launch_fir_hist_update(k, h->d_hist[h->cur ^ 1], s);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_dec state kernel launch failed: %s", hipGetErrorString(e)); }
+  h->cur ^= 1;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_polydec_run_host(acdsp_polydec_t h, const void *h_in, int64_t n_in, void *h_out) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  if (n_in < 0 || n_in % h->d.df != 0 || (n_in > 0 && (!h_in || !h_out))) { return fail(ACDSP_EINVAL, "poly_dec run_host: bad arguments"); }
+  if (n_in == 0) { return ACDSP_OK; }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  const int64_t n_out = n_in / h->d.df;
+  const int64_t si = (n_in + 15) / 16 * 16, so = (n_out + 7) / 8 * 8;
+  if ((rc = h->st.ensure((size_t)h->d.n_channels * si * h->in_eb, (size_t)h->d.n_channels * so * h->out_eb))) { return rc; }
+  HIP_TRY(hipMemcpy2D(h->st.d_in, (size_t)si * h->in_eb, h_in, (size_t)n_in * h->in_eb, (size_t)n_in * h->in_eb,
+                      (size_t)h->d.n_channels, hipMemcpyHostToDevice));
+  if ((rc = acdsp_polydec_run(h, h->st.d_in, si, n_in, h->st.d_out, so, nullptr))) { return rc; }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipMemcpy2D(h_out, (size_t)n_out * h->out_eb, h->st.d_out, (size_t)so * h->out_eb, (size_t)n_out * h->out_eb,
+                      (size_t)h->d.n_channels, hipMemcpyDeviceToHost));
+  return ACDSP_OK;
+}
+
+int32_t acdsp_polydec_reset(acdsp_polydec_t h) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < 2; i++) { HIP_TRY(hipMemset(h->d_hist[i], 0, (size_t)h->d.n_channels * h->hl * h->in_eb)); }
+  return ACDSP_OK;
+}
+
+}  // extern "C"

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import lib, check, Fmt, FirDesc, CicDesc, FTYPES, KINDS, PATHS
+from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, FTYPES, KINDS, PATHS
 
 
 def device_count():
@@ -164,6 +164,47 @@ class Cic:
     def close(self):
         if getattr(self, "_h", None):
             lib.acdsp_cic_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class PolyDec:
+    """n_channels independent ac_poly_dec objects (NTAPS taps per branch, decimation DF)."""
+
+    def __init__(self, n_taps, df, fin, fcoeff, facc, fout, n_channels=1, device=0, force_generic=False):
+        self.n_taps, self.df, self.n_channels = n_taps, df, n_channels
+        self.fin, self.fcoeff, self.facc, self.fout = fin, fcoeff, facc, fout
+        d = PolyDecDesc(n_taps, df, n_channels, fin, fcoeff, facc, fout, device, _lib.FLAG_FORCE_GENERIC if force_generic else 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_polydec_create(C.byref(d), C.byref(self._h)))
+
+    def set_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert c.shape == (self.n_taps * self.df,)
+        check(lib.acdsp_polydec_set_coeffs(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    @property
+    def path(self):
+        return PATHS[lib.acdsp_polydec_path(self._h)]
+
+    def run(self, x, out=None):
+        assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1
+        assert x.dtype == torch_dtype_for(self.fin) and x.shape[1] % self.df == 0
+        n_out = x.shape[1] // self.df
+        if out is None:
+            out = torch.empty((self.n_channels, max(n_out, 1)), dtype=torch_dtype_for(self.fout), device=x.device)
+        check(lib.acdsp_polydec_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), x.shape[1], C.c_void_p(out.data_ptr()),
+                                    out.stride(0), _stream_ptr(x)))
+        return out[:, :n_out]
+
+    def reset(self):
+        check(lib.acdsp_polydec_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.acdsp_polydec_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir1023", "cic_dec", "ddc"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir1023", "cic_dec", "ddc", "polydec"])
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,6 +129,29 @@ def main():
             eng.run(x, y)
         path = eng.path
         samples_per_step = (hi - lo) * n
+    elif args.workload == "polydec":
+        # ac_poly_dec, 16 taps per branch x DF = 8 (128-tap decimate-by-8), ac_fixed<16,2>
+        ch_per_gpu = args.channels or 1024
+        n = args.samples or (1 << 22)
+        fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        eng = A.PolyDec(16, 8, fin, fc, fa, fo, n_channels=hi - lo, device=local_rank)
+        hh = windowed_sinc_raw(127, 0.05, fc.F)
+        hh = np.concatenate([hh, [0]])
+        eng.set_coeffs(np.array([hh[df + tp * 8] for df in range(8) for tp in range(16)], dtype=np.int64))
+        x = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
+        A.fill_stimulus(x, seed, 16, ch0=lo)
+        y = torch.empty((hi - lo, n // 8 + 8), dtype=torch.int16, device=dev)
+        bytes_per_sample = 2.0 + 2.0 / 8
+        macs_per_sample = 0.0
+        name = "ac_poly_dec NTAPS=16 DF=8 ac_fixed<16,2> -> <16,2,RND,SAT>, %d ch x %d samples per GPU (SURVEY 8 f2)" % (ch_per_gpu, n)
+        dtype = "int16 (exact: multi-plane int8 MFMA, 64-bit recombination)"
+        coeffs = None
+
+        def step():
+            eng.run(x, y)
+        samples_per_step = (hi - lo) * n
+        path = "polydec"
     elif args.workload == "ddc":
         # BASELINE configs[4]: CIC R=16 N=5 on ac_fixed<16,1> -> lossless INT <36,21> -> 127-tap FIR (IN <36,21>,
         # COEFF <16,1>); I and Q are separate real streams, 2048 complex = 4096 real streams per GPU
@@ -195,7 +218,10 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    k_avg, k_min = eng.kernel_stats(min(args.steps, 64))   # HIP events around the dominant kernel, launch stream
+    if hasattr(eng, "kernel_stats"):
+        k_avg, k_min = eng.kernel_stats(min(args.steps, 64))   # HIP events around the dominant kernel, launch stream
+    else:                                                     # poly_dec handle: events around the whole step on the launch stream
+        k_avg = k_min = ev0.elapsed_time(ev1) / args.steps
     if args.workload == "ddc":                              # two kernels per step: report their sum
         c_avg, c_min = cic.kernel_stats(min(args.steps, 64))
         k_avg, k_min = k_avg + c_avg, k_min + c_min
@@ -219,7 +245,7 @@ def main():
             "config": {"workload": name, "kernel_path": path, "channels_per_gpu": ch_per_gpu, "samples_per_step": n,
                        "parallelism": "channel-slice x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec", "ddc": "r1_ddc"}[args.workload]),
+                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec", "ddc": "r1_ddc", "polydec": "r1_polydec"}[args.workload]),
                          "algorithmic_bytes_per_launch": bytes_per_sample * samples_per_step, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
                          "algorithmic_bytes_per_sample": bytes_per_sample},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,

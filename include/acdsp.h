@@ -80,7 +80,18 @@ typedef struct {
   int32_t flags;
 } acdsp_cic_desc_t;
 
+/* ac_poly_dec<IN, COEFF, STR_COEFF, ACC, OUT, NTAPS, DF> (reference include/ac_dsp/ac_poly_dec.h:82) */
+typedef struct {
+  int32_t n_taps;             /* NTAPS: taps per polyphase branch; the coefficient struct holds NTAPS*DF words */
+  int32_t df;                 /* decimation factor */
+  int32_t n_channels;
+  acdsp_fmt_t in, coeff, acc, out;
+  int32_t device;
+  int32_t flags;
+} acdsp_polydec_desc_t;
+
 typedef struct acdsp_fir *acdsp_fir_t;
+typedef struct acdsp_polydec *acdsp_polydec_t;
 typedef struct acdsp_cic *acdsp_cic_t;
 
 /* ---- general ---- */
@@ -141,6 +152,17 @@ int32_t acdsp_cic_reset(acdsp_cic_t h);
 int32_t acdsp_cic_path(acdsp_cic_t h);         /* 0: recurrence kernel, 3: FIR-identity MFMA kernel (ACDSP_PATH_MFMA_GEN) */
 int32_t acdsp_cic_last_kernel_ms(acdsp_cic_t h, float *ms);
 int32_t acdsp_cic_kernel_stats(acdsp_cic_t h, int32_t last_k, float *avg_ms, float *min_ms);
+
+/* ---- polyphase decimator (replaces the loop nest of ac_poly_dec::run, ac_poly_dec.h:109-128) ---- */
+int32_t acdsp_polydec_create(const acdsp_polydec_desc_t *desc, acdsp_polydec_t *out);
+int32_t acdsp_polydec_destroy(acdsp_polydec_t h);
+int32_t acdsp_polydec_set_coeffs(acdsp_polydec_t h, const int64_t *coeffs); /* [NTAPS*DF], the STR_COEFF_TYPE array */
+/* n_in must be a multiple of DF (run() consumes whole groups: `while (data_in.available(DF))`); n_in/DF outputs */
+int32_t acdsp_polydec_run(acdsp_polydec_t h, const void *d_in, int64_t in_stride, int64_t n_in, void *d_out,
+                          int64_t out_stride, void *stream);
+int32_t acdsp_polydec_run_host(acdsp_polydec_t h, const void *h_in, int64_t n_in, void *h_out);
+int32_t acdsp_polydec_reset(acdsp_polydec_t h);
+int32_t acdsp_polydec_path(acdsp_polydec_t h);  /* ACDSP_PATH_GENERIC or ACDSP_PATH_MFMA_GEN */
 
 #ifdef __cplusplus
 }

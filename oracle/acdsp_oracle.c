@@ -419,6 +419,53 @@ int64_t orc_cic_run(orc_cic_t *c, const int64_t *x, int64_t n_in, int64_t *y, in
 }
 
 /* ------------------------------------------------------------------ */
+/* Polyphase decimator -- reference include/ac_dsp/ac_poly_dec.h        */
+/* ------------------------------------------------------------------ */
+
+struct orc_polydec {
+  int32_t ntaps, df;
+  orc_fmt_t in, cf, acc, out;
+  int fi, fc, fa;
+  int64_t *taps; /* IN_TYPE taps[NTAPS * DF]  (ac_poly_dec.h:132) */
+};
+
+orc_polydec_t *orc_polydec_new(int32_t ntaps, int32_t df, const orc_fmt_t *in, const orc_fmt_t *coeff, const orc_fmt_t *acc,
+                               const orc_fmt_t *out) {
+  if (ntaps < 1 || df < 1) { return NULL; }
+  orc_polydec_t *f = (orc_polydec_t *)calloc(1, sizeof *f);
+  f->ntaps = ntaps; f->df = df;
+  f->in = *in; f->cf = *coeff; f->acc = *acc; f->out = *out;
+  f->fi = in->W - in->I; f->fc = coeff->W - coeff->I; f->fa = acc->W - acc->I;
+  f->taps = (int64_t *)calloc((size_t)ntaps * (size_t)df, sizeof(int64_t)); /* init_array<AC_VAL_0>, :88 */
+  return f;
+}
+void orc_polydec_free(orc_polydec_t *f) {
+  if (!f) { return; }
+  free(f->taps); free(f);
+}
+
+int64_t orc_polydec_run(orc_polydec_t *f, const int64_t *c, const int64_t *x, int64_t n_in, int64_t *y) {
+  const int NT = f->ntaps, DF = f->df;
+  int64_t n_out = 0, pos = 0;
+  while (n_in - pos >= DF) { /* while (data_in.available(DF)) -- :109 */
+    int64_t acc = 0;         /* ACC_TYPE acc, reset after every output (:127) */
+    for (int df = DF - 1; df >= 0; df--) { /* :112 */
+      for (int i = NT * DF - 1; i >= 0; i--) { f->taps[i] = (i == 0) ? x[pos] : f->taps[i - 1]; } /* SHIFT :114-116 */
+      pos++;
+      int64_t acc1 = 0;      /* acc1[df] is zero on entry: cleared after each use (:123) */
+      for (int tp = 0; tp < NT; tp++) { /* MAC :118-121 */
+        int fs;
+        i128 s = add_aligned((i128)acc1, f->fa, (i128)f->taps[tp * DF] * c[tp + NT * df], f->fi + f->fc, &fs);
+        acc1 = requant(s, fs, &f->acc);
+      }
+      acc = requant((i128)acc + (i128)acc1, f->fa, &f->acc); /* acc = acc + acc1[df], :122 */
+    }
+    y[n_out++] = requant((i128)acc, f->fa, &f->out); /* OUT_TYPE acc_t = acc, :125 */
+  }
+  return n_out;
+}
+
+/* ------------------------------------------------------------------ */
 /* Synthetic stimulus (counter hash; the GPU generator is bit-identical) */
 /* ------------------------------------------------------------------ */
 

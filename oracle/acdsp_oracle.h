@@ -76,6 +76,15 @@ int32_t orc_cic_int_type(int32_t interp, int32_t R, int32_t M, int32_t N, const 
  * number produced (or -1 if cap is too small). */
 int64_t orc_cic_run(orc_cic_t *c, const int64_t *x, int64_t n_in, int64_t *y, int64_t cap);
 
+/* ---- polyphase decimator (row f2 of SURVEY 8: reference include/ac_dsp/ac_poly_dec.h:82-138) ---- */
+typedef struct orc_polydec orc_polydec_t;
+orc_polydec_t *orc_polydec_new(int32_t ntaps, int32_t df, const orc_fmt_t *in, const orc_fmt_t *coeff, const orc_fmt_t *acc,
+                               const orc_fmt_t *out);
+void orc_polydec_free(orc_polydec_t *f);
+/* One run() call: consumes floor(n_in / DF) * DF inputs (the reference loops `while (available(DF))`), writes
+ * one output per group; coeffs is the STR_COEFF_TYPE array [NTAPS*DF].  Returns the number of outputs. */
+int64_t orc_polydec_run(orc_polydec_t *f, const int64_t *coeffs, const int64_t *x, int64_t n_in, int64_t *y);
+
 /* ---- synthetic stimulus shared with the GPU generator ---- */
 uint64_t orc_splitmix64(uint64_t seed, uint64_t index);
 /* raw sample for (channel, t): low `bits` bits of the hash, sign-extended */

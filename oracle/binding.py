@@ -59,6 +59,11 @@ lib.orc_cic_int_type.restype = C.c_int32
 lib.orc_cic_int_type.argtypes = [C.c_int32] * 4 + [C.POINTER(Fmt)] * 2
 lib.orc_cic_run.restype = C.c_int64
 lib.orc_cic_run.argtypes = [C.c_void_p, _i64p, C.c_int64, _i64p, C.c_int64]
+lib.orc_polydec_new.restype = C.c_void_p
+lib.orc_polydec_new.argtypes = [C.c_int32, C.c_int32] + [C.POINTER(Fmt)] * 4
+lib.orc_polydec_free.argtypes = [C.c_void_p]
+lib.orc_polydec_run.restype = C.c_int64
+lib.orc_polydec_run.argtypes = [C.c_void_p, _i64p, _i64p, C.c_int64, _i64p]
 lib.orc_stimulus.restype = C.c_int64
 lib.orc_stimulus.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]
 lib.orc_splitmix64.restype = C.c_uint64
@@ -158,3 +163,29 @@ class OracleCic:
         for h in getattr(self, "_h", []):
             if h:
                 lib.orc_cic_free(h)
+
+
+class OraclePolyDec:
+    """n_ch reference-style ac_poly_dec objects; run() consumes floor(n/DF)*DF samples of [n_ch][n]."""
+
+    def __init__(self, ntaps, df, fin, fcoeff, facc, fout, n_ch=1):
+        self.ntaps, self.df, self.n_ch = ntaps, df, n_ch
+        self._h = [lib.orc_polydec_new(ntaps, df, C.byref(fin), C.byref(fcoeff), C.byref(facc), C.byref(fout)) for _ in range(n_ch)]
+        if any(h is None for h in self._h):
+            raise ValueError("oracle: unsupported poly_dec configuration")
+
+    def run(self, coeffs, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert coeffs.shape == (self.ntaps * self.df,)
+        outs = []
+        for ch in range(self.n_ch):
+            y = np.empty(x.shape[1] // self.df + 1, dtype=np.int64)
+            k = lib.orc_polydec_run(self._h[ch], _p(coeffs), _p(x[ch]), x.shape[1], _p(y))
+            outs.append(y[:k].copy())
+        return np.stack(outs)
+
+    def __del__(self):
+        for h in getattr(self, "_h", []):
+            if h:
+                lib.orc_polydec_free(h)

@@ -216,3 +216,27 @@ def test_numpy_stimulus_equals_c_stimulus():
     for c in range(3):
         for t in range(50):
             assert a[c, t] == lib.orc_stimulus(0xACD5, 2 + c, 7 + t, 16)
+
+
+def test_polydec_is_a_decimating_fir_when_lossless():
+    # ac_poly_dec.h:112-128: y[g] = sum_k h[k] x[g*DF + DF-1 - k] with h[df + tp*DF] = c[tp + NTAPS*df]
+    from oracle import OraclePolyDec
+    NT, DF = 5, 3
+    fi, fc, fa = Fmt(16, 2), Fmt(16, 2), Fmt(40, 12)
+    rng = np.random.default_rng(0)
+    c = rng.integers(-2000, 2000, size=NT * DF)
+    x = stimulus(3, 1, 302, 16)                     # 100 groups + 2 left-over samples (not consumed)
+    y = OraclePolyDec(NT, DF, fi, fc, fa, fa).run(c, x)[0]
+    assert len(y) == 100
+    h = [0] * (NT * DF)
+    for df in range(DF):
+        for tp in range(NT):
+            h[df + tp * DF] = int(c[tp + NT * df])
+    xp = [0] * (NT * DF) + [int(v) for v in x[0]]
+    for g in range(100):
+        t = g * DF + DF - 1 + NT * DF
+        assert y[g] == sum(h[k] * xp[t - k] for k in range(NT * DF))
+    # state carries across calls in whole groups
+    o = OraclePolyDec(NT, DF, fi, fc, fa, fa)
+    parts = np.concatenate([o.run(c, x[:, :30]), o.run(c, x[:, 30:300])], axis=1)
+    assert np.array_equal(parts[0], y)
