@@ -35,12 +35,14 @@
 // One wave = one channel x one time chunk; the Toeplitz fragments are per coefficient set, so
 // per-channel coefficients cost nothing extra.
 //
-// Scheduling.  VALU and MFMA instructions share one issue port per SIMD: an MFMA owns it for 4 of
-// its 32 cycles, so ~7 other instructions can hide behind each MFMA -- but only if they come from
-// the partner wave while this one is inside its MFMA run.  Two identical waves drift into the same
-// phase and then total = MFMA time + VALU time.  The kernel therefore runs 8-wave workgroups (two
-// waves per SIMD) in ping-pong: waves 0-3 execute their MFMA run while waves 4-7 execute their
-// epilogue / stores / staging, and an s_barrier swaps the roles (two barriers per step).
+// Scheduling.  On gfx950 the int8 MFMA run and the rest of a SIMD's instruction stream serialise: time per
+// step ~ (#MFMA x 32 cycles) + (#other instructions x ~4 cycles), whatever the wave pairing (measured:
+// two free-running waves per SIMD, an 8-wave ping-pong with s_barrier role swaps, and a software-pipelined
+// 1 MFMA : 4 VALU interleave all land within a few percent, the ping-pong 4 % behind).  The kernel therefore
+// uses independent single-wave workgroups and spends its effort on instruction count: zero high-byte Toeplitz
+// blocks are skipped, the epilogue is 4 VALU ops per output plus a clamping pack, outputs leave through a
+// swizzled LDS tile as two 16-byte-per-lane stores.  The 8-wave ping-pong form stays selectable (kSmallWaves)
+// and is what the large-tap kernel uses, where the Toeplitz fragments are shared through LDS.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -371,6 +373,12 @@ static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const
   return hipGetLastError();
 }
 
+// Waves per workgroup of the register-resident kernel.  8 = ping-pong (MFMA run of waves 0-3 against the
+// epilogue / staging of waves 4-7, s_barrier between): measured 4 % SLOWER than independent single-wave
+// workgroups on MI355X (1.215 vs 1.163 ms on config 2), because MFMA and VALU issue serialise per SIMD
+// whatever the pairing; kept selectable for the record.
+constexpr int kSmallWaves = 1;
+
 // Largest instantiated band skip hs (0, 2 or 3) such that every non-zero high-byte block lies in [hs, NB-1-hs].
 static int pick_hs(int nb, uint64_t hi_mask) {
   const int cand[2] = {3, 2};
@@ -386,9 +394,9 @@ static int pick_hs(int nb, uint64_t hi_mask) {
 template <int NB>
 static hipError_t launch_nb(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   const int hs = epi ? pick_hs(NB, a.hi_mask) : 0;
-  if (NB >= 7 && hs == 3) { return launch_nb_hs<NB, (NB >= 7 ? 3 : 0), 8>(p, d_frag, a, epi, grid, s); }
-  if (NB >= 5 && hs == 2) { return launch_nb_hs<NB, (NB >= 5 ? 2 : 0), 8>(p, d_frag, a, epi, grid, s); }
-  return launch_nb_hs<NB, 0, 8>(p, d_frag, a, epi, grid, s);
+  if (NB >= 7 && hs == 3) { return launch_nb_hs<NB, (NB >= 7 ? 3 : 0), kSmallWaves>(p, d_frag, a, epi, grid, s); }
+  if (NB >= 5 && hs == 2) { return launch_nb_hs<NB, (NB >= 5 ? 2 : 0), kSmallWaves>(p, d_frag, a, epi, grid, s); }
+  return launch_nb_hs<NB, 0, kSmallWaves>(p, d_frag, a, epi, grid, s);
 }
 
 
@@ -624,10 +632,11 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   a.lo_mask = plan.lo_mask;
   a.nb = plan.nb; a.hb0 = 0; a.hb1 = plan.nb - 1;
   a.corr = d_corr;
-  dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)((p.n_ch + 7) / 8));
+  const int wpb = plan.nb > kMaxRegNB ? 8 : kSmallWaves;   // channels (waves) per workgroup
+  dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)((p.n_ch + wpb - 1) / wpb));
   a.dbg = nullptr;
   static const bool dbg_clock = getenv("ACDSP_DEBUG_CLOCK") != nullptr;
-  const size_t n_waves = (size_t)grid.x * grid.y * 8;
+  const size_t n_waves = (size_t)grid.x * grid.y * wpb;
   if (dbg_clock) { if (hipMalloc((void **)&a.dbg, n_waves * 48) != hipSuccess) { a.dbg = nullptr; } else { (void)hipMemsetAsync(a.dbg, 0, n_waves * 48, s); } }
   hipError_t rc = launch_switch(p, plan.nb, d_frag, a, epi, grid, s);
   if (a.dbg) {
