@@ -120,9 +120,30 @@ struct MfmaArgs {
   int64_t *dbg;            // optional: per-wave {shader-clock ticks, 100 MHz real-time ticks} (ACDSP_DEBUG_CLOCK)
 };
 
+// 32-bit epilogue of the int16-output fast path.  V = 2^16 hh + 2^8 mid + ll is the exact dot product (ll
+// already carries 128*sum(c) and the rounding constant); lo = 2^8 mid + ll fits int32 (host-checked), so
+//   V >> rs = (hh << (16 - rs)) + (lo >> rs)            for rs <= 16   (2^16 hh is a multiple of 2^rs)
+//   V >> rs = (hh + (lo >> 16)) >> (rs - 16)            for rs  > 16
+// i.e. 3 (4) VALU ops per output; rs is wave-uniform.
+__device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16i &ll, int rs, int (&o)[16]) {
+  if (rs <= 16) {   // one uniform branch per step, not one per output
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int lo = (int)(((unsigned)mid[r] << 8) + (unsigned)ll[r]);
+      o[r] = (int)((unsigned)hh[r] << (16 - rs)) + (lo >> rs);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int lo = (int)(((unsigned)mid[r] << 8) + (unsigned)ll[r]);
+      o[r] = (hh[r] + (lo >> 16)) >> (rs - 16);
+    }
+  }
+}
+
 // EPI 0: any OUT_TYPE / ACC width through requant64.
-// EPI 1: OUT container int16, Q in {TRN, RND}, O = WRAP, no accumulator wrap possible, right shift >= 8:
-//        all-32-bit epilogue.   EPI 2: the same with O = SAT (v_cvt_pk_i16_i32 clamps and packs).
+// EPI 1: OUT container int16, Q in {TRN, RND}, O = WRAP, no accumulator wrap possible, right shift 1..31:
+//        32-bit epilogue (epi32).   EPI 2: the same with O = SAT (v_cvt_pk_i16_i32 clamps and packs).
 // HS:    compile-time band [HS, NB-1-HS] of K-blocks whose high-byte Toeplitz plane is non-zero.
 // WAVES: 8 = ping-pong workgroup (see header), 1 = single-wave workgroup.
 // FAST:  the chunk is interior: all loads/stores are full vectors, so the loop has no divergent branch
@@ -140,6 +161,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   const int n_col = lane & 31, h = lane >> 5;
   int ch = blockIdx.y * WAVES + wave;
   if (ch >= p.n_ch) { ch = p.n_ch - 1; }  // surplus waves redo the last channel (identical stores): barriers stay uniform
+  ch = __builtin_amdgcn_readfirstlane(ch);  // wave-uniform: row bases live in SGPRs
   const int set = a.frag_per_channel ? ch : 0;
   unsigned char *lds = lds_all + wave * (2 * 4 * ARR + 2048);
   unsigned char *obuf = lds + 2 * 4 * ARR;  // 2 KB output tile (FAST path)
@@ -169,6 +191,18 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
       R[j] = *(const v4i *)src;
     }
   };
+  // FAST, every fetch but the chunk's first: no history and no end of row in reach (32 HB <= 1024), so the
+  // address is a scalar row base plus a loop-invariant 32-bit lane offset -- no per-load VALU.  A fetch past
+  // the chunk's last step is redirected to that step (valid, unused).
+  auto issue_loads_in = [&](int64_t T0) {
+    const int64_t tl = (s1 - 1) * 1024;
+    const char *sb = (const char *)(xrow + ((T0 < tl ? T0 : tl) - 32 * HB));
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
+      R[j] = *(const v4i *)(sb + (unsigned)(16 * pc));
+    }
+  };
   // split into byte planes and stage: arrays [plane][half][chunk] of 16 bytes
   auto stage = [&](unsigned char *buf) {
 #pragma unroll
@@ -190,13 +224,11 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   // epilogue constants
   const int rs = p.in.F + p.cf.F - p.out.F;
   const int64_t corr = a.corr[set];
-  // EPI 1/2: with C = 128*sum(c) + rounding constant (|C| + |S(cl,xl)| < 2^31 is checked on the host)
-  //   q = ((hh << 8) + mid1 + mid2 + ((ll + C) >> 8)) >> (rs - 8)
-  // then a packing v_cvt_pk_i16_i32 that also performs the AC_SAT clamp for the 16-bit OUT_TYPE.
-  // The epilogue runs in the O phase, which has issue slack under the partner wave's MFMA run.
+  // EPI 1/2: C = 128*sum(c) + rounding constant rides in as the initial value of the low-plane accumulator;
+  // epi32() then needs 3 VALU ops per output and v_cvt_pk_i16_i32 packs (and clamps, for AC_SAT).
   const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
-  const int c_ll = (EPI != 0) ? (int)corr_t : 0;   // added to the low-plane sum in the epilogue (int32-safe, host-checked)
-  const int rs8 = rs - 8;
+  const int c_ll = (EPI != 0) ? (int)corr_t : 0;   // preloaded into the low-plane accumulator (int32-safe, host-checked)
+  const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
   int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 32 * n_col + 4 * h;  // EPI 1/2
 
   // The Toeplitz fragments must have landed before the loop: otherwise the compiler keeps
@@ -227,7 +259,8 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   // software pipeline: loads run two steps ahead of the MFMAs, staging one step ahead
   issue_loads(s0 * 1024);
   stage(lds);
-  if (FAST || nsteps > 1) { issue_loads((s0 + 1) * 1024); }
+  if (FAST) { issue_loads_in((s0 + 1) * 1024); }
+  else if (nsteps > 1) { issue_loads((s0 + 1) * 1024); }
   read_group(lds, 0, Bh[0], Bl[0]);
   if (WAVES == 8 && grp == 1) { __builtin_amdgcn_s_barrier(); }  // second half starts one phase later
 
@@ -240,7 +273,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 #endif
     // ---------------- phase M: MFMA run (four independent accumulators: every one is reused only
     // every fourth MFMA, so a single wave keeps the matrix pipe at its 32-cycle issue rate) ----------------
-    v16i hh = {0}, mid1 = {0}, mid2 = {0}, ll = {0};
+    v16i hh = {0}, mid = {0}, ll = ll_init;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       __builtin_amdgcn_sched_barrier(0);
@@ -250,13 +283,13 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
       for (int i = 0; i < GS; i++) {
         const int b = g * GS + i;
         if (b < NB) {
-          // a Toeplitz block whose high-byte plane is all zero contributes nothing to hh / mid1
+          // a Toeplitz block whose high-byte plane is all zero contributes nothing to hh / mid
           if (HS == 0 || (b >= HS && b <= NB - 1 - HS)) {
             hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bh[g & 1][i], hh, 0, 0, 0);
-            mid1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[g & 1][i], mid1, 0, 0, 0);
+            mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[g & 1][i], mid, 0, 0, 0);
           }
           ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bl[g & 1][i], ll, 0, 0, 0);
-          mid2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[g & 1][i], mid2, 0, 0, 0);
+          mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[g & 1][i], mid, 0, 0, 0);
         }
       }
     }
@@ -271,17 +304,13 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 
     // ---------------- phase O: epilogue, stores, staging of the next step, prefetch ----------------
     // D layout: lane (n_col, h), register r: sample T0 + 32 n_col + (r&3) + 8 (r>>2) + 4 h
+    int o16[16];
+    if (EPI != 0) { epi32(hh, mid, ll, rs, o16); }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const int64_t t0 = T0 + 32 * n_col + 8 * g + 4 * h;
       if (EPI != 0) {
-        int o[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int r = 4 * g + rr;
-          const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid1[r]);
-          o[rr] = (A + mid2[r] + ((ll[r] + c_ll) >> 8)) >> rs8;
-        }
+        const int *o = o16 + 4 * g;
         v4s pk;
         if (EPI == 2) {  // OUT_TYPE is a signed 16-bit AC_SAT type: clamp and pack in one instruction
           typedef short v2s __attribute__((ext_vector_type(2)));
@@ -309,7 +338,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           const int r = 4 * g + rr;
-          int64_t v = ((int64_t)hh[r] << 16) + (((int64_t)mid1[r] + (int64_t)mid2[r]) << 8) + (int64_t)ll[r] + corr;
+          int64_t v = ((int64_t)hh[r] << 16) + ((int64_t)mid[r] << 8) + (int64_t)ll[r] + corr;
           int64_t acc = wrap64((int64_t)((uint64_t)v << p.lossless_shift), p.acc.W, p.acc.S);
           int64_t y = requant64(acc, p.acc.F, p.out);
           if (t0 + rr < p.n) { store_raw(p.y, (int64_t)ch * p.out_stride + t0 + rr, p.out_eb, y); }
@@ -329,7 +358,8 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
     if (s + 1 < nsteps) {
       unsigned char *nbuf = lds + ((s + 1) & 1) * (4 * ARR);
       stage(nbuf);                                                      // consumes the loads of step s+1
-      if (FAST || s + 2 < nsteps) { issue_loads(T0 + 2048); }           // FAST: a fetch past the chunk is clamped, harmless
+      if (FAST) { issue_loads_in(T0 + 2048); }                          // past the chunk: redirected, harmless
+      else if (s + 2 < nsteps) { issue_loads(T0 + 2048); }
       read_group(nbuf, 0, Bh[0], Bl[0]);
     }
 #ifdef ACDSP_X_PHASES
@@ -353,7 +383,8 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * (32 + NB - 1) * 16 + 2048)];
   const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
-  const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n;
+  // (a lone first step has no in-row window to park the unused prefetch on: see issue_loads_in)
+  const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n && (s0 > 0 || s1 >= 2);
   const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   if (interior) { fir_mfma_body<NB, EPI, HS, WAVES, true>(p, frag, a, lds); }
   else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
@@ -461,7 +492,7 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
   const int64_t corr = a.corr[0];
   const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
   const int c_ll = (EPI != 0) ? (int)corr_t : 0;
-  const int rs8 = rs - 8;
+  const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
   int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 32 * n_col + 4 * h;
 
   issue_loads(s0 * 1024);
@@ -478,7 +509,7 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
     const v4i *ah = ldsA + lane, *al = ldsA + NB * 64 + lane;
 
     // ---------------- phase M ----------------
-    v16i hh = {0}, mid1 = {0}, mid2 = {0}, ll = {0};
+    v16i hh = {0}, mid = {0}, ll = ll_init;
     v4i Ahc = ah[0], Alc = al[0], Bhc = *(const v4i *)fh, Blc = *(const v4i *)fl;
     for (int b = 0; b < NB; b++) {
       v4i Ahn = Ahc, Aln = Alc, Bhn = Bhc, Bln = Blc;
@@ -488,27 +519,23 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
       }
       if (b >= a.hb0 && b <= a.hb1) {
         hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bhc, hh, 0, 0, 0);
-        mid1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Blc, mid1, 0, 0, 0);
+        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Blc, mid, 0, 0, 0);
       }
       ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Blc, ll, 0, 0, 0);
-      mid2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bhc, mid2, 0, 0, 0);
+      mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bhc, mid, 0, 0, 0);
       Ahc = Ahn; Alc = Aln; Bhc = Bhn; Blc = Bln;
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
 
     // ---------------- phase O ----------------
+    int o16[16];
+    if (EPI != 0) { epi32(hh, mid, ll, rs, o16); }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const int64_t t0 = T0 + 32 * n_col + 8 * g + 4 * h;
       if (EPI != 0) {
-        int o[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int r = 4 * g + rr;
-          const int A = (int)(((unsigned)hh[r] << 8) + (unsigned)mid1[r]);
-          o[rr] = (A + mid2[r] + ((ll[r] + c_ll) >> 8)) >> rs8;
-        }
+        const int *o = o16 + 4 * g;
         v4s pk;
         if (EPI == 2) {
           typedef short v2s __attribute__((ext_vector_type(2)));
@@ -533,7 +560,7 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           const int r = 4 * g + rr;
-          int64_t v = ((int64_t)hh[r] << 16) + (((int64_t)mid1[r] + (int64_t)mid2[r]) << 8) + (int64_t)ll[r] + corr;
+          int64_t v = ((int64_t)hh[r] << 16) + ((int64_t)mid[r] << 8) + (int64_t)ll[r] + corr;
           int64_t acc = wrap64((int64_t)((uint64_t)v << p.lossless_shift), p.acc.W, p.acc.S);
           int64_t y = requant64(acc, p.acc.F, p.out);
           if (t0 + rr < p.n) { store_raw(p.y, (int64_t)ch * p.out_stride + t0 + rr, p.out_eb, y); }
@@ -603,10 +630,12 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   const int64_t hh_max = 128 * plan.sum_abs_hi, mid_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo), ll_max = 128 * plan.sum_abs_lo;
   const int64_t rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs <= 38) ? (int64_t(1) << (rs - 1)) : 0;
   const int64_t corr_abs = (plan.corr < 0 ? -plan.corr : plan.corr) + rnd;
-  const bool small = hh_max * 256 + mid_max + (ll_max + corr_abs + 255) / 256 + 2 < (int64_t(1) << 31) &&
-                     ll_max + corr_abs + 2 < (int64_t(1) << 31);
+  // lo = 2^8 mid + ll (with the preloaded constant) and the shifted sum must stay inside int32
+  const bool small = mid_max * 256 + ll_max + corr_abs + 2 < (int64_t(1) << 31) &&
+                     (rs <= 16 ? (hh_max << (16 - (rs < 16 ? rs : 16))) + ((mid_max * 256 + ll_max + corr_abs) >> (rs > 0 ? rs : 0)) + 2
+                               : hh_max + ((mid_max * 256 + ll_max + corr_abs) >> 16) + 2) < (int64_t(1) << 31);
   if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
-      rs >= 8 && rs <= 38 && acc_wide && small && p.out.W == 16) {
+      rs >= 1 && rs <= 31 && acc_wide && small && p.out.W == 16) {
     return p.out.O == ACDSP_SAT ? 2 : 1;
   }
   return 0;
