@@ -125,21 +125,28 @@ struct MfmaArgs {
 //   V >> rs = (hh << (16 - rs)) + (lo >> rs)            for rs <= 16   (2^16 hh is a multiple of 2^rs)
 //   V >> rs = (hh + (lo >> 16)) >> (rs - 16)            for rs  > 16
 // i.e. 3 (4) VALU ops per output; rs is wave-uniform.
-__device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16i &ll, int rs, int (&o)[16]) {
-  if (rs <= 16) {   // one uniform branch per step, not one per output
+template <bool WIDE>   // WIDE: rs > 16
+__device__ __forceinline__ void epi32_t(const v16i &hh, const v16i &mid, const v16i &ll, int rs, int (&o)[16]) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int lo = (int)(((unsigned)mid[r] << 8) + (unsigned)ll[r]);
-      o[r] = (int)((unsigned)hh[r] << (16 - rs)) + (lo >> rs);
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int lo = (int)(((unsigned)mid[r] << 8) + (unsigned)ll[r]);
-      o[r] = (hh[r] + (lo >> 16)) >> (rs - 16);
-    }
+  for (int r = 0; r < 16; r++) {
+    const int lo = (int)(((unsigned)mid[r] << 8) + (unsigned)ll[r]);
+    o[r] = WIDE ? (hh[r] + (lo >> 16)) >> (rs - 16) : (int)((unsigned)hh[r] << (16 - rs)) + (lo >> rs);
   }
 }
+__device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16i &ll, int rs, int (&o)[16]) {
+  if (rs <= 16) { epi32_t<false>(hh, mid, ll, rs, o); }   // one uniform branch per step, not one per output
+  else { epi32_t<true>(hh, mid, ll, rs, o); }
+}
+
+// B-fragment read-ahead group size and target waves per SIMD of the register-resident kernel (tuning knobs:
+// (3, 2) measured 1.117 ms on config 2, (1, 3) 1.068 ms but spills on dense coefficient sets -> 2.2 ms).
+#ifndef ACDSP_GS
+#define ACDSP_GS 3
+#endif
+#ifndef ACDSP_OCC
+#define ACDSP_OCC 2
+#endif
+constexpr int kGroupSize = ACDSP_GS, kOccupancy = ACDSP_OCC;
 
 // EPI 0: any OUT_TYPE / ACC width through requant64.
 // EPI 1: OUT container int16, Q in {TRN, RND}, O = WRAP, no accumulator wrap possible, right shift 1..31:
@@ -241,7 +248,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   // consume them; sched_barrier(0) pins the "reads of group g+1, then MFMAs of group g" order, which
   // the scheduler would otherwise re-serialise into read-wait-MFMA per block.  Group 0 of a step is
   // read at the end of the previous O phase, so its latency hides behind the barrier.
-  constexpr int GS = 3, NG = (NB + GS - 1) / GS;
+  constexpr int GS = kGroupSize, NG = (NB + GS - 1) / GS;
   v4i Bh[2][GS], Bl[2][GS];
   auto read_group = [&](const unsigned char *buf, int g, v4i (&dh)[GS], v4i (&dl)[GS]) {
     const unsigned char *fh = buf + (0 * 2 + h) * ARR + n_col * 16;
@@ -377,8 +384,204 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Software-pipelined body for interior chunks of single-wave workgroups (the steady state of every long
+// run).  The plain body above alternates an MFMA run (M) with ~120 dependent VALU/LDS/VMEM instructions
+// (O): measured 1290 + 1220 shader cycles per step, i.e. the matrix pipe idles half the time even with two
+// waves per SIMD.  Here step s's MFMAs run with everything else of the neighbouring steps interleaved in
+// the same instruction stream -- the epilogue and write-out of step s-1 (from a second accumulator set),
+// the byte-plane staging of step s+1 and the global loads of step s+2 -- so the wave always has MFMAs to
+// issue and the other work hides in their shadow (tools/mfma_probe.hip: 39 cycles/MFMA with the epilogue
+// interleaved vs 36 bare).  The loop is unrolled by two so the accumulator sets and the B-fragment
+// double buffer swap roles by renaming; it contains no branch.
+template <int NB, int EPI, int HS>
+__device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
+                                                   unsigned char *lds) {
+  static_assert(EPI == 1 || EPI == 2, "32-bit epilogue classes only");
+  constexpr int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, JN = (NP + 63) / 64, ARR = NC * 16;
+  // two accumulator sets + all Toeplitz fragments leave room for GS = 2 only when some high-byte blocks are skipped
+  constexpr int GS = (HS == 0 && NB >= 8) ? 1 : 2, NG = (NB + GS - 1) / GS;
+  const int lane = threadIdx.x & 63;
+  const int n_col = lane & 31, h = lane >> 5;
+  int ch = blockIdx.y;
+  if (ch >= p.n_ch) { ch = p.n_ch - 1; }
+  ch = __builtin_amdgcn_readfirstlane(ch);
+  const int set = a.frag_per_channel ? ch : 0;
+  unsigned char *obuf = lds + 2 * 4 * ARR;
+
+  v4i Ah[NB], Al[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    Ah[b] = frag[((int64_t)set * 2 * NB + 0 * NB + b) * 64 + lane];
+    Al[b] = frag[((int64_t)set * 2 * NB + 1 * NB + b) * 64 + lane];
+  }
+  const int16_t *xrow = (const int16_t *)p.x + (int64_t)ch * p.in_stride;
+  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)ch * p.hl + p.hl;
+  int16_t *yout = (int16_t *)p.y + (int64_t)ch * p.out_stride;
+  const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
+  const int nsteps = (int)(s1 - s0);
+
+  v4i R[JN];
+  auto issue_loads_first = [&](int64_t T0) {   // may reach into the history rows
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
+      int64_t t = T0 - 32 * HB + 8 * pc;
+      const int16_t *src = (t < 0) ? hrow + t : xrow + ((t < a.n8) ? t : 0);
+      R[j] = *(const v4i *)src;
+    }
+  };
+  auto issue_loads_in = [&](int64_t T0) {      // see fir_mfma_body
+    const int64_t tl = (s1 - 1) * 1024;
+    const char *sb = (const char *)(xrow + ((T0 < tl ? T0 : tl) - 32 * HB));
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
+      R[j] = *(const v4i *)(sb + (unsigned)(16 * pc));
+    }
+  };
+  auto stage = [&](unsigned char *buf) {
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      // surplus lanes hold a copy of the last piece and store it again: no exec-mask branch in the loop
+      const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
+      {
+        const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
+        unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
+        unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
+        unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
+        unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        *(v2u *)(buf + (0 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){hi0, hi1};
+        *(v2u *)(buf + (1 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){lo0, lo1};
+      }
+    }
+  };
+
+  const int rs = p.in.F + p.cf.F - p.out.F;
+  const int c_ll = (int)(a.corr[set] + ((p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0));
+  const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
+
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // Toeplitz fragments landed (keeps their vmcnt out of the loop)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // B fragments: groups of GS K-blocks, double buffered; the group sequence runs on across steps, so the
+  // buffer of group g of a step with parity PAR is (PAR * NG + g) & 1.
+  v4i Bh[2][GS], Bl[2][GS];
+  auto read_group = [&](const unsigned char *buf, int g, v4i (&dh)[GS], v4i (&dl)[GS]) {
+    const unsigned char *fh = buf + (0 * 2 + h) * ARR + n_col * 16;
+    const unsigned char *fl = buf + (1 * 2 + h) * ARR + n_col * 16;
+#pragma unroll
+    for (int i = 0; i < GS; i++) {
+      const int b = g * GS + i;
+      if (b < NB) {
+        dh[i] = *(const v4i *)(fh + 16 * b);
+        dl[i] = *(const v4i *)(fl + 16 * b);
+      }
+    }
+  };
+  // epilogue of a finished step: 16 outputs per lane -> packed int16 -> swizzled 2 KB LDS tile (fir_mfma_body)
+  auto emit = [&](auto wide_c, const v16i &hh, const v16i &mid, const v16i &ll) {
+    int o[16];
+    epi32_t<decltype(wide_c)::value>(hh, mid, ll, rs, o);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      v4s pk;
+      if (EPI == 2) {
+        typedef short v2s __attribute__((ext_vector_type(2)));
+        const v2s p0 = __builtin_amdgcn_cvt_pk_i16(o[4 * g], o[4 * g + 1]), p1 = __builtin_amdgcn_cvt_pk_i16(o[4 * g + 2], o[4 * g + 3]);
+        pk = (v4s){p0.x, p0.y, p1.x, p1.y};
+      } else {
+        pk = (v4s){(short)o[4 * g], (short)o[4 * g + 1], (short)o[4 * g + 2], (short)o[4 * g + 3]};
+      }
+      const int P = 4 * n_col + g;
+      *(v4s *)(obuf + (((P & ~15) | ((P + (P >> 4)) & 15)) * 16 + 8 * h)) = pk;
+    }
+  };
+  // ... and its row-contiguous write-out: two coalesced 16-byte-per-lane stores
+  auto flush = [&](int64_t T0) {
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int P = 64 * half + lane;
+      const v4i val = *(const v4i *)(obuf + ((P & ~15) | ((P + (P >> 4)) & 15)) * 16);
+      *(v4i *)(yout + T0 + 512 * half + 8 * lane) = val;
+    }
+  };
+
+  // One step.  PAR: step parity (selects buffers by renaming); PREV: there is a finished step in (ph, pm, pl).
+  auto run_step = [&](auto wide_c, auto par_c, auto prev_c, int s, v16i &hh, v16i &mid, v16i &ll, const v16i &ph, const v16i &pm,
+                      const v16i &pl) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool PREV = decltype(prev_c)::value;
+    const int64_t T0 = (s0 + s) * 1024;
+    const unsigned char *buf = lds + PAR * (4 * ARR);
+    unsigned char *nbuf = lds + (PAR ^ 1) * (4 * ARR);
+    hh = (v16i){0}; mid = (v16i){0}; ll = ll_init;
+    // side work, spread over the first groups: S = stage step s+1, L = fetch step s+2, E1 = epilogue of step
+    // s-1 into the LDS tile, E2 = its write-out
+    constexpr int gS = 0, gL = (NG > 1) ? 1 : 0, gE1 = (NG > 1) ? 1 : 0, gE2 = (NG > 2) ? 2 : NG - 1;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int dummy = 0; (void)dummy;
+      const int cb = (PAR * NG + g) & 1, nb_ = cb ^ 1;
+      if (NG == 1 && g == gS) { stage(nbuf); }
+      if (g + 1 < NG) { read_group(buf, g + 1, Bh[nb_], Bl[nb_]); }
+      else { read_group(nbuf, 0, Bh[nb_], Bl[nb_]); }          // first group of the next step (staged in group 0)
+      if (NG > 1 && g == gS) { stage(nbuf); }
+      if (g == gL) { issue_loads_in(T0 + 2048); }
+      if (PREV && g == gE1) { emit(wide_c, ph, pm, pl); }
+      if (PREV && g == gE2) { flush(T0 - 1024); }
+#pragma unroll
+      for (int i = 0; i < GS; i++) {
+        const int b = g * GS + i;
+        if (b < NB) {
+          if (HS == 0 || (b >= HS && b <= NB - 1 - HS)) {
+            hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bh[cb][i], hh, 0, 0, 0);
+            mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[cb][i], mid, 0, 0, 0);
+          }
+          ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bl[cb][i], ll, 0, 0, 0);
+          mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[cb][i], mid, 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using std::integral_constant;
+  typedef integral_constant<int, 0> P0; typedef integral_constant<int, 1> P1;
+  typedef integral_constant<bool, true> WithPrev; typedef integral_constant<bool, false> NoPrev;
+
+  // prologue: step s0 staged, step s0+1 in flight, first B group read
+  issue_loads_first(s0 * 1024);
+  stage(lds);
+  issue_loads_in((s0 + 1) * 1024);
+  read_group(lds, 0, Bh[0], Bl[0]);
+
+  auto go = [&](auto wide_c) {   // the loop exists once per epilogue shift class: no branch inside it
+    v16i hA, mA, lA, hB, mB, lB;
+    run_step(wide_c, P0(), NoPrev(), 0, hA, mA, lA, hA, mA, lA);
+    int s = 1;
+    for (; s + 1 < nsteps; s += 2) {
+      run_step(wide_c, P1(), WithPrev(), s, hB, mB, lB, hA, mA, lA);
+      run_step(wide_c, P0(), WithPrev(), s + 1, hA, mA, lA, hB, mB, lB);
+    }
+    if (s < nsteps) {
+      run_step(wide_c, P1(), WithPrev(), s, hB, mB, lB, hA, mA, lA);
+      emit(wide_c, hB, mB, lB);
+      flush((s0 + s) * 1024);
+    } else {
+      emit(wide_c, hA, mA, lA);
+      flush((s0 + s - 1) * 1024);
+    }
+  };
+  if (rs <= 16) { go(integral_constant<bool, false>()); }
+  else { go(integral_constant<bool, true>()); }
+}
+
 template <int NB, int EPI, int HS, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 2)
+__global__ void __launch_bounds__(64 * WAVES, kOccupancy)
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * (32 + NB - 1) * 16 + 2048)];
   const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
@@ -386,8 +589,13 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   // (a lone first step has no in-row window to park the unused prefetch on: see issue_loads_in)
   const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n && (s0 > 0 || s1 >= 2);
   const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
-  if (interior) { fir_mfma_body<NB, EPI, HS, WAVES, true>(p, frag, a, lds); }
-  else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
+  if constexpr (WAVES == 1 && EPI != 0) {
+    if (interior) { fir_mfma_pipe_body<NB, EPI, HS>(p, frag, a, lds); }
+    else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
+  } else {
+    if (interior) { fir_mfma_body<NB, EPI, HS, WAVES, true>(p, frag, a, lds); }
+    else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
+  }
   if (a.dbg && (threadIdx.x & 63) == 0) {
     const int64_t w = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6);
     a.dbg[2 * w] = (int64_t)(__builtin_readcyclecounter() - c0);

@@ -115,9 +115,12 @@ static void run(const char *name, int waves, int steps, const v4i *frag, const s
 
 // mode P: software-pipelined: the epilogue VALU of step s-1 is interleaved with the MFMAs of step s
 // (sched_group_barrier: 1 MFMA, then VPM VALU), four accumulators, 1 wave per SIMD.
-template <int NB, int VPM, int WPS>
-__global__ void __launch_bounds__(64, WPS) probe_pipe(const v4i *__restrict__ frag, short *__restrict__ y, int steps) {
+static long long *g_clk;
+
+template <int NB, int VPM, int WPS, int AG = 0>
+__global__ void __launch_bounds__(64, WPS) probe_pipe(const v4i *__restrict__ frag, short *__restrict__ y, int steps, long long *clk) {
   const int lane = threadIdx.x;
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   v4i Ah[NB], Al[NB], Xh[NB], Xl[NB];
 #pragma unroll
   for (int b = 0; b < NB; b++) {
@@ -130,14 +133,21 @@ __global__ void __launch_bounds__(64, WPS) probe_pipe(const v4i *__restrict__ fr
     v16i hh = {0}, m1 = {0}, m2 = {0}, ll = {0};
 #pragma unroll
     for (int b = 0; b < NB; b++) {
+      if (AG) {   // accumulators pinned to the AGPR half of the register file
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(hh) : "v"(Ah[b]), "v"(Xh[b]));
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(m1) : "v"(Ah[b]), "v"(Xl[b]));
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(ll) : "v"(Al[b]), "v"(Xl[b]));
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(m2) : "v"(Al[b]), "v"(Xh[b]));
+      } else {
       hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xh[b], hh, 0, 0, 0);
       m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Xl[b], m1, 0, 0, 0);
       ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xl[b], ll, 0, 0, 0);
       m2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Xh[b], m2, 0, 0, 0);
+      }
     }
-    // epilogue of the previous step (independent of this step's MFMAs)
+    // epilogue of the previous step (independent of this step's MFMAs); VPM < 0: MFMAs only
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
+    for (int r = 0; r < (VPM < 0 ? 2 : 16); r += 2) {
       const int A0 = (int)(((unsigned)ph[r] << 8) + (unsigned)pm1[r]);
       const int A1 = (int)(((unsigned)ph[r + 1] << 8) + (unsigned)pm1[r + 1]);
       const int q0 = (A0 + pm2[r] + ((pl[r] + 77) >> 8)) >> 6;
@@ -156,25 +166,29 @@ __global__ void __launch_bounds__(64, WPS) probe_pipe(const v4i *__restrict__ fr
     ph = hh; pm1 = m1; pm2 = m2; pl = ll;
     Xh[0].x += sink & 1;   // keep the loop honest
   }
+  if (blockIdx.x == 0 && lane == 0) { clk[0] = (long long)(__builtin_readcyclecounter() - c0); clk[1] = (long long)(__builtin_amdgcn_s_memrealtime() - r0); }
   if (sink == 0x7fffffff) { y[lane] = (short)(sink + ph[0] + pm1[1] + pm2[2] + pl[3]); }
   else if (lane == 77) { y[0] = (short)(ph[0] + pm1[1] + pm2[2] + pl[3]); }
 }
 
-template <int NB, int VPM, int WPS>
+template <int NB, int VPM, int WPS, int AG = 0>
 static void run_pipe(const char *name, int waves, int steps, const v4i *frag, short *y) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int it = 0; it < 2; it++) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((probe_pipe<NB, VPM, WPS>), dim3(waves), dim3(64), 0, 0, frag, y, steps);
+    hipLaunchKernelGGL((probe_pipe<NB, VPM, WPS, AG>), dim3(waves), dim3(64), 0, 0, frag, y, steps, g_clk);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
   }
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
   double mfma = (double)waves * steps * NB * 4;
-  printf("%-34s waves %5d steps %4d  %.3f ms  %.1f TOPS  %.1f cyc/MFMA/SIMD@2.4GHz\n", name, waves, steps, ms,
-         mfma * 2 * 32768 / (ms * 1e-3) / 1e12, ms * 1e-3 * 2.4e9 / (mfma / 1024.0));
+  long long hc[2]; CK(hipMemcpy(hc, g_clk, 16, hipMemcpyDeviceToHost));
+  const double ghz = (double)hc[0] / ((double)hc[1] * 10.0);   // s_memrealtime ticks at 100 MHz
+  printf("%-34s waves %5d steps %4d  %.3f ms  %.1f TOPS  %.1f cyc/MFMA/SIMD@2.4GHz  shader clock %.2f GHz -> %.1f real cyc/MFMA (wave 0: %.1f cyc/MFMA)\n",
+         name, waves, steps, ms, mfma * 2 * 32768 / (ms * 1e-3) / 1e12, ms * 1e-3 * 2.4e9 / (mfma / 1024.0), ghz,
+         ms * 1e-3 * ghz * 1e9 / (mfma / 1024.0), (double)hc[0] / (steps * NB * 4.0));
 }
 
 int main() {
@@ -190,11 +204,17 @@ int main() {
     for (size_t i = 0; i < hx.size(); i++) { hx[i] = (short)((i * 2654435761u) >> 11); }
     for (long off = 0; off + (long)hx.size() <= 1025 * stride; off += hx.size()) { CK(hipMemcpy(x + off, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); }
   }
+  CK(hipMalloc(&g_clk, 16));
   run<9, 6, 1>("mfma only, 4 acc, 1 wave/SIMD", 1024, 512, frag, x, y, stride);
   run<9, 6, 2>("mfma only, 4 acc, 2 waves/SIMD", 2048, 512, frag, x, y, stride);
   run_pipe<9, 0, 1>("pipelined epi, no hints, 1 w/SIMD", 1024, 512, frag, y);
   run_pipe<9, 3, 1>("pipelined epi, 1 MFMA : 3 VALU, 1w", 1024, 512, frag, y);
   run_pipe<9, 4, 1>("pipelined epi, 1 MFMA : 4 VALU, 1w", 1024, 512, frag, y);
   run_pipe<9, 4, 2>("pipelined epi, 1 MFMA : 4 VALU, 2w", 2048, 512, frag, y);
+  run_pipe<9, -1, 1>("pipe kernel, MFMA only, 1w", 1024, 512, frag, y);
+  run_pipe<9, -1, 2>("pipe kernel, MFMA only, 2w", 2048, 512, frag, y);
+  run_pipe<9, 0, 1, 1>("AGPR acc: pipelined epi, 1w", 1024, 512, frag, y);
+  run_pipe<9, 0, 2, 1>("AGPR acc: pipelined epi, 2w", 2048, 512, frag, y);
+  run_pipe<9, 0, 2, 0>("VGPR acc: pipelined epi, 2w", 2048, 512, frag, y);
   return 0;
 }
