@@ -151,6 +151,8 @@ constexpr int kGroupSize = ACDSP_GS, kOccupancy = ACDSP_OCC;
 // EPI 0: any OUT_TYPE / ACC width through requant64.
 // EPI 1: OUT container int16, Q in {TRN, RND}, O = WRAP, no accumulator wrap possible, right shift 1..31:
 //        32-bit epilogue (epi32).   EPI 2: the same with O = SAT (v_cvt_pk_i16_i32 clamps and packs).
+// EPI 3: OUT container int64, signed, Q in {TRN, RND}, O = WRAP, no accumulator wrap possible (the OUT = ACC row
+//        of config 2): 64-bit shift-and-wrap epilogue, stored straight from registers; pipelined body only.
 // HS:    compile-time band [HS, NB-1-HS] of K-blocks whose high-byte Toeplitz plane is non-zero.
 // WAVES: 8 = ping-pong workgroup (see header), 1 = single-wave workgroup.
 // FAST:  the chunk is interior: all loads/stores are full vectors, so the loop has no divergent branch
@@ -397,7 +399,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 template <int NB, int EPI, int HS>
 __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
                                                    unsigned char *lds) {
-  static_assert(EPI == 1 || EPI == 2, "32-bit epilogue classes only");
+  static_assert(EPI >= 1 && EPI <= 3, "fast epilogue classes only");
   constexpr int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, JN = (NP + 63) / 64, ARR = NC * 16;
   // two accumulator sets + all Toeplitz fragments leave room for GS = 2 only when some high-byte blocks are skipped
   constexpr int GS = (HS == 0 && NB >= 8) ? 1 : 2, NG = (NB + GS - 1) / GS;
@@ -483,7 +485,31 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     }
   };
   // epilogue of a finished step: 16 outputs per lane -> packed int16 -> swizzled 2 KB LDS tile (fir_mfma_body)
-  auto emit = [&](auto wide_c, const v16i &hh, const v16i &mid, const v16i &ll) {
+  int64_t *yout64 = (int64_t *)p.y + (int64_t)ch * p.out_stride;
+  const int e3_sr = rs > 0 ? rs : 0, e3_wl = 64 - p.out.W, e3_sl = (rs < 0 ? -rs : 0) + e3_wl;
+  auto emit = [&](auto wide_c, int64_t T0, const v16i &hh, const v16i &mid, const v16i &ll) {
+    if constexpr (EPI == 3) {
+      // y = wrap_W((V + rnd) >> rs) (or V << -rs), V = 2^16 hh + 2^8 mid + ll.  The 1024 outputs of the step form an
+      // 8 KB tile of 16-byte slots (slot = 16 n + 4 g + 2 h + half), XOR-swizzled with the column so that both the
+      // ds_write_b128 here (8 consecutive columns per LDS cycle) and the row-contiguous ds_read_b128 of flush() are
+      // bank-conflict free; the write-out is then whole 128-byte lines (32-byte pieces straight from registers ran
+      // at 2.9 TB/s).
+      typedef long v2l __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        int64_t v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int r = 4 * g + rr;
+          const int64_t V = ((int64_t)hh[r] << 16) + ((int64_t)mid[r] << 8) + (int64_t)ll[r];
+          v[rr] = (int64_t)((uint64_t)(V >> e3_sr) << e3_sl) >> e3_wl;
+        }
+        const int slot = 16 * n_col + ((4 * g + 2 * h) ^ (n_col & 15));
+        *(v2l *)(obuf + slot * 16) = (v2l){v[0], v[1]};
+        *(v2l *)(obuf + (slot ^ 1) * 16) = (v2l){v[2], v[3]};
+      }
+      return;
+    }
     int o[16];
     epi32_t<decltype(wide_c)::value>(hh, mid, ll, rs, o);
 #pragma unroll
@@ -502,6 +528,15 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   };
   // ... and its row-contiguous write-out: two coalesced 16-byte-per-lane stores
   auto flush = [&](int64_t T0) {
+    if constexpr (EPI == 3) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int P = 64 * k + lane;
+        const v4i val = *(const v4i *)(obuf + (P ^ ((P >> 4) & 15)) * 16);
+        *(v4i *)((char *)(yout64 + T0) + (unsigned)(16 * P)) = val;
+      }
+      return;
+    }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       const int P = 64 * half + lane;
@@ -532,7 +567,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       else { read_group(nbuf, 0, Bh[nb_], Bl[nb_]); }          // first group of the next step (staged in group 0)
       if (NG > 1 && g == gS) { stage(nbuf); }
       if (g == gL) { issue_loads_in(T0 + 2048); }
-      if (PREV && g == gE1) { emit(wide_c, ph, pm, pl); }
+      if (PREV && g == gE1) { emit(wide_c, T0 - 1024, ph, pm, pl); }
       if (PREV && g == gE2) { flush(T0 - 1024); }
 #pragma unroll
       for (int i = 0; i < GS; i++) {
@@ -569,21 +604,21 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     }
     if (s < nsteps) {
       run_step(wide_c, P1(), WithPrev(), s, hB, mB, lB, hA, mA, lA);
-      emit(wide_c, hB, mB, lB);
+      emit(wide_c, (s0 + s) * 1024, hB, mB, lB);
       flush((s0 + s) * 1024);
     } else {
-      emit(wide_c, hA, mA, lA);
+      emit(wide_c, (s0 + s - 1) * 1024, hA, mA, lA);
       flush((s0 + s - 1) * 1024);
     }
   };
-  if (rs <= 16) { go(integral_constant<bool, false>()); }
+  if (EPI == 3 || rs <= 16) { go(integral_constant<bool, false>()); }
   else { go(integral_constant<bool, true>()); }
 }
 
 template <int NB, int EPI, int HS, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES, kOccupancy)
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * (32 + NB - 1) * 16 + 2048)];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * (32 + NB - 1) * 16 + (EPI == 3 ? 8192 : 2048))];
   const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
   // (a lone first step has no in-row window to park the unused prefetch on: see issue_loads_in)
@@ -591,6 +626,7 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (WAVES == 1 && EPI != 0) {
     if (interior) { fir_mfma_pipe_body<NB, EPI, HS>(p, frag, a, lds); }
+    else if constexpr (EPI == 3) { fir_mfma_body<NB, 0, 0, WAVES, false>(p, frag, a, lds); }   // edges: generic epilogue
     else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
   } else {
     if (interior) { fir_mfma_body<NB, EPI, HS, WAVES, true>(p, frag, a, lds); }
@@ -608,6 +644,7 @@ static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const
   const dim3 blk(64 * WAVES);
   if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   else if (epi == 2) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
+  else if (epi == 3 && WAVES == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 3, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 0, 0, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   return hipGetLastError();
 }
@@ -845,6 +882,11 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
       rs >= 1 && rs <= 31 && acc_wide && small && p.out.W == 16) {
     return p.out.O == ACDSP_SAT ? 2 : 1;
+  }
+  // wide rows: 64-bit shift-and-wrap epilogue of the pipelined body (the low plane still carries C in 32 bits)
+  if (p.out_eb == 8 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && p.out.O == ACDSP_WRAP && acc_wide &&
+      rs >= -16 && rs <= 38 && p.out.W >= 2 && p.out.W <= 64 && (rs < 0 ? -rs : 0) + (64 - p.out.W) <= 63 && ll_max + corr_abs + 2 < (int64_t(1) << 31) && plan.nb <= kMaxRegNB) {
+    return 3;
   }
   return 0;
 }

@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir1023", "cic_dec", "ddc", "polydec"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "ddc", "polydec"])
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,7 +97,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     seed = 0xACD5
 
-    if args.workload in ("fir255", "fir255_dense", "fir1023"):
+    if args.workload in ("fir255", "fir255_dense", "fir255_wide", "fir1023"):
         n_taps = 1023 if args.workload == "fir1023" else 255
         ch_per_gpu = args.channels or 1024
         n = args.samples or (1 << 20)
@@ -106,8 +106,10 @@ def main():
         if args.workload == "fir1023":     # BASELINE configs[3]: ac_fir_prog_coeffs, 1023 taps, ACC <42,14>, 1024 ch per GPU
             fa = A.Fmt(42, 14)
             coeffs = windowed_sinc_raw(n_taps, 0.05, fc.F)
-        elif args.workload == "fir255":
+        elif args.workload in ("fir255", "fir255_wide"):
             coeffs = windowed_sinc_raw(n_taps, 0.1, fc.F)  # symmetric windowed sinc, sum|c| < 2
+            if args.workload == "fir255_wide":             # SURVEY 8(d) second row: OUT_TYPE = ACC_TYPE, 8-byte containers
+                fo = fa
         else:  # every Toeplitz byte-plane block populated
             coeffs = np.random.default_rng(1).integers(-32768, 32640, size=n_taps, dtype=np.int64)
         lo, hi = shard(ch_per_gpu * world, world, rank)
@@ -115,11 +117,13 @@ def main():
         eng.set_coeffs(coeffs)
         x = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
         A.fill_stimulus(x, seed, args.stim_bits or 16, ch0=lo)
-        y = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
-        bytes_per_sample = 4.0                   # 2 B read + 2 B written
+        y = torch.empty((hi - lo, n + args.pad), dtype=A.torch_dtype_for(fo), device=dev)[:, :n]
+        bytes_per_sample = 2.0 + y.element_size()  # 2 B read + 2 B (8 B for the wide row) written
         macs_per_sample = 4.0 * 32 * eng_nb(n_taps)  # int8 MACs issued: 4 byte-plane products x padded band
         name = "ac_fir_load_coeffs 255-tap ac_fixed<16,2> -> <16,2,RND,SAT>, ACC <40,12>, %d ch x %d samples per GPU " \
                "(BASELINE configs[1])" % (ch_per_gpu, n)
+        if args.workload == "fir255_wide":
+            name = name.replace("-> <16,2,RND,SAT>", "-> OUT = ACC <40,12> (int64 containers)").replace("(BASELINE configs[1])", "(BASELINE configs[1], wide-output row)")
         if args.workload == "fir1023":
             name = "ac_fir_prog_coeffs 1023-tap ac_fixed<16,2> -> <16,2,RND,SAT>, ACC <42,14>, %d ch x %d samples per GPU " \
                    "(BASELINE configs[3])" % (ch_per_gpu, n)
@@ -245,7 +249,7 @@ def main():
             "config": {"workload": name, "kernel_path": path, "channels_per_gpu": ch_per_gpu, "samples_per_step": n,
                        "parallelism": "channel-slice x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec", "ddc": "r1_ddc", "polydec": "r1_polydec"}[args.workload]),
+                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir255_wide": "r1_fir255_wide", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec", "ddc": "r1_ddc", "polydec": "r1_polydec"}[args.workload]),
                          "algorithmic_bytes_per_launch": bytes_per_sample * samples_per_step, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
                          "algorithmic_bytes_per_sample": bytes_per_sample},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,

@@ -132,6 +132,39 @@ def test_mfma_path_ftypes_and_wide_output(ftype):
                expect_path="mfma_i8")
 
 
+@pytest.mark.parametrize("fo", [
+    A.Fmt(16, 2, True, "RND", "SAT"),    # rs = 14: the config-2 epilogue
+    A.Fmt(16, 2, True, "TRN", "WRAP"),
+    A.Fmt(16, 8, True, "RND", "SAT"),    # rs = 20 (> 16): the other shift class of the 32-bit epilogue
+    A.Fmt(16, 8, True, "TRN", "WRAP"),
+    A.Fmt(16, 1, True, "RND", "WRAP"),   # rs = 13, output wraps
+    A.Fmt(16, -8, True, "RND", "SAT"),   # rs = 4: every output saturates or nearly so
+    A.Fmt(40, 12),                       # OUT = ACC: 64-bit shift-and-wrap epilogue (config 2, wide row)
+    A.Fmt(40, 12, True, "RND", "WRAP"),
+    A.Fmt(34, 4, True, "TRN", "WRAP"),   # rs = -2 (left shift) and a wrapping 34-bit result
+    A.Fmt(24, 10, True, "RND", "WRAP"),  # rs = 14 into an int32 container: generic epilogue
+])
+@pytest.mark.parametrize("n_taps", [255, 130, 33])
+def test_mfma_pipelined_interior_chunks(fo, n_taps):
+    # runs long enough (>= 2 steps of 1024 per chunk) for the software-pipelined body, ragged tail through the
+    # edge body, a second call continuing from carried state
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    c = windowed_sinc(n_taps, 0.1, fc)
+    check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=5, n=9 * 1024 + 77, coeffs=c, expect_path="mfma_i8",
+               splits=[4096], seed=n_taps)
+
+
+def test_mfma_pipelined_dense_and_per_channel_sets():
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    rng = np.random.default_rng(77)
+    c = rng.integers(-32768, 32640, size=255)
+    for fo in (A.Fmt(16, 2, True, "RND", "SAT"), fa):
+        check_case(255, "SHIFT_REG", fin, fc, fa, fo, n_ch=3, n=8 * 1024, coeffs=c, expect_path="mfma_i8")
+    cc = rng.integers(-3000, 3000, size=(4, 200))
+    check_case(200, "C_BUFF", fin, fc, fa, A.Fmt(16, 2, True, "RND", "SAT"), n_ch=4, n=6 * 1024 + 5, coeffs=cc,
+               per_channel=True, expect_path="mfma_i8", splits=[3000])
+
+
 @pytest.mark.parametrize("pattern", ["small_only", "big_multiples_of_256", "single_tap", "all_zero", "two_islands"])
 def test_mfma_zero_block_skipping(pattern):
     # Toeplitz blocks whose hi or lo byte plane is entirely zero are skipped: exercise every mask shape
