@@ -26,6 +26,7 @@
 // padded by slot/R so that the 16 columns of a read hit 16 different 16-byte bank groups.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "fir_kernels.hpp"
@@ -34,7 +35,7 @@ namespace acdsp {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int kGenMaxPX = 8, kGenMaxPC = 3, kGenMaxNB = 8, kGenMaxFrag = kGenMaxPC * kGenMaxNB;  // A fragments: [b][q], <= 96 VGPRs
+constexpr int kGenMaxPX = 8, kGenMaxPC = 3, kGenMaxNB = 8;  // A fragments: [b][q], <= 96 VGPRs
 
 // ---------------------------------------------------------------------------------------------
 // host: coefficient planes and A fragments
@@ -102,6 +103,13 @@ struct GenArgs {
   int64_t n_out;              // outputs per channel in this call
   int64_t steps_per_wave, n_steps;
   int64_t n16;                // n_in rounded up to 16: rows are readable that far
+  int32_t obuf_off;           // byte offset of the 256-output tile in LDS (row-contiguous write-out)
+  int32_t chunk0;             // first chunk (of steps_per_wave steps) this launch covers: blockIdx.x + chunk0
+  // branch-free output conversion of the fast kernel (host-derived from out_mode / the formats):
+  //   v = wrapS_{64-ka}(y << ls);  v = ((v + rnd) >> rs) << ls2;  v = clamp(v, lo, hi);  v = wrapS_{64-ko}(v)
+  int32_t e_ls, e_ka, e_rs, e_ls2, e_ko;
+  int64_t e_rnd, e_lo, e_hi;
+  int32_t out_vec_ok;         // output rows are 16-byte aligned: whole steps leave as 1 KB-per-instruction stores
 };
 
 __device__ inline int phys_slot(int s, const GenArgs &a) {
@@ -139,7 +147,7 @@ __global__ void __launch_bounds__(64, SMALL ? 3 : 2) fir_gen_kernel(FirParams p,
 
   const TIN *xrow = (const TIN *)p.x + (int64_t)ch * p.in_stride;
   const TIN *hrow = (const TIN *)p.hist + (int64_t)ch * p.hl + p.hl;
-  const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t s0 = ((int64_t)blockIdx.x + a.chunk0) * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
 
   // Slots of the next step are fetched into registers while the current step multiplies (when the
@@ -195,7 +203,9 @@ __global__ void __launch_bounds__(64, SMALL ? 3 : 2) fir_gen_kernel(FirParams p,
   if (prefetch) { fetch(s0); }
   for (int64_t st = s0; st < s1; st++) {
     const int64_t m0 = st * 256;
-    __syncthreads();   // previous step's fragment reads are done
+    // (single-wave workgroup: LDS operations of a wave execute in order, so neither the staging writes after the
+    // previous step's fragment reads nor the reads below need a barrier -- and a __syncthreads() here would drain the
+    // prefetch loads and the stores with s_waitcnt vmcnt(0))
     if (prefetch) {
 #pragma unroll
       for (int j = 0; j < SPLMAX; j++) {
@@ -212,7 +222,6 @@ __global__ void __launch_bounds__(64, SMALL ? 3 : 2) fir_gen_kernel(FirParams p,
         stage_slot(raw, sl);
       }
     }
-    __syncthreads();
     if (prefetch && st + 1 < s1) { fetch(st + 1); }
 
     // ---- MFMA: plane products of equal weight share an accumulator ----
@@ -239,28 +248,225 @@ __global__ void __launch_bounds__(64, SMALL ? 3 : 2) fir_gen_kernel(FirParams p,
     }
 
     // ---- epilogue: lane (n_col, kg) holds outputs m0 + 16 n_col + 4 kg + r ----
+    int64_t o[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const int64_t m = m0 + 16 * n_col + 4 * kg + r;
       uint64_t y = (uint64_t)a.corr;
 #pragma unroll
       for (int w = 0; w < PX + kGenMaxPC - 1; w++) {
         if (w < PX + PC - 1 && w < 8) { y += (uint64_t)(int64_t)acc[w][r] << (8 * w); }
       }
-      if (m < a.n_out) {
-        int64_t o;
-        if (a.out_mode == 1) {
-          if (a.out_simple == 2) { o = wrap64((int64_t)y, a.w_int, 1); }
-          else if (a.out_simple == 1) { o = wrap64(wrap64((int64_t)y, a.w_int, 1), p.out.W, p.out.S); }
-          else { o = requant64(wrap64((int64_t)y, a.w_int, 1), p.in.F, p.out); }
-        } else {
-          const int64_t accv = wrap64((int64_t)(y << p.lossless_shift), p.acc.W, p.acc.S);
-          o = requant64(accv, p.acc.F, p.out);
+      if (a.out_mode == 1) {
+        if (a.out_simple == 2) { o[r] = wrap64((int64_t)y, a.w_int, 1); }
+        else if (a.out_simple == 1) { o[r] = wrap64(wrap64((int64_t)y, a.w_int, 1), p.out.W, p.out.S); }
+        else { o[r] = requant64(wrap64((int64_t)y, a.w_int, 1), p.in.F, p.out); }
+      } else {
+        const int64_t accv = wrap64((int64_t)(y << p.lossless_shift), p.acc.W, p.acc.S);
+        o[r] = requant64(accv, p.acc.F, p.out);
+      }
+    }
+    if (a.out_vec_ok && m0 + 256 <= a.n_out && p.out_eb >= 4) {
+      // The step's 256 outputs are contiguous in the row: pass them through an XOR-swizzled LDS tile (conflict-free
+      // ds_write_b128 per column group and ds_read_b128 per row run) and write whole 128-byte lines, 1 KB per
+      // instruction.  (8-byte pieces at 32-byte stride straight from the lanes: 17.2 ms on config 3, 11.2 ms with
+      // the stores compiled out.)
+      unsigned char *ob = lds + a.obuf_off;
+      typedef long v2l __attribute__((ext_vector_type(2)));
+      if (p.out_eb == 8) {
+        const int L = 8 * n_col + 2 * kg;                       // 16-byte slot of outputs r = 0, 1; r = 2, 3 follow
+        const int sw = (n_col >> 1) & 7;
+        *(v2l *)(ob + ((L ^ sw) * 16)) = (v2l){o[0], o[1]};
+        *(v2l *)(ob + (((L + 1) ^ sw) * 16)) = (v2l){o[2], o[3]};
+        int64_t *dst = (int64_t *)p.y + (int64_t)ch * p.out_stride + m0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const int P = 64 * k + lane;
+          const v4i val = *(const v4i *)(ob + ((P ^ ((P >> 4) & 7)) * 16));
+          *(v4i *)((char *)dst + 16 * P) = val;
         }
-        store_raw(p.y, (int64_t)ch * p.out_stride + m, p.out_eb, o);
+      } else {
+        const int L = 4 * n_col + kg;
+        *(v4i *)(ob + ((L ^ ((n_col >> 2) & 3)) * 16)) = (v4i){(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+        int32_t *dst = (int32_t *)p.y + (int64_t)ch * p.out_stride + m0;
+        const v4i val = *(const v4i *)(ob + ((lane ^ ((lane >> 4) & 3)) * 16));
+        *(v4i *)((char *)dst + 16 * lane) = val;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int64_t m = m0 + 16 * n_col + 4 * kg + r;
+        if (m < a.n_out) { store_raw(p.y, (int64_t)ch * p.out_stride + m, p.out_eb, o[r]); }
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast variant for the shapes the BASELINE configurations use (dispatch table in launch_fir_gen): every loop bound is
+// a template parameter, the output conversion is the branch-free shift / clamp / wrap form above and the launch covers
+// only chunks whose steps are complete, so the step loop is ONE basic block: the next step's slots stay in flight
+// (counted s_waitcnt vmcnt(k)) while this step multiplies, converts and writes out.  The general kernel above had
+// ~1500 basic blocks and an s_waitcnt vmcnt(0) in front of every MFMA group -- the prefetch never overlapped anything.
+//   PCT / NBT: coefficient digits / K blocks compiled in (fragments beyond the plan's pc / nb are zero)
+//   SPL: slots per lane (exact)        OEB: output container bytes
+template <typename TIN, int PX, int PCT, int NBT, int SPL, int OEB>
+__global__ void __launch_bounds__(64, 2) fir_gen_fast_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [PX][phys slots][16] + output tile
+  const int lane = threadIdx.x;
+  const int n_col = lane & 15, kg = lane >> 4;
+  const int ch = blockIdx.y;
+  const int NB = a.pl.nb, PC = a.pl.pc, R = a.pl.R;
+  const int plane_bytes = a.obuf_off / PX;
+
+  v4i A[NBT][PCT];
+#pragma unroll
+  for (int b = 0; b < NBT; b++) {
+#pragma unroll
+    for (int q = 0; q < PCT; q++) {
+      A[b][q] = (b < NB && q < PC) ? frag[((size_t)q * NB + b) * 64 + lane] : (v4i){0, 0, 0, 0};
+    }
+  }
+  const TIN *xrow = (const TIN *)p.x + (int64_t)ch * p.in_stride;
+  const TIN *hrow = (const TIN *)p.hist + (int64_t)ch * p.hl + p.hl;
+  const int64_t s0 = ((int64_t)blockIdx.x + a.chunk0) * a.steps_per_wave;
+  const int64_t s1 = s0 + a.steps_per_wave;            // the launch covers complete chunks only
+
+  v4i pre[SPL][sizeof(TIN)];
+  int sl_of[SPL], ps_of[SPL];
+#pragma unroll
+  for (int j = 0; j < SPL; j++) {
+    sl_of[j] = (lane + 64 * j < a.n_slots) ? lane + 64 * j : a.n_slots - 1;   // surplus lanes repeat the last slot
+    ps_of[j] = phys_slot(sl_of[j], a) * 16;
+  }
+  auto fetch = [&](int64_t st) {
+    const int64_t W0 = a.first + st * 256 * R - a.pl.off;
+#pragma unroll
+    for (int j = 0; j < SPL; j++) {
+      const int64_t t = W0 + 16 * (int64_t)sl_of[j];
+      const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
+#pragma unroll
+      for (int q = 0; q < (int)sizeof(TIN); q++) { pre[j][q] = ((const v4i *)src)[q]; }
+    }
+  };
+  auto stage_slot = [&](const v4i (&raw)[sizeof(TIN)], int ps16) {
+    union { v4i v[sizeof(TIN)]; unsigned d[4 * sizeof(TIN)]; } u;
+#pragma unroll
+    for (int q = 0; q < (int)sizeof(TIN); q++) { u.v[q] = raw[q]; }
+#pragma unroll
+    for (int pp = 0; pp < PX; pp++) {
+      v4i o;
+      if (sizeof(TIN) == 2) {
+        const unsigned sel = pp == 0 ? 0x06040200u : 0x07050301u;
+        o.x = (int)__builtin_amdgcn_perm(u.d[1], u.d[0], sel); o.y = (int)__builtin_amdgcn_perm(u.d[3], u.d[2], sel);
+        o.z = (int)__builtin_amdgcn_perm(u.d[5], u.d[4], sel); o.w = (int)__builtin_amdgcn_perm(u.d[7], u.d[6], sel);
+      } else if (sizeof(TIN) == 4) {
+        o.x = (int)gather4(u.d[0], u.d[1], u.d[2], u.d[3], pp); o.y = (int)gather4(u.d[4], u.d[5], u.d[6], u.d[7], pp);
+        o.z = (int)gather4(u.d[8], u.d[9], u.d[10], u.d[11], pp); o.w = (int)gather4(u.d[12], u.d[13], u.d[14], u.d[15], pp);
+      } else {
+        const int hi = pp >> 2, bp = pp & 3;
+        o.x = (int)gather4(u.d[0 + hi], u.d[2 + hi], u.d[4 + hi], u.d[6 + hi], bp);
+        o.y = (int)gather4(u.d[8 + hi], u.d[10 + hi], u.d[12 + hi], u.d[14 + hi], bp);
+        o.z = (int)gather4(u.d[16 + hi], u.d[18 + hi], u.d[20 + hi], u.d[22 + hi], bp);
+        o.w = (int)gather4(u.d[24 + hi], u.d[26 + hi], u.d[28 + hi], u.d[30 + hi], bp);
+      }
+      if (pp < PX - 1) { o ^= (v4i){(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u}; }
+      *(v4i *)(lds + pp * plane_bytes + ps16) = o;
+    }
+  };
+  int xs_of[NBT];   // LDS byte offset of this lane's X fragment per K block
+#pragma unroll
+  for (int b = 0; b < NBT; b++) { xs_of[b] = phys_slot(R * n_col + 4 * b + kg, a) * 16; }
+  unsigned char *ob = lds + a.obuf_off;
+  char *yrow = (char *)p.y + (int64_t)ch * p.out_stride * OEB;
+
+  // write-out of a finished step: the tile holds its 256 outputs in row order (swizzled 16-byte slots)
+  auto flush = [&](int64_t st) {
+    const int64_t m0 = st * 256;
+    if (OEB == 8) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int P = 64 * k + lane;
+        const v4i val = *(const v4i *)(ob + ((P ^ ((P >> 4) & 7)) * 16));
+        *(v4i *)(yrow + m0 * 8 + 16 * P) = val;
+      }
+    } else if (OEB == 4) {
+      const v4i val = *(const v4i *)(ob + ((lane ^ ((lane >> 4) & 3)) * 16));
+      *(v4i *)(yrow + m0 * 4 + 16 * lane) = val;
+    } else {
+      const int P = lane & 31;                       // both wave halves store the same 512 bytes: no exec-mask branch
+      const v4i val = *(const v4i *)(ob + P * 16);
+      *(v4i *)(yrow + m0 * 2 + 16 * P) = val;
+    }
+  };
+  // One step.  Program order: stage step st (its slots were fetched one step ago), write out step st-1, fetch step
+  // st+1, multiply, convert into the LDS tile.  The stores therefore sit BEFORE the fetch in the stream: the
+  // s_waitcnt in front of the next staging waits for loads that are the youngest VMEM operations, and the stores get a
+  // whole step to drain.
+  auto body = [&](int64_t st, auto first_c) {
+#pragma unroll
+    for (int j = 0; j < SPL; j++) { stage_slot(pre[j], ps_of[j]); }
+    if (!decltype(first_c)::value) { flush(st - 1); }
+    fetch(st + 1 < s1 ? st + 1 : st);   // the last step re-fetches itself: no branch in the loop
+
+    v4i acc[PX + PCT - 1];
+#pragma unroll
+    for (int w = 0; w < PX + PCT - 1; w++) { acc[w] = (v4i){0, 0, 0, 0}; }
+#pragma unroll
+    for (int b = 0; b < NBT; b++) {
+      v4i X[PX];
+#pragma unroll
+      for (int pp = 0; pp < PX; pp++) { X[pp] = *(const v4i *)(lds + pp * plane_bytes + xs_of[b]); }
+#pragma unroll
+      for (int q = 0; q < PCT; q++) {
+#pragma unroll
+        for (int pp = 0; pp < PX; pp++) {
+          acc[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b][q], X[pp], acc[pp + q], 0, 0, 0);
+        }
+      }
+    }
+
+    // lane (n_col, kg) holds outputs 16 n_col + 4 kg + r of the step
+    int64_t o[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      uint64_t y = (uint64_t)a.corr;
+#pragma unroll
+      for (int w = 0; w < PX + PCT - 1; w++) {
+        if (w < 8) { y += (uint64_t)(int64_t)acc[w][r] << (8 * w); }
+      }
+      int64_t v = (int64_t)(y << a.e_ls);
+      v = (int64_t)((uint64_t)v << a.e_ka) >> a.e_ka;
+      v = (int64_t)((uint64_t)((v + a.e_rnd) >> a.e_rs) << a.e_ls2);
+      v = v < a.e_lo ? a.e_lo : (v > a.e_hi ? a.e_hi : v);
+      o[r] = (int64_t)((uint64_t)v << a.e_ko) >> a.e_ko;
+    }
+    typedef long v2l __attribute__((ext_vector_type(2)));
+    if (OEB == 8) {
+      const int L = 8 * n_col + 2 * kg, sw = (n_col >> 1) & 7;
+      *(v2l *)(ob + ((L ^ sw) * 16)) = (v2l){o[0], o[1]};
+      *(v2l *)(ob + (((L + 1) ^ sw) * 16)) = (v2l){o[2], o[3]};
+    } else if (OEB == 4) {
+      const int L = 4 * n_col + kg;
+      *(v4i *)(ob + ((L ^ ((n_col >> 2) & 3)) * 16)) = (v4i){(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+    } else {
+      typedef short v4s_ __attribute__((ext_vector_type(4)));
+      *(v4s_ *)(ob + (4 * n_col + kg) * 8) = (v4s_){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+    }
+  };
+
+  fetch(s0);
+  body(s0, std::integral_constant<bool, true>());
+  for (int64_t st = s0 + 1; st < s1; st++) { body(st, std::integral_constant<bool, false>()); }
+  flush(s1 - 1);
+}
+
+template <typename TIN, int PX, int PCT, int NBT, int SPL, int OEB>
+static hipError_t launch_fast(dim3 grid, size_t lds_bytes, hipStream_t s, const FirParams &p, const v4i *frag, const GenArgs &a) {
+  hipError_t e = hipFuncSetAttribute((const void *)fir_gen_fast_kernel<TIN, PX, PCT, NBT, SPL, OEB>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) { return e; }
+  hipLaunchKernelGGL((fir_gen_fast_kernel<TIN, PX, PCT, NBT, SPL, OEB>), grid, dim3(64), lds_bytes, s, p, frag, a);
+  return hipGetLastError();
 }
 
 template <typename TIN>
@@ -311,13 +517,60 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   if (spw < 4) { spw = 4; }
   a.steps_per_wave = spw;
   a.n16 = (p.n + 15) / 16 * 16;
-  const int phys = a.pad ? a.n_slots + a.n_slots / pl.R : a.n_slots;
-  const size_t lds_bytes = (size_t)a.px * (phys + 1) * 16;
-  dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)p.n_ch);
+  a.out_vec_ok = ((uintptr_t)p.y % 16 == 0) && ((p.out_stride * p.out_eb) % 16 == 0);
+  a.chunk0 = 0;
+  const int spl = (a.n_slots + 63) / 64;
+
+  // Fast kernel: table of compiled shapes (BASELINE configs 3, 5a, 5b and the poly_dec row); nbt = K blocks compiled in.
+  int nbt = 0;
+  const int in_eb = p.in_eb, oeb = p.out_eb, px = a.px, pc = pl.pc, nb = pl.nb;
+  if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 3 && spl == 3 && oeb == 8) { nbt = 3; }        // CIC R8 N5 on int32 -> int64
+  else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 6 && spl == 5 && oeb == 8) { nbt = 6; }   // CIC R16 N5 on int16 -> int64
+  else if (in_eb == 8 && px == 5 && pc <= 2 && nb <= 3 && spl == 1 && oeb == 4) { nbt = 3; }   // 127-tap FIR on 36-bit words -> int32
+  else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && spl == 3 && oeb == 2) { nbt = 4; }   // 128-tap decimate-by-8 on int16 -> int16
+  // ... and a conversion the branch-free form covers: signed wrapping accumulator, signed OUT, TRN/RND, WRAP/SAT
+  bool conv_ok = p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
+                 p.out.W >= 2 && p.out.W <= 64;
+  int f_src = 0;
+  if (out_mode == 1) { a.e_ls = 0; a.e_ka = 64 - w_int; f_src = p.in.F; conv_ok = conv_ok && w_int >= 2 && w_int <= 64; }
+  else {
+    a.e_ls = p.lossless_shift; a.e_ka = 64 - p.acc.W; f_src = p.acc.F;
+    conv_ok = conv_ok && p.acc.S && p.acc.W >= 2 && p.acc.W <= 64 && p.lossless_shift >= 0 && p.lossless_shift < 64;
+  }
+  const int rs = f_src - p.out.F, src_w = out_mode == 1 ? w_int : p.acc.W;
+  a.e_rs = rs > 0 ? rs : 0; a.e_ls2 = rs < 0 ? -rs : 0;
+  a.e_rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs < 63) ? (int64_t(1) << (rs - 1)) : 0;
+  conv_ok = conv_ok && a.e_rs <= 62 && src_w + a.e_ls2 <= 62;      // neither the rounding add nor the left shift can leave int64
+  if (p.out.O == ACDSP_SAT) {
+    a.e_hi = (int64_t)((uint64_t(1) << (p.out.W - 1)) - 1); a.e_lo = -a.e_hi - 1; a.e_ko = 0;
+  } else {
+    a.e_hi = INT64_MAX; a.e_lo = INT64_MIN; a.e_ko = 64 - p.out.W;
+  }
+
+  const int phys_nb = nbt > pl.nb ? nbt : pl.nb;                     // zero-fragment blocks still read their (stale) slots
+  const int slots_alloc = 15 * pl.R + 4 * phys_nb;
+  const int phys = a.pad ? slots_alloc + slots_alloc / pl.R : slots_alloc;
+  a.obuf_off = a.px * (phys + 1) * 16;
+  const size_t lds_bytes = (size_t)a.obuf_off + 2048;
+  const int64_t n_chunks = (a.n_steps + spw - 1) / spw;
+  const int64_t fast_chunks = (nbt && conv_ok && a.out_vec_ok) ? n_out / (spw * 256) : 0;   // chunks made of complete steps only
+  const v4i *fr = (const v4i *)d_frag;
+  hipError_t e = hipSuccess;
+  if (fast_chunks > 0) {
+    dim3 grid((unsigned)fast_chunks, (unsigned)p.n_ch);
+    if (in_eb == 4) { e = launch_fast<int32_t, 4, 2, 3, 3, 8>(grid, lds_bytes, s, p, fr, a); }
+    else if (in_eb == 8) { e = launch_fast<int64_t, 5, 2, 3, 1, 4>(grid, lds_bytes, s, p, fr, a); }
+    else if (oeb == 8) { e = launch_fast<int16_t, 2, 3, 6, 5, 8>(grid, lds_bytes, s, p, fr, a); }
+    else { e = launch_fast<int16_t, 2, 2, 4, 3, 2>(grid, lds_bytes, s, p, fr, a); }
+    if (e != hipSuccess) { return e; }
+  }
+  if (fast_chunks >= n_chunks) { return hipSuccess; }
+  a.chunk0 = (int32_t)fast_chunks;                                    // ragged tail (and every unlisted shape): general kernel
+  dim3 grid((unsigned)(n_chunks - fast_chunks), (unsigned)p.n_ch);
   switch (p.in_eb) {
-    case 2: return launch_px<int16_t>(a.px, grid, lds_bytes, s, p, (const v4i *)d_frag, a);
-    case 4: return launch_px<int32_t>(a.px, grid, lds_bytes, s, p, (const v4i *)d_frag, a);
-    default: return launch_px<int64_t>(a.px, grid, lds_bytes, s, p, (const v4i *)d_frag, a);
+    case 2: return launch_px<int16_t>(a.px, grid, lds_bytes, s, p, fr, a);
+    case 4: return launch_px<int32_t>(a.px, grid, lds_bytes, s, p, fr, a);
+    default: return launch_px<int64_t>(a.px, grid, lds_bytes, s, p, fr, a);
   }
 }
 

@@ -157,3 +157,24 @@ def test_recurrence_and_mfma_kernels_agree(monkeypatch):
     y2 = c2.run(xa).cpu().numpy()
     assert c2.path == "mfma_gen"
     assert np.array_equal(y1, y2)
+
+
+@pytest.mark.parametrize("q,o", [("TRN", "WRAP"), ("RND", "WRAP"), ("TRN", "SAT"), ("RND", "SAT"), ("RND_CONV", "SAT_SYM")])
+def test_long_runs_take_the_branch_free_kernel(q, o):
+    """Runs long enough for whole chunks of complete 256-output steps (fir_gen_fast_kernel) plus a ragged tail
+    (general kernel); the last mode pair is outside the fast conversion and must still match."""
+    rng = np.random.default_rng(11)
+    # BASELINE config 3 shape with a narrowing OUT_TYPE
+    fin, fout = A.Fmt(32, 16), A.Fmt(20, 14, True, q, o)
+    x = rand_raw(rng, fin, (3, 8 * 5000 + 64))   # bursts of whole 16-sample slots: matrix-core kernels
+    cic = A.Cic(False, 8, 1, 5, fin, fout, n_channels=3)
+    y = run_engine(cic, x, [8 * 2048])
+    assert cic.path == "mfma_gen"
+    assert np.array_equal(y, run_oracle(False, 8, 1, 5, fin, fout, x, [8 * 2048]))
+    # DDC stage A: R = 16 on ac_fixed<16,1> into the lossless <36,21> (three coefficient digits, six K blocks)
+    fin, fout = A.Fmt(16, 1), A.Fmt(36, 21, True, q, o)
+    x = rand_raw(rng, fin, (3, 16 * 3000 + 48))
+    cic = A.Cic(False, 16, 1, 5, fin, fout, n_channels=3)
+    y = run_engine(cic, x)
+    assert cic.path == "mfma_gen"
+    assert np.array_equal(y, run_oracle(False, 16, 1, 5, fin, fout, x))

@@ -413,3 +413,14 @@ def test_two_handles_on_two_streams_are_independent():
         for rep in range(3):
             yo = orc.run(c, xs[i])
         assert np.array_equal(outs[i].cpu().numpy().astype(np.int64), yo)
+
+
+@pytest.mark.parametrize("fo", [A.Fmt(24, 9, True, "RND", "SAT"), A.Fmt(24, 9, True, "TRN", "WRAP"), A.Fmt(30, 9, True, "RND", "WRAP"),
+                                A.Fmt(60, 30), A.Fmt(24, 9, True, "RND_ZERO", "SAT")])
+def test_wide_input_long_run_takes_the_branch_free_gen_kernel(fo):
+    # DDC stage B: 127 taps on the CIC's 36-bit words (int64 containers, five byte planes); the last OUT_TYPE is
+    # outside the fast conversion (general kernel for everything)
+    fin, fc, fa = A.Fmt(36, 21), A.Fmt(16, 1), A.Fmt(60, 30)
+    c = windowed_sinc(127, 0.2, fc)
+    check_case(127, "SHIFT_REG", fin, fc, fa, fo, n_ch=3, n=5000, kind="const", coeffs=c, expect_path="mfma_gen", splits=[2048],
+               seed=9)

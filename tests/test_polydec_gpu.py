@@ -57,3 +57,10 @@ def test_rejects_partial_groups():
     import ctypes as C
     rc = A.lib.acdsp_polydec_run(eng._h, C.c_void_p(x.data_ptr()), 10, 10, C.c_void_p(x.data_ptr()), 10, None)
     assert rc == 1   # ACDSP_EINVAL: run() only ever consumes whole groups of DF samples
+
+
+def test_long_burst_takes_the_branch_free_kernel():
+    # the bench row: 16 taps per branch x DF 8 on ac_fixed<16,2>, complete 256-output steps + ragged tail
+    check(16, 8, A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16), A.Fmt(16, 2, True, "RND", "SAT"), n_groups=4096 + 70, expect="mfma_gen",
+          splits=[2048], seed=5)
+    check(16, 8, A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16), A.Fmt(16, 4, True, "TRN", "WRAP"), n_groups=3000, expect="mfma_gen", seed=6)
