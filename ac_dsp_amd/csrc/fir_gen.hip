@@ -515,6 +515,8 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   a.n_steps = (n_out + 255) / 256;
   int64_t spw = (a.n_steps * p.n_ch + 16383) / 16384;
   if (spw < 4) { spw = 4; }
+  static const char *spw_env = getenv("ACDSP_GEN_SPW");   // tuning knob: steps (of 256 outputs) per wave
+  if (spw_env && atoi(spw_env) > 0) { spw = atoi(spw_env); }
   a.steps_per_wave = spw;
   a.n16 = (p.n + 15) / 16 * 16;
   a.out_vec_ok = ((uintptr_t)p.y % 16 == 0) && ((p.out_stride * p.out_eb) % 16 == 0);

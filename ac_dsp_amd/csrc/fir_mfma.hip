@@ -410,6 +410,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   ch = __builtin_amdgcn_readfirstlane(ch);
   const int set = a.frag_per_channel ? ch : 0;
   unsigned char *obuf = lds + 2 * 4 * ARR;
+  unsigned char *dummy = obuf + (EPI == 3 ? 8192 : 2048);   // 1 KB sink for the surplus lanes of stage()
 
   v4i Ah[NB], Al[NB];
 #pragma unroll
@@ -446,18 +447,21 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   auto stage = [&](unsigned char *buf) {
 #pragma unroll
     for (int j = 0; j < JN; j++) {
-      // surplus lanes hold a copy of the last piece and store it again: no exec-mask branch in the loop
-      const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
-      {
-        const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
-        unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
-        unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
-        unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
-        unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
-        typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        *(v2u *)(buf + (0 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){hi0, hi1};
-        *(v2u *)(buf + (1 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){lo0, lo1};
-      }
+      // surplus lanes (last j only) store their copy of the last piece into a private dummy slot: no exec-mask branch
+      // in the loop, and no 32 lanes hammering one address (same-address ds_writes serialise: measured as 27 % of
+      // the LDS cycles in SQ_LDS_BANK_CONFLICT)
+      const int pc = lane + 64 * j;
+      const bool live = (64 * (j + 1) <= NP) || pc < NP;
+      const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
+      unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
+      unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
+      unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
+      unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
+      typedef unsigned v2u __attribute__((ext_vector_type(2)));
+      unsigned char *dh = live ? buf + (0 * 2 + hh_) * ARR + c * 16 + sub * 8 : dummy + lane * 8;
+      unsigned char *dl = live ? buf + (1 * 2 + hh_) * ARR + c * 16 + sub * 8 : dummy + 512 + lane * 8;
+      *(v2u *)dh = (v2u){hi0, hi1};
+      *(v2u *)dl = (v2u){lo0, lo1};
     }
   };
 
@@ -618,7 +622,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
 template <int NB, int EPI, int HS, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES, kOccupancy)
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * (32 + NB - 1) * 16 + (EPI == 3 ? 8192 : 2048))];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * (32 + NB - 1) * 16 + (EPI == 3 ? 8192 : 2048)) + 1024];
   const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
   // (a lone first step has no in-row window to park the unused prefetch on: see issue_loads_in)
