@@ -116,6 +116,7 @@ struct MfmaArgs {
   int32_t frag_per_channel;
   uint64_t hi_mask, lo_mask;  // bit b: K-block b of the hi / lo coefficient plane has a non-zero entry (any set)
   int32_t nb, hb0, hb1;       // big-NB kernel: K-blocks, and the range [hb0, hb1] of non-zero high-byte blocks
+  int64_t step0;              // big-NB kernels: first 1024-sample step of this launch (split launches)
   const int64_t *corr;     // [n_sets] 128 * sum(c) per coefficient set
   int64_t *dbg;            // optional: per-wave {shader-clock ticks, 100 MHz real-time ticks} (ACDSP_DEBUG_CLOCK)
 };
@@ -706,7 +707,7 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
 
   const int16_t *xrow = (const int16_t *)p.x + (int64_t)ch * p.in_stride;
   const int16_t *hrow = (const int16_t *)p.hist + (int64_t)ch * p.hl + p.hl;
-  const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t s0 = a.step0 + (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
   const int nsteps = (int)(s1 - s0);
 
@@ -836,11 +837,145 @@ template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 fir_mfma_big_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-  const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t s0 = a.step0 + (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
   const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n;
   if (interior) { fir_mfma_big_body<EPI, true>(p, frag, a, lds_dyn); }
   else { fir_mfma_big_body<EPI, false>(p, frag, a, lds_dyn); }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Double-wide variant for complete chunks: a step is 2048 outputs (two column sets of 32 blocks), so every
+// A fragment fetched from LDS feeds eight MFMAs instead of four.  With NB = 33 the single-wide kernel moves
+// 4 KB of LDS per four MFMAs per wave -- ~220 of the 256 B/clk the LDS delivers, i.e. it is LDS-bound as much as
+// MFMA-bound; here it is 6 KB per eight.  The two sets share their halo (one staged array of 64 + NB - 1 chunks,
+// single-buffered: a wave stages step s+1 in its own O phase, after its own M phase is done reading).
+// Launched over chunks of complete double steps only (EPI 1 / 2); the ragged rest goes to fir_mfma_big_kernel.
+template <int EPI>
+__global__ void __launch_bounds__(512, 1)
+fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+  const int NB = a.nb;
+  const int HB = NB - 1, NC = 64 + HB, NP = 4 * NC, ARR = NC * 16;
+  constexpr int JN = 6;   // NP <= 4 * 96
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = wave >> 2;
+  const int n_col = lane & 31, h = lane >> 5;
+  int ch = blockIdx.y * 8 + wave;
+  if (ch >= p.n_ch) { ch = p.n_ch - 1; }
+  v4i *ldsA = (v4i *)lds_all;
+  const int wave_bytes = 4 * ARR + 4096;
+  unsigned char *lds = lds_all + 2 * NB * 1024 + wave * wave_bytes;
+  unsigned char *obuf = lds + 4 * ARR;
+  for (int i = threadIdx.x; i < 2 * NB * 64; i += 512) { ldsA[i] = frag[i]; }
+
+  const int16_t *xrow = (const int16_t *)p.x + (int64_t)ch * p.in_stride;
+  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)ch * p.hl + p.hl;
+  const int64_t d0 = (int64_t)blockIdx.x * a.steps_per_wave;   // in double steps; the launch covers complete chunks
+  const int nsteps = (int)a.steps_per_wave;
+  const int64_t t_last = (d0 + nsteps - 1) * 2048;
+
+  v4i R[JN];
+  auto issue_loads = [&](int64_t T0) {
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
+      int64_t t = T0 - 32 * HB + 8 * pc;
+      const int16_t *src = (t < 0) ? hrow + t : xrow + ((t < a.n8) ? t : 0);
+      R[j] = *(const v4i *)src;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+      const int pc = lane + 64 * j;
+      if (pc < NP) {
+        const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
+        unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
+        unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
+        unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
+        unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        *(v2u *)(lds + (0 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){hi0, hi1};
+        *(v2u *)(lds + (1 * 2 + hh_) * ARR + c * 16 + sub * 8) = (v2u){lo0, lo1};
+      }
+    }
+  };
+
+  const int rs = p.in.F + p.cf.F - p.out.F;
+  const int c_ll = (int)(a.corr[0] + ((p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0));
+  const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
+  int16_t *yout = (int16_t *)p.y + (int64_t)ch * p.out_stride;
+  const unsigned char *fh = lds + (0 * 2 + h) * ARR + n_col * 16;
+  const unsigned char *fl = lds + (1 * 2 + h) * ARR + n_col * 16;
+  const v4i *ah = ldsA + lane, *al = ldsA + NB * 64 + lane;
+
+  issue_loads(d0 * 2048);
+  __syncthreads();          // A fragments visible to every wave
+  stage();
+  issue_loads(nsteps > 1 ? (d0 + 1) * 2048 : t_last);
+  if (grp == 1) { __builtin_amdgcn_s_barrier(); }
+
+  for (int s = 0; s < nsteps; s++) {
+    const int64_t T0 = (d0 + s) * 2048;
+    // ---------------- phase M: column set 0 = chunks n + b, set 1 = chunks 32 + n + b ----------------
+    v16i h0 = {0}, m0 = {0}, l0 = ll_init, h1 = {0}, m1 = {0}, l1 = ll_init;
+    v4i Ahc = ah[0], Alc = al[0];
+    v4i Bh0c = *(const v4i *)fh, Bl0c = *(const v4i *)fl, Bh1c = *(const v4i *)(fh + 512), Bl1c = *(const v4i *)(fl + 512);
+    for (int b = 0; b < NB; b++) {
+      v4i Ahn = Ahc, Aln = Alc, Bh0n = Bh0c, Bl0n = Bl0c, Bh1n = Bh1c, Bl1n = Bl1c;
+      if (b + 1 < NB) {
+        Ahn = ah[(b + 1) * 64]; Aln = al[(b + 1) * 64];
+        Bh0n = *(const v4i *)(fh + 16 * (b + 1)); Bl0n = *(const v4i *)(fl + 16 * (b + 1));
+        Bh1n = *(const v4i *)(fh + 512 + 16 * (b + 1)); Bl1n = *(const v4i *)(fl + 512 + 16 * (b + 1));
+      }
+      if (b >= a.hb0 && b <= a.hb1) {
+        h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bh0c, h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bh1c, h1, 0, 0, 0);
+        m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bl0c, m0, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bl1c, m1, 0, 0, 0);
+      }
+      l0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bl0c, l0, 0, 0, 0);
+      l1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bl1c, l1, 0, 0, 0);
+      m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bh0c, m0, 0, 0, 0);
+      m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bh1c, m1, 0, 0, 0);
+      Ahc = Ahn; Alc = Aln; Bh0c = Bh0n; Bl0c = Bl0n; Bh1c = Bh1n; Bl1c = Bl1n;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+
+    // ---------------- phase O ----------------
+#pragma unroll
+    for (int set = 0; set < 2; set++) {
+      int o[16];
+      if (set == 0) { epi32(h0, m0, l0, rs, o); } else { epi32(h1, m1, l1, rs, o); }
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        v4s pk;
+        if (EPI == 2) {
+          typedef short v2s __attribute__((ext_vector_type(2)));
+          const v2s p0 = __builtin_amdgcn_cvt_pk_i16(o[4 * g], o[4 * g + 1]), p1 = __builtin_amdgcn_cvt_pk_i16(o[4 * g + 2], o[4 * g + 3]);
+          pk = (v4s){p0.x, p0.y, p1.x, p1.y};
+        } else {
+          pk = (v4s){(short)o[4 * g], (short)o[4 * g + 1], (short)o[4 * g + 2], (short)o[4 * g + 3]};
+        }
+        const int P = 4 * n_col + g;
+        *(v4s *)(obuf + 2048 * set + (((P & ~15) | ((P + (P >> 4)) & 15)) * 16 + 8 * h)) = pk;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {   // 4 KB contiguous: four coalesced 16-byte-per-lane stores
+      const int P = 64 * (q & 1) + lane;
+      const v4i val = *(const v4i *)(obuf + 2048 * (q >> 1) + ((P & ~15) | ((P + (P >> 4)) & 15)) * 16);
+      *(v4i *)(yout + T0 + 512 * q + 8 * lane) = val;
+    }
+    if (s + 1 < nsteps) {
+      stage();
+      const int64_t tn = T0 + 4096;
+      issue_loads(tn < t_last ? tn : t_last);
+    }
+    if (grp == 0 || s + 1 < nsteps) { __builtin_amdgcn_s_barrier(); }
+  }
 }
 
 static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArgs a, int epi, dim3 grid, hipStream_t s) {
@@ -854,8 +989,30 @@ static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArg
       while (!((a.hi_mask >> a.hb1) & 1)) { a.hb1--; }
     }
   }
-  const size_t lds_bytes = (size_t)2 * nb * 1024 + 8 * ((size_t)2 * 4 * (32 + nb - 1) * 16 + 2048);
   hipError_t e = hipSuccess;
+  a.step0 = 0;
+  // complete chunks of double steps on the double-wide kernel ...
+  const int64_t spw2 = a.steps_per_wave >= 8 ? a.steps_per_wave / 2 : 4;
+  const int64_t fast_chunks = (epi == 1 || epi == 2) && a.out_vec_ok ? (p.n / 2048) / spw2 : 0;
+  if (fast_chunks > 0) {
+    MfmaArgs a2 = a;
+    a2.steps_per_wave = spw2;
+    const size_t lds2 = (size_t)2 * nb * 1024 + 8 * ((size_t)4 * (64 + nb - 1) * 16 + 4096);
+    dim3 g2((unsigned)fast_chunks, grid.y);
+    if (epi == 1) {
+      e = hipFuncSetAttribute((const void *)fir_mfma_big2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big2_kernel<1>), g2, dim3(512), lds2, s, p, (const v4i *)d_frag, a2); }
+    } else {
+      e = hipFuncSetAttribute((const void *)fir_mfma_big2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big2_kernel<2>), g2, dim3(512), lds2, s, p, (const v4i *)d_frag, a2); }
+    }
+    if (e != hipSuccess) { return e; }
+    a.step0 = fast_chunks * spw2 * 2;
+    if (a.step0 >= a.n_steps) { return hipGetLastError(); }
+    grid.x = (unsigned)((a.n_steps - a.step0 + a.steps_per_wave - 1) / a.steps_per_wave);
+  }
+  // ... the ragged rest (and the generic epilogue class) on the single-wide kernel
+  const size_t lds_bytes = (size_t)2 * nb * 1024 + 8 * ((size_t)2 * 4 * (32 + nb - 1) * 16 + 2048);
   if (epi == 1) {
     e = hipFuncSetAttribute((const void *)fir_mfma_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big_kernel<1>), grid, dim3(512), lds_bytes, s, p, (const v4i *)d_frag, a); }
@@ -913,7 +1070,7 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   a.frag_per_channel = frag_per_channel;
   a.hi_mask = plan.hi_mask;
   a.lo_mask = plan.lo_mask;
-  a.nb = plan.nb; a.hb0 = 0; a.hb1 = plan.nb - 1;
+  a.nb = plan.nb; a.hb0 = 0; a.hb1 = plan.nb - 1; a.step0 = 0;
   a.corr = d_corr;
   const int wpb = plan.nb > kMaxRegNB ? 8 : kSmallWaves;   // channels (waves) per workgroup
   dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)((p.n_ch + wpb - 1) / wpb));

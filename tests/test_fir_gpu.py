@@ -311,6 +311,17 @@ def test_mfma_path_large_tap_counts(n_taps):
                expect_path="mfma_i8")
 
 
+@pytest.mark.parametrize("n_taps,fo", [(1023, A.Fmt(16, 2, True, "RND", "SAT")), (700, A.Fmt(16, 2, True, "TRN", "WRAP")),
+                                       (300, A.Fmt(16, 8, True, "RND", "SAT"))])
+def test_mfma_large_tap_counts_double_wide_chunks(n_taps, fo):
+    # long enough for complete chunks of 2048-output steps (fir_mfma_big2_kernel) + a ragged rest on the single-wide
+    # kernel; 9 channels = one full workgroup of 8 waves + one with surplus waves
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16)
+    c = windowed_sinc(n_taps, 0.05, fc)
+    check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=9, n=2 * 8192 + 1500, coeffs=c, expect_path="mfma_i8", splits=[8192 + 8],
+               seed=n_taps)
+
+
 def test_config4_shape_1023_taps_prog_coeffs():
     """BASELINE config 4 shape (ac_fir_prog_coeffs, 1023 taps, <16,2>, ACC <42,14>) at a reduced size."""
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
