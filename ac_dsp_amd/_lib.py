@@ -10,7 +10,7 @@ Q_MODES = {"TRN": 0, "RND": 1, "TRN_ZERO": 2, "RND_ZERO": 3, "RND_INF": 4, "RND_
 O_MODES = {"WRAP": 0, "SAT": 1, "SAT_ZERO": 2, "SAT_SYM": 3}
 FTYPES = {"SHIFT_REG": 0, "ROTATE_SHIFT": 1, "C_BUFF": 2, "FOLD_EVEN": 3, "FOLD_ODD": 4, "TRANSPOSED": 5,
           "FOLD_EVEN_ANTI": 6, "FOLD_ODD_ANTI": 7}
-KINDS = {"const": 0, "load": 1, "prog": 2}
+KINDS = {"const": 0, "load": 1, "prog": 2, "reg_share": 3}
 PATHS = {0: "generic", 1: "lossless64", 2: "mfma_i8", 3: "mfma_gen"}
 FLAG_FORCE_GENERIC = 1
 

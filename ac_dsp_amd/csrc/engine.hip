@@ -269,13 +269,16 @@ namespace {
 // Effective direct-form coefficients of the folded architectures (lossless paths only):
 // FOLD_EVEN uses c[0..N/2-1] on both halves (ac_fir_const_coeffs.h:248-251), FOLD_ODD uses
 // c[0..mid] with the centre tap alone (:265-273).  Taps the reference never reads become 0.
+// ftype: kernel-side value (internal_ftype): the anti-symmetric folds of ac_fir_reg_share negate the mirrored half.
 std::vector<int64_t> effective_coeffs(const int64_t *c, int N, int ftype) {
   std::vector<int64_t> e(N, 0);
-  if (ftype == ACDSP_FOLD_EVEN) {
-    for (int i = 0; i < N / 2; i++) { e[i] += c[i]; e[N - 1 - i] += c[i]; }
-  } else if (ftype == ACDSP_FOLD_ODD) {
+  if (ftype == ACDSP_FOLD_EVEN || ftype == kRsFoldEven || ftype == kRsFoldEvenAnti) {
+    const int64_t sg = ftype == kRsFoldEvenAnti ? -1 : 1;
+    for (int i = 0; i < N / 2; i++) { e[i] += c[i]; e[N - 1 - i] += sg * c[i]; }
+  } else if (ftype == ACDSP_FOLD_ODD || ftype == kRsFoldOdd || ftype == kRsFoldOddAnti) {
+    const int64_t sg = ftype == kRsFoldOddAnti ? -1 : 1;
     int mid = (N - 1) / 2;
-    for (int i = 0; i < mid; i++) { e[i] += c[i]; e[N - 1 - i] += c[i]; }
+    for (int i = 0; i < mid; i++) { e[i] += c[i]; e[N - 1 - i] += sg * c[i]; }
     e[mid] += c[mid];
   } else {
     for (int i = 0; i < N; i++) { e[i] = c[i]; }
@@ -283,12 +286,28 @@ std::vector<int64_t> effective_coeffs(const int64_t *c, int N, int ftype) {
   return e;
 }
 
-int fir_validate(const acdsp_fir_desc_t &d) {
-  if (d.ftype == ACDSP_FOLD_EVEN_ANTI || d.ftype == ACDSP_FOLD_ODD_ANTI) {
-    return fail(ACDSP_EUNSUPPORTED,
-                "FOLD_*_ANTI: the reference run() has no branch for these (output is an unassigned value)");
+// Kernel-side tap-order code of a (class, FTYPE) pair; -1 where the reference class has no branch for the FTYPE.
+int internal_ftype(int kind, int ftype) {
+  if (kind != ACDSP_FIR_REG_SHARE) { return (ftype >= ACDSP_SHIFT_REG && ftype <= ACDSP_TRANSPOSED) ? ftype : -1; }
+  switch (ftype) {   // ac_fir_reg_share.h:288-306
+    case ACDSP_SHIFT_REG: return kRsShiftReg;
+    case ACDSP_FOLD_EVEN: return kRsFoldEven;
+    case ACDSP_FOLD_EVEN_ANTI: return kRsFoldEvenAnti;
+    case ACDSP_FOLD_ODD: return kRsFoldOdd;
+    case ACDSP_FOLD_ODD_ANTI: return kRsFoldOddAnti;
+    default: return -1;
   }
+}
+inline bool is_fold_odd(int ift) { return ift == ACDSP_FOLD_ODD || ift == kRsFoldOdd || ift == kRsFoldOddAnti; }
+
+int fir_validate(const acdsp_fir_desc_t &d) {
+  if (d.kind < ACDSP_FIR_CONST || d.kind > ACDSP_FIR_REG_SHARE) { return fail(ACDSP_EINVAL, "bad FIR class %d", d.kind); }
   if (d.ftype < 0 || d.ftype > ACDSP_FOLD_ODD_ANTI) { return fail(ACDSP_EINVAL, "bad ftype %d", d.ftype); }
+  if (internal_ftype(d.kind, d.ftype) < 0) {
+    return fail(ACDSP_EUNSUPPORTED, d.kind == ACDSP_FIR_REG_SHARE
+                    ? "ac_fir_reg_share::run() has no branch for this FTYPE (output would be an unassigned value)"
+                    : "FOLD_*_ANTI: the reference run() has no branch for these (output is an unassigned value)");
+  }
   if (d.n_taps < 1 || d.n_taps > 2048) { return fail(ACDSP_EUNSUPPORTED, "n_taps=%d outside 1..2048", d.n_taps); }
   if (d.n_channels < 1 || d.n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", d.n_channels); }
   int rc;
@@ -299,7 +318,7 @@ int fir_validate(const acdsp_fir_desc_t &d) {
   // 128-bit exact intermediates must hold: product, aligned sum.
   int fi = d.in.W - d.in.I, fc = d.coeff.W - d.coeff.I, fa = d.acc.W - d.acc.I;
   int wp = d.in.W + d.coeff.W + 2, fp = fi + fc;
-  if (d.ftype == ACDSP_FOLD_ODD) { wp = d.acc.W + d.coeff.W + 1; fp = fa + fc; }
+  if (is_fold_odd(internal_ftype(d.kind, d.ftype))) { wp = d.acc.W + d.coeff.W + 1; fp = fa + fc; }
   int f = fp > fa ? fp : fa;
   if (wp + (f - fp) > 125 || d.acc.W + (f - fa) > 125) {
     return fail(ACDSP_EUNSUPPORTED, "type combination needs more than 128-bit intermediates");
@@ -326,10 +345,11 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   h->use_rt = desc->ftype == ACDSP_TRANSPOSED && desc->kind != ACDSP_FIR_CONST;
   const int fi = desc->in.W - desc->in.I, fc = desc->coeff.W - desc->coeff.I, fa = desc->acc.W - desc->acc.I;
   bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && !h->use_rt;
-  if (desc->ftype == ACDSP_FOLD_ODD) {
-    // the ACC_TYPE `fold` variable must hold x[i] + x[N-1-i] without wrapping
+  const int ift = internal_ftype(desc->kind, desc->ftype);
+  if (is_fold_odd(ift)) {
+    // the ACC_TYPE `fold` variable must hold x[i] +/- x[N-1-i] without wrapping (a difference needs a signed type)
     int need_i = desc->in.I + 1 + ((desc->acc.S && !desc->in.S) ? 1 : 0);
-    lossless = lossless && desc->acc.I >= need_i && (desc->acc.S || !desc->in.S);
+    lossless = lossless && desc->acc.I >= need_i && (desc->acc.S || (!desc->in.S && ift != kRsFoldOddAnti));
   }
   h->lossless = lossless;
   h->coeffs_set = false;
@@ -409,7 +429,7 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
     memset(&worst, 0, sizeof worst);
     bool ok = true;
     for (size_t st = 0; st < n_sets && ok; st++) {
-      std::vector<int64_t> eff = effective_coeffs(coeffs + st * d.n_taps, d.n_taps, d.ftype);
+      std::vector<int64_t> eff = effective_coeffs(coeffs + st * d.n_taps, d.n_taps, internal_ftype(d.kind, d.ftype));
       FirMfmaPlan pl;
       ok = fir_mfma_build_fragments(eff.data(), d.n_taps, &pl, frag.data() + st * per_set);
       if (!ok) { break; }
@@ -434,7 +454,7 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   static const bool no_gen = getenv("ACDSP_NO_GEN") != nullptr;
   if (!h->mfma_ok && h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && !d.coeffs_per_channel && !no_gen &&
       (d.in.W + (d.in.S ? 0 : 1) + 7) / 8 <= h->in_eb) {
-    std::vector<int64_t> eff = effective_coeffs(coeffs, d.n_taps, d.ftype);
+    std::vector<int64_t> eff = effective_coeffs(coeffs, d.n_taps, internal_ftype(d.kind, d.ftype));
     std::vector<uint32_t> gfrag;
     if (fir_gen_plan(eff.data(), d.n_taps, 1, 0, &h->gplan, &gfrag)) {
       HIP_TRY(hipMemcpy(h->d_gfrag, gfrag.data(), gfrag.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -480,7 +500,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   if (rc) { return rc; }
   hipStream_t s = (hipStream_t)stream;
   FirParams k;
-  k.n_taps = d.n_taps; k.ftype = d.ftype; k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
+  k.n_taps = d.n_taps; k.ftype = internal_ftype(d.kind, d.ftype); k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
   k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
   k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl; k.use_rt = h->use_rt ? 1 : 0;
   k.lossless_shift = k.acc.F - k.in.F - k.cf.F;

@@ -9,6 +9,7 @@
 //   FOLD_EVEN                 i = N/2-1..0, exact pre-add            :244-253
 //   FOLD_ODD                  i = 0..(N-1)/2, pre-add held in ACC_TYPE :260-275
 //   TRANSPOSED                partial-sum chain through reg_trans[]   :281-296
+//   ac_fir_reg_share cores    ascending, blocks of BLK_SZ; anti-symmetric folds   ac_fir_reg_share.h:136-260
 // (the load_/prog_ cores are the same loops: ac_fir_load_coeffs.h:180-278,
 // ac_fir_prog_coeffs.h:147-247).  The shift register of the reference becomes
 // a window of the input stream: reg[k] after firShiftReg(x[t]) is x[t-k], with
@@ -70,9 +71,22 @@ __global__ void __launch_bounds__(kTile) fir_direct_kernel(FirParams p) {
       case ACDSP_FOLD_EVEN:
         for (int i = 0; i < N / 2; i++) { s += (uint64_t)cf[i] * (uint64_t)(w[-i] + w[-(N - 1 - i)]); }
         break;
-      case ACDSP_FOLD_ODD: {
+      case ACDSP_FOLD_ODD:
+      case kRsFoldOdd: {
         const int mid = (N - 1) / 2;
         for (int i = 0; i < mid; i++) { s += (uint64_t)cf[i] * (uint64_t)(w[-i] + w[-(N - 1 - i)]); }
+        s += (uint64_t)cf[mid] * (uint64_t)w[-mid];
+        break;
+      }
+      case kRsFoldEven:
+        for (int i = 0; i < N / 2; i++) { s += (uint64_t)cf[i] * (uint64_t)(w[-i] + w[-(N - 1 - i)]); }
+        break;
+      case kRsFoldEvenAnti:
+        for (int i = 0; i < N / 2; i++) { s += (uint64_t)cf[i] * (uint64_t)(w[-i] - w[-(N - 1 - i)]); }
+        break;
+      case kRsFoldOddAnti: {
+        const int mid = (N - 1) / 2;
+        for (int i = 0; i < mid; i++) { s += (uint64_t)cf[i] * (uint64_t)(w[-i] - w[-(N - 1 - i)]); }
         s += (uint64_t)cf[mid] * (uint64_t)w[-mid];
         break;
       }
@@ -88,8 +102,27 @@ __global__ void __launch_bounds__(kTile) fir_direct_kernel(FirParams p) {
         for (int i = N - 1; i >= 0; i--) { acc = mac_q(acc, (i128)w[-i] * cf[i], fp, p.acc); }
         break;
       case ACDSP_C_BUFF:
+      case kRsShiftReg:        // ac_fir_reg_share.h:136-150: ascending
         for (int i = 0; i < N; i++) { acc = mac_q(acc, (i128)w[-i] * cf[i], fp, p.acc); }
         break;
+      case kRsFoldEven:        // :157-171
+      case kRsFoldEvenAnti:    // :178-192
+        for (int i = 0; i < N / 2; i++) {
+          i128 pre = p.ftype == kRsFoldEven ? (i128)w[-i] + (i128)w[-(N - 1 - i)] : (i128)w[-i] - (i128)w[-(N - 1 - i)];
+          acc = mac_q(acc, (i128)cf[i] * pre, fp, p.acc);
+        }
+        break;
+      case kRsFoldOdd:         // :199-219 (same loop as ACDSP_FOLD_ODD)
+      case kRsFoldOddAnti: {   // :226-246
+        const int mid = (N - 1) / 2;
+        for (int i = 0; i <= mid; i++) {
+          i128 pre = (i == mid) ? (i128)w[-i]
+                                : (p.ftype == kRsFoldOdd ? (i128)w[-i] + (i128)w[-(N - 1 - i)] : (i128)w[-i] - (i128)w[-(N - 1 - i)]);
+          int64_t fold = requant128(pre, p.in.F, p.acc);  // ACC_TYPE fold
+          acc = mac_q(acc, (i128)cf[i] * (i128)fold, p.cf.F + p.acc.F, p.acc);
+        }
+        break;
+      }
       case ACDSP_FOLD_EVEN:
         for (int i = N / 2 - 1; i >= 0; i--) {
           i128 pre = (i128)w[-i] + (i128)w[-(N - 1 - i)];

@@ -50,6 +50,10 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
                            const int64_t *d_corr, hipStream_t s);
 
 // Generalised exact FIR on the matrix cores (fir_gen.hip): wide inputs / coefficients, decimation.
+// FirParams::ftype values of the ac_fir_reg_share cores (ascending MAC order, anti-symmetric folds:
+// reference ac_fir_reg_share.h:136-260); the const/load/prog cores use the public ACDSP_* values.
+enum { kRsShiftReg = 16, kRsFoldEven = 17, kRsFoldEvenAnti = 18, kRsFoldOdd = 19, kRsFoldOddAnti = 20 };
+
 struct FirGenPlan {
   int32_t pc, nb, off, R;   // coefficient byte planes, 64-sample K blocks, T_n - W_n, decimation
   int64_t sum_h;            // sum of the taps mod 2^64 (re-bias correction)

@@ -40,10 +40,15 @@ typedef struct { int32_t W, I, S, Q, O; } acdsp_fmt_t;
 
 enum { ACDSP_TRN = 0, ACDSP_RND, ACDSP_TRN_ZERO, ACDSP_RND_ZERO, ACDSP_RND_INF, ACDSP_RND_MIN_INF, ACDSP_RND_CONV, ACDSP_RND_CONV_ODD };
 enum { ACDSP_WRAP = 0, ACDSP_SAT, ACDSP_SAT_ZERO, ACDSP_SAT_SYM };
-/* FTYPE, reference ac_fir_const_coeffs.h:96.  The *_ANTI values are rejected:
- * the reference run() has no branch for them and writes an unassigned value. */
+/* FTYPE, reference ac_fir_const_coeffs.h:96.  For the const/load/prog classes the *_ANTI values are rejected:
+ * their run() has no branch for them and writes an unassigned value; ac_fir_reg_share gives them a meaning. */
 enum { ACDSP_SHIFT_REG = 0, ACDSP_ROTATE_SHIFT, ACDSP_C_BUFF, ACDSP_FOLD_EVEN, ACDSP_FOLD_ODD, ACDSP_TRANSPOSED, ACDSP_FOLD_EVEN_ANTI, ACDSP_FOLD_ODD_ANTI };
-enum { ACDSP_FIR_CONST = 0, ACDSP_FIR_LOAD = 1, ACDSP_FIR_PROG = 2 };
+enum { ACDSP_FIR_CONST = 0, ACDSP_FIR_LOAD = 1, ACDSP_FIR_PROG = 2,
+       /* ac_fir_reg_share (reference ac_fir_reg_share.h:101-310): ftype is one of SHIFT_REG, FOLD_EVEN, FOLD_EVEN_ANTI,
+        * FOLD_ODD, FOLD_ODD_ANTI (run() has no branch for the others, :288-306); the MAC loops walk the taps in ascending
+        * order (:136-260).  Coefficients are handed over in TAP order: the header resolves the class's coefficient-memory
+        * addressing (MEM_WORD_WIDTH / BLK_SZ / BLK_OFFSET) before acdsp_fir_set_coeffs. */
+       ACDSP_FIR_REG_SHARE = 3 };
 
 enum {
   ACDSP_OK = 0,

@@ -239,6 +239,77 @@ int32_t orc_fir_step(orc_fir_t *f, const int64_t *c, int64_t x, int64_t *y) {
   return 0;
 }
 
+/* ---- ac_fir_reg_share (row f1 of SURVEY 8): reference include/ac_dsp/ac_fir_reg_share.h ----
+ * One run() call: firShiftReg(data_in) on the (externally owned) register array (:120-126,:286), then the
+ * MAC core selected by ftype, which walks the taps in ASCENDING order in blocks of blk_sz and reads the
+ * coefficient of tap i + index from coeffs[ram_addr + block_count], ram_addr advancing by mem_word_width
+ * per block and block_count starting at blk_offset (:136-260).  `c` is the caller's coefficient array
+ * [n_taps] exactly as passed to run().  Returns -1 where the reference indexes outside its arrays (tap
+ * count of the loop not a multiple of blk_sz, or a coefficient index >= n_taps) and for ftypes run() has
+ * no branch for (ROTATE_SHIFT, C_BUFF, TRANSPOSED: core_out stays unassigned, :288-306).              */
+int32_t orc_fir_reg_share_step(orc_fir_t *f, const int64_t *c, int32_t mem_word_width, int32_t blk_sz, int32_t blk_offset,
+                               int64_t x, int64_t *y) {
+  const int N = f->n;
+  int count; /* taps visited by the BLK loop */
+  switch (f->ftype) {
+    case ORC_SHIFT_REG: count = N; break;
+    case ORC_FOLD_EVEN: case ORC_FOLD_EVEN_ANTI: count = N / 2; break;
+    case ORC_FOLD_ODD: case ORC_FOLD_ODD_ANTI: count = ((N - 1) / 2) + 1; break;
+    default: return -1;
+  }
+  if (blk_sz < 1 || mem_word_width < 0 || blk_offset < 0 || count % blk_sz != 0) { return -1; }
+  if (count > 0 && ((count / blk_sz) - 1) * mem_word_width + blk_offset + blk_sz > N) { return -1; }
+  fir_shift_reg(f, x); /* filter.firShiftReg(data_in) */
+  int64_t acc = 0;     /* ACC_TYPE acc = 0.0 */
+  int ram_addr = 0;
+  for (int i = 0; i < count; i += blk_sz, ram_addr += mem_word_width) { /* BLK */
+    int index = 0;
+    for (int block_count = blk_offset; block_count < blk_offset + blk_sz; block_count++) { /* MAC */
+      const int64_t cf = c[ram_addr + block_count];
+      const int t = i + index;
+      switch (f->ftype) {
+        case ORC_SHIFT_REG: /* :136-150  acc += reg[i+index] * coeffs[...] */
+          acc = mac(f, acc, (i128)f->reg[t] * cf, f->fi + f->fc);
+          break;
+        case ORC_FOLD_EVEN: /* :157-171  (reg + reg) is the exact sum type */
+          acc = mac(f, acc, ((i128)f->reg[t] + (i128)f->reg[N - 1 - t]) * cf, f->fi + f->fc);
+          break;
+        case ORC_FOLD_EVEN_ANTI: /* :178-192 */
+          acc = mac(f, acc, ((i128)f->reg[t] - (i128)f->reg[N - 1 - t]) * cf, f->fi + f->fc);
+          break;
+        default: { /* FOLD_ODD :199-219, FOLD_ODD_ANTI :226-246: `fold` is an ACC_TYPE variable */
+          int64_t fold;
+          if (t == (N - 1) / 2) {
+            fold = requant((i128)f->reg[t], f->fi, &f->acc);
+          } else if (f->ftype == ORC_FOLD_ODD) {
+            fold = requant((i128)f->reg[t] + (i128)f->reg[(N - 1) - t], f->fi, &f->acc);
+          } else {
+            fold = requant((i128)f->reg[t] - (i128)f->reg[(N - 1) - t], f->fi, &f->acc);
+          }
+          acc = mac(f, acc, (i128)cf * (i128)fold, f->fc + f->fa);
+          break;
+        }
+      }
+      index++;
+    }
+  }
+  *y = requant((i128)acc, f->fa, &f->out); /* data_out = acc; data_out = core_out */
+  return 0;
+}
+
+int32_t orc_fir_reg_share_run(orc_fir_t *f, const int64_t *c, int32_t mem_word_width, int32_t blk_sz, int32_t blk_offset,
+                              const int64_t *x, int64_t n, int64_t *y) {
+  for (int64_t t = 0; t < n; t++) {
+    if (orc_fir_reg_share_step(f, c, mem_word_width, blk_sz, blk_offset, x[t], &y[t])) { return -1; }
+  }
+  return 0;
+}
+
+/* ac_firProgCoeffs_delay_line(): data_out = reg[N_TAPS-1]  (:128-130, :310-313) -- IN_TYPE assigned to OUT_TYPE */
+int64_t orc_fir_reg_share_delay_line(const orc_fir_t *f) {
+  return requant((i128)f->reg[f->n - 1], f->fi, &f->out);
+}
+
 int32_t orc_fir_run(orc_fir_t *f, const int64_t *coeffs, const int64_t *x, int64_t n, int64_t *y) {
   for (int64_t t = 0; t < n; t++) { /* while (data_in.available(1)) -- :325 */
     if (orc_fir_step(f, coeffs, x[t], &y[t])) { return -1; }

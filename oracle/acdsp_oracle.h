@@ -65,6 +65,15 @@ int32_t orc_fir_run(orc_fir_t *f, const int64_t *coeffs, const int64_t *x, int64
 int32_t orc_fir_run_many(orc_fir_t **fs, int64_t n_ch, const int64_t *coeffs, int32_t coeffs_per_channel,
                          const int64_t *x, int64_t x_stride, int64_t n, int64_t *y, int64_t y_stride);
 
+/* ac_fir_reg_share<N_TAPS, IN, OUT, COEFF, ACC, MEM_WORD_WIDTH, BLK_SZ, BLK_OFFSET, ftype>::run (row f1 of SURVEY 8:
+ * reference include/ac_dsp/ac_fir_reg_share.h:120-306).  Uses an orc_fir_t made with the FTYPE value; valid ftypes
+ * SHIFT_REG, FOLD_EVEN, FOLD_EVEN_ANTI, FOLD_ODD, FOLD_ODD_ANTI.  `c` = the coeffs[N_TAPS] array as run() receives it. */
+int32_t orc_fir_reg_share_step(orc_fir_t *f, const int64_t *c, int32_t mem_word_width, int32_t blk_sz, int32_t blk_offset,
+                               int64_t x, int64_t *y);
+int32_t orc_fir_reg_share_run(orc_fir_t *f, const int64_t *c, int32_t mem_word_width, int32_t blk_sz, int32_t blk_offset,
+                              const int64_t *x, int64_t n, int64_t *y);
+int64_t orc_fir_reg_share_delay_line(const orc_fir_t *f);
+
 /* ---- CIC ---- */
 typedef struct orc_cic orc_cic_t;
 /* interp = 0: ac_cic_dec_full, 1: ac_cic_intr_full */

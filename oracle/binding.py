@@ -52,6 +52,10 @@ lib.orc_fir_free.argtypes = [C.c_void_p]
 lib.orc_fir_reset.argtypes = [C.c_void_p]
 lib.orc_fir_run.restype = C.c_int32
 lib.orc_fir_run.argtypes = [C.c_void_p, _i64p, _i64p, C.c_int64, _i64p]
+lib.orc_fir_reg_share_run.restype = C.c_int32
+lib.orc_fir_reg_share_run.argtypes = [C.c_void_p, _i64p, C.c_int32, C.c_int32, C.c_int32, _i64p, C.c_int64, _i64p]
+lib.orc_fir_reg_share_delay_line.restype = C.c_int64
+lib.orc_fir_reg_share_delay_line.argtypes = [C.c_void_p]
 lib.orc_cic_new.restype = C.c_void_p
 lib.orc_cic_new.argtypes = [C.c_int32] * 4 + [C.POINTER(Fmt)] * 2
 lib.orc_cic_free.argtypes = [C.c_void_p]
@@ -111,8 +115,10 @@ def cic_int_type(interp, R, M, N, fin):
 class OracleFir:
     """One reference-style FIR object per channel; run() takes/returns [n_ch][n] int64 raw words."""
 
-    def __init__(self, n_taps, ftype, fin, fcoeff, facc, fout, n_ch=1):
-        self.n_taps, self.n_ch = n_taps, n_ch
+    def __init__(self, n_taps, ftype, fin, fcoeff, facc, fout, n_ch=1, reg_share=None):
+        """reg_share = (MEM_WORD_WIDTH, BLK_SZ, BLK_OFFSET): follow ac_fir_reg_share::run instead of the
+        const/load/prog cores (run() then takes the coeffs[N_TAPS] array as that class receives it)."""
+        self.n_taps, self.n_ch, self.reg_share = n_taps, n_ch, reg_share
         ft = FTYPES[ftype] if isinstance(ftype, str) else ftype
         self._h = [lib.orc_fir_new(n_taps, ft, C.byref(fin), C.byref(fcoeff), C.byref(facc), C.byref(fout))
                    for _ in range(n_ch)]
@@ -126,9 +132,18 @@ class OracleFir:
         for ch in range(self.n_ch):
             c = coeffs[ch] if coeffs.ndim == 2 else coeffs
             c = np.ascontiguousarray(c)
-            if lib.orc_fir_run(self._h[ch], _p(c), _p(x[ch]), x.shape[1], _p(y[ch])):
-                raise ValueError("oracle: ftype not handled by the reference run()")
+            if self.reg_share:
+                mww, bs, bo = self.reg_share
+                rc = lib.orc_fir_reg_share_run(self._h[ch], _p(c), mww, bs, bo, _p(x[ch]), x.shape[1], _p(y[ch]))
+            else:
+                rc = lib.orc_fir_run(self._h[ch], _p(c), _p(x[ch]), x.shape[1], _p(y[ch]))
+            if rc:
+                raise ValueError("oracle: ftype / block parameters not handled by the reference run()")
         return y
+
+    def delay_line(self):
+        """ac_fir_reg_share::ac_firProgCoeffs_delay_line(): reg[N_TAPS-1] as OUT_TYPE, per channel"""
+        return np.array([lib.orc_fir_reg_share_delay_line(h) for h in self._h], dtype=np.int64)
 
     def reset(self):
         for h in self._h:

@@ -435,3 +435,50 @@ def test_wide_input_long_run_takes_the_branch_free_gen_kernel(fo):
     c = windowed_sinc(127, 0.2, fc)
     check_case(127, "SHIFT_REG", fin, fc, fa, fo, n_ch=3, n=5000, kind="const", coeffs=c, expect_path="mfma_gen", splits=[2048],
                seed=9)
+
+
+# ---- ac_fir_reg_share: tap-ordered coefficients, ascending MAC order, anti-symmetric folds ----
+
+RS_FTYPES = ["SHIFT_REG", "FOLD_EVEN", "FOLD_EVEN_ANTI", "FOLD_ODD", "FOLD_ODD_ANTI"]
+
+
+def check_reg_share(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=700, splits=None, seed=0, coeffs=None, expect_path=None):
+    rng = np.random.default_rng(seed)
+    x = rand_raw(rng, fin, (n_ch, n))
+    if coeffs is None:
+        coeffs = rand_raw(rng, fc, (n_taps,))
+    fir = A.Fir(n_taps, ftype, fin, fc, fa, fo, n_channels=n_ch, kind="reg_share")
+    fir.set_coeffs(coeffs)
+    if expect_path:
+        assert fir.path == expect_path, fir.path
+    y = run_engine(fir, x, splits)
+    yo = OracleFir(n_taps, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch, reg_share=(1, 1, 0)).run(coeffs, x)
+    bad = np.argwhere(y != yo)
+    assert bad.size == 0, "%d mismatches, first at %s (path %s)" % (len(bad), bad[0], fir.path)
+
+
+@pytest.mark.parametrize("ftype", RS_FTYPES)
+def test_reg_share_lossless_runs_on_the_matrix_cores(ftype):
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    n_taps = 63 if "ODD" in ftype else 64
+    c = np.clip(rand_raw(np.random.default_rng(4), fc, (n_taps,)), -16000, 16000)    # +/- sums of two taps stay int8-splittable
+    check_reg_share(n_taps, ftype, fin, fc, fa, A.Fmt(16, 2, True, "RND", "SAT"), n_ch=5, n=3 * 1024 + 9, coeffs=c,
+                    expect_path="mfma_i8", splits=[1024], seed=1)
+    check_reg_share(n_taps, ftype, fin, fc, fa, fa, n_ch=2, n=900, coeffs=c, expect_path="mfma_i8", seed=2)
+    # reference usage-example types (ac_fir_reg_share.h:50-53): <32,16> data and coefficients, <64,32> MAC type
+    check_reg_share(27 if "ODD" in ftype else 28, ftype, A.Fmt(32, 16), A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(64, 32), splits=[100, 113],
+                    seed=3)
+
+
+@pytest.mark.parametrize("ftype", RS_FTYPES)
+@pytest.mark.parametrize("q,o", [("TRN", "WRAP"), ("RND_CONV", "SAT"), ("TRN_ZERO", "SAT_SYM")])
+def test_reg_share_lossy_accumulator_keeps_the_ascending_mac_order(ftype, q, o):
+    n_taps = 21 if "ODD" in ftype else 22
+    check_reg_share(n_taps, ftype, A.Fmt(14, 4), A.Fmt(12, 2), A.Fmt(20, 8, True, q, o), A.Fmt(10, 5, True, q, o), splits=[7, 300],
+                    expect_path="generic", seed=5)
+
+
+def test_reg_share_rejects_ftypes_without_a_branch():
+    for ft in ("ROTATE_SHIFT", "C_BUFF", "TRANSPOSED"):
+        with pytest.raises(A.AcdspError):
+            A.Fir(8, ft, A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2), kind="reg_share")

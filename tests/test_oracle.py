@@ -240,3 +240,66 @@ def test_polydec_is_a_decimating_fir_when_lossless():
     o = OraclePolyDec(NT, DF, fi, fc, fa, fa)
     parts = np.concatenate([o.run(c, x[:, :30]), o.run(c, x[:, 30:300])], axis=1)
     assert np.array_equal(parts[0], y)
+
+
+# ---- ac_fir_reg_share ----
+
+def _rs(ftype, n, fin, fc, fa, fo, **kw):
+    return OracleFir(n, ftype, fin, fc, fa, fo, reg_share=kw.get("reg_share", (1, 1, 0)))
+
+
+def test_reg_share_impulse_responses_and_delay_line():
+    # known answers by hand: an impulse reads the effective tap sequence back; the anti-symmetric folds negate the
+    # mirrored half (ac_fir_reg_share.h:178-192, 226-246), FOLD_ODD's centre tap passes through once (:207-208)
+    f, a = Fmt(16, 2), Fmt(40, 12)
+    imp = np.zeros((1, 12), dtype=np.int64)
+    imp[0, 0] = 1 << 14                                  # 1.0 in <16,2>
+    c8 = np.array([1, 2, 3, 4, 5, 6, 7, 8], dtype=np.int64) << 14
+    c7 = c8[:7]
+    sc = lambda v: [int(t) << 28 for t in v]             # products carry 28 fraction bits; OUT = ACC keeps them
+    assert _rs("SHIFT_REG", 8, f, f, a, a).run(c8, imp)[0, :9].tolist() == sc([1, 2, 3, 4, 5, 6, 7, 8, 0])
+    assert _rs("FOLD_EVEN", 8, f, f, a, a).run(c8, imp)[0, :9].tolist() == sc([1, 2, 3, 4, 4, 3, 2, 1, 0])
+    assert _rs("FOLD_EVEN_ANTI", 8, f, f, a, a).run(c8, imp)[0, :9].tolist() == sc([1, 2, 3, 4, -4, -3, -2, -1, 0])
+    assert _rs("FOLD_ODD", 7, f, f, a, a).run(c7, imp)[0, :8].tolist() == sc([1, 2, 3, 4, 3, 2, 1, 0])
+    o = _rs("FOLD_ODD_ANTI", 7, f, f, a, a)
+    assert o.run(c7, imp)[0, :8].tolist() == sc([1, 2, 3, 4, -3, -2, -1, 0])
+    # delay line: reg[N-1] (:128-130) -- the impulse has left the 7-deep register after 12 samples
+    assert o.delay_line().tolist() == [0]
+    o2 = _rs("SHIFT_REG", 8, f, f, a, Fmt(16, 2))
+    o2.run(c8, imp[:, :8])
+    assert o2.delay_line().tolist() == [1 << 14]         # the impulse now sits in reg[7]
+
+
+def test_reg_share_blocked_coefficient_memory():
+    # tap t reads coeffs[(t / BLK_SZ) * MEM_WORD_WIDTH + BLK_OFFSET + t % BLK_SZ]  (:141-147)
+    f, a = Fmt(16, 2), Fmt(40, 12)
+    rng = np.random.default_rng(5)
+    x = rng.integers(-32768, 32768, size=(1, 64))
+    mem = rng.integers(-3000, 3000, size=16)
+    # FOLD_EVEN, 16 taps: 8 MACs in 4 blocks of 2, words 4 apart, offset 1 -> addresses 1,2, 5,6, 9,10, 13,14
+    tap = np.zeros(16, dtype=np.int64)
+    tap[:8] = mem[[1, 2, 5, 6, 9, 10, 13, 14]]
+    y_blk = OracleFir(16, "FOLD_EVEN", f, f, a, a, reg_share=(4, 2, 1)).run(mem, x)
+    y_lin = OracleFir(16, "FOLD_EVEN", f, f, a, a, reg_share=(1, 1, 0)).run(tap, x)
+    assert np.array_equal(y_blk, y_lin)
+    # ... and the symmetric fold equals the const/load/prog FOLD_EVEN core on a lossless accumulator
+    assert np.array_equal(y_lin, OracleFir(16, "FOLD_EVEN", f, f, a, a).run(tap, x))
+    # where the reference would index outside its arrays / has no branch: refused
+    for bad in [dict(n=12, ft="SHIFT_REG", rs=(4, 5, 0)), dict(n=12, ft="SHIFT_REG", rs=(4, 3, 1)), dict(n=8, ft="C_BUFF", rs=(1, 1, 0))]:
+        with pytest.raises(ValueError):
+            OracleFir(bad["n"], bad["ft"], f, f, a, a, reg_share=bad["rs"]).run(np.zeros(bad["n"], dtype=np.int64), x)
+
+
+def test_reg_share_ascending_order_differs_from_prog_coeffs_only_when_the_accumulator_saturates():
+    f = Fmt(16, 2)
+    rng = np.random.default_rng(6)
+    x = rng.integers(-32768, 32768, size=(1, 200))
+    c = rng.integers(-32768, 32768, size=9)
+    wide = Fmt(40, 12)
+    assert np.array_equal(OracleFir(9, "SHIFT_REG", f, f, wide, wide, reg_share=(1, 1, 0)).run(c, x),
+                          OracleFir(9, "SHIFT_REG", f, f, wide, wide).run(c, x))
+    sat = Fmt(30, 2, True, "TRN", "SAT")                 # saturates on the way: i = 0..N-1 vs i = N-1..0 give different sums
+    y_rs = OracleFir(9, "SHIFT_REG", f, f, sat, wide, reg_share=(1, 1, 0)).run(c, x)
+    y_pg = OracleFir(9, "SHIFT_REG", f, f, sat, wide).run(c, x)
+    assert not np.array_equal(y_rs, y_pg)
+    assert np.array_equal(y_rs, OracleFir(9, "C_BUFF", f, f, sat, wide).run(c, x))   # C_BUFF is the ascending const/load/prog core
