@@ -108,6 +108,12 @@ bool fir_mfma_build_fragments(const int64_t *c, int n_taps, FirMfmaPlan *plan, u
   return true;
 }
 
+// Bytes of one staged [plane][half] array of nc 16-byte chunks.  The two halves of a plane are written by one
+// ds_write_b64 (lanes alternate between them) and LDS stores see 32 banks: pad so that the arrays sit 16 banks apart
+// (size = 64 mod 128), otherwise chunk c of both halves shares its banks (2-way conflict on every staging store:
+// SQ_LDS_BANK_CONFLICT was 27 % of SQ_LDS_IDX_ACTIVE).
+__host__ __device__ constexpr int staged_array_bytes(int nc) { return ((nc * 16 + 63) / 128) * 128 + 64; }
+
 struct MfmaArgs {
   int64_t steps_per_wave;  // 1024-sample steps per wave
   int64_t n_steps;         // ceil(n / 1024)
@@ -165,7 +171,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   constexpr int NC = 32 + HB;         // chunks staged per step
   constexpr int NP = 4 * NC;          // 16-byte raw pieces per step
   constexpr int JN = (NP + 63) / 64;  // raw loads per lane per step
-  constexpr int ARR = NC * 16;        // bytes of one [plane][half] array
+  constexpr int ARR = staged_array_bytes(NC);   // bytes of one [plane][half] array
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = (WAVES == 8) ? (wave >> 2) : 0;  // waves w and w+4 share a SIMD
   const int n_col = lane & 31, h = lane >> 5;
@@ -401,7 +407,7 @@ template <int NB, int EPI, int HS>
 __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
                                                    unsigned char *lds) {
   static_assert(EPI >= 1 && EPI <= 3, "fast epilogue classes only");
-  constexpr int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, JN = (NP + 63) / 64, ARR = NC * 16;
+  constexpr int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, JN = (NP + 63) / 64, ARR = staged_array_bytes(NC);
   // two accumulator sets + all Toeplitz fragments leave room for GS = 2 only when some high-byte blocks are skipped
   constexpr int GS = (HS == 0 && NB >= 8) ? 1 : 2, NG = (NB + GS - 1) / GS;
   const int lane = threadIdx.x & 63;
@@ -623,7 +629,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
 template <int NB, int EPI, int HS, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES, kOccupancy)
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * (32 + NB - 1) * 16 + (EPI == 3 ? 8192 : 2048)) + 1024];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * staged_array_bytes(32 + NB - 1) + (EPI == 3 ? 8192 : 2048)) + 1024];
   const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
   // (a lone first step has no in-row window to park the unused prefetch on: see issue_loads_in)
@@ -691,7 +697,7 @@ template <int EPI, bool FAST>
 __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
                                                   unsigned char *lds_all) {
   const int NB = a.nb;
-  const int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, ARR = NC * 16;
+  const int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, ARR = staged_array_bytes(NC);
   constexpr int JN = 4;   // NP <= 256
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = wave >> 2;
@@ -856,7 +862,7 @@ __global__ void __launch_bounds__(512, 1)
 fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
   const int NB = a.nb;
-  const int HB = NB - 1, NC = 64 + HB, NP = 4 * NC, ARR = NC * 16;
+  const int HB = NB - 1, NC = 64 + HB, NP = 4 * NC, ARR = staged_array_bytes(NC);
   constexpr int JN = 6;   // NP <= 4 * 96
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = wave >> 2;
@@ -997,7 +1003,7 @@ static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArg
   if (fast_chunks > 0) {
     MfmaArgs a2 = a;
     a2.steps_per_wave = spw2;
-    const size_t lds2 = (size_t)2 * nb * 1024 + 8 * ((size_t)4 * (64 + nb - 1) * 16 + 4096);
+    const size_t lds2 = (size_t)2 * nb * 1024 + 8 * ((size_t)4 * staged_array_bytes(64 + nb - 1) + 4096);
     dim3 g2((unsigned)fast_chunks, grid.y);
     if (epi == 1) {
       e = hipFuncSetAttribute((const void *)fir_mfma_big2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1012,7 +1018,7 @@ static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArg
     grid.x = (unsigned)((a.n_steps - a.step0 + a.steps_per_wave - 1) / a.steps_per_wave);
   }
   // ... the ragged rest (and the generic epilogue class) on the single-wide kernel
-  const size_t lds_bytes = (size_t)2 * nb * 1024 + 8 * ((size_t)2 * 4 * (32 + nb - 1) * 16 + 2048);
+  const size_t lds_bytes = (size_t)2 * nb * 1024 + 8 * ((size_t)2 * 4 * staged_array_bytes(32 + nb - 1) + 2048);
   if (epi == 1) {
     e = hipFuncSetAttribute((const void *)fir_mfma_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big_kernel<1>), grid, dim3(512), lds_bytes, s, p, (const v4i *)d_frag, a); }
