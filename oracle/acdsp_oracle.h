@@ -21,9 +21,10 @@
  *     reproduces them at 84-90 dB.  Bit-level FIR behaviour with default
  *     AC_TRN/AC_WRAP types is pinned only through that and through the CIC
  *     vectors (same wrap add / cast rules).
- *   - Non-default Q/O modes, saturating accumulators: PARITY UNPINNED by any
- *     reference vector; cross-checked against the independent template
- *     implementation in include/ac_types/ac_fixed.h only.
+ *   - Non-default Q/O modes, saturating accumulators, ac_poly_dec and
+ *     ac_fir_reg_share (no reference test or vector exists for either):
+ *     PARITY UNPINNED by any reference vector; cross-checked against the
+ *     independent template implementation in include/ac_types/ac_fixed.h only.
  */
 #ifndef ACDSP_ORACLE_H
 #define ACDSP_ORACLE_H
