@@ -101,6 +101,14 @@ SYMBOLS = {
     "acdsp_polydec_run_host": (_i32, [_vp, _vp, _i64, _vp]),
     "acdsp_polydec_reset": (_i32, [_vp]),
     "acdsp_polydec_path": (_i32, [_vp]),
+    "acdsp_ddc_create": (_i32, [C.POINTER(CicDesc), C.POINTER(FirDesc), C.POINTER(_vp)]),
+    "acdsp_ddc_destroy": (_i32, [_vp]),
+    "acdsp_ddc_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
+    "acdsp_ddc_out_count": (_i64, [_vp, _i64]),
+    "acdsp_ddc_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64), _vp]),
+    "acdsp_ddc_reset": (_i32, [_vp]),
+    "acdsp_ddc_path": (_i32, [_vp]),
+    "acdsp_ddc_kernel_stats": (_i32, [_vp, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 for _name, (_res, _args) in SYMBOLS.items():
     _f = getattr(lib, _name)  # AttributeError here == the library does not export what the header declares

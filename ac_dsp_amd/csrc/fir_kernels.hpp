@@ -66,6 +66,12 @@ bool fir_gen_plan(const int64_t *h, int n_taps, int R, int first_mod16, FirGenPl
 hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32_t *d_frag, int out_mode, int w_int,
                           int64_t first, int64_t n_out, hipStream_t s);
 
+// Fused decimator -> FIR cascade on the matrix cores (fir_gen.hip).  pa = stage A as for launch_fir_gen with
+// out_mode 1 (history of >= 256*R + off + 16 samples), pb = stage B formats + output buffer (int32 containers).
+// hipErrorNotSupported: shapes outside the compiled ones (run the two kernels instead).
+hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint32_t *d_fragA, int w_int, int64_t first,
+                          const FirParams &pb, const FirGenPlan &plb, const uint32_t *d_fragB, int64_t n_out, hipStream_t s);
+
 // Polyphase decimator, exact per-MAC order (polydec.hip); p.coeffs = STR_COEFF_TYPE array [ntaps*df], p.n = inputs used
 hipError_t launch_polydec_generic(const FirParams &p, int ntaps, int df, int64_t n_out, hipStream_t s);
 

@@ -209,3 +209,61 @@ class PolyDec:
 
     def __del__(self):
         self.close()
+
+
+class Ddc:
+    """n_channels independent cascades ac_cic_dec_full(R, M, N) -> FIR on the decimator's lossless INT_TYPE words
+    (C ABI acdsp_ddc_*): one fused kernel for the BASELINE config-5 shape class, the two stage kernels otherwise."""
+
+    def __init__(self, R, M, N, fin, n_taps, ftype, fcoeff, facc, fout, n_channels=1, kind="const", device=0, flags=0):
+        self.fin, self.fout, self.n_channels, self.n_taps = fin, fout, n_channels, n_taps
+        probe = CicDesc(0, R, M, N, n_channels, fin, fin, device, flags)
+        it = Fmt()
+        check(lib.acdsp_cic_int_type(C.byref(probe), C.byref(it)))
+        self.int_type = Fmt(it.W, it.I, True)
+        cd = CicDesc(0, R, M, N, n_channels, fin, self.int_type, device, flags)
+        fd = FirDesc(KINDS[kind], FTYPES[ftype] if isinstance(ftype, str) else ftype, n_taps, n_channels, 0, self.int_type, fcoeff,
+                     facc, fout, device, flags)
+        self._h = C.c_void_p()
+        check(lib.acdsp_ddc_create(C.byref(cd), C.byref(fd), C.byref(self._h)))
+
+    def set_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert c.shape == (self.n_taps,)
+        check(lib.acdsp_ddc_set_coeffs(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    @property
+    def path(self):
+        return {0: "two_kernels", 1: "fused"}[lib.acdsp_ddc_path(self._h)]
+
+    def out_count(self, n_in):
+        return lib.acdsp_ddc_out_count(self._h, n_in)
+
+    def run(self, x, out=None):
+        assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1
+        assert x.dtype == torch_dtype_for(self.fin), (x.dtype, self.fin)
+        n_in = x.shape[1]
+        no = self.out_count(n_in)
+        if out is None:
+            out = torch.empty((self.n_channels, (max(no, 1) + 7) // 8 * 8), dtype=torch_dtype_for(self.fout), device=x.device)
+        assert out.dtype == torch_dtype_for(self.fout) and out.stride(1) == 1 and out.shape[1] >= no
+        n_out = C.c_int64()
+        check(lib.acdsp_ddc_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), n_in, C.c_void_p(out.data_ptr()), out.stride(0),
+                                C.byref(n_out), _stream_ptr(x)))
+        return out[:, :n_out.value]
+
+    def reset(self):
+        check(lib.acdsp_ddc_reset(self._h))
+
+    def kernel_stats(self, last_k):
+        a, m = C.c_float(), C.c_float()
+        check(lib.acdsp_ddc_kernel_stats(self._h, last_k, C.byref(a), C.byref(m)))
+        return a.value, m.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.acdsp_ddc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

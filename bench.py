@@ -164,13 +164,13 @@ def main():
         cin, mid = A.Fmt(16, 1), A.Fmt(36, 21)
         fc, fa, fo = A.Fmt(16, 1), A.Fmt(60, 30), A.Fmt(24, 9, True, "RND", "SAT")
         lo, hi = shard(ch_per_gpu * world, world, rank)
-        cic = A.Cic(False, 16, 1, 5, cin, mid, n_channels=hi - lo, device=local_rank)
-        eng = A.Fir(127, "SHIFT_REG", mid, fc, fa, fo, n_channels=hi - lo, kind="const", device=local_rank)
+        # one handle for the cascade: fused kernel (the 36-bit intermediate never reaches HBM); ACDSP_NO_FUSE=1 -> two kernels
+        eng = A.Ddc(16, 1, 5, cin, 127, "SHIFT_REG", fc, fa, fo, n_channels=hi - lo, kind="const", device=local_rank)
+        assert (eng.int_type.W, eng.int_type.I) == (mid.W, mid.I)
         coeffs = windowed_sinc_raw(127, 0.2, fc.F)
         eng.set_coeffs(coeffs)
         x = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
         A.fill_stimulus(x, seed, 16, ch0=lo)
-        u = torch.empty((hi - lo, n // 16 + 8), dtype=torch.int64, device=dev)
         y = torch.empty((hi - lo, n // 16 + 8), dtype=torch.int32, device=dev)
         bytes_per_sample = 2.0 + 4.0 / 16      # 2 B read per real input sample + 4 B written per 16 (intermediate stays on chip ideally)
         macs_per_sample = 0.0
@@ -179,9 +179,8 @@ def main():
         dtype = "int64 (CIC wrap arithmetic, FIR exact dot product)"
 
         def step():
-            uu = cic.run(x, u)
-            eng.run(uu, y)
-        path = "cic_dec + fir_" + eng.path
+            eng.run(x, y)
+        path = "ddc_" + eng.path
         samples_per_step = (hi - lo) * n
         coeffs = None
     else:
@@ -226,9 +225,6 @@ def main():
         k_avg, k_min = eng.kernel_stats(min(args.steps, 64))   # HIP events around the dominant kernel, launch stream
     else:                                                     # poly_dec handle: events around the whole step on the launch stream
         k_avg = k_min = ev0.elapsed_time(ev1) / args.steps
-    if args.workload == "ddc":                              # two kernels per step: report their sum
-        c_avg, c_min = cic.kernel_stats(min(args.steps, 64))
-        k_avg, k_min = k_avg + c_avg, k_min + c_min
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

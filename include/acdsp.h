@@ -98,6 +98,7 @@ typedef struct {
 typedef struct acdsp_fir *acdsp_fir_t;
 typedef struct acdsp_polydec *acdsp_polydec_t;
 typedef struct acdsp_cic *acdsp_cic_t;
+typedef struct acdsp_ddc *acdsp_ddc_t;
 
 /* ---- general ---- */
 int32_t acdsp_abi_version(void);
@@ -168,6 +169,23 @@ int32_t acdsp_polydec_run(acdsp_polydec_t h, const void *d_in, int64_t in_stride
 int32_t acdsp_polydec_run_host(acdsp_polydec_t h, const void *h_in, int64_t n_in, void *h_out);
 int32_t acdsp_polydec_reset(acdsp_polydec_t h);
 int32_t acdsp_polydec_path(acdsp_polydec_t h);  /* ACDSP_PATH_GENERIC or ACDSP_PATH_MFMA_GEN */
+
+/* ---- DDC cascade: ac_cic_dec_full -> FIR on the decimator's lossless INT_TYPE words ----
+ * Replaces the pair of run() calls `cic.run(in, mid); fir.run(mid, out);` on many channels (the reference couples the
+ * two blocks through an ac_channel of INT_TYPE words, cf. ac_cic_dec_full.h:164-177).  cic->out and fir->in must both be
+ * the decimator's INT_TYPE (acdsp_cic_int_type).  For the BASELINE config-5 shape class (int16 input, 36-bit words,
+ * <= 127 taps, int32 output containers) both stages run in ONE kernel and the INT_TYPE stream never reaches HBM
+ * (acdsp_ddc_path = 1); otherwise the two stage kernels run back to back through an internal buffer (path 0).
+ * Results are identical to running the two handles separately; state carries across calls like theirs. */
+int32_t acdsp_ddc_create(const acdsp_cic_desc_t *cic, const acdsp_fir_desc_t *fir, acdsp_ddc_t *out);
+int32_t acdsp_ddc_destroy(acdsp_ddc_t h);
+int32_t acdsp_ddc_set_coeffs(acdsp_ddc_t h, const int64_t *coeffs);   /* FIR coefficients, raw COEFF_TYPE words [n_taps] */
+int64_t acdsp_ddc_out_count(acdsp_ddc_t h, int64_t n_in);
+int32_t acdsp_ddc_run(acdsp_ddc_t h, const void *d_in, int64_t in_stride, int64_t n_in, void *d_out, int64_t out_stride,
+                      int64_t *n_out, void *stream);
+int32_t acdsp_ddc_reset(acdsp_ddc_t h);
+int32_t acdsp_ddc_path(acdsp_ddc_t h);                                  /* 1: fused kernel, 0: two kernels */
+int32_t acdsp_ddc_kernel_stats(acdsp_ddc_t h, int32_t last_k, float *avg_ms, float *min_ms);
 
 #ifdef __cplusplus
 }
