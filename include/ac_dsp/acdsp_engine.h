@@ -240,6 +240,44 @@ private:
   int n_ch_, device_;
 };
 
+// DDC cascade on device-resident streams: n_channels x { ac_cic_dec_full<IN, INT, R, M, N> -> FIR<INT, OUT, COEFF, ACC> }
+// with INT = the decimator's lossless INT_TYPE (INT_TYPE::width etc. are checked by the engine).  The BASELINE
+// config-5 shape class runs as ONE kernel (the INT_TYPE stream stays on chip); others as the two stage kernels.
+template <class IN_TYPE, class INT_TYPE, class OUT_TYPE, class COEFF_TYPE, class ACC_TYPE>
+class ddc_engine {
+public:
+  ddc_engine(unsigned R, unsigned M, unsigned N, int fir_kind, int ftype, int n_taps, int n_channels = 1, int device = -1) : h_(0) {
+    acdsp_cic_desc_t c;
+    c.interp = 0; c.R = (int32_t)R; c.M = (int32_t)M; c.N = (int32_t)N; c.n_channels = n_channels;
+    c.in = fmt_of<IN_TYPE>(); c.out = fmt_of<INT_TYPE>(); c.device = device < 0 ? default_device() : device; c.flags = 0;
+    acdsp_fir_desc_t f;
+    f.kind = fir_kind; f.ftype = ftype; f.n_taps = n_taps; f.n_channels = n_channels; f.coeffs_per_channel = 0;
+    f.in = fmt_of<INT_TYPE>(); f.coeff = fmt_of<COEFF_TYPE>(); f.acc = fmt_of<ACC_TYPE>(); f.out = fmt_of<OUT_TYPE>();
+    f.device = c.device; f.flags = 0;
+    n_taps_ = n_taps;
+    check(acdsp_ddc_create(&c, &f, &h_), "acdsp_ddc_create");
+  }
+  ~ddc_engine() { if (h_) { acdsp_ddc_destroy(h_); } }
+  void set_coeffs(const COEFF_TYPE *c) {
+    std::vector<int64_t> r((size_t)n_taps_);
+    for (size_t i = 0; i < r.size(); i++) { r[i] = raw_of(c[i]); }
+    check(acdsp_ddc_set_coeffs(h_, r.data()), "acdsp_ddc_set_coeffs");
+  }
+  int64_t out_count(int64_t n_in) { return acdsp_ddc_out_count(h_, n_in); }
+  bool fused() { return acdsp_ddc_path(h_) == 1; }
+  void run_device(const void *d_in, int64_t in_stride, int64_t n_in, void *d_out, int64_t out_stride, int64_t *n_out, void *stream = 0) {
+    check(acdsp_ddc_run(h_, d_in, in_stride, n_in, d_out, out_stride, n_out, stream), "acdsp_ddc_run");
+  }
+  void reset() { check(acdsp_ddc_reset(h_), "acdsp_ddc_reset"); }
+  acdsp_ddc_t handle() { return h_; }
+
+private:
+  ddc_engine(const ddc_engine &);
+  ddc_engine &operator=(const ddc_engine &);
+  acdsp_ddc_t h_;
+  int n_taps_;
+};
+
 }  // namespace acdsp
 
 #endif
