@@ -48,6 +48,11 @@ class PolyDecDesc(C.Structure):
                 ("facc", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
 
 
+class PolyIntrDesc(C.Structure):
+    _fields_ = [("n_taps", C.c_int32), ("coeff_sz", C.c_int32), ("ifac", C.c_int32), ("ftype", C.c_int32), ("n_channels", C.c_int32),
+                ("fin", Fmt), ("fcoeff", Fmt), ("facc", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
+
+
 class CicDesc(C.Structure):
     _fields_ = [("interp", C.c_int32), ("R", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("n_channels", C.c_int32), ("fin", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
@@ -101,6 +106,13 @@ SYMBOLS = {
     "acdsp_polydec_run_host": (_i32, [_vp, _vp, _i64, _vp]),
     "acdsp_polydec_reset": (_i32, [_vp]),
     "acdsp_polydec_path": (_i32, [_vp]),
+    "acdsp_polyintr_create": (_i32, [C.POINTER(PolyIntrDesc), C.POINTER(_vp)]),
+    "acdsp_polyintr_destroy": (_i32, [_vp]),
+    "acdsp_polyintr_set_ctrl": (_i32, [_vp, C.POINTER(_i64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
+    "acdsp_polyintr_out_count": (_i64, [_vp, _i64]),
+    "acdsp_polyintr_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64), _vp]),
+    "acdsp_polyintr_run_host": (_i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "acdsp_polyintr_reset": (_i32, [_vp]),
     "acdsp_ddc_create": (_i32, [C.POINTER(CicDesc), C.POINTER(FirDesc), C.POINTER(_vp)]),
     "acdsp_ddc_destroy": (_i32, [_vp]),
     "acdsp_ddc_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),

@@ -1201,3 +1201,183 @@ int32_t acdsp_ddc_kernel_stats(acdsp_ddc_t h, int32_t last_k, float *avg_ms, flo
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// polyphase interpolator (second half): ac_poly_intr
+// ---------------------------------------------------------------------------------------------
+struct acdsp_polyintr {
+  acdsp_polyintr_desc_t d;
+  int in_eb, out_eb, hl;
+  bool ctrl_set = false;
+  void *d_hist[2] = {nullptr, nullptr};
+  int64_t *d_saved[2] = {nullptr, nullptr};   // sums of the last sample, emitted by the next call (folded cores)
+  int cur = 0;
+  int64_t t_total = 0;
+  int64_t *d_coeffs = nullptr;
+  uint8_t *d_sign = nullptr, *d_corr = nullptr;
+  Staging st;
+};
+
+extern "C" {
+
+int32_t acdsp_polyintr_destroy(acdsp_polyintr_t h) {
+  if (!h) { return ACDSP_OK; }
+  (void)hipSetDevice(h->d.device);
+  for (int i = 0; i < 2; i++) {
+    if (h->d_hist[i]) { (void)hipFree(h->d_hist[i]); }
+    if (h->d_saved[i]) { (void)hipFree(h->d_saved[i]); }
+  }
+  if (h->d_coeffs) { (void)hipFree(h->d_coeffs); }
+  if (h->d_sign) { (void)hipFree(h->d_sign); }
+  if (h->d_corr) { (void)hipFree(h->d_corr); }
+  h->st.destroy();
+  delete h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_polyintr_create(const acdsp_polyintr_desc_t *desc, acdsp_polyintr_t *out) {
+  if (!desc || !out) { return fail(ACDSP_EINVAL, "null argument"); }
+  const acdsp_polyintr_desc_t &d = *desc;
+  if (d.ftype < ACDSP_POLY_FOLD_EVEN || d.ftype > ACDSP_POLY_FOLD_ANTI) { return fail(ACDSP_EINVAL, "bad poly_intr ftype %d", d.ftype); }
+  if (d.n_taps < 1 || d.n_taps > 2048) { return fail(ACDSP_EUNSUPPORTED, "NTAPS=%d outside 1..2048", d.n_taps); }
+  if (d.ifac < 1 || d.ifac > 255) { return fail(ACDSP_EUNSUPPORTED, "IF=%d outside 1..255 (corr[] is ac_int<8,false>)", d.ifac); }
+  if (d.coeff_sz < 1 || d.coeff_sz > (1 << 20)) { return fail(ACDSP_EUNSUPPORTED, "COEFFSZ=%d outside 1..2^20", d.coeff_sz); }
+  if (d.n_channels < 1 || d.n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", d.n_channels); }
+  int rc;
+  if ((rc = check_fmt(d.in, "IN_TYPE")) || (rc = check_fmt(d.coeff, "COEFF_TYPE")) || (rc = check_fmt(d.acc, "ACC_TYPE")) ||
+      (rc = check_fmt(d.out, "OUT_TYPE"))) {
+    return rc;
+  }
+  {  // 128-bit exact intermediates: product coeff * fold (ACC_TYPE) or taps * coeff, aligned with the accumulator
+    const int fi = d.in.W - d.in.I, fc = d.coeff.W - d.coeff.I, fa = d.acc.W - d.acc.I;
+    const int wp = d.ftype == ACDSP_POLY_FOLD_ANTI ? d.in.W + d.coeff.W + 2 : d.acc.W + d.coeff.W + 1;
+    const int fp = d.ftype == ACDSP_POLY_FOLD_ANTI ? fi + fc : fa + fc;
+    const int f = fp > fa ? fp : fa;
+    if (wp + (f - fp) > 125 || d.acc.W + (f - fa) > 125) { return fail(ACDSP_EUNSUPPORTED, "type combination needs more than 128-bit intermediates"); }
+  }
+  if ((rc = check_device(d.device))) { return rc; }
+  acdsp_polyintr *h = new acdsp_polyintr();
+  h->d = d;
+  h->in_eb = elem_bytes(d.in.W); h->out_eb = elem_bytes(d.out.W);
+  h->hl = round_up(d.n_taps + 15, 32);
+  hipError_t e = hipSuccess;
+  const size_t hb = (size_t)d.n_channels * h->hl * h->in_eb, sb = (size_t)d.n_channels * d.ifac * sizeof(int64_t);
+  for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    e = hipMalloc(&h->d_hist[i], hb);
+    if (e == hipSuccess) { e = hipMemset(h->d_hist[i], 0, hb); }
+    if (e == hipSuccess) { e = hipMalloc((void **)&h->d_saved[i], sb); }
+    if (e == hipSuccess) { e = hipMemset(h->d_saved[i], 0, sb); }   // acc_a / acc_b start at 0 (ac_poly_intr.h:117-118)
+  }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_coeffs, (size_t)d.coeff_sz * sizeof(int64_t)); }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_sign, (size_t)d.ifac); }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_corr, (size_t)d.ifac); }
+  if (e != hipSuccess) {
+    acdsp_polyintr_destroy(h);
+    return fail(ACDSP_EHIP, "poly_intr state allocation failed: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_polyintr_set_ctrl(acdsp_polyintr_t h, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr) {
+  if (!h || !coeffs || !sign || !corr) { return fail(ACDSP_EINVAL, "null argument"); }
+  const acdsp_polyintr_desc_t &d = h->d;
+  int rc = check_device(d.device);
+  if (rc) { return rc; }
+  const acdsp::DFmt cf = make_dfmt(d.coeff);
+  for (int i = 0; i < d.coeff_sz; i++) {
+    if (coeffs[i] < cf.lo || coeffs[i] > cf.hi) { return fail(ACDSP_EINVAL, "coefficient %d = %lld is not a COEFF_TYPE raw word", i, (long long)coeffs[i]); }
+  }
+  const int N = d.n_taps, J = d.ifac - 1;
+  const int max_ci = d.ftype == ACDSP_POLY_FOLD_EVEN ? (N / 2 - 1) + J * N / 2
+                     : d.ftype == ACDSP_POLY_FOLD_ODD ? (N - 1) / 2 + (N / 2 + 1) * J : (N - 1) + N * J;
+  if (max_ci >= d.coeff_sz) { return fail(ACDSP_EINVAL, "the reference would read coeffs[%d] of coeffs[COEFFSZ = %d]", max_ci, d.coeff_sz); }
+  for (int j = 0; j < d.ifac; j++) {
+    if (d.ftype != ACDSP_POLY_FOLD_ANTI && corr[j] >= d.ifac) { return fail(ACDSP_EINVAL, "corr[%d] = %d indexes outside the IF = %d accumulator banks", j, corr[j], d.ifac); }
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, (size_t)d.coeff_sz * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_sign, sign, (size_t)d.ifac, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_corr, corr, (size_t)d.ifac, hipMemcpyHostToDevice));
+  h->ctrl_set = true;
+  return ACDSP_OK;
+}
+
+int64_t acdsp_polyintr_out_count(acdsp_polyintr_t h, int64_t n_in) {
+  if (!h || n_in < 0) { return -1; }
+  if (n_in == 0) { return 0; }
+  const int64_t groups = (h->d.ftype != ACDSP_POLY_FOLD_ANTI && h->t_total == 0) ? n_in - 1 : n_in;   // `init` (:175)
+  return groups * h->d.ifac;
+}
+
+int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stride, int64_t n_in, void *d_out, int64_t out_stride,
+                           int64_t *n_out, void *stream) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  if (!h->ctrl_set) { return fail(ACDSP_ESTATE, "poly_intr run before acdsp_polyintr_set_ctrl (the reference reads uninitialised structs)"); }
+  if (n_in < 0 || (n_in > 0 && (!d_in || in_stride < n_in))) { return fail(ACDSP_EINVAL, "poly_intr run: bad input arguments"); }
+  const int64_t no = acdsp_polyintr_out_count(h, n_in);
+  if (n_out) { *n_out = no; }
+  if (n_in == 0) { return ACDSP_OK; }
+  if (no > 0 && (!d_out || out_stride < no)) { return fail(ACDSP_EINVAL, "poly_intr run: output buffer too small for %lld outputs", (long long)no); }
+  const acdsp_polyintr_desc_t &d = h->d;
+  int rc = check_device(d.device);
+  if (rc) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  PolyIntrParams p;
+  memset(&p, 0, sizeof p);
+  p.n_taps = d.n_taps; p.coeff_sz = d.coeff_sz; p.ifac = d.ifac; p.ftype = d.ftype; p.n_ch = d.n_channels;
+  p.in = make_dfmt(d.in); p.cf = make_dfmt(d.coeff); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
+  p.in_eb = h->in_eb; p.out_eb = h->out_eb; p.hl = h->hl;
+  p.skip = (d.ftype != ACDSP_POLY_FOLD_ANTI && h->t_total == 0) ? 1 : 0;
+  p.in_stride = in_stride; p.out_stride = out_stride; p.n = n_in; p.n_out = no;
+  p.x = d_in; p.y = d_out; p.hist = h->d_hist[h->cur];
+  p.coeffs = h->d_coeffs; p.sign = h->d_sign; p.corr = h->d_corr; p.saved = h->d_saved[h->cur];
+  hipError_t e = launch_polyintr(p, h->d_saved[h->cur ^ 1], s);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_intr kernel launch failed: %s", hipGetErrorString(e)); }
+  FirParams k;
+  memset(&k, 0, sizeof k);
+  k.n_ch = d.n_channels; k.in = p.in; k.in_eb = h->in_eb; k.hl = h->hl; k.in_stride = in_stride; k.n = n_in; k.x = d_in; k.hist = p.hist;
+  e = launch_fir_hist_update(k, h->d_hist[h->cur ^ 1], s);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_intr state kernel launch failed: %s", hipGetErrorString(e)); }
+  h->cur ^= 1;
+  h->t_total += n_in;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_polyintr_run_host(acdsp_polyintr_t h, const void *h_in, int64_t n_in, void *h_out, int64_t out_cap, int64_t *n_out) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  if (n_in < 0 || (n_in > 0 && !h_in)) { return fail(ACDSP_EINVAL, "poly_intr run_host: bad arguments"); }
+  const int64_t no = acdsp_polyintr_out_count(h, n_in);
+  if (n_out) { *n_out = no; }
+  if (n_in == 0) { return ACDSP_OK; }
+  if (no > 0 && (!h_out || out_cap < no)) { return fail(ACDSP_EINVAL, "poly_intr run_host: output buffer too small"); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  const int64_t si = (n_in + 15) / 16 * 16, so = (no + 15) / 16 * 16 + 16;
+  if ((rc = h->st.ensure((size_t)h->d.n_channels * si * h->in_eb, (size_t)h->d.n_channels * so * h->out_eb))) { return rc; }
+  HIP_TRY(hipMemcpy2D(h->st.d_in, (size_t)si * h->in_eb, h_in, (size_t)n_in * h->in_eb, (size_t)n_in * h->in_eb,
+                      (size_t)h->d.n_channels, hipMemcpyHostToDevice));
+  int64_t got = 0;
+  if ((rc = acdsp_polyintr_run(h, h->st.d_in, si, n_in, h->st.d_out, so, &got, nullptr))) { return rc; }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  if (got > 0) {
+    HIP_TRY(hipMemcpy2D(h_out, (size_t)out_cap * h->out_eb, h->st.d_out, (size_t)so * h->out_eb, (size_t)got * h->out_eb,
+                        (size_t)h->d.n_channels, hipMemcpyDeviceToHost));
+  }
+  return ACDSP_OK;
+}
+
+int32_t acdsp_polyintr_reset(acdsp_polyintr_t h) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(hipMemset(h->d_hist[i], 0, (size_t)h->d.n_channels * h->hl * h->in_eb));
+    HIP_TRY(hipMemset(h->d_saved[i], 0, (size_t)h->d.n_channels * h->d.ifac * sizeof(int64_t)));
+  }
+  h->t_total = 0;
+  return ACDSP_OK;
+}
+
+}  // extern "C"

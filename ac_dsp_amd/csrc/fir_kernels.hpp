@@ -72,6 +72,20 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
 hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint32_t *d_fragA, int w_int, int64_t first,
                           const FirParams &pb, const FirGenPlan &plb, const uint32_t *d_fragB, int64_t n_out, hipStream_t s);
 
+// Polyphase interpolator (polyintr.hip): ftype 0 FOLD_EVEN, 1 FOLD_ODD, 2 FOLD_ANTI (ac_poly_intr.h:71)
+struct PolyIntrParams {
+  int32_t n_taps, coeff_sz, ifac, ftype, n_ch;
+  DFmt in, cf, acc, out;
+  int32_t in_eb, out_eb, hl;
+  int32_t skip;               // 1: the stream's very first sample is in this call and emits nothing (folded cores)
+  int64_t in_stride, out_stride, n, n_out;   // n inputs -> n_out outputs per channel
+  const void *x; void *y; const void *hist;
+  const int64_t *coeffs;      // [coeff_sz]
+  const uint8_t *sign, *corr; // [ifac]
+  const int64_t *saved;       // [n_ch][ifac] sums of the previous call's last sample (folded cores)
+};
+hipError_t launch_polyintr(const PolyIntrParams &p, int64_t *saved_next, hipStream_t s);
+
 // Polyphase decimator, exact per-MAC order (polydec.hip); p.coeffs = STR_COEFF_TYPE array [ntaps*df], p.n = inputs used
 hipError_t launch_polydec_generic(const FirParams &p, int ntaps, int df, int64_t n_out, hipStream_t s);
 

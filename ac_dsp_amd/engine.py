@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, FTYPES, KINDS, PATHS
+from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, PolyIntrDesc, FTYPES, KINDS, PATHS
 
 
 def device_count():
@@ -263,6 +263,52 @@ class Ddc:
     def close(self):
         if getattr(self, "_h", None):
             lib.acdsp_ddc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+POLY_FTYPES = {"FOLD_EVEN": 0, "FOLD_ODD": 1, "FOLD_ANTI": 2}   # the enum of ac_poly_intr.h:71
+
+
+class PolyIntr:
+    """n_channels independent ac_poly_intr objects (C ABI acdsp_polyintr_*): IF outputs per input sample."""
+
+    def __init__(self, n_taps, coeff_sz, ifac, ftype, fin, fcoeff, facc, fout, n_channels=1, device=0):
+        self.fin, self.fout, self.n_channels, self.coeff_sz, self.ifac = fin, fout, n_channels, coeff_sz, ifac
+        d = PolyIntrDesc(n_taps, coeff_sz, ifac, POLY_FTYPES[ftype] if isinstance(ftype, str) else ftype, n_channels, fin, fcoeff,
+                         facc, fout, device, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_polyintr_create(C.byref(d), C.byref(self._h)))
+
+    def set_ctrl(self, coeffs, sign, corr):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        sg = np.ascontiguousarray(sign, dtype=np.uint8)
+        cr = np.ascontiguousarray(corr, dtype=np.uint8)
+        assert c.shape == (self.coeff_sz,) and sg.shape == (self.ifac,) and cr.shape == (self.ifac,)
+        check(lib.acdsp_polyintr_set_ctrl(self._h, c.ctypes.data_as(C.POINTER(C.c_int64)), sg.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                          cr.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def out_count(self, n_in):
+        return lib.acdsp_polyintr_out_count(self._h, n_in)
+
+    def run(self, x):
+        assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1
+        assert x.dtype == torch_dtype_for(self.fin), (x.dtype, self.fin)
+        no = self.out_count(x.shape[1])
+        out = torch.empty((self.n_channels, max(no, 1)), dtype=torch_dtype_for(self.fout), device=x.device)
+        n_out = C.c_int64()
+        check(lib.acdsp_polyintr_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), x.shape[1], C.c_void_p(out.data_ptr()),
+                                     out.stride(0), C.byref(n_out), _stream_ptr(x)))
+        return out[:, :n_out.value]
+
+    def reset(self):
+        check(lib.acdsp_polyintr_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.acdsp_polyintr_destroy(self._h)
             self._h = None
 
     def __del__(self):

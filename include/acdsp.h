@@ -95,10 +95,25 @@ typedef struct {
   int32_t flags;
 } acdsp_polydec_desc_t;
 
+/* ac_poly_intr<IN, COEFF, ACC, OUT, STR_CTRL, STR_COEFF, NTAPS, COEFFSZ, IF, ftype> (reference include/ac_dsp/ac_poly_intr.h:275).
+ * ftype is THAT header's enum (ac_poly_intr.h:71), not the FIR FTYPE. */
+enum { ACDSP_POLY_FOLD_EVEN = 0, ACDSP_POLY_FOLD_ODD = 1, ACDSP_POLY_FOLD_ANTI = 2 };
+typedef struct {
+  int32_t n_taps;             /* NTAPS: length of the shift register */
+  int32_t coeff_sz;           /* COEFFSZ: words in the coefficient struct */
+  int32_t ifac;               /* IF: interpolation factor = outputs per input sample */
+  int32_t ftype;              /* ACDSP_POLY_* */
+  int32_t n_channels;
+  acdsp_fmt_t in, coeff, acc, out;
+  int32_t device;
+  int32_t flags;
+} acdsp_polyintr_desc_t;
+
 typedef struct acdsp_fir *acdsp_fir_t;
 typedef struct acdsp_polydec *acdsp_polydec_t;
 typedef struct acdsp_cic *acdsp_cic_t;
 typedef struct acdsp_ddc *acdsp_ddc_t;
+typedef struct acdsp_polyintr *acdsp_polyintr_t;
 
 /* ---- general ---- */
 int32_t acdsp_abi_version(void);
@@ -186,6 +201,19 @@ int32_t acdsp_ddc_run(acdsp_ddc_t h, const void *d_in, int64_t in_stride, int64_
 int32_t acdsp_ddc_reset(acdsp_ddc_t h);
 int32_t acdsp_ddc_path(acdsp_ddc_t h);                                  /* 1: fused kernel, 0: two kernels */
 int32_t acdsp_ddc_kernel_stats(acdsp_ddc_t h, int32_t last_k, float *avg_ms, float *min_ms);
+
+/* ---- polyphase interpolator (reference ac_poly_intr.h:104-320) ----
+ * One input sample -> IF outputs.  The folded cores emit the sums of a sample one sample later (accumulator banks
+ * acc_a / acc_b, :153-175), so the stream's very first sample produces nothing.  set_ctrl = the `read_ctrl` call of run()
+ * (:291-294): coeffs[COEFFSZ] from the coefficient struct, sign[IF] / corr[IF] from the control struct. */
+int32_t acdsp_polyintr_create(const acdsp_polyintr_desc_t *desc, acdsp_polyintr_t *out);
+int32_t acdsp_polyintr_destroy(acdsp_polyintr_t h);
+int32_t acdsp_polyintr_set_ctrl(acdsp_polyintr_t h, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr);
+int64_t acdsp_polyintr_out_count(acdsp_polyintr_t h, int64_t n_in);
+int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stride, int64_t n_in, void *d_out, int64_t out_stride,
+                           int64_t *n_out, void *stream);
+int32_t acdsp_polyintr_run_host(acdsp_polyintr_t h, const void *h_in, int64_t n_in, void *h_out, int64_t out_cap, int64_t *n_out);
+int32_t acdsp_polyintr_reset(acdsp_polyintr_t h);
 
 #ifdef __cplusplus
 }

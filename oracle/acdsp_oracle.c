@@ -540,6 +540,119 @@ int64_t orc_polydec_run(orc_polydec_t *f, const int64_t *c, const int64_t *x, in
 /* Synthetic stimulus (counter hash; the GPU generator is bit-identical) */
 /* ------------------------------------------------------------------ */
 
+/* ---- ac_poly_intr (second half of SURVEY 8 row f2): reference include/ac_dsp/ac_poly_intr.h ----
+ * One core call = one input sample (run() reads one flag per call and, when it is false, calls the core once,
+ * :289-320).  ftype: 0 FOLD_EVEN (:126-177), 1 FOLD_ODD (:179-236), 2 FOLD_ANTI (:238-258) -- the enum of
+ * ac_poly_intr.h:71, NOT the FIR FTYPE.  State: taps[], the two accumulator banks acc_a / acc_b, flip, init (:107-123). */
+struct orc_polyintr {
+  int32_t ntaps, coeffsz, ifac, ftype;
+  orc_fmt_t in, cf, acc, out;
+  int fi, fc, fa;
+  int64_t *taps, *acc_a, *acc_b;
+  int flip, init;
+};
+
+orc_polyintr_t *orc_polyintr_new(int32_t ntaps, int32_t coeffsz, int32_t ifac, int32_t ftype, const orc_fmt_t *in,
+                                 const orc_fmt_t *coeff, const orc_fmt_t *acc, const orc_fmt_t *out) {
+  if (ntaps < 1 || coeffsz < 1 || ifac < 1 || ifac > 255 || ftype < 0 || ftype > 2) { return NULL; }
+  orc_polyintr_t *f = (orc_polyintr_t *)calloc(1, sizeof *f);
+  f->ntaps = ntaps; f->coeffsz = coeffsz; f->ifac = ifac; f->ftype = ftype;
+  f->in = *in; f->cf = *coeff; f->acc = *acc; f->out = *out;
+  f->fi = in->W - in->I; f->fc = coeff->W - coeff->I; f->fa = acc->W - acc->I;
+  f->taps = (int64_t *)calloc((size_t)ntaps, sizeof(int64_t));  /* init_array<AC_VAL_0>, :117-119 */
+  f->acc_a = (int64_t *)calloc((size_t)ifac, sizeof(int64_t));
+  f->acc_b = (int64_t *)calloc((size_t)ifac, sizeof(int64_t));
+  f->flip = 0; f->init = 0;                                      /* :120-121 */
+  return f;
+}
+void orc_polyintr_free(orc_polyintr_t *f) {
+  if (!f) { return; }
+  free(f->taps); free(f->acc_a); free(f->acc_b); free(f);
+}
+
+/* Returns the number of outputs written to y (0 or IF), or -1 where the reference would index outside coeffs[] / the
+ * accumulator banks. */
+int64_t orc_polyintr_step(orc_polyintr_t *f, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr, int64_t x, int64_t *y) {
+  const int N = f->ntaps, IF = f->ifac;
+  int64_t n_out = 0;
+  for (int i = N - 1; i >= 1; i--) { f->taps[i] = f->taps[i - 1]; } /* SHIFT_REG */
+  for (int j = 0; j < IF; j++) {                                      /* INTR_F */
+    if (j == 0) {
+      f->taps[0] = x;                                                 /* data_in.read() */
+      f->flip = !f->flip;
+    }
+    int64_t acc = 0; /* acc = 0.0 */
+    if (f->ftype == 2) { /* :246-255: plain MAC, i = N-1 .. 0, output written at once */
+      for (int i = N - 1; i >= 0; i--) {
+        const int ci = i + N * j;
+        if (ci >= f->coeffsz) { return -1; }
+        int fs;
+        i128 s = add_aligned((i128)acc, f->fa, (i128)f->taps[i] * coeffs[ci], f->fi + f->fc, &fs);
+        acc = requant(s, fs, &f->acc);
+      }
+      y[n_out++] = requant((i128)acc, f->fa, &f->out);
+      continue;
+    }
+    if (f->ftype == 0) { /* MAC_E :141-151: i = N/2-1 .. 0 */
+      for (int i = (N / 2) - 1; i >= 0; i--) {
+        /* IN_TYPE tp = sign[j] ? taps[N-1-i] : -taps[N-1-i]  (the negation is assigned to an IN_TYPE) */
+        int64_t tp = sign[j] ? f->taps[N - 1 - i] : requant(-(i128)f->taps[N - 1 - i], f->fi, &f->in);
+        int64_t fold = requant((i128)f->taps[i] + (i128)tp, f->fi, &f->acc); /* ACC_TYPE fold */
+        const int ci = i + j * N / 2;                                         /* C precedence: (j * NTAPS) / 2 */
+        if (ci >= f->coeffsz) { return -1; }
+        int fs;
+        i128 s = add_aligned((i128)acc, f->fa, (i128)coeffs[ci] * (i128)fold, f->fc + f->fa, &fs);
+        acc = requant(s, fs, &f->acc);
+      }
+    } else { /* MAC_O :194-209: i = 0 .. (N-1)/2, centre tap passes through */
+      for (int i = 0; i < ((N - 1) / 2) + 1; i++) {
+        int64_t fold;
+        if (i == (N - 1) / 2) {
+          fold = requant((i128)f->taps[i], f->fi, &f->acc);
+        } else {
+          int64_t tp = sign[j] ? f->taps[N - 1 - i] : requant(-(i128)f->taps[N - 1 - i], f->fi, &f->in);
+          fold = requant((i128)f->taps[i] + (i128)tp, f->fi, &f->acc);
+        }
+        const int ci = i + (N / 2 + 1) * j;
+        if (ci >= f->coeffsz) { return -1; }
+        int fs;
+        i128 s = add_aligned((i128)acc, f->fa, (i128)coeffs[ci] * (i128)fold, f->fc + f->fa, &fs);
+        acc = requant(s, fs, &f->acc);
+      }
+    }
+    if (corr[j] >= IF) { return -1; }
+    int64_t t1, t2; /* :153-161 / :211-221: this sample's sums go to one bank, the outputs come from the other */
+    if (f->flip) {
+      f->acc_b[j] = acc; t1 = f->acc_a[j]; t2 = f->acc_a[corr[j]];
+    } else {
+      f->acc_a[j] = acc; t1 = f->acc_b[j]; t2 = f->acc_b[corr[j]];
+    }
+    if (f->init) {
+      if (j != corr[j]) { /* symmetric-pair technique :163-171 */
+        int64_t tn = sign[j] ? requant(-(i128)t2, f->fa, &f->acc) : t2; /* ACC_TYPE tn */
+        i128 sum = (i128)t1 + (i128)tn;                                    /* exact sum type */
+        i128 half = sum >> 1;                                              /* ac_fixed >> 1: same type, LSB dropped */
+        y[n_out++] = requant(half, f->fa, &f->out);
+      } else {
+        y[n_out++] = requant((i128)t1, f->fa, &f->out);
+      }
+    }
+  }
+  f->init = 1;
+  return n_out;
+}
+
+int64_t orc_polyintr_run(orc_polyintr_t *f, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr, const int64_t *x,
+                         int64_t n_in, int64_t *y) {
+  int64_t k = 0;
+  for (int64_t t = 0; t < n_in; t++) {
+    int64_t r = orc_polyintr_step(f, coeffs, sign, corr, x[t], y + k);
+    if (r < 0) { return -1; }
+    k += r;
+  }
+  return k;
+}
+
 uint64_t orc_splitmix64(uint64_t seed, uint64_t index) {
   uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

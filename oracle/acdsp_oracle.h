@@ -21,8 +21,9 @@
  *     reproduces them at 84-90 dB.  Bit-level FIR behaviour with default
  *     AC_TRN/AC_WRAP types is pinned only through that and through the CIC
  *     vectors (same wrap add / cast rules).
- *   - Non-default Q/O modes, saturating accumulators, ac_poly_dec and
- *     ac_fir_reg_share (no reference test or vector exists for either):
+ *   - Non-default Q/O modes, saturating accumulators, ac_poly_dec,
+ *     ac_poly_intr and ac_fir_reg_share (no reference test or vector exists
+ *     for any of them):
  *     PARITY UNPINNED by any reference vector; cross-checked against the
  *     independent template implementation in include/ac_types/ac_fixed.h only.
  */
@@ -94,6 +95,17 @@ void orc_polydec_free(orc_polydec_t *f);
 /* One run() call: consumes floor(n_in / DF) * DF inputs (the reference loops `while (available(DF))`), writes
  * one output per group; coeffs is the STR_COEFF_TYPE array [NTAPS*DF].  Returns the number of outputs. */
 int64_t orc_polydec_run(orc_polydec_t *f, const int64_t *coeffs, const int64_t *x, int64_t n_in, int64_t *y);
+
+/* ---- polyphase interpolator (row f2 of SURVEY 8: reference include/ac_dsp/ac_poly_intr.h:104-320) ----
+ * ftype 0 FOLD_EVEN, 1 FOLD_ODD, 2 FOLD_ANTI (the enum of ac_poly_intr.h:71).  One step = one input sample = one call of
+ * the selected core; coeffs[COEFFSZ], sign[IF], corr[IF] are the members of the coefficient / control structs. */
+typedef struct orc_polyintr orc_polyintr_t;
+orc_polyintr_t *orc_polyintr_new(int32_t ntaps, int32_t coeffsz, int32_t ifac, int32_t ftype, const orc_fmt_t *in,
+                                 const orc_fmt_t *coeff, const orc_fmt_t *acc, const orc_fmt_t *out);
+void orc_polyintr_free(orc_polyintr_t *f);
+int64_t orc_polyintr_step(orc_polyintr_t *f, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr, int64_t x, int64_t *y);
+int64_t orc_polyintr_run(orc_polyintr_t *f, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr, const int64_t *x,
+                         int64_t n_in, int64_t *y);
 
 /* ---- synthetic stimulus shared with the GPU generator ---- */
 uint64_t orc_splitmix64(uint64_t seed, uint64_t index);

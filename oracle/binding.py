@@ -68,6 +68,12 @@ lib.orc_polydec_new.argtypes = [C.c_int32, C.c_int32] + [C.POINTER(Fmt)] * 4
 lib.orc_polydec_free.argtypes = [C.c_void_p]
 lib.orc_polydec_run.restype = C.c_int64
 lib.orc_polydec_run.argtypes = [C.c_void_p, _i64p, _i64p, C.c_int64, _i64p]
+_u8p = C.POINTER(C.c_uint8)
+lib.orc_polyintr_new.restype = C.c_void_p
+lib.orc_polyintr_new.argtypes = [C.c_int32] * 4 + [C.POINTER(Fmt)] * 4
+lib.orc_polyintr_free.argtypes = [C.c_void_p]
+lib.orc_polyintr_run.restype = C.c_int64
+lib.orc_polyintr_run.argtypes = [C.c_void_p, _i64p, _u8p, _u8p, _i64p, C.c_int64, _i64p]
 lib.orc_stimulus.restype = C.c_int64
 lib.orc_stimulus.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]
 lib.orc_splitmix64.restype = C.c_uint64
@@ -204,3 +210,37 @@ class OraclePolyDec:
         for h in getattr(self, "_h", []):
             if h:
                 lib.orc_polydec_free(h)
+
+
+POLY_FTYPES = {"FOLD_EVEN": 0, "FOLD_ODD": 1, "FOLD_ANTI": 2}
+
+
+class OraclePolyIntr:
+    """One ac_poly_intr object per channel (reference ac_poly_intr.h:104-320); run() -> [n_ch][outputs] int64 raw words."""
+
+    def __init__(self, n_taps, coeff_sz, ifac, ftype, fin, fcoeff, facc, fout, n_ch=1):
+        self.ifac, self.n_ch = ifac, n_ch
+        ft = POLY_FTYPES[ftype] if isinstance(ftype, str) else ftype
+        self._h = [lib.orc_polyintr_new(n_taps, coeff_sz, ifac, ft, C.byref(fin), C.byref(fcoeff), C.byref(facc), C.byref(fout))
+                   for _ in range(n_ch)]
+        if any(h is None for h in self._h):
+            raise ValueError("oracle: unsupported poly_intr configuration")
+
+    def run(self, coeffs, sign, corr, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64)
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        sg = np.ascontiguousarray(sign, dtype=np.uint8)
+        cr = np.ascontiguousarray(corr, dtype=np.uint8)
+        outs = []
+        for ch in range(self.n_ch):
+            y = np.empty(x.shape[1] * self.ifac + 1, dtype=np.int64)
+            k = lib.orc_polyintr_run(self._h[ch], _p(c), sg.ctypes.data_as(_u8p), cr.ctypes.data_as(_u8p), _p(x[ch]), x.shape[1], _p(y))
+            if k < 0:
+                raise ValueError("oracle: the reference would index outside coeffs[] / the accumulator banks")
+            outs.append(y[:k].copy())
+        return np.stack(outs)
+
+    def __del__(self):
+        for h in getattr(self, "_h", []):
+            if h:
+                lib.orc_polyintr_free(h)

@@ -303,3 +303,43 @@ def test_reg_share_ascending_order_differs_from_prog_coeffs_only_when_the_accumu
     y_pg = OracleFir(9, "SHIFT_REG", f, f, sat, wide).run(c, x)
     assert not np.array_equal(y_rs, y_pg)
     assert np.array_equal(y_rs, OracleFir(9, "C_BUFF", f, f, sat, wide).run(c, x))   # C_BUFF is the ascending const/load/prog core
+
+
+# ---- ac_poly_intr (second half) ----
+
+def test_poly_intr_known_answers():
+    from oracle import OraclePolyIntr
+    f, a = Fmt(16, 2), Fmt(40, 12)
+    one = 1 << 14
+    x = np.zeros((1, 8), dtype=np.int64)
+    x[0, 0] = one                                        # unit impulse
+    # FOLD_ANTI is the plain polyphase MAC (ac_poly_intr.h:246-256): phase j of sample n = sum_i taps[i] * c[i + N*j],
+    # written at once -> the impulse reads the IF x NTAPS coefficient table back column by column
+    N, IF = 3, 2
+    c = (np.arange(1, N * IF + 1, dtype=np.int64)) << 14
+    y = OraclePolyIntr(N, N * IF, IF, "FOLD_ANTI", f, f, a, a).run(c, [1, 1], [0, 1], x)[0]
+    sc = lambda v: [int(t) << 28 for t in v]
+    assert y[:8].tolist() == sc([1, 4, 2, 5, 3, 6, 0, 0])
+    # FOLD_EVEN, corr[j] = j: sum_i c[i + (j*N)/2] * (taps[i] + taps[N-1-i]), emitted ONE SAMPLE LATER (:153-175): the first
+    # sample produces nothing, so 8 inputs give 7 * IF outputs; N = 4 -> symmetric impulse response c0 c1 c1 c0 per phase
+    N, IF = 4, 2
+    c = np.array([1, 2, 5, 7], dtype=np.int64) << 14
+    y = OraclePolyIntr(N, 4, IF, "FOLD_EVEN", f, f, a, a).run(c, [1, 1], [0, 1], x)[0]
+    assert len(y) == 7 * IF
+    assert y[0::2][:5].tolist() == sc([1, 2, 2, 1, 0]) and y[1::2][:5].tolist() == sc([5, 7, 7, 5, 0])
+    # sign[j] = 0: the mirrored tap is negated (anti-symmetric phase)
+    y = OraclePolyIntr(N, 4, IF, "FOLD_EVEN", f, f, a, a).run(c, [0, 1], [0, 1], x)[0]
+    assert y[0::2][:5].tolist() == sc([1, 2, -2, -1, 0])
+    # symmetric-pair technique: corr = [1, 0], sign = [1, 1] -> out_j = (acc_j - acc_corr(j)) >> 1   (tn = -t2 when sign[j])
+    y = OraclePolyIntr(N, 4, IF, "FOLD_EVEN", f, f, a, a).run(c, [1, 1], [1, 0], x)[0]
+    assert y[0::2][:4].tolist() == [(p - q) >> 1 for p, q in zip(sc([1, 2, 2, 1]), sc([5, 7, 7, 5]))]
+    # FOLD_ODD: centre tap passes through once, coefficient stride N/2 + 1 per phase (:207)
+    N, IF = 5, 2
+    c = np.array([1, 2, 3, 4, 5, 6], dtype=np.int64) << 14
+    y = OraclePolyIntr(N, 6, IF, "FOLD_ODD", f, f, a, a).run(c, [1, 1], [0, 1], x)[0]
+    assert y[0::2][:6].tolist() == sc([1, 2, 3, 2, 1, 0]) and y[1::2][:6].tolist() == sc([4, 5, 6, 5, 4, 0])
+    # out-of-range table / bank indices are refused (the reference would read outside its arrays)
+    with pytest.raises(ValueError):
+        OraclePolyIntr(4, 3, 2, "FOLD_EVEN", f, f, a, a).run(c[:3], [1, 1], [0, 1], x)
+    with pytest.raises(ValueError):
+        OraclePolyIntr(4, 4, 2, "FOLD_EVEN", f, f, a, a).run(c[:4], [1, 1], [0, 2], x)

@@ -1,0 +1,105 @@
+"""GPU parity tests, polyphase interpolator (second half): acdsp_polyintr_* vs the oracle restatement of
+reference include/ac_dsp/ac_poly_intr.h:104-320 (the reference ships no test or vector for this class)."""
+import numpy as np
+import pytest
+import torch
+
+import ac_dsp_amd as A
+from oracle import OraclePolyIntr
+from helpers import ofmt
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_raw(rng, fmt, shape):
+    lo = -(1 << (fmt.W - 1)) if fmt.S else 0
+    hi = (1 << (fmt.W - 1)) - 1 if fmt.S else (1 << fmt.W) - 1
+    return rng.integers(lo, hi + 1, size=shape, dtype=np.int64)
+
+
+def table_size(n_taps, ifac, ftype):
+    j = ifac - 1
+    return {"FOLD_EVEN": (n_taps // 2 - 1) + j * n_taps // 2, "FOLD_ODD": (n_taps - 1) // 2 + (n_taps // 2 + 1) * j,
+            "FOLD_ANTI": (n_taps - 1) + n_taps * j}[ftype] + 1
+
+
+def check(n_taps, ifac, ftype, fin, fc, fa, fo, n_ch=3, n=300, splits=None, seed=0, pairs=False):
+    rng = np.random.default_rng(seed)
+    csz = table_size(n_taps, ifac, ftype) + 2                       # COEFFSZ may exceed what the loops read
+    c = rand_raw(rng, fc, (csz,))
+    sign = rng.integers(0, 2, size=ifac)
+    corr = np.arange(ifac)
+    if pairs:                                                       # symmetric-pair technique: phase j paired with IF-1-j
+        corr = ifac - 1 - corr
+    x = rand_raw(rng, fin, (n_ch, n))
+    eng = A.PolyIntr(n_taps, csz, ifac, ftype, fin, fc, fa, fo, n_channels=n_ch)
+    eng.set_ctrl(c, sign, corr)
+    orc = OraclePolyIntr(n_taps, csz, ifac, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    bounds = [0] + list(splits or []) + [n]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        xd = torch.from_numpy(x[:, a:b].copy()).to(A.torch_dtype_for(fin)).cuda()
+        y = eng.run(xd).cpu().numpy().astype(np.int64)
+        yo = orc.run(c, sign, corr, x[:, a:b])
+        assert y.shape == yo.shape, (y.shape, yo.shape)
+        bad = np.argwhere(y != yo)
+        assert bad.size == 0, "%d mismatches, first at %s" % (len(bad), bad[0])
+    return eng
+
+
+@pytest.mark.parametrize("ftype,n_taps", [("FOLD_EVEN", 8), ("FOLD_EVEN", 7), ("FOLD_ODD", 9), ("FOLD_ODD", 6), ("FOLD_ANTI", 5)])
+@pytest.mark.parametrize("ifac,pairs", [(1, False), (4, False), (4, True), (3, True)])
+def test_usage_example_types_all_cores(ftype, n_taps, ifac, pairs):
+    # types of the reference usage example (ac_poly_intr.h:44-48): <32,16> data / coefficients, <64,32> accumulator and output;
+    # ragged bursts incl. a one-sample first burst (emits nothing on the folded cores)
+    check(n_taps, ifac, ftype, A.Fmt(32, 16), A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(64, 32), splits=[1, 2, 50], seed=n_taps * 10 + ifac,
+          pairs=pairs)
+
+
+@pytest.mark.parametrize("ftype", ["FOLD_EVEN", "FOLD_ODD", "FOLD_ANTI"])
+@pytest.mark.parametrize("q,o", [("TRN", "WRAP"), ("RND", "SAT"), ("RND_CONV", "SAT_SYM"), ("TRN_ZERO", "SAT_ZERO")])
+def test_lossy_types_keep_every_quantisation_step(ftype, q, o):
+    # narrow saturating ACC_TYPE: the IN_TYPE negation, the ACC_TYPE fold, every `acc +=`, the ACC_TYPE -t2 and the
+    # final >> 1 all quantise; full-scale inputs so that -min(IN_TYPE) occurs
+    fin, fc = A.Fmt(12, 3, True, q, o), A.Fmt(10, 2)
+    fa, fo = A.Fmt(18, 7, True, q, o), A.Fmt(9, 5, True, q, o)
+    eng = check(9 if ftype == "FOLD_ODD" else 8, 4, ftype, fin, fc, fa, fo, n=400, splits=[100], seed=5, pairs=True)
+    # extreme stream: alternating full-scale values
+    x = np.tile(np.array([-2048, 2047, -2048, -2048], dtype=np.int64), (1, 50))
+    xd = torch.from_numpy(x).to(torch.int16).cuda()
+    eng2 = A.PolyIntr(8, 40, 4, ftype, fin, fc, fa, fo, n_channels=1)
+    rng = np.random.default_rng(9)
+    c = rand_raw(rng, fc, (40,))
+    sign, corr = [0, 1, 0, 1], [3, 2, 1, 0]
+    eng2.set_ctrl(c, sign, corr)
+    orc = OraclePolyIntr(8, 40, 4, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo))
+    assert np.array_equal(eng2.run(xd).cpu().numpy().astype(np.int64), orc.run(c, sign, corr, x))
+
+
+def test_control_reload_mid_stream_uses_the_sums_of_their_own_time():
+    # new coefficients / control arrive between two samples: the group emitted by the next sample still carries the sums
+    # formed with the OLD coefficients (acc banks, :153-161) but is combined with the NEW sign / corr
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    rng = np.random.default_rng(3)
+    x = rand_raw(rng, fin, (2, 64))
+    eng = A.PolyIntr(8, 16, 4, "FOLD_EVEN", fin, fc, fa, fa, n_channels=2)
+    orc = OraclePolyIntr(8, 16, 4, "FOLD_EVEN", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fa), n_ch=2)
+    ys, yos = [], []
+    for k, (a, b) in enumerate([(0, 20), (20, 21), (21, 64)]):
+        c = rand_raw(np.random.default_rng(100 + k), fc, (16,))
+        sign, corr = [k % 2, 1, 0, 1], ([3, 2, 1, 0] if k != 1 else [0, 1, 2, 3])
+        eng.set_ctrl(c, sign, corr)
+        ys.append(eng.run(torch.from_numpy(x[:, a:b].copy()).to(torch.int16).cuda()).cpu().numpy().astype(np.int64))
+        yos.append(orc.run(c, sign, corr, x[:, a:b]))
+    assert np.array_equal(np.concatenate(ys, axis=1), np.concatenate(yos, axis=1))
+
+
+def test_rejects_tables_the_reference_would_overrun():
+    fin, fa = A.Fmt(16, 2), A.Fmt(40, 12)
+    eng = A.PolyIntr(8, 10, 4, "FOLD_EVEN", fin, fin, fa, fa)
+    with pytest.raises(A.AcdspError):
+        eng.set_ctrl(np.zeros(10, dtype=np.int64), [1, 1, 1, 1], [0, 1, 2, 3])      # needs coeffs[3 + 12] of coeffs[10]
+    eng = A.PolyIntr(8, 16, 4, "FOLD_EVEN", fin, fin, fa, fa)
+    with pytest.raises(A.AcdspError):
+        eng.set_ctrl(np.zeros(16, dtype=np.int64), [1, 1, 1, 1], [0, 1, 2, 4])      # corr[3] = 4 outside the IF = 4 banks
+    with pytest.raises(A.AcdspError):
+        eng.run(torch.zeros((1, 16), dtype=torch.int16, device="cuda"))              # run before the control structs arrived
