@@ -53,6 +53,11 @@ class PolyIntrDesc(C.Structure):
                 ("fin", Fmt), ("fcoeff", Fmt), ("facc", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
 
 
+class IntgDumpDesc(C.Structure):
+    _fields_ = [("ns", C.c_int32), ("chn", C.c_int32), ("n_objects", C.c_int32), ("fin", Fmt), ("facc", Fmt), ("fout", Fmt),
+                ("device", C.c_int32), ("flags", C.c_int32)]
+
+
 class CicDesc(C.Structure):
     _fields_ = [("interp", C.c_int32), ("R", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("n_channels", C.c_int32), ("fin", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
@@ -113,6 +118,12 @@ SYMBOLS = {
     "acdsp_polyintr_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64), _vp]),
     "acdsp_polyintr_run_host": (_i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "acdsp_polyintr_reset": (_i32, [_vp]),
+    "acdsp_intgdump_create": (_i32, [C.POINTER(IntgDumpDesc), C.POINTER(_vp)]),
+    "acdsp_intgdump_destroy": (_i32, [_vp]),
+    "acdsp_intgdump_counts": (_i32, [_vp, C.POINTER(_i64), _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "acdsp_intgdump_run": (_i32, [_vp, _vp, _i64, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64), _vp]),
+    "acdsp_intgdump_run_host": (_i32, [_vp, _vp, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64)]),
+    "acdsp_intgdump_reset": (_i32, [_vp]),
     "acdsp_ddc_create": (_i32, [C.POINTER(CicDesc), C.POINTER(FirDesc), C.POINTER(_vp)]),
     "acdsp_ddc_destroy": (_i32, [_vp]),
     "acdsp_ddc_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),

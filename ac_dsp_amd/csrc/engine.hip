@@ -1381,3 +1381,159 @@ int32_t acdsp_polyintr_reset(acdsp_polyintr_t h) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// integrate-and-dump: ac_intg_dump
+// ---------------------------------------------------------------------------------------------
+struct acdsp_intgdump {
+  acdsp_intgdump_desc_t d;
+  int in_eb, out_eb;
+  int64_t *d_temp[2] = {nullptr, nullptr};
+  int cur = 0;
+  int64_t *d_blk = nullptr;     // [3][cap] off / rounds / out
+  int32_t *d_chain = nullptr;   // [cap]
+  int64_t blk_cap = 0;
+  Staging st;
+};
+
+namespace {
+// per block: rounds consumed and whether it dumps (ac_intg_dump.h:138-146)
+inline int64_t intg_rounds(int64_t n_sample, int ns, bool *dumps) {
+  *dumps = n_sample >= 1 && n_sample <= ns;
+  return *dumps ? n_sample : ns;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t acdsp_intgdump_destroy(acdsp_intgdump_t h) {
+  if (!h) { return ACDSP_OK; }
+  (void)hipSetDevice(h->d.device);
+  for (int i = 0; i < 2; i++) { if (h->d_temp[i]) { (void)hipFree(h->d_temp[i]); } }
+  if (h->d_blk) { (void)hipFree(h->d_blk); }
+  if (h->d_chain) { (void)hipFree(h->d_chain); }
+  h->st.destroy();
+  delete h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_intgdump_create(const acdsp_intgdump_desc_t *desc, acdsp_intgdump_t *out) {
+  if (!desc || !out) { return fail(ACDSP_EINVAL, "null argument"); }
+  const acdsp_intgdump_desc_t &d = *desc;
+  if (d.ns < 1 || d.ns > (1 << 24)) { return fail(ACDSP_EUNSUPPORTED, "NS=%d outside 1..2^24", d.ns); }
+  if (d.chn < 1 || d.chn > 4096) { return fail(ACDSP_EUNSUPPORTED, "CHN=%d outside 1..4096", d.chn); }
+  if (d.n_objects < 1 || d.n_objects > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_objects=%d outside 1..65535", d.n_objects); }
+  int rc;
+  if ((rc = check_fmt(d.in, "IN_TYPE")) || (rc = check_fmt(d.acc, "ACC_TYPE")) || (rc = check_fmt(d.out, "OUT_TYPE"))) { return rc; }
+  if ((rc = check_device(d.device))) { return rc; }
+  acdsp_intgdump *h = new acdsp_intgdump();
+  h->d = d;
+  h->in_eb = elem_bytes(d.in.W); h->out_eb = elem_bytes(d.out.W);
+  hipError_t e = hipSuccess;
+  const size_t tb = (size_t)d.n_objects * d.chn * sizeof(int64_t);
+  for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    e = hipMalloc((void **)&h->d_temp[i], tb);
+    if (e == hipSuccess) { e = hipMemset(h->d_temp[i], 0, tb); }   // temp[i] = 0.0 (ac_intg_dump.h:86-89)
+  }
+  if (e != hipSuccess) { acdsp_intgdump_destroy(h); return fail(ACDSP_EHIP, "intg_dump state allocation failed: %s", hipGetErrorString(e)); }
+  *out = h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_intgdump_counts(acdsp_intgdump_t h, const int64_t *n_sample, int64_t n_blocks, int64_t *n_in, int64_t *n_out) {
+  if (!h || (n_blocks > 0 && !n_sample) || n_blocks < 0) { return fail(ACDSP_EINVAL, "intg_dump counts: bad arguments"); }
+  int64_t rounds = 0, groups = 0;
+  for (int64_t b = 0; b < n_blocks; b++) {
+    bool dumps;
+    rounds += intg_rounds(n_sample[b], h->d.ns, &dumps);
+    groups += dumps ? 1 : 0;
+  }
+  if (n_in) { *n_in = rounds * h->d.chn; }
+  if (n_out) { *n_out = groups * h->d.chn; }
+  return ACDSP_OK;
+}
+
+int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stride, const int64_t *n_sample, int64_t n_blocks,
+                           void *d_out, int64_t out_stride, int64_t *n_out, void *stream) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  int64_t ni = 0, no = 0;
+  int rc = acdsp_intgdump_counts(h, n_sample, n_blocks, &ni, &no);
+  if (rc) { return rc; }
+  if (n_out) { *n_out = no; }
+  if (n_blocks == 0) { return ACDSP_OK; }
+  if (n_blocks > (1 << 24)) { return fail(ACDSP_EUNSUPPORTED, "intg_dump run: more than 2^24 blocks in one call"); }
+  if ((ni > 0 && (!d_in || in_stride < ni)) || (no > 0 && (!d_out || out_stride < no))) { return fail(ACDSP_EINVAL, "intg_dump run: buffers too small"); }
+  const acdsp_intgdump_desc_t &d = h->d;
+  if ((rc = check_device(d.device))) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  if (n_blocks > h->blk_cap) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h->d_blk) { HIP_TRY(hipFree(h->d_blk)); h->d_blk = nullptr; }
+    if (h->d_chain) { HIP_TRY(hipFree(h->d_chain)); h->d_chain = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->d_blk, (size_t)3 * n_blocks * sizeof(int64_t)));
+    HIP_TRY(hipMalloc((void **)&h->d_chain, (size_t)n_blocks * sizeof(int32_t)));
+    h->blk_cap = n_blocks;
+  }
+  std::vector<int64_t> blk((size_t)3 * n_blocks);
+  std::vector<int32_t> chain((size_t)n_blocks);
+  int64_t off = 0, grp = 0;
+  int32_t start = 0;
+  for (int64_t b = 0; b < n_blocks; b++) {
+    bool dumps;
+    const int64_t r = intg_rounds(n_sample[b], d.ns, &dumps);
+    blk[(size_t)b] = off; blk[(size_t)(n_blocks + b)] = r; blk[(size_t)(2 * n_blocks + b)] = dumps ? grp : -1;
+    chain[(size_t)b] = start;
+    off += r;
+    if (dumps) { grp++; start = (int32_t)(b + 1); }
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_blk, blk.data(), blk.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));   // blk / chain are stack vectors
+  IntgDumpParams p;
+  memset(&p, 0, sizeof p);
+  p.chn = d.chn; p.n_obj = d.n_objects; p.n_blocks = (int32_t)n_blocks;
+  p.in = make_dfmt(d.in); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
+  p.in_eb = h->in_eb; p.out_eb = h->out_eb; p.in_stride = in_stride; p.out_stride = out_stride;
+  p.x = d_in; p.y = d_out; p.temp = h->d_temp[h->cur];
+  p.blk_off = h->d_blk; p.blk_rounds = h->d_blk + n_blocks; p.blk_out = h->d_blk + 2 * n_blocks; p.blk_chain = h->d_chain;
+  hipError_t e = launch_intg_dump(p, h->d_temp[h->cur ^ 1], s);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "intg_dump kernel launch failed: %s", hipGetErrorString(e)); }
+  h->cur ^= 1;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_intgdump_run_host(acdsp_intgdump_t h, const void *h_in, const int64_t *n_sample, int64_t n_blocks, void *h_out,
+                                int64_t out_cap, int64_t *n_out) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  int64_t ni = 0, no = 0;
+  int rc = acdsp_intgdump_counts(h, n_sample, n_blocks, &ni, &no);
+  if (rc) { return rc; }
+  if (n_out) { *n_out = no; }
+  if (n_blocks == 0) { return ACDSP_OK; }
+  if ((ni > 0 && !h_in) || (no > 0 && (!h_out || out_cap < no))) { return fail(ACDSP_EINVAL, "intg_dump run_host: bad buffers"); }
+  if ((rc = check_device(h->d.device))) { return rc; }
+  const int64_t si = ni > 0 ? ni : 1, so = no > 0 ? no : 1;
+  if ((rc = h->st.ensure((size_t)h->d.n_objects * si * h->in_eb, (size_t)h->d.n_objects * so * h->out_eb))) { return rc; }
+  if (ni > 0) {
+    HIP_TRY(hipMemcpy2D(h->st.d_in, (size_t)si * h->in_eb, h_in, (size_t)ni * h->in_eb, (size_t)ni * h->in_eb, (size_t)h->d.n_objects,
+                        hipMemcpyHostToDevice));
+  }
+  if ((rc = acdsp_intgdump_run(h, h->st.d_in, si, n_sample, n_blocks, h->st.d_out, so, nullptr, nullptr))) { return rc; }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  if (no > 0) {
+    HIP_TRY(hipMemcpy2D(h_out, (size_t)out_cap * h->out_eb, h->st.d_out, (size_t)so * h->out_eb, (size_t)no * h->out_eb,
+                        (size_t)h->d.n_objects, hipMemcpyDeviceToHost));
+  }
+  return ACDSP_OK;
+}
+
+int32_t acdsp_intgdump_reset(acdsp_intgdump_t h) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < 2; i++) { HIP_TRY(hipMemset(h->d_temp[i], 0, (size_t)h->d.n_objects * h->d.chn * sizeof(int64_t))); }
+  return ACDSP_OK;
+}
+
+}  // extern "C"

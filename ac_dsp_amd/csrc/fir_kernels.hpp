@@ -86,6 +86,20 @@ struct PolyIntrParams {
 };
 hipError_t launch_polyintr(const PolyIntrParams &p, int64_t *saved_next, hipStream_t s);
 
+// Integrate-and-dump (intg_dump.hip).  Block b covers rounds [blk_off[b], blk_off[b] + blk_rounds[b]) of the interleaved
+// stream; blk_out[b] = index of its output group or -1 (no dump); blk_chain[b] = first block of its carry chain.
+struct IntgDumpParams {
+  int32_t chn, n_obj, n_blocks;
+  DFmt in, acc, out;
+  int32_t in_eb, out_eb;
+  int64_t in_stride, out_stride;
+  const void *x; void *y;
+  const int64_t *temp;        // [n_obj][chn] ACC raw words carried in
+  const int64_t *blk_off, *blk_rounds, *blk_out;
+  const int32_t *blk_chain;
+};
+hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStream_t s);
+
 // Polyphase decimator, exact per-MAC order (polydec.hip); p.coeffs = STR_COEFF_TYPE array [ntaps*df], p.n = inputs used
 hipError_t launch_polydec_generic(const FirParams &p, int ntaps, int df, int64_t n_out, hipStream_t s);
 

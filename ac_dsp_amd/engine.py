@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, PolyIntrDesc, FTYPES, KINDS, PATHS
+from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, PolyIntrDesc, IntgDumpDesc, FTYPES, KINDS, PATHS
 
 
 def device_count():
@@ -309,6 +309,45 @@ class PolyIntr:
     def close(self):
         if getattr(self, "_h", None):
             lib.acdsp_polyintr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class IntgDump:
+    """n_objects independent ac_intg_dump<IN, ACC, OUT, N_TYPE, NS, CHN> objects (C ABI acdsp_intgdump_*); rows are the
+    interleaved streams, n_sample the per-block N_TYPE words (shared by the objects)."""
+
+    def __init__(self, ns, chn, fin, facc, fout, n_objects=1, device=0):
+        self.fin, self.fout, self.n_objects, self.chn = fin, fout, n_objects, chn
+        d = IntgDumpDesc(ns, chn, n_objects, fin, facc, fout, device, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_intgdump_create(C.byref(d), C.byref(self._h)))
+
+    def counts(self, n_sample):
+        ns = np.ascontiguousarray(n_sample, dtype=np.int64)
+        ni, no = C.c_int64(), C.c_int64()
+        check(lib.acdsp_intgdump_counts(self._h, ns.ctypes.data_as(C.POINTER(C.c_int64)), len(ns), C.byref(ni), C.byref(no)))
+        return ni.value, no.value
+
+    def run(self, x, n_sample):
+        ns = np.ascontiguousarray(n_sample, dtype=np.int64)
+        ni, no = self.counts(ns)
+        assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_objects and x.stride(1) == 1 and x.shape[1] >= ni
+        assert x.dtype == torch_dtype_for(self.fin), (x.dtype, self.fin)
+        out = torch.empty((self.n_objects, max(no, 1)), dtype=torch_dtype_for(self.fout), device=x.device)
+        n_out = C.c_int64()
+        check(lib.acdsp_intgdump_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), ns.ctypes.data_as(C.POINTER(C.c_int64)), len(ns),
+                                     C.c_void_p(out.data_ptr()), out.stride(0), C.byref(n_out), _stream_ptr(x)))
+        return out[:, :n_out.value]
+
+    def reset(self):
+        check(lib.acdsp_intgdump_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.acdsp_intgdump_destroy(self._h)
             self._h = None
 
     def __del__(self):

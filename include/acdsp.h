@@ -109,11 +109,22 @@ typedef struct {
   int32_t flags;
 } acdsp_polyintr_desc_t;
 
+/* ac_intg_dump<IN, ACC, OUT, N_TYPE, NS, CHN> (reference include/ac_dsp/ac_intg_dump.h:113) */
+typedef struct {
+  int32_t ns;                 /* NS: most rounds a block may accumulate */
+  int32_t chn;                /* CHN: channels interleaved in one object's stream */
+  int32_t n_objects;          /* independent ac_intg_dump objects (rows of the buffers) */
+  acdsp_fmt_t in, acc, out;
+  int32_t device;
+  int32_t flags;
+} acdsp_intgdump_desc_t;
+
 typedef struct acdsp_fir *acdsp_fir_t;
 typedef struct acdsp_polydec *acdsp_polydec_t;
 typedef struct acdsp_cic *acdsp_cic_t;
 typedef struct acdsp_ddc *acdsp_ddc_t;
 typedef struct acdsp_polyintr *acdsp_polyintr_t;
+typedef struct acdsp_intgdump *acdsp_intgdump_t;
 
 /* ---- general ---- */
 int32_t acdsp_abi_version(void);
@@ -214,6 +225,20 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
                            int64_t *n_out, void *stream);
 int32_t acdsp_polyintr_run_host(acdsp_polyintr_t h, const void *h_in, int64_t n_in, void *h_out, int64_t out_cap, int64_t *n_out);
 int32_t acdsp_polyintr_reset(acdsp_polyintr_t h);
+
+/* ---- integrate and dump (reference ac_intg_dump.h:93-147) ----
+ * Rows = objects; a row is the interleaved stream the reference reads from data_in (round-major, channel-minor).
+ * n_sample[n_blocks] (host array, shared by the objects) are the N_TYPE words read at the start of each block: a block
+ * with 1 <= n_sample <= NS takes n_sample rounds and yields CHN outputs, any other value takes NS rounds and yields none
+ * (its sums carry on, :138-146).  The call must hold whole blocks (the reference would read an empty channel otherwise). */
+int32_t acdsp_intgdump_create(const acdsp_intgdump_desc_t *desc, acdsp_intgdump_t *out);
+int32_t acdsp_intgdump_destroy(acdsp_intgdump_t h);
+int32_t acdsp_intgdump_counts(acdsp_intgdump_t h, const int64_t *n_sample, int64_t n_blocks, int64_t *n_in, int64_t *n_out);
+int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stride, const int64_t *n_sample, int64_t n_blocks,
+                           void *d_out, int64_t out_stride, int64_t *n_out, void *stream);
+int32_t acdsp_intgdump_run_host(acdsp_intgdump_t h, const void *h_in, const int64_t *n_sample, int64_t n_blocks, void *h_out,
+                                int64_t out_cap, int64_t *n_out);
+int32_t acdsp_intgdump_reset(acdsp_intgdump_t h);
 
 #ifdef __cplusplus
 }

@@ -653,6 +653,38 @@ int64_t orc_polyintr_run(orc_polyintr_t *f, const int64_t *coeffs, const uint8_t
   return k;
 }
 
+/* ---- ac_intg_dump: reference include/ac_dsp/ac_intg_dump.h:77-151 ----
+ * State: ACC_TYPE temp[CHN], zero-initialised (:84-90).  One block of run() (:133-147): read n_sample, then for
+ * j = 1..NS and every channel i read one sample, temp[i] = ACC(temp[i] + sample) (:97), and when j == n_sample write
+ * OUT(temp[i]) and clear temp[i] (:98-102); the block ends after the channel loop in which that happened (:144) -- or
+ * after NS rounds without any output when n_sample is 0 or > NS (the sums then carry into the next block).
+ * x is the interleaved stream (round-major, channel-minor); returns the number of outputs, *used = samples consumed. */
+int64_t orc_intg_dump_run(int64_t *temp, int32_t ns, int32_t chn, const orc_fmt_t *in, const orc_fmt_t *acc, const orc_fmt_t *out,
+                          const int64_t *n_sample, int64_t n_blocks, const int64_t *x, int64_t *y, int64_t *used) {
+  const int fi = in->W - in->I, fa = acc->W - acc->I;
+  int64_t k = 0, pos = 0;
+  for (int64_t b = 0; b < n_blocks; b++) {
+    const int64_t n_sample_t = n_sample[b];
+    int flag = 0;
+    for (int j = 1; j <= ns; j++) {
+      for (int i = 0; i < chn; i++) {
+        const int64_t data_in_t = x[pos++];
+        int fs;
+        i128 s = add_aligned((i128)temp[i], fa, (i128)data_in_t, fi, &fs);
+        temp[i] = requant(s, fs, acc);
+        if (j == n_sample_t) {
+          y[k++] = requant((i128)temp[i], fa, out);
+          temp[i] = 0;
+          flag = 1;
+        }
+      }
+      if (flag) { break; }
+    }
+  }
+  if (used) { *used = pos; }
+  return k;
+}
+
 uint64_t orc_splitmix64(uint64_t seed, uint64_t index) {
   uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

@@ -22,8 +22,8 @@
  *     AC_TRN/AC_WRAP types is pinned only through that and through the CIC
  *     vectors (same wrap add / cast rules).
  *   - Non-default Q/O modes, saturating accumulators, ac_poly_dec,
- *     ac_poly_intr and ac_fir_reg_share (no reference test or vector exists
- *     for any of them):
+ *     ac_poly_intr, ac_intg_dump and ac_fir_reg_share (no reference test or
+ *     vector exists for any of them):
  *     PARITY UNPINNED by any reference vector; cross-checked against the
  *     independent template implementation in include/ac_types/ac_fixed.h only.
  */
@@ -106,6 +106,12 @@ void orc_polyintr_free(orc_polyintr_t *f);
 int64_t orc_polyintr_step(orc_polyintr_t *f, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr, int64_t x, int64_t *y);
 int64_t orc_polyintr_run(orc_polyintr_t *f, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr, const int64_t *x,
                          int64_t n_in, int64_t *y);
+
+/* ---- integrate and dump (row f4 of SURVEY 8: reference include/ac_dsp/ac_intg_dump.h:77-151) ----
+ * temp[CHN] is the object's state (zeros after construction); n_sample[n_blocks] are the N_TYPE words read at the start
+ * of each block; x = the interleaved input stream.  Returns the outputs written; *used = input samples consumed. */
+int64_t orc_intg_dump_run(int64_t *temp, int32_t ns, int32_t chn, const orc_fmt_t *in, const orc_fmt_t *acc, const orc_fmt_t *out,
+                          const int64_t *n_sample, int64_t n_blocks, const int64_t *x, int64_t *y, int64_t *used);
 
 /* ---- synthetic stimulus shared with the GPU generator ---- */
 uint64_t orc_splitmix64(uint64_t seed, uint64_t index);

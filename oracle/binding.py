@@ -74,6 +74,8 @@ lib.orc_polyintr_new.argtypes = [C.c_int32] * 4 + [C.POINTER(Fmt)] * 4
 lib.orc_polyintr_free.argtypes = [C.c_void_p]
 lib.orc_polyintr_run.restype = C.c_int64
 lib.orc_polyintr_run.argtypes = [C.c_void_p, _i64p, _u8p, _u8p, _i64p, C.c_int64, _i64p]
+lib.orc_intg_dump_run.restype = C.c_int64
+lib.orc_intg_dump_run.argtypes = [_i64p, C.c_int32, C.c_int32] + [C.POINTER(Fmt)] * 3 + [_i64p, C.c_int64, _i64p, _i64p, _i64p]
 lib.orc_stimulus.restype = C.c_int64
 lib.orc_stimulus.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]
 lib.orc_splitmix64.restype = C.c_uint64
@@ -244,3 +246,26 @@ class OraclePolyIntr:
         for h in getattr(self, "_h", []):
             if h:
                 lib.orc_polyintr_free(h)
+
+
+class OracleIntgDump:
+    """ac_intg_dump objects (reference ac_intg_dump.h:77-151), one per row; state temp[CHN] carries across run() calls."""
+
+    def __init__(self, ns, chn, fin, facc, fout, n_obj=1):
+        self.ns, self.chn, self.fin, self.facc, self.fout, self.n_obj = ns, chn, fin, facc, fout, n_obj
+        self.temp = np.zeros((n_obj, chn), dtype=np.int64)
+
+    def run(self, x, n_sample):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64)
+        ns = np.ascontiguousarray(n_sample, dtype=np.int64)
+        outs = []
+        for o in range(self.n_obj):
+            y = np.empty(len(ns) * self.chn + 1, dtype=np.int64)
+            used = np.zeros(1, dtype=np.int64)
+            t = np.ascontiguousarray(self.temp[o])
+            k = lib.orc_intg_dump_run(_p(t), self.ns, self.chn, C.byref(self.fin), C.byref(self.facc), C.byref(self.fout), _p(ns), len(ns),
+                                      _p(x[o]), _p(y), _p(used))
+            assert used[0] <= x.shape[1], "stream shorter than the blocks need"
+            self.temp[o] = t
+            outs.append(y[:k].copy())
+        return np.stack(outs)

@@ -1,0 +1,55 @@
+"""GPU parity tests, integrate-and-dump: acdsp_intgdump_* vs the oracle restatement of reference
+include/ac_dsp/ac_intg_dump.h:93-147 (the reference ships no test or vector for this class)."""
+import numpy as np
+import pytest
+import torch
+
+import ac_dsp_amd as A
+from oracle import OracleIntgDump
+from helpers import ofmt
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_raw(rng, fmt, shape):
+    lo = -(1 << (fmt.W - 1)) if fmt.S else 0
+    hi = (1 << (fmt.W - 1)) - 1 if fmt.S else (1 << fmt.W) - 1
+    return rng.integers(lo, hi + 1, size=shape, dtype=np.int64)
+
+
+def check(ns, chn, fin, fa, fo, calls, n_obj=3, seed=0):
+    rng = np.random.default_rng(seed)
+    eng = A.IntgDump(ns, chn, fin, fa, fo, n_objects=n_obj)
+    orc = OracleIntgDump(ns, chn, ofmt(fin), ofmt(fa), ofmt(fo), n_obj=n_obj)
+    for n_sample in calls:
+        ni, no = eng.counts(n_sample)
+        x = rand_raw(rng, fin, (n_obj, max(ni, 1)))
+        y = eng.run(torch.from_numpy(x).to(A.torch_dtype_for(fin)).cuda(), n_sample).cpu().numpy().astype(np.int64)
+        yo = orc.run(x, n_sample)
+        assert y.shape == yo.shape == (n_obj, no)
+        assert np.array_equal(y, yo)
+
+
+def test_usage_example_types_and_carry_across_blocks_and_calls():
+    # reference usage example: <32,16> in, <64,32> out (ac_intg_dump.h:46-50); blocks that dump, blocks whose n_sample is 0
+    # or larger than NS (NS rounds, no output, the sums carry into the next block and across run() calls)
+    check(16, 4, A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(64, 32), [[3, 16, 1, 20, 5], [0, 0, 7], [9], [1, 1, 1, 1, 16, 16, 2]], seed=1)
+
+
+@pytest.mark.parametrize("q,o", [("TRN", "WRAP"), ("RND", "SAT"), ("RND_CONV", "SAT_SYM"), ("TRN_ZERO", "SAT_ZERO")])
+def test_every_add_is_an_acc_type_assignment(q, o):
+    # narrow accumulator with fewer fraction bits than the input: each `temp[i] + data_in` is quantised and may saturate
+    check(64, 3, A.Fmt(16, 4), A.Fmt(18, 8, True, q, o), A.Fmt(10, 7, True, q, o), [[64, 33, 1, 70, 12], [5, 64]], seed=2)
+
+
+def test_many_objects_long_blocks_unsigned():
+    rng = np.random.default_rng(3)
+    n_sample = rng.integers(1, 257, size=200)
+    check(256, 2, A.Fmt(12, 12, False), A.Fmt(24, 24, False), A.Fmt(24, 24, False), [n_sample], n_obj=64, seed=3)
+
+
+def test_rejects_short_buffers():
+    eng = A.IntgDump(8, 2, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16))
+    x = torch.zeros((1, 8), dtype=torch.int16, device="cuda")
+    with pytest.raises(AssertionError):
+        eng.run(x, [5])                      # needs 10 samples

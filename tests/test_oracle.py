@@ -343,3 +343,29 @@ def test_poly_intr_known_answers():
         OraclePolyIntr(4, 3, 2, "FOLD_EVEN", f, f, a, a).run(c[:3], [1, 1], [0, 1], x)
     with pytest.raises(ValueError):
         OraclePolyIntr(4, 4, 2, "FOLD_EVEN", f, f, a, a).run(c[:4], [1, 1], [0, 2], x)
+
+
+# ---- ac_intg_dump ----
+
+def test_intg_dump_known_answers():
+    from oracle import OracleIntgDump
+    f, a = Fmt(16, 8), Fmt(32, 24)                       # same fraction (8 bits): raw words add as integers
+    o = OracleIntgDump(4, 2, f, a, a)                    # NS = 4, two interleaved channels
+    # block 1: n_sample = 3 -> three rounds, sums 1+3+5 / 2+4+6; block 2: n_sample = 1 -> one round
+    x = np.array([[1, 2, 3, 4, 5, 6, 10, 20]], dtype=np.int64)
+    assert o.run(x, [3, 1])[0].tolist() == [9, 12, 10, 20]
+    # n_sample = 0 and n_sample > NS: NS rounds, nothing written, the sums carry into the next block (:138-146)
+    x = np.arange(1, 2 * (4 + 4 + 2) + 1, dtype=np.int64)[None, :]
+    y = o.run(x, [0, 9, 2])[0]
+    ch0, ch1 = x[0, 0::2], x[0, 1::2]
+    assert y.tolist() == [int(ch0.sum()), int(ch1.sum())] and o.temp.tolist() == [[0, 0]]
+    # the undumped sum also survives the end of a call
+    o.run(np.array([[1, 1, 2, 2, 3, 3, 4, 4]], dtype=np.int64), [7])
+    assert o.temp.tolist() == [[10, 10]]
+    assert o.run(np.array([[5, 6]], dtype=np.int64), [1])[0].tolist() == [15, 16]
+    # every add is an ACC_TYPE assignment: a saturating accumulator clips on the way, a wrapping one does not
+    sat, wrap = Fmt(8, 8, True, "TRN", "SAT"), Fmt(8, 8, True, "TRN", "WRAP")
+    fi = Fmt(8, 8)
+    x = np.array([[100, 100, -100, -100]], dtype=np.int64)
+    assert OracleIntgDump(8, 1, fi, sat, Fmt(16, 16)).run(x, [4])[0].tolist() == [127 - 200]
+    assert OracleIntgDump(8, 1, fi, wrap, Fmt(16, 16)).run(x, [4])[0].tolist() == [0]
