@@ -58,6 +58,11 @@ class IntgDumpDesc(C.Structure):
                 ("device", C.c_int32), ("flags", C.c_int32)]
 
 
+class StreamHdr(C.Structure):
+    _fields_ = [("magic", C.c_char * 8), ("version", C.c_uint32), ("elem_bytes", C.c_uint32), ("fmt", Fmt), ("reserved", C.c_uint32),
+                ("n_channels", C.c_uint64), ("n_samples", C.c_uint64), ("stride", C.c_uint64)]
+
+
 class CicDesc(C.Structure):
     _fields_ = [("interp", C.c_int32), ("R", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("n_channels", C.c_int32), ("fin", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
@@ -124,6 +129,9 @@ SYMBOLS = {
     "acdsp_intgdump_run": (_i32, [_vp, _vp, _i64, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64), _vp]),
     "acdsp_intgdump_run_host": (_i32, [_vp, _vp, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64)]),
     "acdsp_intgdump_reset": (_i32, [_vp]),
+    "acdsp_stream_write": (_i32, [C.c_char_p, C.POINTER(StreamHdr), _vp]),
+    "acdsp_stream_read_header": (_i32, [C.c_char_p, C.POINTER(StreamHdr)]),
+    "acdsp_stream_read": (_i32, [C.c_char_p, _vp, C.c_uint64]),
     "acdsp_ddc_create": (_i32, [C.POINTER(CicDesc), C.POINTER(FirDesc), C.POINTER(_vp)]),
     "acdsp_ddc_destroy": (_i32, [_vp]),
     "acdsp_ddc_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),

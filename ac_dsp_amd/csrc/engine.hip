@@ -1537,3 +1537,56 @@ int32_t acdsp_intgdump_reset(acdsp_intgdump_t h) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// raw-integer stream files (second half): the [channel][time] layout of section 3 of DESIGN.md on disk /
+// on the wire -- a 64-byte little-endian header followed by n_channels rows of `stride` containers.  Host-side only.
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+static const char kStreamMagic[8] = {'A', 'C', 'D', 'S', 'P', 'R', 'A', 'W'};
+static_assert(sizeof(acdsp_stream_hdr_t) == 64, "stream header is 64 bytes on disk");
+
+int32_t acdsp_stream_write(const char *path, const acdsp_stream_hdr_t *hdr, const void *data) {
+  if (!path || !hdr || (!data && hdr->n_channels * hdr->stride > 0)) { return fail(ACDSP_EINVAL, "stream_write: null argument"); }
+  if (hdr->elem_bytes != (uint32_t)elem_bytes(hdr->fmt.W) || hdr->stride < hdr->n_samples) {
+    return fail(ACDSP_EINVAL, "stream_write: elem_bytes must be acdsp_elem_bytes(W) and stride >= n_samples");
+  }
+  FILE *f = fopen(path, "wb");
+  if (!f) { return fail(ACDSP_EINVAL, "stream_write: cannot open %s", path); }
+  acdsp_stream_hdr_t h = *hdr;
+  memcpy(h.magic, kStreamMagic, 8);
+  h.version = 1; h.reserved = 0;
+  const size_t bytes = (size_t)h.n_channels * (size_t)h.stride * h.elem_bytes;
+  const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (bytes == 0 || fwrite(data, 1, bytes, f) == bytes);
+  fclose(f);
+  return ok ? ACDSP_OK : fail(ACDSP_EINVAL, "stream_write: short write to %s", path);
+}
+
+int32_t acdsp_stream_read_header(const char *path, acdsp_stream_hdr_t *hdr) {
+  if (!path || !hdr) { return fail(ACDSP_EINVAL, "stream_read_header: null argument"); }
+  FILE *f = fopen(path, "rb");
+  if (!f) { return fail(ACDSP_EINVAL, "stream_read_header: cannot open %s", path); }
+  const bool ok = fread(hdr, sizeof *hdr, 1, f) == 1;
+  fclose(f);
+  if (!ok || memcmp(hdr->magic, kStreamMagic, 8) != 0 || hdr->version != 1) { return fail(ACDSP_EINVAL, "%s is not an ACDSPRAW v1 stream", path); }
+  if (hdr->fmt.W < 1 || hdr->fmt.W > 64 || hdr->elem_bytes != (uint32_t)elem_bytes(hdr->fmt.W) || hdr->stride < hdr->n_samples) {
+    return fail(ACDSP_EINVAL, "%s: inconsistent stream header", path);
+  }
+  return ACDSP_OK;
+}
+
+int32_t acdsp_stream_read(const char *path, void *data, uint64_t cap_bytes) {
+  acdsp_stream_hdr_t h;
+  int rc = acdsp_stream_read_header(path, &h);
+  if (rc) { return rc; }
+  const uint64_t bytes = h.n_channels * h.stride * h.elem_bytes;
+  if (bytes > cap_bytes || (bytes > 0 && !data)) { return fail(ACDSP_EINVAL, "stream_read: buffer of %llu bytes for %llu", (unsigned long long)cap_bytes, (unsigned long long)bytes); }
+  FILE *f = fopen(path, "rb");
+  if (!f) { return fail(ACDSP_EINVAL, "stream_read: cannot open %s", path); }
+  const bool ok = fseek(f, (long)sizeof h, SEEK_SET) == 0 && (bytes == 0 || fread(data, 1, (size_t)bytes, f) == bytes);
+  fclose(f);
+  return ok ? ACDSP_OK : fail(ACDSP_EINVAL, "stream_read: %s is truncated", path);
+}
+
+}  // extern "C"

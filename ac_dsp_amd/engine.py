@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, PolyIntrDesc, IntgDumpDesc, FTYPES, KINDS, PATHS
+from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, PolyIntrDesc, IntgDumpDesc, StreamHdr, FTYPES, KINDS, PATHS
 
 
 def device_count():
@@ -352,3 +352,19 @@ class IntgDump:
 
     def __del__(self):
         self.close()
+
+
+def save_stream(path, x, fmt):
+    """[n_channels][n] raw words (numpy, any integer dtype) -> ACDSPRAW file (include/acdsp.h: acdsp_stream_hdr_t)."""
+    a = np.ascontiguousarray(np.atleast_2d(x), dtype=_np_dtype_for(fmt))
+    h = StreamHdr(b"", 1, a.dtype.itemsize, fmt, 0, a.shape[0], a.shape[1], a.shape[1])
+    check(lib.acdsp_stream_write(str(path).encode(), C.byref(h), a.ctypes.data_as(C.c_void_p)))
+
+
+def load_stream(path):
+    """ACDSPRAW file -> (raw words [n_channels][n_samples] int64, Fmt)."""
+    h = StreamHdr()
+    check(lib.acdsp_stream_read_header(str(path).encode(), C.byref(h)))
+    a = np.empty((h.n_channels, h.stride), dtype=_np_dtype_for(h.fmt))
+    check(lib.acdsp_stream_read(str(path).encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
+    return a[:, :h.n_samples].astype(np.int64), Fmt(h.fmt.W, h.fmt.I, h.fmt.S, h.fmt.Q, h.fmt.O)

@@ -119,6 +119,17 @@ typedef struct {
   int32_t flags;
 } acdsp_intgdump_desc_t;
 
+/* Raw-integer stream file / wire format: this 64-byte little-endian header, then n_channels rows of `stride` containers
+ * (two's-complement raw words, acdsp_elem_bytes(W) bytes each) -- the [channel][time] layout the kernels take. */
+typedef struct {
+  char magic[8];              /* "ACDSPRAW" (filled in by acdsp_stream_write) */
+  uint32_t version;           /* 1 */
+  uint32_t elem_bytes;        /* 2, 4 or 8 = acdsp_elem_bytes(fmt.W) */
+  acdsp_fmt_t fmt;            /* the ac_fixed<W,I,S,Q,O> the words are in */
+  uint32_t reserved;          /* 0 */
+  uint64_t n_channels, n_samples, stride;   /* stride >= n_samples, in elements */
+} acdsp_stream_hdr_t;
+
 typedef struct acdsp_fir *acdsp_fir_t;
 typedef struct acdsp_polydec *acdsp_polydec_t;
 typedef struct acdsp_cic *acdsp_cic_t;
@@ -239,6 +250,11 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
 int32_t acdsp_intgdump_run_host(acdsp_intgdump_t h, const void *h_in, const int64_t *n_sample, int64_t n_blocks, void *h_out,
                                 int64_t out_cap, int64_t *n_out);
 int32_t acdsp_intgdump_reset(acdsp_intgdump_t h);
+
+/* ---- raw-integer stream files (host side; no device needed) ---- */
+int32_t acdsp_stream_write(const char *path, const acdsp_stream_hdr_t *hdr, const void *data);
+int32_t acdsp_stream_read_header(const char *path, acdsp_stream_hdr_t *hdr);
+int32_t acdsp_stream_read(const char *path, void *data, uint64_t cap_bytes);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,32 @@ def test_descriptor_layout_matches_header():
     assert C.sizeof(L.Fmt) == 20
     assert C.sizeof(L.FirDesc) == 5 * 4 + 4 * 20 + 2 * 4
     assert C.sizeof(L.CicDesc) == 5 * 4 + 2 * 20 + 2 * 4
+    assert C.sizeof(L.PolyDecDesc) == 3 * 4 + 4 * 20 + 2 * 4
+    assert C.sizeof(L.PolyIntrDesc) == 5 * 4 + 4 * 20 + 2 * 4
+    assert C.sizeof(L.IntgDumpDesc) == 3 * 4 + 3 * 20 + 2 * 4
+    assert C.sizeof(L.StreamHdr) == 64
     assert [L.lib.acdsp_elem_bytes(w) for w in (1, 16, 17, 32, 33, 64)] == [2, 2, 4, 4, 8, 8]
+
+
+def test_raw_integer_stream_files_round_trip(tmp_path):
+    # host-side file format (no device involved): 64-byte header + [channel][stride] containers
+    import numpy as np
+    import ac_dsp_amd as A
+    rng = np.random.default_rng(1)
+    for fmt, dt in ((A.Fmt(16, 2), np.int16), (A.Fmt(36, 21), np.int64), (A.Fmt(24, 9, True, "RND", "SAT"), np.int32)):
+        x = rng.integers(-(1 << (fmt.W - 1)), 1 << (fmt.W - 1), size=(5, 37))
+        f = tmp_path / ("s%d.acdspraw" % fmt.W)
+        A.save_stream(f, x, fmt)
+        raw = open(f, "rb").read()
+        assert raw[:8] == b"ACDSPRAW" and len(raw) == 64 + 5 * 37 * np.dtype(dt).itemsize
+        y, g = A.load_stream(f)
+        assert np.array_equal(x, y) and (g.W, g.I, g.S, g.Q, g.O) == (fmt.W, fmt.I, fmt.S, fmt.Q, fmt.O)
+    bad = tmp_path / "bad"
+    bad.write_bytes(b"not a stream at all, just sixty-four bytes of something else....")
+    with pytest.raises(A.AcdspError):
+        A.load_stream(bad)
+    with pytest.raises(A.AcdspError):
+        A.load_stream(tmp_path / "missing")
 
 
 def test_no_cpu_fallback_without_device():
