@@ -30,6 +30,9 @@ struct CicParams {
 };
 
 hipError_t launch_cic(const CicParams &p, hipStream_t s);
+// Interpolator through its FIR identity (polyphase form), one thread per output; taps = z^-(N-1) * boxcar(R*me)^N as raw
+// int64 words (n_taps = N*R*me), every tap < 2^31.
+hipError_t launch_cic_intr_fir(const CicParams &p, const int64_t *d_taps, int n_taps, hipStream_t s);
 hipError_t launch_cic_hist_update(const CicParams &p, void *hist_next, hipStream_t s);
 
 }  // namespace acdsp

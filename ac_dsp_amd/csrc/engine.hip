@@ -165,6 +165,7 @@ struct acdsp_cic {
   bool gen_have[16] = {false};
   FirGenPlan gen_plan[16];
   uint32_t *d_gfrag = nullptr;   // [16][3*8*64*4]
+  int64_t *d_taps = nullptr;     // interpolator: the identity's taps for the polyphase kernel
   int last_path = 0;
   int64_t t_total = 0;  // inputs consumed so far (all calls)
   void *d_hist[2] = {nullptr, nullptr};
@@ -643,8 +644,8 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
     e = hipMalloc(&h->d_hist[i], hb);
     if (e == hipSuccess) { e = hipMemset(h->d_hist[i], 0, hb); }
   }
-  if (e == hipSuccess && !desc->interp) {
-    // FIR identity of the decimator: h = z^-(N-1) * boxcar(R*M')^N, all arithmetic mod 2^64 (then mod 2^outW)
+  {
+    // FIR identity of both directions: h = z^-(N-1) * boxcar(R*M')^N, all arithmetic mod 2^64 (then mod 2^outW)
     const int L = desc->R * h->me;
     std::vector<uint64_t> c(1, 1);
     for (int st = 0; st < desc->N; st++) {
@@ -657,7 +658,11 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
     FirGenPlan probe;
     std::vector<uint32_t> fr;
     static const bool no_gen = getenv("ACDSP_NO_GEN") != nullptr;
-    h->gen_ok = !no_gen && (desc->in.W + (desc->in.S ? 0 : 1) + 7) / 8 <= h->in_eb &&
+    if (e == hipSuccess && desc->interp && !no_gen) {   // interpolator: polyphase FIR kernel reads the taps themselves
+      e = hipMalloc((void **)&h->d_taps, h->h_taps.size() * sizeof(int64_t));
+      if (e == hipSuccess) { e = hipMemcpy(h->d_taps, h->h_taps.data(), h->h_taps.size() * sizeof(int64_t), hipMemcpyHostToDevice); }
+    }
+    h->gen_ok = e == hipSuccess && !desc->interp && !no_gen && (desc->in.W + (desc->in.S ? 0 : 1) + 7) / 8 <= h->in_eb &&
                 fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), desc->R, 15, &probe, &fr) &&   // worst-case window offset
                 fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), desc->R, 0, &probe, &fr);
     if (h->gen_ok) { e = hipMalloc((void **)&h->d_gfrag, (size_t)16 * 3 * 8 * 64 * 4 * sizeof(uint32_t)); }
@@ -674,6 +679,7 @@ int32_t acdsp_cic_destroy(acdsp_cic_t h) {
   if (!h) { return ACDSP_OK; }
   (void)hipSetDevice(h->d.device);
   if (h->d_gfrag) { (void)hipFree(h->d_gfrag); }
+  if (h->d_taps) { (void)hipFree(h->d_taps); }
   for (int i = 0; i < 2; i++) {
     if (h->d_hist[i]) { (void)hipFree(h->d_hist[i]); }
   }
@@ -782,7 +788,8 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
     }
     if (use_gen) { gfrag = h->d_gfrag + (size_t)fm * 3 * 8 * 64 * 4; gpl = h->gen_plan[fm]; }
   }
-  h->last_path = use_gen ? ACDSP_PATH_MFMA_GEN : 0;
+  const bool use_intr_fir = d.interp && h->d_taps != nullptr;
+  h->last_path = use_gen ? ACDSP_PATH_MFMA_GEN : (use_intr_fir ? ACDSP_PATH_LOSSLESS64 : 0);
   HIP_TRY(hipEventRecord(h->tm.start(), s));
   hipError_t e;
   if (use_gen) {
@@ -794,6 +801,8 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
     k.in_stride = in_stride; k.out_stride = out_stride; k.n = n_in;
     k.x = d_in; k.y = d_out; k.hist = h->d_hist[h->cur];
     e = launch_fir_gen(k, gpl, gfrag, 1, h->it.W, p.first, no, s);
+  } else if (use_intr_fir) {
+    e = launch_cic_intr_fir(p, h->d_taps, (int)h->h_taps.size(), s);
   } else {
     e = launch_cic(p, s);
   }

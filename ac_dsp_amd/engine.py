@@ -124,7 +124,7 @@ class Cic:
 
     @property
     def path(self):
-        return {0: "recurrence", 3: "mfma_gen"}[lib.acdsp_cic_path(self._h)]
+        return {0: "recurrence", 1: "fir_identity", 3: "mfma_gen"}[lib.acdsp_cic_path(self._h)]
 
     def run(self, x, out=None):
         assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1
