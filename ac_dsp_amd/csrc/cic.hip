@@ -257,6 +257,8 @@ static hipError_t launch_n(const CicParams &p, dim3 grid, hipStream_t s) {
 // (N me)-tap FIR on the input: a handful of MACs per output instead of N serial wide adds per output on one lane.
 // One thread per output, consecutive threads = consecutive q: the 8-byte stores of a wave are one contiguous 512-byte
 // run (the recurrence kernel wrote 128-byte row segments from 64 different rows: 0.7 TB/s).
+constexpr int kIntrTile = 4096;   // outputs per workgroup (one block per 256 outputs was bound by the workgroup dispatch rate)
+
 template <typename TIN>
 __global__ void __launch_bounds__(256) cic_intr_fir_kernel(CicParams p, const int64_t *__restrict__ taps, int n_taps, uint32_t rcp,
                                                            int kmax) {
@@ -268,13 +270,13 @@ __global__ void __launch_bounds__(256) cic_intr_fir_kernel(CicParams p, const in
   XW *xw = (XW *)(lds_raw + (size_t)((n_taps + 1) / 2 * 2) * 4);
   const int ch = blockIdx.y;
   const int64_t lo = p.q_begin > p.q_skip ? p.q_begin : p.q_skip;    // first emitted iteration of this call
-  const int64_t q0 = lo + (int64_t)blockIdx.x * 256;
+  const int64_t q0 = lo + (int64_t)blockIdx.x * kIntrTile;           // a block owns kIntrTile consecutive outputs
   const int R = p.R;
   const int64_t n_base = q0 / R;                                      // wave-uniform 64-bit division, once
   const int r0 = (int)(q0 - n_base * R);
   for (int i = threadIdx.x; i < n_taps; i += 256) { lt[i] = (int32_t)taps[i]; }
-  // window: global inputs n_base - (kmax-1) .. n_base + (r0 + 255) / R
-  const int n_win = kmax + (r0 + 255) / R;
+  // window: global inputs n_base - (kmax-1) .. n_base + (r0 + kIntrTile - 1) / R
+  const int n_win = kmax + (r0 + kIntrTile - 1) / R;
   const TIN *xrow = (const TIN *)p.x + (int64_t)ch * p.in_stride;
   const TIN *hrow = (const TIN *)p.hist + (int64_t)ch * p.hl + p.hl;  // hrow[t], t < 0
   for (int j = threadIdx.x; j < n_win; j += 256) {
@@ -286,31 +288,34 @@ __global__ void __launch_bounds__(256) cic_intr_fir_kernel(CicParams p, const in
     xw[j] = (XW)x;
   }
   __syncthreads();
-  const int64_t q = q0 + threadIdx.x;
-  if (q >= p.q_end) { return; }
-  const unsigned t = (unsigned)r0 + threadIdx.x;                      // < R + 256 < 2^16
-  const unsigned dn = __umulhi(t, rcp);                               // t / R (exact for t < 2^16)
-  const int r = (int)(t - dn * (unsigned)R);
-  const XW *xp = xw + (kmax - 1) + dn;                                // xp[-k] = x[n_hi - k]
-  int64_t acc = 0;
-  for (int d = r, k = 0; d < n_taps; d += R, k++) {
-    if (sizeof(TIN) > 4) { acc = (int64_t)((uint64_t)acc + (uint64_t)(int64_t)lt[d] * (uint64_t)xp[-k]); }
-    else { acc += (int64_t)lt[d] * (int64_t)(int32_t)xp[-k]; }        // v_mad_i64_i32
+#pragma unroll 2
+  for (int i = 0; i < kIntrTile / 256; i++) {
+    const int64_t q = q0 + threadIdx.x + 256 * i;                     // consecutive lanes = consecutive outputs
+    if (q >= p.q_end) { return; }
+    const unsigned t = (unsigned)r0 + threadIdx.x + 256u * i;         // < R + kIntrTile < 2^16
+    const unsigned dn = __umulhi(t, rcp);                             // t / R (exact for t < 2^16)
+    const int r = (int)(t - dn * (unsigned)R);
+    const XW *xp = xw + (kmax - 1) + dn;                              // xp[-k] = x[n_hi - k]
+    int64_t acc = 0;
+    for (int d = r, k = 0; d < n_taps; d += R, k++) {
+      if (sizeof(TIN) > 4) { acc = (int64_t)((uint64_t)acc + (uint64_t)(int64_t)lt[d] * (uint64_t)xp[-k]); }
+      else { acc += (int64_t)lt[d] * (int64_t)(int32_t)xp[-k]; }      // v_mad_i64_i32
+    }
+    int64_t o;
+    if (p.out_simple == 2) { o = wrap64(acc, p.w_int, 1); }
+    else if (p.out_simple == 1) { o = wrap64(wrap64(acc, p.w_int, 1), p.out.W, p.out.S); }
+    else { o = requant64(wrap64(acc, p.w_int, 1), p.in.F, p.out); }
+    store_raw(p.y, (int64_t)ch * p.out_stride + (q - lo), p.out_eb, o);
   }
-  int64_t o;
-  if (p.out_simple == 2) { o = wrap64(acc, p.w_int, 1); }
-  else if (p.out_simple == 1) { o = wrap64(wrap64(acc, p.w_int, 1), p.out.W, p.out.S); }
-  else { o = requant64(wrap64(acc, p.w_int, 1), p.in.F, p.out); }
-  store_raw(p.y, (int64_t)ch * p.out_stride + (q - lo), p.out_eb, o);
 }
 
 hipError_t launch_cic_intr_fir(const CicParams &p, const int64_t *d_taps, int n_taps, hipStream_t s) {
   const int64_t lo = p.q_begin > p.q_skip ? p.q_begin : p.q_skip;
   if (p.q_end <= lo) { return hipSuccess; }
-  dim3 grid((unsigned)((p.q_end - lo + 255) / 256), (unsigned)p.n_ch);
+  dim3 grid((unsigned)((p.q_end - lo + kIntrTile - 1) / kIntrTile), (unsigned)p.n_ch);
   const uint32_t rcp = (uint32_t)((0x100000000ull + p.R - 1) / p.R);
   const int kmax = (n_taps + p.R - 1) / p.R;
-  const size_t lds = (size_t)((n_taps + 1) / 2 * 2) * 4 + (size_t)(kmax + 255 / p.R + 2) * 8;
+  const size_t lds = (size_t)((n_taps + 1) / 2 * 2) * 4 + (size_t)(kmax + (kIntrTile - 1) / p.R + 2) * 8;
   switch (p.in_eb) {
     case 2: hipLaunchKernelGGL(cic_intr_fir_kernel<int16_t>, grid, dim3(256), lds, s, p, d_taps, n_taps, rcp, kmax); break;
     case 4: hipLaunchKernelGGL(cic_intr_fir_kernel<int32_t>, grid, dim3(256), lds, s, p, d_taps, n_taps, rcp, kmax); break;
