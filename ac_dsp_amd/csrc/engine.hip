@@ -1338,6 +1338,12 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
   p.in = make_dfmt(d.in); p.cf = make_dfmt(d.coeff); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
   p.in_eb = h->in_eb; p.out_eb = h->out_eb; p.hl = h->hl;
   p.skip = (d.ftype != ACDSP_POLY_FOLD_ANTI && h->t_total == 0) ? 1 : 0;
+  {  // exact-accumulation class (see polyintr_acc_fast): the `fold` needs one more integer bit than IN_TYPE
+    const int fi = p.in.F, fc = p.cf.F, fa = p.acc.F;
+    p.lossless_shift = fa - fi - fc;
+    p.lossless = !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && d.in.S && d.acc.S && d.acc.O == ACDSP_WRAP && p.lossless_shift >= 0 &&
+                 d.acc.I >= d.in.I + 1 && d.acc.W <= 63 && (d.in.O == ACDSP_WRAP || d.in.O == ACDSP_SAT || d.in.O == ACDSP_SAT_SYM || d.in.O == ACDSP_SAT_ZERO);
+  }
   p.in_stride = in_stride; p.out_stride = out_stride; p.n = n_in; p.n_out = no;
   p.x = d_in; p.y = d_out; p.hist = h->d_hist[h->cur];
   p.coeffs = h->d_coeffs; p.sign = h->d_sign; p.corr = h->d_corr; p.saved = h->d_saved[h->cur];
@@ -1503,6 +1509,7 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
   p.chn = d.chn; p.n_obj = d.n_objects; p.n_blocks = (int32_t)n_blocks;
   p.in = make_dfmt(d.in); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
   p.in_eb = h->in_eb; p.out_eb = h->out_eb; p.in_stride = in_stride; p.out_stride = out_stride;
+  p.lossless = d.acc.O == ACDSP_WRAP && p.acc.F >= p.in.F && p.acc.F - p.in.F < 64 - d.in.W;
   p.x = d_in; p.y = d_out; p.temp = h->d_temp[h->cur];
   p.blk_off = h->d_blk; p.blk_rounds = h->d_blk + n_blocks; p.blk_out = h->d_blk + 2 * n_blocks; p.blk_chain = h->d_chain;
   hipError_t e = launch_intg_dump(p, h->d_temp[h->cur ^ 1], s);

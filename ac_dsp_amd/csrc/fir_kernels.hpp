@@ -78,6 +78,7 @@ struct PolyIntrParams {
   DFmt in, cf, acc, out;
   int32_t in_eb, out_eb, hl;
   int32_t skip;               // 1: the stream's very first sample is in this call and emits nothing (folded cores)
+  int32_t lossless, lossless_shift;   // exact-accumulation class: int64 dot products, shift = F_acc - F_in - F_coeff
   int64_t in_stride, out_stride, n, n_out;   // n inputs -> n_out outputs per channel
   const void *x; void *y; const void *hist;
   const int64_t *coeffs;      // [coeff_sz]
@@ -90,6 +91,7 @@ hipError_t launch_polyintr(const PolyIntrParams &p, int64_t *saved_next, hipStre
 // stream; blk_out[b] = index of its output group or -1 (no dump); blk_chain[b] = first block of its carry chain.
 struct IntgDumpParams {
   int32_t chn, n_obj, n_blocks;
+  int32_t lossless;           // ACC_TYPE is AC_WRAP with F_acc >= F_in: integer sums mod 2^W
   DFmt in, acc, out;
   int32_t in_eb, out_eb;
   int64_t in_stride, out_stride;

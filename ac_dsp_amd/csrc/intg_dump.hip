@@ -14,6 +14,17 @@ __device__ inline i128 id_shl128(i128 v, int s) { return (i128)((u128)v << s); }
 
 __device__ int64_t intg_chain(const IntgDumpParams &p, int obj, int i, int first_blk, int last_blk) {
   int64_t acc = (first_blk == 0) ? p.temp[((int64_t)obj * p.chn) + i] : 0;
+  if (p.lossless) {   // wrapping ACC_TYPE with at least IN_TYPE's fraction bits: every add is exact mod 2^W -> one wrap at the end
+    uint64_t sum = (uint64_t)acc;
+    const int sh = p.acc.F - p.in.F;
+    for (int b = first_blk; b <= last_blk; b++) {
+      const int64_t r0 = p.blk_off[b];
+      for (int64_t r = 0; r < p.blk_rounds[b]; r++) {
+        sum += (uint64_t)load_raw(p.x, (int64_t)obj * p.in_stride + (r0 + r) * p.chn + i, p.in_eb, p.in.S) << sh;
+      }
+    }
+    return wrap64((int64_t)sum, p.acc.W, p.acc.S);
+  }
   const int f = p.in.F > p.acc.F ? p.in.F : p.acc.F;
   for (int b = first_blk; b <= last_blk; b++) {
     const int64_t r0 = p.blk_off[b];

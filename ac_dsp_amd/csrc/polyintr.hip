@@ -11,6 +11,8 @@
 // sample n carries  t1 = acc_{n-1}[j], t2 = acc_{n-1}[corr[j]]  and writes  (t1 + (sign[j] ? ACC(-t2) : t2)) >> 1  when
 // corr[j] != j, else t1; the very first sample emits nothing.  acc_{n-1} of a call's first sample was formed with the
 // coefficients of its own time, so it is carried in the handle (`saved`), not recomputed.
+#include <type_traits>
+
 #include "fir_kernels.hpp"
 
 namespace acdsp {
@@ -58,6 +60,37 @@ __device__ int64_t polyintr_acc(const PolyIntrParams &p, int ch, int64_t m, int 
   return acc;
 }
 
+// Lossless class (host-checked: signed IN, signed wrapping ACC with F_acc >= F_in + F_coeff and room for the fold): every
+// `acc +=` is exact, so the sub-filter sum is an integer dot product mod 2^64 wrapped once to ACC_TYPE.  The only
+// non-linear step left is the IN_TYPE negation of the most negative word, reproduced by a select.
+__device__ int64_t polyintr_acc_fast(const PolyIntrParams &p, int ch, int64_t m, int j) {
+  const int N = p.n_taps;
+  auto xs = [&](int64_t t) -> int64_t {
+    if (t >= 0) { return load_raw(p.x, (int64_t)ch * p.in_stride + t, p.in_eb, 1); }
+    if (t >= -(int64_t)p.hl) { return load_raw(p.hist, (int64_t)ch * p.hl + p.hl + t, p.in_eb, 1); }
+    return 0;
+  };
+  uint64_t acc = 0;
+  if (p.ftype == 2) {
+    for (int i = N - 1; i >= 0; i--) { acc += (uint64_t)xs(m - i) * (uint64_t)p.coeffs[i + N * j]; }
+  } else {
+    const bool sg = p.sign[j] != 0;
+    const int64_t neg_min = p.in.O == ACDSP_WRAP ? p.in.lo : ((p.in.O == ACDSP_SAT || p.in.O == ACDSP_SAT_SYM) ? p.in.hi : 0);
+    const int mid = (N - 1) / 2;
+    const int cnt = p.ftype == 0 ? N / 2 : mid + 1;
+    const int cbase = p.ftype == 0 ? j * N / 2 : (N / 2 + 1) * j;
+    for (int i = 0; i < cnt; i++) {
+      int64_t fold = xs(m - i);
+      if (p.ftype == 0 || i != mid) {
+        const int64_t far = xs(m - (N - 1 - i));
+        fold += sg ? far : (far == p.in.lo ? neg_min : -far);
+      }
+      acc += (uint64_t)p.coeffs[cbase + i] * (uint64_t)fold;
+    }
+  }
+  return wrap64((int64_t)(acc << p.lossless_shift), p.acc.W, 1);
+}
+
 __global__ void polyintr_kernel(PolyIntrParams p) {
   const int ch = blockIdx.y;
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // output index of this call
@@ -67,11 +100,12 @@ __global__ void polyintr_kernel(PolyIntrParams p) {
   const int64_t grp = o / IF + p.skip;                                 // local index of the sample that emits this group
   int64_t y;
   if (p.ftype == 2) {
-    y = requant64(polyintr_acc(p, ch, grp, j), p.acc.F, p.out);
+    y = requant64(p.lossless ? polyintr_acc_fast(p, ch, grp, j) : polyintr_acc(p, ch, grp, j), p.acc.F, p.out);
   } else {
     const int cj = p.corr[j];
     int64_t t1, t2;
     if (grp == 0) { t1 = p.saved[(int64_t)ch * IF + j]; t2 = p.saved[(int64_t)ch * IF + cj]; }   // sums of the previous call's last sample
+    else if (p.lossless) { t1 = polyintr_acc_fast(p, ch, grp - 1, j); t2 = (cj == j) ? t1 : polyintr_acc_fast(p, ch, grp - 1, cj); }
     else { t1 = polyintr_acc(p, ch, grp - 1, j); t2 = (cj == j) ? t1 : polyintr_acc(p, ch, grp - 1, cj); }
     if (cj != j) {
       const int64_t tn = p.sign[j] ? requant128(-(i128)t2, p.acc.F, p.acc) : t2;
@@ -83,18 +117,111 @@ __global__ void polyintr_kernel(PolyIntrParams p) {
   store_raw(p.y, (int64_t)ch * p.out_stride + o, p.out_eb, y);
 }
 
+// Tiled form of the lossless class: a workgroup owns kPiTile consecutive outputs of one channel, stages the input window
+// and the coefficient table in LDS once, and each thread produces its outputs with int64 MACs from LDS (no per-thread
+// 64-bit divisions, no global gathers).  The thread-per-output kernel above ran 203 ms on the bench row (0.02 TB/s).
+constexpr int kPiTile = 2048;
+
+// NARROW: IN_TYPE and COEFF_TYPE fit 31 / 32 bits: LDS words and the MAC (v_mad_i64_i32) are 32-bit.
+template <bool NARROW>
+__global__ void __launch_bounds__(256) polyintr_fast_kernel(PolyIntrParams p, uint32_t rcp, int n_win_max) {
+  typedef typename std::conditional<NARROW, int32_t, int64_t>::type WT;
+  extern __shared__ __attribute__((aligned(8))) unsigned char pi_lds[];
+  WT *cf = (WT *)pi_lds;                           // [coeff_sz]
+  WT *xw = cf + (p.coeff_sz + 1) / 2 * 2;          // [n_win_max]
+  const int ch = blockIdx.y;
+  const int IF = p.ifac, N = p.n_taps;
+  const int64_t o0 = (int64_t)blockIdx.x * kPiTile;
+  const int64_t g0 = o0 / IF;                      // wave-uniform, once
+  const int rem0 = (int)(o0 - g0 * IF);
+  const int lag = p.ftype == 2 ? 0 : 1;            // the folded cores emit the sums of the previous sample
+  // window: local samples m_lo - (N-1) .. m_lo + groups, m_lo = g0 + skip - lag
+  const int64_t m_lo = g0 + p.skip - lag;
+  const int n_groups = (rem0 + kPiTile - 1) / IF + 1;
+  const int n_win = N - 1 + n_groups;
+  for (int i = threadIdx.x; i < p.coeff_sz; i += 256) { cf[i] = (WT)p.coeffs[i]; }
+  for (int i = threadIdx.x; i < n_win; i += 256) {
+    const int64_t t = m_lo - (N - 1) + i;
+    int64_t v = 0;
+    if (t >= 0) { if (t < p.n) { v = load_raw(p.x, (int64_t)ch * p.in_stride + t, p.in_eb, 1); } }
+    else if (t >= -(int64_t)p.hl) { v = load_raw(p.hist, (int64_t)ch * p.hl + p.hl + t, p.in_eb, 1); }
+    xw[i] = (WT)v;
+  }
+  __syncthreads();
+  const int64_t neg_min = p.in.O == ACDSP_WRAP ? p.in.lo : ((p.in.O == ACDSP_SAT || p.in.O == ACDSP_SAT_SYM) ? p.in.hi : 0);
+  const int mid = (N - 1) / 2;
+  const int cnt = p.ftype == 0 ? N / 2 : mid + 1;
+  auto sub = [&](const WT *w, int j) -> int64_t {   // w[-i] = taps[i] of the sample
+    uint64_t acc = 0;
+    if (p.ftype == 2) {
+      for (int i = N - 1; i >= 0; i--) {
+        if (NARROW) { acc = (uint64_t)((int64_t)acc + (int64_t)(int32_t)w[-i] * (int64_t)(int32_t)cf[i + N * j]); }
+        else { acc += (uint64_t)w[-i] * (uint64_t)cf[i + N * j]; }
+      }
+    } else {
+      const bool sg = p.sign[j] != 0;
+      const int cbase = p.ftype == 0 ? j * N / 2 : (N / 2 + 1) * j;
+      for (int i = 0; i < cnt; i++) {
+        int64_t fold = w[-i];
+        if (p.ftype == 0 || i != mid) {
+          const int64_t far = w[-(N - 1 - i)];
+          fold += sg ? far : (far == p.in.lo ? neg_min : -far);
+        }
+        if (NARROW) { acc = (uint64_t)((int64_t)acc + (int64_t)(int32_t)cf[cbase + i] * (int64_t)(int32_t)fold); }   // |fold| < 2^31
+        else { acc += (uint64_t)cf[cbase + i] * (uint64_t)fold; }
+      }
+    }
+    return wrap64((int64_t)(acc << p.lossless_shift), p.acc.W, 1);
+  };
+  for (int it = 0; it < kPiTile / 256; it++) {
+    const int64_t o = o0 + threadIdx.x + 256 * it;
+    if (o >= p.n_out) { return; }
+    const unsigned t = (unsigned)rem0 + threadIdx.x + 256u * it;     // < IF + kPiTile < 2^16
+    const unsigned dg = __umulhi(t, rcp);
+    const int j = (int)(t - dg * (unsigned)IF);
+    const int64_t m = m_lo + dg;                                     // local sample whose sums this output carries
+    const WT *w = xw + (N - 1) + dg;
+    int64_t y;
+    if (p.ftype == 2) {
+      y = requant64(sub(w, j), p.acc.F, p.out);
+    } else {
+      const int cj = p.corr[j];
+      int64_t t1, t2;
+      if (m < 0) { t1 = p.saved[(int64_t)ch * IF + j]; t2 = p.saved[(int64_t)ch * IF + cj]; }
+      else { t1 = sub(w, j); t2 = (cj == j) ? t1 : sub(w, cj); }
+      if (cj != j) {
+        const int64_t tn = p.sign[j] ? wrap64(-t2, p.acc.W, 1) : t2;
+        y = requant64((t1 + tn) >> 1, p.acc.F, p.out);
+      } else {
+        y = requant64(t1, p.acc.F, p.out);
+      }
+    }
+    store_raw(p.y, (int64_t)ch * p.out_stride + o, p.out_eb, y);
+  }
+}
+
 // sums of the call's last sample -> the handle (they are emitted by the next call's first sample)
 __global__ void polyintr_save_kernel(PolyIntrParams p, int64_t *saved_next) {
   const int ch = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p.ifac) { return; }
-  saved_next[(int64_t)ch * p.ifac + j] = polyintr_acc(p, ch, p.n - 1, j);
+  saved_next[(int64_t)ch * p.ifac + j] = p.lossless ? polyintr_acc_fast(p, ch, p.n - 1, j) : polyintr_acc(p, ch, p.n - 1, j);
 }
 
 hipError_t launch_polyintr(const PolyIntrParams &p, int64_t *saved_next, hipStream_t s) {
   if (p.n_out > 0) {
-    dim3 grid((unsigned)((p.n_out + 255) / 256), (unsigned)p.n_ch);
-    hipLaunchKernelGGL(polyintr_kernel, grid, dim3(256), 0, s, p);
+    const int n_win_max = p.n_taps + kPiTile / p.ifac + 4;
+    const size_t lds = ((size_t)p.coeff_sz + (size_t)n_win_max) * sizeof(int64_t);
+    if (p.lossless && lds <= 60 * 1024) {
+      dim3 grid((unsigned)((p.n_out + kPiTile - 1) / kPiTile), (unsigned)p.n_ch);
+      const uint32_t rcp = (uint32_t)((0x100000000ull + p.ifac - 1) / p.ifac);
+      const bool narrow = p.in.W <= 30 && p.cf.W <= 32;
+      if (narrow) { hipLaunchKernelGGL(polyintr_fast_kernel<true>, grid, dim3(256), lds, s, p, rcp, n_win_max); }
+      else { hipLaunchKernelGGL(polyintr_fast_kernel<false>, grid, dim3(256), lds, s, p, rcp, n_win_max); }
+    } else {
+      dim3 grid((unsigned)((p.n_out + 255) / 256), (unsigned)p.n_ch);
+      hipLaunchKernelGGL(polyintr_kernel, grid, dim3(256), 0, s, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { return e; }
   }

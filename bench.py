@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "ddc", "polydec"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "cic_intr", "ddc", "polydec", "polyintr", "intgdump"])
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,6 +156,70 @@ def main():
             eng.run(x, y)
         samples_per_step = (hi - lo) * n
         path = "polydec"
+    elif args.workload == "polyintr":
+        # ac_poly_intr FOLD_EVEN, 16 taps x IF = 8, ac_fixed<16,2>; 8 outputs per input sample
+        ch_per_gpu = args.channels or 1024
+        n = args.samples or (1 << 18)
+        fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        eng = A.PolyIntr(16, 64, 8, "FOLD_EVEN", fin, fc, fa, fo, n_channels=hi - lo, device=local_rank)
+        eng.set_ctrl(windowed_sinc_raw(127, 0.05, fc.F)[:64], [1] * 8, list(range(8)))
+        x = torch.empty((hi - lo, n), dtype=torch.int16, device=dev)
+        A.fill_stimulus(x, seed, 16, ch0=lo)
+        eng.run(x[:, :16])                       # past the stream's first sample: every later call emits IF per input
+        bytes_per_sample = 2.0 + 2.0 * 8
+        macs_per_sample = 0.0
+        name = "ac_poly_intr FOLD_EVEN NTAPS=16 IF=8 ac_fixed<16,2> -> <16,2,RND,SAT>, %d ch x %d input samples per GPU (SURVEY 8 f2)" % (ch_per_gpu, n)
+        dtype = "int64 (exact per-MAC order, ACC <40,12>)"
+        coeffs = None
+
+        def step():
+            eng.run(x)
+        samples_per_step = (hi - lo) * n
+        path = "polyintr"
+    elif args.workload == "intgdump":
+        # ac_intg_dump, 4 interleaved channels per object, dumps every 64 rounds
+        ch_per_gpu = args.channels or 1024
+        n = args.samples or (1 << 20)            # interleaved samples per object
+        fin, fa, fo = A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        eng = A.IntgDump(64, 4, fin, fa, fo, n_objects=hi - lo, device=local_rank)
+        n_sample = np.full(n // (64 * 4), 64, dtype=np.int64)
+        x = torch.empty((hi - lo, n), dtype=torch.int16, device=dev)
+        A.fill_stimulus(x, seed, 16, ch0=lo)
+        bytes_per_sample = 2.0 + 4.0 / 64
+        macs_per_sample = 0.0
+        name = "ac_intg_dump NS=64 CHN=4 ac_fixed<16,8> -> <32,16>, %d objects x %d interleaved samples per GPU (SURVEY 8 f4)" % (ch_per_gpu, n)
+        dtype = "int64 (every add quantised to ACC <32,16>)"
+        coeffs = None
+
+        def step():
+            eng.run(x, n_sample)
+        samples_per_step = (hi - lo) * n
+        path = "intgdump"
+    elif args.workload == "cic_intr":
+        # ac_cic_intr_full N=5 R=8 on ac_fixed<32,16> (named in north_star; no BASELINE config): 8 outputs per input
+        ch_per_gpu = args.channels or 1024
+        n = args.samples or (1 << 18)
+        fin = A.Fmt(32, 16)
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        it = A.Cic(True, 8, 1, 5, fin, fin, n_channels=1, device=local_rank).int_type
+        fo = A.Fmt(it.W, it.I)
+        eng = A.Cic(True, 8, 1, 5, fin, fo, n_channels=hi - lo, device=local_rank)
+        x = torch.empty((hi - lo, n), dtype=torch.int32, device=dev)
+        A.fill_stimulus(x, seed, 32, ch0=lo)
+        y = torch.empty((hi - lo, n * 8 + 64), dtype=torch.int64, device=dev)
+        eng.run(x[:, :64], y)                    # steady state: later calls emit R outputs per input
+        bytes_per_sample = 4.0 + 8.0 * 8
+        macs_per_sample = 0.0
+        name = "ac_cic_intr_full N=5 R=8 M=1 ac_fixed<32,16> -> <%d,%d>, %d ch x %d input samples per GPU" % (it.W, it.I, ch_per_gpu, n)
+        dtype = "int64 (wrap arithmetic mod 2^%d)" % it.W
+        coeffs = None
+
+        def step():
+            eng.run(x, y)
+        samples_per_step = (hi - lo) * n
+        path = "cic_intr_" + eng.path
     elif args.workload == "ddc":
         # BASELINE configs[4]: CIC R=16 N=5 on ac_fixed<16,1> -> lossless INT <36,21> -> 127-tap FIR (IN <36,21>,
         # COEFF <16,1>); I and Q are separate real streams, 2048 complex = 4096 real streams per GPU
@@ -245,7 +309,7 @@ def main():
             "config": {"workload": name, "kernel_path": path, "channels_per_gpu": ch_per_gpu, "samples_per_step": n,
                        "parallelism": "channel-slice x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir255_wide": "r1_fir255_wide", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec", "ddc": "r1_ddc", "polydec": "r1_polydec"}[args.workload]),
+                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir255_wide": "r1_fir255_wide", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec", "ddc": "r1_ddc", "polydec": "r1_polydec"}.get(args.workload, "none")),
                          "algorithmic_bytes_per_launch": bytes_per_sample * samples_per_step, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
                          "algorithmic_bytes_per_sample": bytes_per_sample},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,

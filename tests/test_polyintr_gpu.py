@@ -103,3 +103,24 @@ def test_rejects_tables_the_reference_would_overrun():
         eng.set_ctrl(np.zeros(16, dtype=np.int64), [1, 1, 1, 1], [0, 1, 2, 4])      # corr[3] = 4 outside the IF = 4 banks
     with pytest.raises(A.AcdspError):
         eng.run(torch.zeros((1, 16), dtype=torch.int16, device="cuda"))              # run before the control structs arrived
+
+
+@pytest.mark.parametrize("ftype,n_taps", [("FOLD_EVEN", 16), ("FOLD_ODD", 15), ("FOLD_ANTI", 12)])
+@pytest.mark.parametrize("in_o", ["WRAP", "SAT", "SAT_SYM", "SAT_ZERO"])
+def test_lossless_class_int64_kernel(ftype, n_taps, in_o):
+    # ACC <40,12> holds every product and the fold exactly (28 = 14 + 14 fraction bits): the exact-accumulation kernel.
+    # Streams full of the most negative word exercise the one non-linear step left, the IN_TYPE negation (:145)
+    fin = A.Fmt(16, 2, True, "TRN", in_o)
+    fc, fa = A.Fmt(16, 2), A.Fmt(40, 12)
+    for fo, pairs in ((A.Fmt(16, 2, True, "RND", "SAT"), True), (fa, False)):
+        check(n_taps, 8, ftype, fin, fc, fa, fo, n_ch=4, n=500, splits=[1, 255], seed=n_taps, pairs=pairs)
+    rng = np.random.default_rng(7)
+    csz = table_size(n_taps, 4, ftype)
+    c = rand_raw(rng, fc, (csz,))
+    x = rng.choice(np.array([-32768, 32767, -32768, 0, 1, -1], dtype=np.int64), size=(2, 300))
+    sign, corr = [0, 0, 1, 0], [1, 0, 3, 2]
+    eng = A.PolyIntr(n_taps, csz, 4, ftype, fin, fc, fa, fa, n_channels=2)
+    eng.set_ctrl(c, sign, corr)
+    orc = OraclePolyIntr(n_taps, csz, 4, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fa), n_ch=2)
+    y = eng.run(torch.from_numpy(x).to(torch.int16).cuda()).cpu().numpy().astype(np.int64)
+    assert np.array_equal(y, orc.run(c, sign, corr, x))
