@@ -87,10 +87,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the HIP engine)")
+    if os.environ.get("ACDSP_BENCH_ONE_GPU"):      # self-test of the multi-rank path on a 1-GPU box: every rank on device 0, gloo
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("ACDSP_BENCH_ONE_GPU"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch one process per GPU"
 
     import ac_dsp_amd as A
