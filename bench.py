@@ -316,7 +316,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir255_wide": "r1_fir255_wide", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec", "ddc": "r1_ddc", "polydec": "r1_polydec"}.get(args.workload, "none")),
                          "algorithmic_bytes_per_launch": bytes_per_sample * samples_per_step, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
-                         "algorithmic_bytes_per_sample": bytes_per_sample},
+                         "algorithmic_bytes_per_sample": bytes_per_sample,
+                         # north_star's wording "HBM-read roofline": input bytes only (SURVEY 8d asks for both views)
+                         "read_only": {"bytes_per_sample": float(x.element_size()),
+                                       "achieved": x.element_size() * samples_per_step / (k_avg * 1e-3) / 1e9,
+                                       "frac": x.element_size() * samples_per_step / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
         }
         if macs_per_sample:
