@@ -1408,6 +1408,7 @@ struct acdsp_intgdump {
   int64_t *d_blk = nullptr;     // [3][cap] off / rounds / out
   int32_t *d_chain = nullptr;   // [cap]
   int64_t blk_cap = 0;
+  bool pending = false;         // the last call ended on a block that did not dump: temp[] is non-zero
   Staging st;
 };
 
@@ -1510,11 +1511,13 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
   p.in = make_dfmt(d.in); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
   p.in_eb = h->in_eb; p.out_eb = h->out_eb; p.in_stride = in_stride; p.out_stride = out_stride;
   p.lossless = d.acc.O == ACDSP_WRAP && p.acc.F >= p.in.F && p.acc.F - p.in.F < 64 - d.in.W;
+  p.tile_ok = p.lossless && !h->pending && grp == n_blocks;
   p.x = d_in; p.y = d_out; p.temp = h->d_temp[h->cur];
   p.blk_off = h->d_blk; p.blk_rounds = h->d_blk + n_blocks; p.blk_out = h->d_blk + 2 * n_blocks; p.blk_chain = h->d_chain;
   hipError_t e = launch_intg_dump(p, h->d_temp[h->cur ^ 1], s);
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "intg_dump kernel launch failed: %s", hipGetErrorString(e)); }
   h->cur ^= 1;
+  h->pending = start != (int32_t)n_blocks;   // the call ended on blocks that did not dump: their sums sit in temp[]
   return ACDSP_OK;
 }
 
@@ -1549,6 +1552,7 @@ int32_t acdsp_intgdump_reset(acdsp_intgdump_t h) {
   if (rc) { return rc; }
   HIP_TRY(hipDeviceSynchronize());
   for (int i = 0; i < 2; i++) { HIP_TRY(hipMemset(h->d_temp[i], 0, (size_t)h->d.n_objects * h->d.chn * sizeof(int64_t))); }
+  h->pending = false;
   return ACDSP_OK;
 }
 

@@ -92,6 +92,7 @@ hipError_t launch_polyintr(const PolyIntrParams &p, int64_t *saved_next, hipStre
 struct IntgDumpParams {
   int32_t chn, n_obj, n_blocks;
   int32_t lossless;           // ACC_TYPE is AC_WRAP with F_acc >= F_in: integer sums mod 2^W
+  int32_t tile_ok;            // lossless, every block of the call dumps and the handle carries no undumped sum in
   DFmt in, acc, out;
   int32_t in_eb, out_eb;
   int64_t in_stride, out_stride;
