@@ -510,13 +510,19 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   k.hist = h->d_hist[h->cur]; k.coeffs = h->d_coeffs; k.rt = h->d_rt[h->cur];
 
   int path = h->path;
-  if (path == ACDSP_PATH_MFMA_I8) {
-    const bool aligned = ((uintptr_t)d_in % 16 == 0) && (in_stride % 8 == 0);
-    if (!aligned) { path = ACDSP_PATH_LOSSLESS64; }
-  }
-  if (path == ACDSP_PATH_MFMA_GEN) {   // 16-sample slots: rows must be 16-byte aligned and readable up to the next multiple of 16
-    const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0) && in_stride >= (n + 15) / 16 * 16;
-    if (!aligned) { path = ACDSP_PATH_LOSSLESS64; }
+  if (path == ACDSP_PATH_MFMA_I8 || path == ACDSP_PATH_MFMA_GEN) {
+    // The matrix-core kernels read rows with 16-byte vector loads (fir_gen: in whole 16-sample slots).  Rows that are
+    // not laid out that way are first copied, on the device, into an aligned staging image (one extra read + write of
+    // the input: still ~30x faster than sending the call to the VALU dot-product kernel).
+    const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0) &&
+                         (path == ACDSP_PATH_MFMA_I8 || in_stride >= (n + 15) / 16 * 16);
+    if (!aligned) {
+      const int64_t si = (n + 15) / 16 * 16;
+      if ((rc = h->st.ensure((size_t)d.n_channels * si * h->in_eb, 0))) { return rc; }
+      HIP_TRY(hipMemcpy2DAsync(h->st.d_in, (size_t)si * h->in_eb, d_in, (size_t)in_stride * h->in_eb, (size_t)n * h->in_eb,
+                               (size_t)d.n_channels, hipMemcpyDeviceToDevice, s));
+      k.x = h->st.d_in; k.in_stride = si;
+    }
   }
   HIP_TRY(hipEventRecord(h->tm.start(), s));
   hipError_t e;

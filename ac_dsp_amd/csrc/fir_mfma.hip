@@ -347,7 +347,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
         } else {
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
-            if (t0 + rr < p.n) { dst[rr] = (int16_t)o[rr]; }
+            if (t0 + rr < p.n) { dst[rr] = pk[rr]; }   // pk: already clamped for AC_SAT
           }
         }
       } else {
@@ -809,7 +809,7 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
         } else {
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
-            if (t0 + rr < p.n) { dst[rr] = (int16_t)o[rr]; }
+            if (t0 + rr < p.n) { dst[rr] = pk[rr]; }   // pk: already clamped for AC_SAT
           }
         }
       } else {

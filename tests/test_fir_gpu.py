@@ -253,6 +253,47 @@ def test_unaligned_rows_take_a_correct_path():
     assert np.array_equal(y, OracleFir(N, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch).run(c, x))
 
 
+def test_unaligned_long_rows_are_staged_for_the_matrix_core_kernels():
+    # odd row start and stride on a long run: the engine copies the rows into an aligned image on the device and still runs
+    # the (pipelined) MFMA kernel; same for the wide-input gen kernel; state carries across an aligned / unaligned mix
+    rng = np.random.default_rng(12)
+    for fin, fc, fa, fo, N, dt, path in ((A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT"), 200, torch.int16, "mfma_i8"),
+                                         (A.Fmt(36, 21), A.Fmt(16, 1), A.Fmt(60, 30), A.Fmt(24, 9, True, "RND", "SAT"), 127, torch.int64, "mfma_gen")):
+        n_ch, n = 3, 7001
+        c = windowed_sinc(N, 0.1, fc)
+        x = rand_raw(rng, fin, (n_ch, 2 * n))
+        fir = A.Fir(N, "SHIFT_REG", fin, fc, fa, fo, n_channels=n_ch, kind="const")
+        fir.set_coeffs(c)
+        assert fir.path == path
+        big = torch.zeros((n_ch, 2 * n + 7), dtype=dt, device="cuda")
+        big[:, 3:3 + 2 * n] = torch.from_numpy(x).to(dt).cuda()
+        y1 = fir.run(big[:, 3:3 + n]).cpu().numpy().astype(np.int64)
+        y2 = fir.run(big[:, 3 + n:3 + 2 * n]).cpu().numpy().astype(np.int64)
+        yo = OracleFir(N, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch).run(c, x)
+        assert np.array_equal(np.concatenate([y1, y2], axis=1), yo)
+
+
+@pytest.mark.parametrize("in_w,out_w", [(1024, 1024), (1024, 1023), (1023, 1024), (1023, 1023)])
+def test_ragged_tail_and_unaligned_output_saturate(in_w, out_w):
+    # n = 1023 with full-scale random coefficients: the last, incomplete group of four outputs and every output of an
+    # unaligned output row leave through the element-wise stores, which must clamp like the packed ones (AC_SAT)
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+    rng = np.random.default_rng(1)
+    n_ch, N, n = 9, 200, 1023
+    c = np.minimum(rng.integers(-32768, 32768, size=(N,)), 32639)
+    x = rng.integers(-32768, 32768, size=(n_ch, n))
+    yo = OracleFir(N, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch).run(c, x)
+    assert (np.abs(yo) >= 32767).mean() > 0.3          # most outputs saturate
+    fir = A.Fir(N, "SHIFT_REG", fin, fc, fa, fo, n_channels=n_ch)
+    fir.set_coeffs(c)
+    assert fir.path == "mfma_i8"
+    xin = torch.zeros((n_ch, in_w), dtype=torch.int16, device="cuda")
+    xin[:, :n] = torch.from_numpy(x).to(torch.int16).cuda()
+    out = torch.zeros((n_ch, out_w), dtype=torch.int16, device="cuda")
+    y = fir.run(xin[:, :n], out)[:, :n].cpu().numpy().astype(np.int64)
+    assert np.array_equal(y, yo)
+
+
 def test_anti_ftypes_are_rejected():
     with pytest.raises(A.AcdspError):
         A.Fir(8, "FOLD_EVEN_ANTI", A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2))
