@@ -1,0 +1,174 @@
+"""Randomised differential tests on the GPU: engine vs oracle over shapes the targeted tests do not enumerate -- odd burst
+lengths, unaligned row starts and strides on either side, call splitting, every kernel family.  Seeds are fixed; raise
+ACDSP_FUZZ_CASES for a longer hunt (tools: `ACDSP_FUZZ_CASES=400 python -m pytest tests/test_fuzz_gpu.py -m gpu`)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ac_dsp_amd as A
+from oracle import OracleFir, OracleCic
+from helpers import ofmt
+
+pytestmark = pytest.mark.gpu
+CASES = int(os.environ.get("ACDSP_FUZZ_CASES", "40"))
+
+
+def rand_raw(rng, fmt, shape):
+    lo = -(1 << (fmt.W - 1)) if fmt.S else 0
+    hi = (1 << (fmt.W - 1)) - 1 if fmt.S else (1 << fmt.W) - 1
+    return rng.integers(lo, hi + 1, size=shape, dtype=np.int64)
+
+
+def padded_view(x, dt, lead, tail):
+    """device tensor view of x whose rows start `lead` elements into a wider buffer (stride = n + lead + tail)"""
+    n_ch, n = x.shape
+    big = torch.zeros((n_ch, n + lead + tail), dtype=dt, device="cuda")
+    big[:, lead:lead + n] = torch.from_numpy(x).to(dt).cuda()
+    return big[:, lead:lead + n]
+
+
+FIR_TYPES = [
+    (A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)),                       # int8-split MFMA class
+    (A.Fmt(16, 1), A.Fmt(16, 1), A.Fmt(44, 14)),
+    (A.Fmt(36, 21), A.Fmt(16, 1), A.Fmt(60, 30)),                      # wide words: multi-plane MFMA
+    (A.Fmt(24, 8), A.Fmt(18, 2), A.Fmt(50, 12)),
+    (A.Fmt(14, 4), A.Fmt(12, 2), A.Fmt(20, 8, True, "RND", "SAT")),    # lossy accumulator: exact-order VALU kernel
+]
+FIR_OUTS = [A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(16, 2, True, "TRN", "WRAP"), A.Fmt(16, 6, True, "RND", "SAT"), A.Fmt(40, 12),
+            A.Fmt(24, 9, True, "RND", "SAT"), A.Fmt(34, 4, True, "TRN", "WRAP"), A.Fmt(12, 5, True, "RND_CONV", "SAT_SYM")]
+
+
+@pytest.mark.parametrize("seed", range(CASES))
+def test_fir_random_shapes(seed):
+    rng = np.random.default_rng(1000 + seed)
+    fin, fc, fa = FIR_TYPES[rng.integers(len(FIR_TYPES))]
+    fo = FIR_OUTS[rng.integers(len(FIR_OUTS))]
+    kind = ["const", "load", "prog", "reg_share"][rng.integers(4)]
+    ftypes = ["SHIFT_REG", "FOLD_EVEN", "FOLD_ODD"] + (["FOLD_EVEN_ANTI", "FOLD_ODD_ANTI"] if kind == "reg_share" else ["ROTATE_SHIFT", "C_BUFF", "TRANSPOSED"])
+    ftype = ftypes[rng.integers(len(ftypes))]
+    n_taps = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 100, 127, 255, 257, 258, 300, 700]))
+    if kind == "reg_share" or fa.O:
+        n_taps = min(n_taps, 100)                                       # keep the oracle's i128 loops short
+    n_ch = int(rng.choice([1, 2, 7, 8, 9, 17]))
+    per_ch = bool(rng.integers(2)) and n_taps <= 257 and fin.W <= 16
+    n_total = int(rng.choice([1, 5, 100, 1023, 1024, 1025, 2048, 3000, 5000, 9000]))
+    scale = 1 if rng.integers(3) else 8                                 # sometimes small coefficients (zero high-byte planes)
+    c = rand_raw(rng, fc, (n_ch, n_taps) if per_ch else (n_taps,)) // scale
+    x = rand_raw(rng, fin, (n_ch, n_total))
+    fir = A.Fir(n_taps, ftype, fin, fc, fa, fo, n_channels=n_ch, kind=kind, coeffs_per_channel=per_ch)
+    fir.set_coeffs(c)
+    orc = OracleFir(n_taps, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch, reg_share=(1, 1, 0) if kind == "reg_share" else None)
+    yo = orc.run(c, x)
+    cuts = sorted(set(int(v) for v in rng.integers(0, n_total + 1, size=rng.integers(0, 3))))
+    bounds = [0] + cuts + [n_total]
+    dt_in, dt_out = A.torch_dtype_for(fin), A.torch_dtype_for(fo)
+    outs = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b == a:
+            continue
+        xv = padded_view(x[:, a:b], dt_in, int(rng.integers(0, 9)), int(rng.integers(0, 9)))
+        out = torch.zeros((n_ch, b - a + int(rng.integers(0, 9))), dtype=dt_out, device="cuda")
+        out = out[:, int(rng.integers(0, min(4, out.shape[1] - (b - a) + 1))):]
+        y = fir.run(xv, out)[:, :b - a].cpu().numpy().astype(np.int64)
+        outs.append(y)
+    y = np.concatenate(outs, axis=1)
+    bad = np.argwhere(y != yo)
+    assert bad.size == 0, "seed %d: %d mismatches, first %s (path %s, %s %s taps %d ch %d n %d cuts %s per_ch %s)" % (
+        seed, len(bad), bad[0], fir.path, kind, ftype, n_taps, n_ch, n_total, cuts, per_ch)
+
+
+@pytest.mark.parametrize("seed", range(CASES))
+def test_cic_random_shapes(seed):
+    rng = np.random.default_rng(2000 + seed)
+    interp = bool(rng.integers(2))
+    R = int(rng.choice([2, 3, 7, 8, 16, 32]))
+    M = int(rng.choice([1, 2, 3]))
+    N = int(rng.choice([1, 2, 4, 5]))
+    fin = [A.Fmt(16, 1), A.Fmt(32, 16), A.Fmt(12, 12, False), A.Fmt(20, 4)][rng.integers(4)]
+    try:
+        probe = A.Cic(interp, R, M, N, fin, fin, n_channels=1)
+    except A.AcdspError:
+        pytest.skip("outside the reference's own limits")
+    it = probe.int_type
+    fout = [A.Fmt(it.W, it.I), A.Fmt(it.W, it.I), A.Fmt(20, 14, True, "RND", "SAT"), A.Fmt(16, it.I - (it.W - 16), True, "TRN", "WRAP")][rng.integers(4)]
+    if fout.W > 64 or it.W > 64:
+        pytest.skip("wider than 64 bits")
+    n_ch = int(rng.choice([1, 3, 64, 65]))
+    n_total = int(rng.choice([1, 17, 256, 1000, 4096, 20000])) if not interp else int(rng.choice([1, 2, 17, 300, 2500]))
+    x = rand_raw(rng, fin, (n_ch, n_total))
+    cic = A.Cic(interp, R, M, N, fin, fout, n_channels=n_ch)
+    orc = OracleCic(interp, R, M, N, ofmt(fin), ofmt(fout), n_ch=n_ch)
+    cuts = sorted(set(int(v) for v in rng.integers(0, n_total + 1, size=rng.integers(0, 3))))
+    bounds = [0] + cuts + [n_total]
+    dt = A.torch_dtype_for(fin)
+    ys, yos = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b == a:
+            continue
+        lead = int(rng.integers(0, 5)) * (0 if rng.integers(2) else 1)
+        xv = padded_view(x[:, a:b], dt, lead, int(rng.integers(0, 20)))
+        ys.append(cic.run(xv).cpu().numpy().astype(np.int64))
+        yos.append(orc.run(x[:, a:b]))
+    y, yo = np.concatenate(ys, axis=1), np.concatenate(yos, axis=1)
+    assert y.shape == yo.shape, (y.shape, yo.shape)
+    bad = np.argwhere(y != yo)
+    assert bad.size == 0, "seed %d: %d mismatches, first %s (interp %s R %d M %d N %d ch %d n %d cuts %s)" % (
+        seed, len(bad), bad[0], interp, R, M, N, n_ch, n_total, cuts)
+
+
+@pytest.mark.parametrize("seed", range(max(CASES // 4, 8)))
+def test_ddc_random_bursts(seed):
+    # fused cascade (config-5 shape class): bursts of any length (whole 16-sample slots readable: rows are padded), any split
+    from test_ddc_gpu import oracle_cascade
+    from test_fir_gpu import windowed_sinc
+    rng = np.random.default_rng(3000 + seed)
+    cin, fc, fa = A.Fmt(16, 1), A.Fmt(16, 1), A.Fmt(60, 30)
+    fo = [A.Fmt(24, 9, True, "RND", "SAT"), A.Fmt(32, 12, True, "TRN", "WRAP"), A.Fmt(20, 6, True, "RND", "SAT")][rng.integers(3)]
+    n_taps = int(rng.choice([127, 101, 64]))
+    n_ch = int(rng.choice([1, 2, 5]))
+    n_total = int(rng.choice([40, 1000, 16 * 300 + 5, 16 * 1024 * 3 + 77, 50000]))
+    x = rand_raw(rng, cin, (n_ch, n_total))
+    c = windowed_sinc(n_taps, 0.2, fc)
+    ddc = A.Ddc(16, 1, 5, cin, n_taps, "SHIFT_REG", fc, fa, fo, n_channels=n_ch)
+    ddc.set_coeffs(c)
+    cuts = sorted(set(int(v) for v in rng.integers(0, n_total + 1, size=rng.integers(0, 3))))
+    bounds = [0] + cuts + [n_total]
+    ys = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b == a:
+            continue
+        w = (b - a + 15) // 16 * 16 + 16 * int(rng.integers(0, 2))
+        big = torch.zeros((n_ch, w), dtype=torch.int16, device="cuda")
+        big[:, :b - a] = torch.from_numpy(x[:, a:b]).to(torch.int16).cuda()
+        ys.append(ddc.run(big[:, :b - a]).cpu().numpy().astype(np.int64))
+    y = np.concatenate(ys, axis=1)
+    yo = oracle_cascade(16, 1, 5, cin, ddc.int_type, n_taps, "SHIFT_REG", fc, fa, fo, c, x, cuts)
+    assert y.shape == yo.shape
+    bad = np.argwhere(y != yo)
+    assert bad.size == 0, "seed %d: %d mismatches, first %s (path %s taps %d n %d cuts %s)" % (seed, len(bad), bad[0], ddc.path, n_taps, n_total, cuts)
+
+
+@pytest.mark.parametrize("seed", range(max(CASES // 2, 10)))
+def test_intg_dump_random_block_sequences(seed):
+    # mixes dumping blocks with n_sample = 0 / > NS blocks across calls: tiled kernel, general kernel and the carried sums
+    from oracle import OracleIntgDump
+    rng = np.random.default_rng(4000 + seed)
+    ns = int(rng.choice([4, 64, 100]))
+    chn = int(rng.choice([1, 2, 3, 4, 8]))
+    fin = [A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(12, 12, False)][rng.integers(3)]
+    fa, fo = [(A.Fmt(40, 20), A.Fmt(40, 20)), (A.Fmt(20, 10, True, "TRN", "SAT"), A.Fmt(12, 8, True, "RND", "SAT")),
+              (A.Fmt(48, 40, False), A.Fmt(48, 40, False))][rng.integers(3)]
+    n_obj = int(rng.choice([1, 5]))
+    eng = A.IntgDump(ns, chn, fin, fa, fo, n_objects=n_obj)
+    orc = OracleIntgDump(ns, chn, ofmt(fin), ofmt(fa), ofmt(fo), n_obj=n_obj)
+    for _ in range(int(rng.integers(1, 5))):
+        nb = int(rng.integers(1, 200))
+        n_sample = rng.integers(1, ns + 1, size=nb)
+        if rng.integers(2):
+            n_sample[rng.integers(0, nb, size=max(1, nb // 10))] = rng.choice([0, ns + 5])
+        ni, no = eng.counts(n_sample)
+        x = rand_raw(rng, fin, (n_obj, ni))
+        y = eng.run(torch.from_numpy(x).to(A.torch_dtype_for(fin)).cuda(), n_sample).cpu().numpy().astype(np.int64)
+        assert np.array_equal(y, orc.run(x, n_sample)), seed
