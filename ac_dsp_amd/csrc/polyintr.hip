@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) polyintr_fast_kernel(PolyIntrParams p, ui
     const int64_t o = o0 + threadIdx.x + 256 * it;
     if (o >= p.n_out) { return; }
     const unsigned t = (unsigned)rem0 + threadIdx.x + 256u * it;     // < IF + kPiTile < 2^16
-    const unsigned dg = __umulhi(t, rcp);
+    const unsigned dg = IF == 1 ? t : __umulhi(t, rcp);              // ceil(2^32 / 1) does not fit the 32-bit reciprocal
     const int j = (int)(t - dg * (unsigned)IF);
     const int64_t m = m_lo + dg;                                     // local sample whose sums this output carries
     const WT *w = xw + (N - 1) + dg;

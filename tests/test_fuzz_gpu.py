@@ -172,3 +172,43 @@ def test_intg_dump_random_block_sequences(seed):
         x = rand_raw(rng, fin, (n_obj, ni))
         y = eng.run(torch.from_numpy(x).to(A.torch_dtype_for(fin)).cuda(), n_sample).cpu().numpy().astype(np.int64)
         assert np.array_equal(y, orc.run(x, n_sample)), seed
+
+
+@pytest.mark.parametrize("seed", range(max(CASES // 2, 10)))
+def test_poly_dec_and_intr_random_shapes(seed):
+    from oracle import OraclePolyDec, OraclePolyIntr
+    rng = np.random.default_rng(5000 + seed)
+    lossless = bool(rng.integers(2))
+    fin, fc = (A.Fmt(16, 2), A.Fmt(16, 2)) if rng.integers(2) else (A.Fmt(20, 6), A.Fmt(14, 3))
+    fa = A.Fmt(fin.W + fc.W + 9, fin.I + fc.I + 9) if lossless else A.Fmt(22, 9, True, ["TRN", "RND", "RND_CONV"][rng.integers(3)], ["WRAP", "SAT"][rng.integers(2)])
+    fo = [A.Fmt(16, 2, True, "RND", "SAT"), fa, A.Fmt(18, 7, True, "TRN", "WRAP")][rng.integers(3)]
+    n_ch = int(rng.choice([1, 3, 9]))
+    # ---- decimator
+    nt, df = int(rng.choice([1, 3, 8, 16])), int(rng.choice([1, 2, 5, 8, 16]))
+    c = rand_raw(rng, fc, (nt * df,))
+    dec = A.PolyDec(nt, df, fin, fc, fa, fo, n_channels=n_ch)
+    dec.set_coeffs(c)
+    od = OraclePolyDec(nt, df, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    for groups in (int(rng.integers(1, 40)), int(rng.choice([16, 704, 2048 + 16 * int(rng.integers(0, 9))]))):
+        x = rand_raw(rng, fin, (n_ch, groups * df))
+        y = dec.run(torch.from_numpy(x).to(A.torch_dtype_for(fin)).cuda()).cpu().numpy().astype(np.int64)
+        assert np.array_equal(y, od.run(c, x)), ("dec", seed, dec.path)
+    # ---- interpolator
+    ftype = ["FOLD_EVEN", "FOLD_ODD", "FOLD_ANTI"][rng.integers(3)]
+    n_taps, ifac = int(rng.choice([2, 5, 8, 15, 16])), int(rng.choice([1, 2, 3, 8]))
+    j = ifac - 1
+    csz = {"FOLD_EVEN": (n_taps // 2 - 1) + j * n_taps // 2, "FOLD_ODD": (n_taps - 1) // 2 + (n_taps // 2 + 1) * j,
+           "FOLD_ANTI": (n_taps - 1) + n_taps * j}[ftype] + 1 + int(rng.integers(0, 3))
+    if csz < 1:
+        csz = 1
+    ci = rand_raw(rng, fc, (csz,))
+    sign = rng.integers(0, 2, size=ifac)
+    corr = rng.permutation(ifac) if rng.integers(2) else np.arange(ifac)
+    pi = A.PolyIntr(n_taps, csz, ifac, ftype, fin, fc, fa, fo, n_channels=n_ch)
+    pi.set_ctrl(ci, sign, corr)
+    oi = OraclePolyIntr(n_taps, csz, ifac, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    for n in (1, int(rng.integers(1, 50)), int(rng.choice([300, 1500]))):
+        x = rand_raw(rng, fin, (n_ch, n))
+        y = pi.run(torch.from_numpy(x).to(A.torch_dtype_for(fin)).cuda()).cpu().numpy().astype(np.int64)
+        yo = oi.run(ci, sign, corr, x)
+        assert y.shape == yo.shape and np.array_equal(y, yo), ("intr", seed, ftype, n_taps, ifac)
