@@ -123,23 +123,25 @@ __global__ void polyintr_kernel(PolyIntrParams p) {
 constexpr int kPiTile = 2048;
 
 // NARROW: IN_TYPE and COEFF_TYPE fit 31 / 32 bits: LDS words and the MAC (v_mad_i64_i32) are 32-bit.
-template <bool NARROW>
+template <bool NARROW, int FT>
 __global__ void __launch_bounds__(256) polyintr_fast_kernel(PolyIntrParams p, uint32_t rcp, int n_win_max) {
   typedef typename std::conditional<NARROW, int32_t, int64_t>::type WT;
   extern __shared__ __attribute__((aligned(8))) unsigned char pi_lds[];
   WT *cf = (WT *)pi_lds;                           // [coeff_sz]
   WT *xw = cf + (p.coeff_sz + 1) / 2 * 2;          // [n_win_max]
+  unsigned char *sgn = (unsigned char *)(xw + n_win_max), *cor = sgn + 256;   // [IF] each
   const int ch = blockIdx.y;
   const int IF = p.ifac, N = p.n_taps;
   const int64_t o0 = (int64_t)blockIdx.x * kPiTile;
   const int64_t g0 = o0 / IF;                      // wave-uniform, once
   const int rem0 = (int)(o0 - g0 * IF);
-  const int lag = p.ftype == 2 ? 0 : 1;            // the folded cores emit the sums of the previous sample
+  const int lag = FT == 2 ? 0 : 1;            // the folded cores emit the sums of the previous sample
   // window: local samples m_lo - (N-1) .. m_lo + groups, m_lo = g0 + skip - lag
   const int64_t m_lo = g0 + p.skip - lag;
   const int n_groups = (rem0 + kPiTile - 1) / IF + 1;
   const int n_win = N - 1 + n_groups;
   for (int i = threadIdx.x; i < p.coeff_sz; i += 256) { cf[i] = (WT)p.coeffs[i]; }
+  if ((int)threadIdx.x < p.ifac) { sgn[threadIdx.x] = p.sign[threadIdx.x]; cor[threadIdx.x] = p.corr[threadIdx.x]; }
   for (int i = threadIdx.x; i < n_win; i += 256) {
     const int64_t t = m_lo - (N - 1) + i;
     int64_t v = 0;
@@ -150,20 +152,20 @@ __global__ void __launch_bounds__(256) polyintr_fast_kernel(PolyIntrParams p, ui
   __syncthreads();
   const int64_t neg_min = p.in.O == ACDSP_WRAP ? p.in.lo : ((p.in.O == ACDSP_SAT || p.in.O == ACDSP_SAT_SYM) ? p.in.hi : 0);
   const int mid = (N - 1) / 2;
-  const int cnt = p.ftype == 0 ? N / 2 : mid + 1;
+  const int cnt = FT == 0 ? N / 2 : mid + 1;
   auto sub = [&](const WT *w, int j) -> int64_t {   // w[-i] = taps[i] of the sample
     uint64_t acc = 0;
-    if (p.ftype == 2) {
+    if (FT == 2) {
       for (int i = N - 1; i >= 0; i--) {
         if (NARROW) { acc = (uint64_t)((int64_t)acc + (int64_t)(int32_t)w[-i] * (int64_t)(int32_t)cf[i + N * j]); }
         else { acc += (uint64_t)w[-i] * (uint64_t)cf[i + N * j]; }
       }
     } else {
-      const bool sg = p.sign[j] != 0;
-      const int cbase = p.ftype == 0 ? j * N / 2 : (N / 2 + 1) * j;
+      const bool sg = sgn[j] != 0;
+      const int cbase = FT == 0 ? j * N / 2 : (N / 2 + 1) * j;
       for (int i = 0; i < cnt; i++) {
         int64_t fold = w[-i];
-        if (p.ftype == 0 || i != mid) {
+        if (FT == 0 || i != mid) {
           const int64_t far = w[-(N - 1 - i)];
           fold += sg ? far : (far == p.in.lo ? neg_min : -far);
         }
@@ -182,15 +184,15 @@ __global__ void __launch_bounds__(256) polyintr_fast_kernel(PolyIntrParams p, ui
     const int64_t m = m_lo + dg;                                     // local sample whose sums this output carries
     const WT *w = xw + (N - 1) + dg;
     int64_t y;
-    if (p.ftype == 2) {
+    if (FT == 2) {
       y = requant64(sub(w, j), p.acc.F, p.out);
     } else {
-      const int cj = p.corr[j];
+      const int cj = cor[j];
       int64_t t1, t2;
       if (m < 0) { t1 = p.saved[(int64_t)ch * IF + j]; t2 = p.saved[(int64_t)ch * IF + cj]; }
       else { t1 = sub(w, j); t2 = (cj == j) ? t1 : sub(w, cj); }
       if (cj != j) {
-        const int64_t tn = p.sign[j] ? wrap64(-t2, p.acc.W, 1) : t2;
+        const int64_t tn = sgn[j] ? wrap64(-t2, p.acc.W, 1) : t2;
         y = requant64((t1 + tn) >> 1, p.acc.F, p.out);
       } else {
         y = requant64(t1, p.acc.F, p.out);
@@ -211,13 +213,18 @@ __global__ void polyintr_save_kernel(PolyIntrParams p, int64_t *saved_next) {
 hipError_t launch_polyintr(const PolyIntrParams &p, int64_t *saved_next, hipStream_t s) {
   if (p.n_out > 0) {
     const int n_win_max = p.n_taps + kPiTile / p.ifac + 4;
-    const size_t lds = ((size_t)p.coeff_sz + (size_t)n_win_max) * sizeof(int64_t);
+    const size_t lds = ((size_t)p.coeff_sz + 2 + (size_t)n_win_max) * sizeof(int64_t) + 512;
     if (p.lossless && lds <= 60 * 1024) {
       dim3 grid((unsigned)((p.n_out + kPiTile - 1) / kPiTile), (unsigned)p.n_ch);
       const uint32_t rcp = (uint32_t)((0x100000000ull + p.ifac - 1) / p.ifac);
       const bool narrow = p.in.W <= 30 && p.cf.W <= 32;
-      if (narrow) { hipLaunchKernelGGL(polyintr_fast_kernel<true>, grid, dim3(256), lds, s, p, rcp, n_win_max); }
-      else { hipLaunchKernelGGL(polyintr_fast_kernel<false>, grid, dim3(256), lds, s, p, rcp, n_win_max); }
+#define ACDSP_PI_LAUNCH(NV, FV) hipLaunchKernelGGL((polyintr_fast_kernel<NV, FV>), grid, dim3(256), lds, s, p, rcp, n_win_max)
+      if (narrow) {
+        if (p.ftype == 0) { ACDSP_PI_LAUNCH(true, 0); } else if (p.ftype == 1) { ACDSP_PI_LAUNCH(true, 1); } else { ACDSP_PI_LAUNCH(true, 2); }
+      } else {
+        if (p.ftype == 0) { ACDSP_PI_LAUNCH(false, 0); } else if (p.ftype == 1) { ACDSP_PI_LAUNCH(false, 1); } else { ACDSP_PI_LAUNCH(false, 2); }
+      }
+#undef ACDSP_PI_LAUNCH
     } else {
       dim3 grid((unsigned)((p.n_out + 255) / 256), (unsigned)p.n_ch);
       hipLaunchKernelGGL(polyintr_kernel, grid, dim3(256), 0, s, p);
