@@ -926,26 +926,41 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
     const int64_t T0 = (d0 + s) * 2048;
     // ---------------- phase M: column set 0 = chunks n + b, set 1 = chunks 32 + n + b ----------------
     v16i h0 = {0}, m0 = {0}, l0 = ll_init, h1 = {0}, m1 = {0}, l1 = ll_init;
-    v4i Ahc = ah[0], Alc = al[0];
-    v4i Bh0c = *(const v4i *)fh, Bl0c = *(const v4i *)fl, Bh1c = *(const v4i *)(fh + 512), Bl1c = *(const v4i *)(fl + 512);
-    for (int b = 0; b < NB; b++) {
-      v4i Ahn = Ahc, Aln = Alc, Bh0n = Bh0c, Bl0n = Bl0c, Bh1n = Bh1c, Bl1n = Bl1c;
+    // fragments of K-block b live in slot b % 3 and are fetched two blocks ahead (one block = 4..8 MFMAs = 128..256
+    // cycles, less than an LDS round trip when all eight waves of the workgroup are reading)
+    struct Frag { v4i Ah, Al, Bh0, Bl0, Bh1, Bl1; };
+    auto fetch = [&](Frag &f, int bb) {
+      f.Ah = ah[bb * 64]; f.Al = al[bb * 64];
+      f.Bh0 = *(const v4i *)(fh + 16 * bb); f.Bl0 = *(const v4i *)(fl + 16 * bb);
+      f.Bh1 = *(const v4i *)(fh + 512 + 16 * bb); f.Bl1 = *(const v4i *)(fl + 512 + 16 * bb);
+    };
+    auto mac = [&](const Frag &f, int bb) {
+      if (bb >= a.hb0 && bb <= a.hb1) {
+        h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.Ah, f.Bh0, h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.Ah, f.Bh1, h1, 0, 0, 0);
+        m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.Ah, f.Bl0, m0, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.Ah, f.Bl1, m1, 0, 0, 0);
+      }
+      l0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.Al, f.Bl0, l0, 0, 0, 0);
+      l1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.Al, f.Bl1, l1, 0, 0, 0);
+      m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.Al, f.Bh0, m0, 0, 0, 0);
+      m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.Al, f.Bh1, m1, 0, 0, 0);
+    };
+    Frag F0, F1, F2;
+    fetch(F0, 0);
+    if (NB > 1) { fetch(F1, 1); } else { F1 = F0; }
+    F2 = F0;
+    for (int b = 0; b < NB; b += 3) {
+      if (b + 2 < NB) { fetch(F2, b + 2); }
+      mac(F0, b);
       if (b + 1 < NB) {
-        Ahn = ah[(b + 1) * 64]; Aln = al[(b + 1) * 64];
-        Bh0n = *(const v4i *)(fh + 16 * (b + 1)); Bl0n = *(const v4i *)(fl + 16 * (b + 1));
-        Bh1n = *(const v4i *)(fh + 512 + 16 * (b + 1)); Bl1n = *(const v4i *)(fl + 512 + 16 * (b + 1));
+        if (b + 3 < NB) { fetch(F0, b + 3); }
+        mac(F1, b + 1);
       }
-      if (b >= a.hb0 && b <= a.hb1) {
-        h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bh0c, h0, 0, 0, 0);
-        h1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bh1c, h1, 0, 0, 0);
-        m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bl0c, m0, 0, 0, 0);
-        m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahc, Bl1c, m1, 0, 0, 0);
+      if (b + 2 < NB) {
+        if (b + 4 < NB) { fetch(F1, b + 4); }
+        mac(F2, b + 2);
       }
-      l0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bl0c, l0, 0, 0, 0);
-      l1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bl1c, l1, 0, 0, 0);
-      m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bh0c, m0, 0, 0, 0);
-      m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alc, Bh1c, m1, 0, 0, 0);
-      Ahc = Ahn; Alc = Aln; Bh0c = Bh0n; Bl0c = Bl0n; Bh1c = Bh1n; Bl1c = Bl1n;
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
