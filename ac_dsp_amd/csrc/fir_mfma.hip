@@ -855,7 +855,9 @@ fir_mfma_big_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
 // A fragment fetched from LDS feeds eight MFMAs instead of four.  With NB = 33 the single-wide kernel moves
 // 4 KB of LDS per four MFMAs per wave -- ~220 of the 256 B/clk the LDS delivers, i.e. it is LDS-bound as much as
 // MFMA-bound; here it is 6 KB per eight.  The two sets share their halo (one staged array of 64 + NB - 1 chunks,
-// single-buffered: a wave stages step s+1 in its own O phase, after its own M phase is done reading).
+// single-buffered: a wave stages step s+1 in its own O phase, after its own M phase is done reading).  The eight
+// waves of a workgroup share only the A fragments and run free (the ping-pong barriers of the single-wide kernel
+// cost 20 % here: 2.86 -> 2.30 ms on config 4).
 // Launched over chunks of complete double steps only (EPI 1 / 2); the ragged rest goes to fir_mfma_big_kernel.
 template <int EPI>
 __global__ void __launch_bounds__(512, 1)
@@ -865,7 +867,6 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   const int HB = NB - 1, NC = 64 + HB, NP = 4 * NC, ARR = staged_array_bytes(NC);
   constexpr int JN = 6;   // NP <= 4 * 96
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int grp = wave >> 2;
   const int n_col = lane & 31, h = lane >> 5;
   int ch = blockIdx.y * 8 + wave;
   if (ch >= p.n_ch) { ch = p.n_ch - 1; }
@@ -920,7 +921,6 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   __syncthreads();          // A fragments visible to every wave
   stage();
   issue_loads(nsteps > 1 ? (d0 + 1) * 2048 : t_last);
-  if (grp == 1) { __builtin_amdgcn_s_barrier(); }
 
   for (int s = 0; s < nsteps; s++) {
     const int64_t T0 = (d0 + s) * 2048;
@@ -963,7 +963,6 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
 
     // ---------------- phase O ----------------
 #pragma unroll
@@ -995,7 +994,6 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
       const int64_t tn = T0 + 4096;
       issue_loads(tn < t_last ? tn : t_last);
     }
-    if (grp == 0 || s + 1 < nsteps) { __builtin_amdgcn_s_barrier(); }
   }
 }
 
