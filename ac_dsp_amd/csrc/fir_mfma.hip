@@ -691,7 +691,8 @@ static hipError_t launch_nb(const FirParams &p, const uint32_t *d_frag, const Mf
 // Large tap counts (NB = 10 .. 33, e.g. the 1023-tap configuration): the 2*NB Toeplitz fragments no
 // longer fit the register file, so they live in LDS (2 KB per K-block, one shared coefficient set per
 // launch) and are read next to the data fragments: four ds_read_b128 per four MFMAs, ~50 % of the LDS
-// bandwidth.  Same one-channel-per-wave mapping, same 8-wave ping-pong, run-time K loop.
+// bandwidth.  Same one-channel-per-wave mapping, eight free-running waves per workgroup (they share only the A
+// fragments; ping-pong barriers measured 20 % slower on the double-wide variant below), run-time K loop.
 // =============================================================================================
 template <int EPI, bool FAST>
 __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
@@ -700,7 +701,6 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
   const int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, ARR = staged_array_bytes(NC);
   constexpr int JN = 4;   // NP <= 256
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int grp = wave >> 2;
   const int n_col = lane & 31, h = lane >> 5;
   int ch = blockIdx.y * 8 + wave;
   if (ch >= p.n_ch) { ch = p.n_ch - 1; }
@@ -755,7 +755,6 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
   __syncthreads();          // A fragments visible to every wave (also drains the first loads: once per chunk)
   stage(lds);
   if (FAST || nsteps > 1) { issue_loads((s0 + 1) * 1024); }
-  if (grp == 1) { __builtin_amdgcn_s_barrier(); }
 
   for (int s = 0; s < nsteps; s++) {
     const int64_t T0 = (s0 + s) * 1024;
@@ -782,7 +781,6 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
       Ahc = Ahn; Alc = Aln; Bhc = Bhn; Blc = Bln;
     }
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
 
     // ---------------- phase O ----------------
     int o16[16];
@@ -835,7 +833,6 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
       stage(lds + ((s + 1) & 1) * (4 * ARR));
       if (FAST || s + 2 < nsteps) { issue_loads(T0 + 2048); }
     }
-    if (grp == 0 || s + 1 < nsteps) { __builtin_amdgcn_s_barrier(); }
   }
 }
 
