@@ -1080,6 +1080,8 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   // >= 16384 waves when the problem allows it; a chunk re-reads NB-1 halo blocks per step anyway
   int64_t spw = (a.n_steps * p.n_ch + 16383) / 16384;
   if (spw < 8) { spw = 8; }
+  static const char *spw_env = getenv("ACDSP_FIR_SPW");   // tuning knob: 1024-sample steps per wave
+  if (spw_env && atoi(spw_env) > 1) { spw = atoi(spw_env); }
   a.steps_per_wave = spw;
   const int oeb = p.out_eb;
   a.out_vec_ok = ((uintptr_t)p.y % (4 * oeb) == 0) && ((p.out_stride * oeb) % (4 * oeb) == 0);
