@@ -129,6 +129,12 @@ SYMBOLS = {
     "acdsp_intgdump_run": (_i32, [_vp, _vp, _i64, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64), _vp]),
     "acdsp_intgdump_run_host": (_i32, [_vp, _vp, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64)]),
     "acdsp_intgdump_reset": (_i32, [_vp]),
+    "acdsp_fir_state_size": (_i64, [_vp]),
+    "acdsp_fir_state_get": (_i32, [_vp, _vp, C.c_uint64]),
+    "acdsp_fir_state_set": (_i32, [_vp, _vp, C.c_uint64]),
+    "acdsp_cic_state_size": (_i64, [_vp]),
+    "acdsp_cic_state_get": (_i32, [_vp, _vp, C.c_uint64]),
+    "acdsp_cic_state_set": (_i32, [_vp, _vp, C.c_uint64]),
     "acdsp_stream_write": (_i32, [C.c_char_p, C.POINTER(StreamHdr), _vp]),
     "acdsp_stream_read_header": (_i32, [C.c_char_p, C.POINTER(StreamHdr)]),
     "acdsp_stream_read": (_i32, [C.c_char_p, _vp, C.c_uint64]),

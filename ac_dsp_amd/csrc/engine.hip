@@ -6,6 +6,7 @@
 // every run() launches HIP kernels, and creation fails without a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -37,7 +38,16 @@ int fail(int code, const char *fmt, ...) {
     if (e_ != hipSuccess) { return fail(ACDSP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
   } while (0)
 
+// Device check of every entry point.  The architecture test (hipGetDeviceProperties: ~100 us) runs once per device and
+// process; later calls only make `device` the calling thread's current device when it is not already.
 int check_device(int device) {
+  static std::atomic<uint64_t> verified{0};   // bit d: device d has been seen to be a gfx950
+  if (device >= 0 && device < 64 && ((verified.load(std::memory_order_relaxed) >> device) & 1)) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == device) { return ACDSP_OK; }
+    HIP_TRY(hipSetDevice(device));
+    return ACDSP_OK;
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { return fail(ACDSP_ENODEVICE, "no HIP device visible"); }
   if (device < 0 || device >= n) { return fail(ACDSP_EINVAL, "device %d out of range (%d devices)", device, n); }
@@ -47,6 +57,7 @@ int check_device(int device) {
     return fail(ACDSP_ENODEVICE, "device %d is %s; this engine is built for gfx950 only", device, prop.gcnArchName);
   }
   HIP_TRY(hipSetDevice(device));
+  if (device < 64) { verified.fetch_or(uint64_t(1) << device, std::memory_order_relaxed); }
   return ACDSP_OK;
 }
 
@@ -345,9 +356,13 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   // the const-coefficient class may trade it for an input history.
   h->use_rt = desc->ftype == ACDSP_TRANSPOSED && desc->kind != ACDSP_FIR_CONST;
   const int fi = desc->in.W - desc->in.I, fc = desc->coeff.W - desc->coeff.I, fa = desc->acc.W - desc->acc.I;
-  bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && !h->use_rt;
+  // exact-dot-product class: the kernels compute `sum << (fa - fi - fc)` in 64 bits, so the shift must be 0..63 (formats
+  // with I outside [0, W] can ask for more: those stay on the per-tap path)
+  bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && !h->use_rt;
   const int ift = internal_ftype(desc->kind, desc->ftype);
   if (is_fold_odd(ift)) {
+    // the ACC_TYPE `fold` must also keep every fraction bit of the pre-add (fc < 0 would let fa >= fi + fc pass with fa < fi)
+    lossless = lossless && fa >= fi;
     // the ACC_TYPE `fold` variable must hold x[i] +/- x[N-1-i] without wrapping (a difference needs a signed type)
     int need_i = desc->in.I + 1 + ((desc->acc.S && !desc->in.S) ? 1 : 0);
     lossless = lossless && desc->acc.I >= need_i && (desc->acc.S || (!desc->in.S && ift != kRsFoldOddAnti));
@@ -634,7 +649,7 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
   if (desc->R > 256) { return fail(ACDSP_EUNSUPPORTED, "CIC: R=%d > 256 (8-bit rate counter in the reference)", desc->R); }
   if (desc->interp && desc->R < 2) { return fail(ACDSP_EUNSUPPORTED, "CIC interpolator: R=1 never re-arms in the reference (ac_cic_full_core.h:146-158)"); }
   if (desc->interp && desc->N > 255) { return fail(ACDSP_EUNSUPPORTED, "CIC: N too large"); }
-  if (desc->n_channels < 1) { return fail(ACDSP_EINVAL, "CIC: n_channels must be >= 1"); }
+  if (desc->n_channels < 1 || desc->n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "CIC: n_channels=%d outside 1..65535", desc->n_channels); }
   if ((rc = check_device(desc->device))) { return rc; }
   acdsp_cic *h = new acdsp_cic();
   h->d = *desc;
@@ -897,7 +912,7 @@ int32_t acdsp_polydec_create(const acdsp_polydec_desc_t *desc, acdsp_polydec_t *
   h->in_eb = elem_bytes(desc->in.W);
   h->out_eb = elem_bytes(desc->out.W);
   h->hl = round_up(desc->n_taps * desc->df + 15, 32);
-  h->lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc;
+  h->lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64;
   const size_t hb = (size_t)desc->n_channels * h->hl * h->in_eb;
   hipError_t e = hipSuccess;
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
@@ -1347,7 +1362,7 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
   {  // exact-accumulation class (see polyintr_acc_fast): the `fold` needs one more integer bit than IN_TYPE
     const int fi = p.in.F, fc = p.cf.F, fa = p.acc.F;
     p.lossless_shift = fa - fi - fc;
-    p.lossless = !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && d.in.S && d.acc.S && d.acc.O == ACDSP_WRAP && p.lossless_shift >= 0 &&
+    p.lossless = !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && d.in.S && d.acc.S && d.acc.O == ACDSP_WRAP && p.lossless_shift >= 0 && p.lossless_shift < 64 && fa >= fi &&
                  d.acc.I >= d.in.I + 1 && d.acc.W <= 63 && (d.in.O == ACDSP_WRAP || d.in.O == ACDSP_SAT || d.in.O == ACDSP_SAT_SYM || d.in.O == ACDSP_SAT_ZERO);
   }
   p.in_stride = in_stride; p.out_stride = out_stride; p.n = n_in; p.n_out = no;
@@ -1565,6 +1580,129 @@ int32_t acdsp_intgdump_reset(acdsp_intgdump_t h) {
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
+// state save / restore (SURVEY 8b export list, section 5 checkpoint / resume hook)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// 64-byte little-endian header in front of the raw state words.
+struct StateHdr {
+  char magic[8];            // "ACDSPST1"
+  uint32_t version;         // 1
+  uint32_t kind;            // 1: FIR input history, 2: FIR reg_trans partial sums, 3: CIC input history + input count
+  uint32_t n_channels;
+  uint32_t elem_bytes;      // bytes per state word (IN container, or 8 for reg_trans)
+  uint64_t per_channel;     // state words per channel
+  int64_t t_total;          // CIC: inputs consumed so far (decimation / interpolation phase); 0 for FIR
+  uint32_t p0, p1, p2, p3;  // FIR: n_taps, ftype, class, 0;  CIC: R, M, N, interp
+  uint64_t reserved;
+};
+static_assert(sizeof(StateHdr) == 64, "state header is 64 bytes");
+const char kStateMagic[8] = {'A', 'C', 'D', 'S', 'P', 'S', 'T', '1'};
+
+StateHdr fir_state_hdr(const acdsp_fir *h) {
+  StateHdr s;
+  memset(&s, 0, sizeof s);
+  memcpy(s.magic, kStateMagic, 8);
+  s.version = 1;
+  s.kind = h->use_rt ? 2 : 1;
+  s.n_channels = (uint32_t)h->d.n_channels;
+  s.elem_bytes = h->use_rt ? 8 : (uint32_t)h->in_eb;
+  s.per_channel = h->use_rt ? (uint64_t)h->d.n_taps : (uint64_t)h->hl;
+  s.p0 = (uint32_t)h->d.n_taps; s.p1 = (uint32_t)h->d.ftype; s.p2 = (uint32_t)h->d.kind;
+  return s;
+}
+StateHdr cic_state_hdr(const acdsp_cic *h) {
+  StateHdr s;
+  memset(&s, 0, sizeof s);
+  memcpy(s.magic, kStateMagic, 8);
+  s.version = 1;
+  s.kind = 3;
+  s.n_channels = (uint32_t)h->d.n_channels;
+  s.elem_bytes = (uint32_t)h->in_eb;
+  s.per_channel = (uint64_t)h->hl;
+  s.t_total = h->t_total;
+  s.p0 = (uint32_t)h->d.R; s.p1 = (uint32_t)h->d.M; s.p2 = (uint32_t)h->d.N; s.p3 = (uint32_t)h->d.interp;
+  return s;
+}
+uint64_t state_payload(const StateHdr &s) { return (uint64_t)s.n_channels * s.per_channel * s.elem_bytes; }
+
+// everything but t_total must agree between the blob and the handle it is loaded into
+bool state_compatible(const StateHdr &blob, const StateHdr &mine) {
+  return memcmp(blob.magic, kStateMagic, 8) == 0 && blob.version == 1 && blob.kind == mine.kind && blob.n_channels == mine.n_channels &&
+         blob.elem_bytes == mine.elem_bytes && blob.per_channel == mine.per_channel && blob.p0 == mine.p0 && blob.p1 == mine.p1 &&
+         blob.p2 == mine.p2 && blob.p3 == mine.p3;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t acdsp_fir_state_size(acdsp_fir_t h) { return h ? (int64_t)(sizeof(StateHdr) + state_payload(fir_state_hdr(h))) : -1; }
+
+int32_t acdsp_fir_state_get(acdsp_fir_t h, void *buf, uint64_t cap_bytes) {
+  if (!h || !buf) { return fail(ACDSP_EINVAL, "null argument"); }
+  const StateHdr s = fir_state_hdr(h);
+  const uint64_t pay = state_payload(s);
+  if (cap_bytes < sizeof s + pay) { return fail(ACDSP_EINVAL, "fir_state_get: buffer of %llu bytes, state needs %llu", (unsigned long long)cap_bytes, (unsigned long long)(sizeof s + pay)); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());   // run() is asynchronous: the state of the last call must have landed
+  memcpy(buf, &s, sizeof s);
+  HIP_TRY(hipMemcpy((char *)buf + sizeof s, h->use_rt ? (const void *)h->d_rt[h->cur] : h->d_hist[h->cur], pay, hipMemcpyDeviceToHost));
+  return ACDSP_OK;
+}
+
+int32_t acdsp_fir_state_set(acdsp_fir_t h, const void *buf, uint64_t bytes) {
+  if (!h || !buf) { return fail(ACDSP_EINVAL, "null argument"); }
+  const StateHdr mine = fir_state_hdr(h);
+  StateHdr s;
+  if (bytes < sizeof s) { return fail(ACDSP_EINVAL, "fir_state_set: blob shorter than its header"); }
+  memcpy(&s, buf, sizeof s);
+  if (!state_compatible(s, mine) || bytes != sizeof s + state_payload(mine)) {
+    return fail(ACDSP_EINVAL, "fir_state_set: blob does not belong to a filter of this class / tap count / channel count");
+  }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->use_rt ? (void *)h->d_rt[h->cur] : h->d_hist[h->cur], (const char *)buf + sizeof s, state_payload(mine), hipMemcpyHostToDevice));
+  return ACDSP_OK;
+}
+
+int64_t acdsp_cic_state_size(acdsp_cic_t h) { return h ? (int64_t)(sizeof(StateHdr) + state_payload(cic_state_hdr(h))) : -1; }
+
+int32_t acdsp_cic_state_get(acdsp_cic_t h, void *buf, uint64_t cap_bytes) {
+  if (!h || !buf) { return fail(ACDSP_EINVAL, "null argument"); }
+  const StateHdr s = cic_state_hdr(h);
+  const uint64_t pay = state_payload(s);
+  if (cap_bytes < sizeof s + pay) { return fail(ACDSP_EINVAL, "cic_state_get: buffer of %llu bytes, state needs %llu", (unsigned long long)cap_bytes, (unsigned long long)(sizeof s + pay)); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  memcpy(buf, &s, sizeof s);
+  HIP_TRY(hipMemcpy((char *)buf + sizeof s, h->d_hist[h->cur], pay, hipMemcpyDeviceToHost));
+  return ACDSP_OK;
+}
+
+int32_t acdsp_cic_state_set(acdsp_cic_t h, const void *buf, uint64_t bytes) {
+  if (!h || !buf) { return fail(ACDSP_EINVAL, "null argument"); }
+  const StateHdr mine = cic_state_hdr(h);
+  StateHdr s;
+  if (bytes < sizeof s) { return fail(ACDSP_EINVAL, "cic_state_set: blob shorter than its header"); }
+  memcpy(&s, buf, sizeof s);
+  if (!state_compatible(s, mine) || bytes != sizeof s + state_payload(mine) || s.t_total < 0) {
+    return fail(ACDSP_EINVAL, "cic_state_set: blob does not belong to a CIC filter of these parameters / channel count");
+  }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->d_hist[h->cur], (const char *)buf + sizeof s, state_payload(mine), hipMemcpyHostToDevice));
+  h->t_total = s.t_total;
+  return ACDSP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
 // raw-integer stream files (second half): the [channel][time] layout of section 3 of DESIGN.md on disk /
 // on the wire -- a 64-byte little-endian header followed by n_channels rows of `stride` containers.  Host-side only.
 // ---------------------------------------------------------------------------------------------
@@ -1573,17 +1711,27 @@ extern "C" {
 static const char kStreamMagic[8] = {'A', 'C', 'D', 'S', 'P', 'R', 'A', 'W'};
 static_assert(sizeof(acdsp_stream_hdr_t) == 64, "stream header is 64 bytes on disk");
 
+// n_channels * stride * elem_bytes of a header, or false when the product leaves 64 bits (a header from an untrusted file
+// could otherwise wrap to a small size that passes the capacity check)
+static bool stream_payload_bytes(const acdsp_stream_hdr_t &h, uint64_t *bytes) {
+  uint64_t rows = 0;
+  return !__builtin_mul_overflow(h.n_channels, h.stride, &rows) && !__builtin_mul_overflow(rows, (uint64_t)h.elem_bytes, bytes);
+}
+
 int32_t acdsp_stream_write(const char *path, const acdsp_stream_hdr_t *hdr, const void *data) {
   if (!path || !hdr || (!data && hdr->n_channels * hdr->stride > 0)) { return fail(ACDSP_EINVAL, "stream_write: null argument"); }
   if (hdr->elem_bytes != (uint32_t)elem_bytes(hdr->fmt.W) || hdr->stride < hdr->n_samples) {
     return fail(ACDSP_EINVAL, "stream_write: elem_bytes must be acdsp_elem_bytes(W) and stride >= n_samples");
   }
+  int rc = check_fmt(hdr->fmt, "stream format");
+  if (rc) { return rc; }
+  uint64_t bytes = 0;
+  if (!stream_payload_bytes(*hdr, &bytes)) { return fail(ACDSP_EINVAL, "stream_write: n_channels * stride * elem_bytes overflows"); }
   FILE *f = fopen(path, "wb");
   if (!f) { return fail(ACDSP_EINVAL, "stream_write: cannot open %s", path); }
   acdsp_stream_hdr_t h = *hdr;
   memcpy(h.magic, kStreamMagic, 8);
   h.version = 1; h.reserved = 0;
-  const size_t bytes = (size_t)h.n_channels * (size_t)h.stride * h.elem_bytes;
   const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (bytes == 0 || fwrite(data, 1, bytes, f) == bytes);
   fclose(f);
   return ok ? ACDSP_OK : fail(ACDSP_EINVAL, "stream_write: short write to %s", path);
@@ -1594,10 +1742,17 @@ int32_t acdsp_stream_read_header(const char *path, acdsp_stream_hdr_t *hdr) {
   FILE *f = fopen(path, "rb");
   if (!f) { return fail(ACDSP_EINVAL, "stream_read_header: cannot open %s", path); }
   const bool ok = fread(hdr, sizeof *hdr, 1, f) == 1;
+  long fsize = -1;
+  if (ok && fseek(f, 0, SEEK_END) == 0) { fsize = ftell(f); }
   fclose(f);
   if (!ok || memcmp(hdr->magic, kStreamMagic, 8) != 0 || hdr->version != 1) { return fail(ACDSP_EINVAL, "%s is not an ACDSPRAW v1 stream", path); }
-  if (hdr->fmt.W < 1 || hdr->fmt.W > 64 || hdr->elem_bytes != (uint32_t)elem_bytes(hdr->fmt.W) || hdr->stride < hdr->n_samples) {
+  uint64_t bytes = 0;
+  if (check_fmt(hdr->fmt, "stream format") != ACDSP_OK || hdr->elem_bytes != (uint32_t)elem_bytes(hdr->fmt.W) || hdr->stride < hdr->n_samples ||
+      !stream_payload_bytes(*hdr, &bytes)) {
     return fail(ACDSP_EINVAL, "%s: inconsistent stream header", path);
+  }
+  if (fsize < 0 || (uint64_t)fsize < sizeof *hdr || (uint64_t)fsize - sizeof *hdr < bytes) {
+    return fail(ACDSP_EINVAL, "%s: header announces %llu payload bytes, the file holds fewer", path, (unsigned long long)bytes);
   }
   return ACDSP_OK;
 }
@@ -1606,7 +1761,8 @@ int32_t acdsp_stream_read(const char *path, void *data, uint64_t cap_bytes) {
   acdsp_stream_hdr_t h;
   int rc = acdsp_stream_read_header(path, &h);
   if (rc) { return rc; }
-  const uint64_t bytes = h.n_channels * h.stride * h.elem_bytes;
+  uint64_t bytes = 0;
+  if (!stream_payload_bytes(h, &bytes)) { return fail(ACDSP_EINVAL, "stream_read: inconsistent stream header"); }
   if (bytes > cap_bytes || (bytes > 0 && !data)) { return fail(ACDSP_EINVAL, "stream_read: buffer of %llu bytes for %llu", (unsigned long long)cap_bytes, (unsigned long long)bytes); }
   FILE *f = fopen(path, "rb");
   if (!f) { return fail(ACDSP_EINVAL, "stream_read: cannot open %s", path); }

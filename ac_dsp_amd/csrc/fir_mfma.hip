@@ -1044,6 +1044,9 @@ static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArg
 
 // Can the all-32-bit epilogue be used for this plan / type combination?  0: no, 1: WRAP, 2: SAT
 int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
+  // an unsigned AC_WRAP accumulator turns every negative sum into 2^W - |v| before OUT_TYPE sees it (the reference's
+  // `acc += ...` assignment): only the generic epilogue wraps to ACC_TYPE, the fast ones convert the signed sum
+  if (!p.acc.S) { return 0; }
   const int rs = p.in.F + p.cf.F - p.out.F;
   // |y| <= 32768 * sum|c| must fit the accumulator (no AC_WRAP event possible) ...
   const int acc_bits = p.acc.W - (p.acc.S ? 1 : 0) - p.lossless_shift;

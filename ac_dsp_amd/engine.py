@@ -80,6 +80,15 @@ class Fir:
         check(lib.acdsp_fir_run_host(self._h, x.ctypes.data_as(C.c_void_p), x.shape[1], y.ctypes.data_as(C.c_void_p)))
         return y
 
+    def state(self):
+        """Versioned state blob (bytes): input history / reg_trans of every channel (acdsp_fir_state_get)."""
+        buf = (C.c_char * lib.acdsp_fir_state_size(self._h))()
+        check(lib.acdsp_fir_state_get(self._h, buf, len(buf)))
+        return bytes(buf)
+
+    def set_state(self, blob):
+        check(lib.acdsp_fir_state_set(self._h, C.c_char_p(blob), len(blob)))
+
     def reset(self):
         check(lib.acdsp_fir_reset(self._h))
 
@@ -147,6 +156,15 @@ class Cic:
         check(lib.acdsp_cic_run_host(self._h, x.ctypes.data_as(C.c_void_p), x.shape[1], y.ctypes.data_as(C.c_void_p),
                                      y.shape[1], C.byref(n_out)))
         return y[:, :n_out.value]
+
+    def state(self):
+        """Versioned state blob (bytes): input history and input count (phase) of every channel (acdsp_cic_state_get)."""
+        buf = (C.c_char * lib.acdsp_cic_state_size(self._h))()
+        check(lib.acdsp_cic_state_get(self._h, buf, len(buf)))
+        return bytes(buf)
+
+    def set_state(self, blob):
+        check(lib.acdsp_cic_state_set(self._h, C.c_char_p(blob), len(blob)))
 
     def reset(self):
         check(lib.acdsp_cic_reset(self._h))

@@ -251,6 +251,24 @@ int32_t acdsp_intgdump_run_host(acdsp_intgdump_t h, const void *h_in, const int6
                                 int64_t out_cap, int64_t *n_out);
 int32_t acdsp_intgdump_reset(acdsp_intgdump_t h);
 
+/* ---- state save / restore (checkpoint / resume, moving a stream to another GPU) ----
+ * The reference's filter state is plain object members (shift register / reg_trans: ac_fir_const_coeffs.h:124-127;
+ * integrator / comb registers and rate counters: ac_cic_full_core.h:71-74,219) that a caller can copy with the object.
+ * Here it is a versioned little-endian blob: a 64-byte header (magic "ACDSPST1", kind, channel count, word size, words per
+ * channel, the CIC input count, the filter parameters) followed by the raw state words [channel][word]:
+ *   FIR   -- the last `per_channel` input samples of every channel, oldest first (word per_channel-1-k is reg[k] of the
+ *            reference's shift register); TRANSPOSED load/prog filters: reg_trans[0..N_TAPS-1] as int64 ACC raw words;
+ *   CIC   -- the last `per_channel` input samples (both directions are FIR systems of the input)
+ *            plus the number of inputs consumed so far (= rate_cnt phase).
+ * state_get waits for the handle's pending run() calls.  state_set accepts only a blob from a handle of the same class,
+ * parameters and channel count (ACDSP_EINVAL otherwise); coefficients are not part of the state. */
+int64_t acdsp_fir_state_size(acdsp_fir_t h);                                   /* bytes state_get writes; -1 on a null handle */
+int32_t acdsp_fir_state_get(acdsp_fir_t h, void *h_buf, uint64_t cap_bytes);
+int32_t acdsp_fir_state_set(acdsp_fir_t h, const void *h_buf, uint64_t bytes);
+int64_t acdsp_cic_state_size(acdsp_cic_t h);
+int32_t acdsp_cic_state_get(acdsp_cic_t h, void *h_buf, uint64_t cap_bytes);
+int32_t acdsp_cic_state_set(acdsp_cic_t h, const void *h_buf, uint64_t bytes);
+
 /* ---- raw-integer stream files (host side; no device needed) ---- */
 int32_t acdsp_stream_write(const char *path, const acdsp_stream_hdr_t *hdr, const void *data);
 int32_t acdsp_stream_read_header(const char *path, acdsp_stream_hdr_t *hdr);

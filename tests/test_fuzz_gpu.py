@@ -35,6 +35,8 @@ FIR_TYPES = [
     (A.Fmt(36, 21), A.Fmt(16, 1), A.Fmt(60, 30)),                      # wide words: multi-plane MFMA
     (A.Fmt(24, 8), A.Fmt(18, 2), A.Fmt(50, 12)),
     (A.Fmt(14, 4), A.Fmt(12, 2), A.Fmt(20, 8, True, "RND", "SAT")),    # lossy accumulator: exact-order VALU kernel
+    (A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12, False)),                # unsigned wrapping accumulator under signed data
+    (A.Fmt(12, 4, False), A.Fmt(14, 1), A.Fmt(36, 12)),                # unsigned input
 ]
 FIR_OUTS = [A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(16, 2, True, "TRN", "WRAP"), A.Fmt(16, 6, True, "RND", "SAT"), A.Fmt(40, 12),
             A.Fmt(24, 9, True, "RND", "SAT"), A.Fmt(34, 4, True, "TRN", "WRAP"), A.Fmt(12, 5, True, "RND_CONV", "SAT_SYM")]

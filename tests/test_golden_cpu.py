@@ -1,0 +1,100 @@
+"""The CPU oracle against the vectors the reference's own headers produced (tests/golden/ref_hdr, tools/gen_golden):
+every class of SURVEY section 8, all FTYPEs, the BASELINE types, lossy / saturating / unsigned accumulators, mid-stream
+coefficient reloads and chunked calls.  This is what pins oracle/acdsp_oracle.c to the reference's loop source."""
+import numpy as np
+import pytest
+
+import golden_cases as G
+from oracle import Fmt, OracleFir, OracleCic, OraclePolyDec, OraclePolyIntr, OracleIntgDump
+
+FIR = G.load(("const", "load", "prog"))
+RS = G.load(("reg_share",))
+CIC = G.load(("cic_dec", "cic_intr"))
+PDEC = G.load(("poly_dec",))
+PINT = G.load(("poly_intr",))
+IDMP = G.load(("intg_dump",))
+
+
+def F(a):
+    return G.fmt_of(Fmt, a)
+
+
+def test_fixture_inventory():
+    names = [c["name"] for c in FIR]
+    for ft in ("SHIFT_REG", "ROTATE_SHIFT", "C_BUFF", "FOLD_EVEN", "FOLD_ODD", "TRANSPOSED"):
+        for cls in ("const", "load", "prog"):
+            assert any(n.startswith("%s_base_%s_255" % (cls, ft)) for n in names), (cls, ft)
+    assert len(FIR) >= 100 and len(RS) >= 10 and len(CIC) >= 12 and len(PDEC) >= 5 and len(PINT) >= 8 and len(IDMP) >= 4
+
+
+@pytest.mark.parametrize("c", FIR, ids=G.ids(FIR))
+def test_fir_oracle_matches_reference_headers(c):
+    o = OracleFir(c["n_taps"], c["ftype"], F(c["in"]), F(c["coeff"]), F(c["acc"]), F(c["out"]))
+    x = G.arr(c, "x")
+    y = np.concatenate([o.run(cf, x[a:b])[0] for cf, a, b in G.segments(c)])
+    assert np.array_equal(y, G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("c", RS, ids=G.ids(RS))
+def test_reg_share_oracle_matches_reference_header(c):
+    o = OracleFir(c["n_taps"], c["ftype"], F(c["in"]), F(c["coeff"]), F(c["acc"]), F(c["out"]),
+                  reg_share=(c["mem_word_width"], c["blk_sz"], c["blk_offset"]))
+    x = G.arr(c, "x")
+    y, dl = [], []
+    for t in range(len(x)):
+        y.append(o.run(G.arr(c, "coeffs"), x[t:t + 1])[0, 0])
+        dl.append(o.delay_line()[0])
+    assert np.array_equal(np.array(y), G.arr(c, "y"))
+    assert np.array_equal(np.array(dl), G.arr(c, "delay_line"))
+
+
+@pytest.mark.parametrize("c", CIC, ids=G.ids(CIC))
+def test_cic_oracle_matches_reference_headers(c):
+    o = OracleCic(c["class"] == "cic_intr", c["R"], c["M"], c["N"], F(c["in"]), F(c["out"]))
+    x = G.arr(c, "x")
+    pos, ys = 0, []
+    for k, want in zip(c["calls"], c["outs_per_call"]):
+        yk = o.run(x[pos:pos + k])[0]
+        assert len(yk) == want, "call of %d inputs produced %d outputs, the reference %d" % (k, len(yk), want)
+        ys.append(yk)
+        pos += k
+    assert np.array_equal(np.concatenate(ys), G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("c", PDEC, ids=G.ids(PDEC))
+def test_poly_dec_oracle_matches_reference_header(c):
+    o = OraclePolyDec(c["n_taps"], c["df"], F(c["in"]), F(c["coeff"]), F(c["acc"]), F(c["out"]))
+    x = G.arr(c, "x")
+    pos, ys = 0, []
+    for k in c["calls"]:
+        ys.append(o.run(G.arr(c, "coeffs"), x[pos:pos + k])[0])
+        pos += k
+    assert np.array_equal(np.concatenate(ys), G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("c", PINT, ids=G.ids(PINT))
+def test_poly_intr_oracle_matches_reference_header(c):
+    o = OraclePolyIntr(c["n_taps"], c["coeff_sz"], c["ifac"], c["ftype"], F(c["in"]), F(c["coeff"]), F(c["acc"]), F(c["out"]))
+    x = G.arr(c, "x")
+    ra = c["reload_at"]
+    if ra < 0:
+        y = o.run(c["coeffs"], c["sign"], c["corr"], x)[0]
+    else:
+        y = np.concatenate([o.run(c["coeffs"], c["sign"], c["corr"], x[:ra])[0], o.run(c["coeffs2"], c["sign2"], c["corr2"], x[ra:])[0]])
+    assert sum(c["outs_per_sample"]) == len(c["y"])
+    assert np.array_equal(y, G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("c", IDMP, ids=G.ids(IDMP))
+def test_intg_dump_oracle_matches_reference_header(c):
+    o = OracleIntgDump(c["ns"], c["chn"], F(c["in"]), F(c["acc"]), F(c["out"]))
+    x, ns = G.arr(c, "x"), G.arr(c, "n_sample")
+    xp, bp, ys = 0, 0, []
+    for nb in c["blocks_per_call"]:
+        blk = ns[bp:bp + nb]
+        need = int(sum((v if 1 <= v <= c["ns"] else c["ns"]) for v in blk)) * c["chn"]
+        ys.append(o.run(x[xp:xp + need], blk)[0])
+        xp += need
+        bp += nb
+    assert xp == len(x)
+    assert np.array_equal(np.concatenate(ys), G.arr(c, "y"))

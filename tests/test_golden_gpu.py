@@ -1,0 +1,132 @@
+"""The HIP engine (through the C ABI) against the vectors the reference's own headers produced (tests/golden/ref_hdr,
+tools/gen_golden): the third leg of the parity argument -- reference loop source -> vectors <- engine, with the oracle
+pinned on the same vectors by tests/test_golden_cpu.py.  Every case runs as several identical channels so that the
+batched kernels (matrix-core paths included) see more than one row."""
+import numpy as np
+import pytest
+import torch
+
+import ac_dsp_amd as A
+import golden_cases as G
+
+pytestmark = pytest.mark.gpu
+
+FIR = G.load(("const", "load", "prog"))
+RS = G.load(("reg_share",))
+CIC = G.load(("cic_dec", "cic_intr"))
+PDEC = G.load(("poly_dec",))
+PINT = G.load(("poly_intr",))
+IDMP = G.load(("intg_dump",))
+NCH = 3
+
+
+def F(a):
+    return G.fmt_of(A.Fmt, a)
+
+
+def dev(x, fmt):
+    """1-D raw words -> [NCH][n] device tensor of fmt's containers (identical rows)."""
+    return torch.from_numpy(np.tile(np.asarray(x, dtype=np.int64), (NCH, 1))).to(A.torch_dtype_for(fmt)).cuda()
+
+
+def host(t):
+    y = t.cpu().numpy().astype(np.int64)
+    assert all(np.array_equal(y[0], y[i]) for i in range(1, y.shape[0])), "identical channels gave different rows"
+    return y[0]
+
+
+@pytest.mark.parametrize("force_generic", [False, True], ids=["fast", "generic"])
+@pytest.mark.parametrize("c", FIR, ids=G.ids(FIR))
+def test_fir_engine_matches_reference_headers(c, force_generic):
+    fin, fo = F(c["in"]), F(c["out"])
+    fir = A.Fir(c["n_taps"], c["ftype"], fin, F(c["coeff"]), F(c["acc"]), fo, n_channels=NCH, kind=c["class"], force_generic=force_generic)
+    x = G.arr(c, "x")
+    ys, last = [], None
+    for cf, a, b in G.segments(c):
+        if last is None or not np.array_equal(cf, last):
+            fir.set_coeffs(cf)
+            last = cf
+        ys.append(host(fir.run(dev(x[a:b], fin))))
+    y = np.concatenate(ys)
+    want = G.arr(c, "y")
+    bad = np.nonzero(y != want)[0]
+    assert bad.size == 0, "%d mismatches, first at %d: got %d want %d (path %s)" % (len(bad), bad[0], y[bad[0]], want[bad[0]], fir.path)
+
+
+def test_baseline_types_take_the_matrix_core_path():
+    c = next(c for c in FIR if c["name"] == "const_base_SHIFT_REG_255")
+    fir = A.Fir(255, "SHIFT_REG", F(c["in"]), F(c["coeff"]), F(c["acc"]), F(c["out"]), n_channels=NCH, kind="const")
+    fir.set_coeffs(G.arr(c, "coeffs"))
+    assert fir.path == "mfma_i8"
+
+
+@pytest.mark.parametrize("c", RS, ids=G.ids(RS))
+def test_reg_share_engine_matches_reference_header(c):
+    fin = F(c["in"])
+    fir = A.Fir(c["n_taps"], c["ftype"], fin, F(c["coeff"]), F(c["acc"]), F(c["out"]), n_channels=NCH, kind="reg_share")
+    fir.set_coeffs(G.reg_share_taps(c))
+    x = G.arr(c, "x")
+    y = np.concatenate([host(fir.run(dev(x[a:b], fin))) for a, b in ((0, 7), (7, len(x)))])
+    assert np.array_equal(y, G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("c", CIC, ids=G.ids(CIC))
+def test_cic_engine_matches_reference_headers(c):
+    fin = F(c["in"])
+    cic = A.Cic(c["class"] == "cic_intr", c["R"], c["M"], c["N"], fin, F(c["out"]), n_channels=NCH)
+    x = G.arr(c, "x")
+    pos, ys = 0, []
+    for k, want in zip(c["calls"], c["outs_per_call"]):
+        yk = cic.run(dev(x[pos:pos + k], fin))
+        assert yk.shape[1] == want, "call of %d inputs produced %d outputs, the reference %d" % (k, yk.shape[1], want)
+        if want:
+            ys.append(host(yk))
+        pos += k
+    assert np.array_equal(np.concatenate(ys), G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("c", PDEC, ids=G.ids(PDEC))
+def test_poly_dec_engine_matches_reference_header(c):
+    fin = F(c["in"])
+    pd = A.PolyDec(c["n_taps"], c["df"], fin, F(c["coeff"]), F(c["acc"]), F(c["out"]), n_channels=NCH)
+    pd.set_coeffs(G.arr(c, "coeffs"))
+    x = G.arr(c, "x")
+    pos, ys = 0, []
+    for k in c["calls"]:
+        ys.append(host(pd.run(dev(x[pos:pos + k], fin))))
+        pos += k
+    assert np.array_equal(np.concatenate(ys), G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("c", PINT, ids=G.ids(PINT))
+def test_poly_intr_engine_matches_reference_header(c):
+    fin = F(c["in"])
+    pi = A.PolyIntr(c["n_taps"], c["coeff_sz"], c["ifac"], c["ftype"], fin, F(c["coeff"]), F(c["acc"]), F(c["out"]), n_channels=NCH)
+    pi.set_ctrl(c["coeffs"], c["sign"], c["corr"])
+    x = G.arr(c, "x")
+    ra = c["reload_at"]
+    if ra < 0:
+        y = host(pi.run(dev(x, fin)))
+    else:
+        y0 = host(pi.run(dev(x[:ra], fin)))
+        pi.set_ctrl(c["coeffs2"], c["sign2"], c["corr2"])
+        y = np.concatenate([y0, host(pi.run(dev(x[ra:], fin)))])
+    assert np.array_equal(y, G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("c", IDMP, ids=G.ids(IDMP))
+def test_intg_dump_engine_matches_reference_header(c):
+    fin = F(c["in"])
+    eng = A.IntgDump(c["ns"], c["chn"], fin, F(c["acc"]), F(c["out"]), n_objects=NCH)
+    x, ns = G.arr(c, "x"), G.arr(c, "n_sample")
+    xp, bp, ys = 0, 0, []
+    for nb in c["blocks_per_call"]:
+        blk = ns[bp:bp + nb]
+        need = int(sum((v if 1 <= v <= c["ns"] else c["ns"]) for v in blk)) * c["chn"]
+        yk = eng.run(dev(x[xp:xp + need], fin), blk)
+        if yk.shape[1]:
+            ys.append(host(yk))
+        xp += need
+        bp += nb
+    got = np.concatenate(ys) if ys else np.zeros(0, dtype=np.int64)
+    assert np.array_equal(got, G.arr(c, "y"))

@@ -1,0 +1,69 @@
+// cref_bench.cpp -- "C-ref" CPU baseline: the REFERENCE's own header-only path
+// (/root/reference/include/ac_dsp, compiled where it lies) over this repo's ac_types subset, one filter object per
+// channel, channels split over the host threads.  Build container only; the numbers go into BASELINE.md.
+//   cref_bench [threads=nproc] [samples per channel=16384]
+#include <ac_dsp/ac_fir_load_coeffs.h>
+#include <ac_dsp/ac_cic_dec_full.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+typedef ac_fixed<16, 2, true> IN16;
+typedef ac_fixed<40, 12, true> ACC40;
+typedef ac_fixed<16, 2, true, AC_RND, AC_SAT> OUT16;
+typedef ac_fixed<32, 16, true> IN32;
+typedef ac_fixed<47, 31, true> INT47;
+
+template <class F> static double timed(int threads, F work) {
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int i = 0; i < threads; i++) { th.emplace_back(work, i); }
+  for (auto &t : th) { t.join(); }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+typedef ac_fir_load_coeffs<IN16, OUT16, IN16, ACC40, 255, SHIFT_REG> Fir;
+typedef ac_cic_dec_full<IN32, INT47, 8, 1, 5> Cic;
+struct FirJob { Fir fir; ac_channel<IN16> in, cch; ac_channel<OUT16> out; ac_channel<bool> ld; };
+struct CicJob { Cic cic; ac_channel<IN32> in; ac_channel<INT47> out; };
+
+int main(int argc, char **argv) {
+  const int threads = argc > 1 ? atoi(argv[1]) : (int)std::thread::hardware_concurrency();
+  const int n = argc > 2 ? atoi(argv[2]) : 65536;
+  std::vector<long long> sink((size_t)threads, 0);
+  {   // BASELINE configs[1]: ac_fir_load_coeffs, 255 taps, SHIFT_REG; stimulus generation is outside the timed region
+    std::vector<FirJob> jobs((size_t)threads);
+    timed(threads, [&](int id) {
+      uint64_t seed = 0xACD5 + id;
+      FirJob &j = jobs[(size_t)id];
+      for (int i = 0; i < 255; i++) { j.cch.write(gg::rnd_bits<IN16>(seed, 12)); }
+      j.ld.write(true);
+      for (int i = 0; i < n; i++) { j.in.write(gg::rnd<IN16>(seed)); }
+    });
+    const double dt = timed(threads, [&](int id) { FirJob &j = jobs[(size_t)id]; j.fir.run(j.in, j.cch, j.out, j.ld); });
+    for (int id = 0; id < threads; id++) { while (jobs[(size_t)id].out.available(1)) { sink[(size_t)id] += gg::raw(jobs[(size_t)id].out.read()); } }
+    printf("C-ref ac_fir_load_coeffs 255 taps <16,2>, ACC <40,12>, SHIFT_REG: %d threads x %d samples in %.2f s = %.3f Msamples/s\n",
+           threads, n, dt, (double)threads * n / dt / 1e6);
+  }
+  {   // BASELINE configs[2]: ac_cic_dec_full N5 R8 M1 on <32,16>
+    const int nc = n * 16;
+    std::vector<CicJob> jobs((size_t)threads);
+    timed(threads, [&](int id) {
+      uint64_t seed = 0xACD5 + id;
+      for (int i = 0; i < nc; i++) { jobs[(size_t)id].in.write(gg::rnd<IN32>(seed)); }
+    });
+    const double dt = timed(threads, [&](int id) { CicJob &j = jobs[(size_t)id]; j.cic.run(j.in, j.out); });
+    for (int id = 0; id < threads; id++) { while (jobs[(size_t)id].out.available(1)) { sink[(size_t)id] += gg::raw(jobs[(size_t)id].out.read()); } }
+    printf("C-ref ac_cic_dec_full N5 R8 M1 <32,16> -> <47,31>: %d threads x %d samples in %.2f s = %.3f Msamples/s\n", threads, nc, dt,
+           (double)threads * nc / dt / 1e6);
+  }
+  long long t = 0;
+  for (long long v : sink) { t += v; }
+  printf("(checksum %lld)\n", t);
+  return 0;
+}

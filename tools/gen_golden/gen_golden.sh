@@ -1,0 +1,20 @@
+#!/bin/bash
+# tools/gen_golden/gen_golden.sh -- BUILD CONTAINER ONLY (needs /root/reference).  Compiles the reference's headers
+# (where they lie, nothing is copied) over include/ac_types and regenerates tests/golden/ref_hdr/*.json.
+# The binaries live in /tmp; only the JSON vectors (data) are committed.
+set -e
+R=$(cd "$(dirname "$0")/../.." && pwd)
+REF=${ACDSP_REFERENCE:-/root/reference}
+[ -d "$REF/include/ac_dsp" ] || { echo "reference tree not found at $REF"; exit 1; }
+B=${TMPDIR:-/tmp}/acdsp_gen_golden
+OUT=$R/tests/golden/ref_hdr
+mkdir -p "$B" "$OUT"
+CXX="g++ -std=c++11 -O1 -Wno-unknown-pragmas -I$REF/include -I$R/include/ac_types -I$R/tools/gen_golden"
+$CXX "$R/tools/gen_golden/gen_fir.cpp" -o "$B/gen_fir"
+$CXX "$R/tools/gen_golden/gen_cic.cpp" -o "$B/gen_cic_dec"
+$CXX -DGEN_INTR "$R/tools/gen_golden/gen_cic.cpp" -o "$B/gen_cic_intr"
+$CXX "$R/tools/gen_golden/gen_reg_share.cpp" -o "$B/gen_reg_share"
+$CXX "$R/tools/gen_golden/gen_poly_dec.cpp" -o "$B/gen_poly_dec"
+$CXX "$R/tools/gen_golden/gen_poly_intr.cpp" -o "$B/gen_poly_intr"
+for g in gen_fir gen_cic_dec gen_cic_intr gen_reg_share gen_poly_dec gen_poly_intr; do "$B/$g" "$OUT"; done
+ls -la "$OUT"
