@@ -63,6 +63,11 @@ class StreamHdr(C.Structure):
                 ("n_channels", C.c_uint64), ("n_samples", C.c_uint64), ("stride", C.c_uint64)]
 
 
+class MvAvgDesc(C.Structure):
+    _fields_ = [("max_sample", C.c_int32), ("taps", C.c_int32), ("win_mode", C.c_int32), ("n_objects", C.c_int32),
+                ("fin", Fmt), ("fcoeff", Fmt), ("facc", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
+
+
 class CicDesc(C.Structure):
     _fields_ = [("interp", C.c_int32), ("R", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("n_channels", C.c_int32), ("fin", Fmt), ("fout", Fmt), ("device", C.c_int32), ("flags", C.c_int32)]
@@ -129,6 +134,12 @@ SYMBOLS = {
     "acdsp_intgdump_run": (_i32, [_vp, _vp, _i64, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64), _vp]),
     "acdsp_intgdump_run_host": (_i32, [_vp, _vp, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64)]),
     "acdsp_intgdump_reset": (_i32, [_vp]),
+    "acdsp_mvavg_create": (_i32, [C.POINTER(MvAvgDesc), C.POINTER(_vp)]),
+    "acdsp_mvavg_destroy": (_i32, [_vp]),
+    "acdsp_mvavg_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
+    "acdsp_mvavg_out_per_frame": (_i64, [_vp, _i64]),
+    "acdsp_mvavg_run": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, C.POINTER(_i64), _vp]),
+    "acdsp_mvavg_run_host": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64)]),
     "acdsp_fir_state_size": (_i64, [_vp]),
     "acdsp_fir_state_get": (_i32, [_vp, _vp, C.c_uint64]),
     "acdsp_fir_state_set": (_i32, [_vp, _vp, C.c_uint64]),

@@ -1580,6 +1580,129 @@ int32_t acdsp_intgdump_reset(acdsp_intgdump_t h) {
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
+// moving average (second half)
+// ---------------------------------------------------------------------------------------------
+struct acdsp_mvavg {
+  acdsp_mvavg_desc_t d;
+  int in_eb, out_eb;
+  bool coeffs_set = false;
+  int64_t *d_coeffs = nullptr;
+  Staging st;
+};
+
+extern "C" {
+
+int32_t acdsp_mvavg_create(const acdsp_mvavg_desc_t *desc, acdsp_mvavg_t *out) {
+  if (!desc || !out) { return fail(ACDSP_EINVAL, "null argument"); }
+  int rc;
+  if ((rc = check_fmt(desc->in, "IN_TYPE")) || (rc = check_fmt(desc->coeff, "COEFF_TYPE")) || (rc = check_fmt(desc->acc, "ACC_TYPE")) ||
+      (rc = check_fmt(desc->out, "OUT_TYPE"))) {
+    return rc;
+  }
+  if (desc->taps < 1 || desc->taps > 1025) { return fail(ACDSP_EUNSUPPORTED, "mv_avg: TAPS=%d outside 1..1025", desc->taps); }
+  if (!(desc->taps & 1)) { return fail(ACDSP_EUNSUPPORTED, "mv_avg: even TAPS: the reference's MAC loop reads coeffs[TAPS] (ac_mv_avg.h:117-119)"); }
+  if (desc->win_mode < ACDSP_WIN_PLAIN || desc->win_mode > ACDSP_WIN_CLIP) { return fail(ACDSP_EINVAL, "mv_avg: bad window mode %d", desc->win_mode); }
+  if (desc->max_sample < 1) { return fail(ACDSP_EINVAL, "mv_avg: MAX_SAMPLE must be >= 1"); }
+  if (desc->n_objects < 1) { return fail(ACDSP_EINVAL, "mv_avg: n_objects must be >= 1"); }
+  // 128-bit exact intermediates: ACC x COEFF product aligned with the accumulator
+  const int fc = desc->coeff.W - desc->coeff.I;
+  if (desc->acc.W + desc->coeff.W + 2 + (fc < 0 ? -fc : 0) > 125) { return fail(ACDSP_EUNSUPPORTED, "mv_avg: type combination needs more than 128-bit intermediates"); }
+  if ((rc = check_device(desc->device))) { return rc; }
+  acdsp_mvavg *h = new acdsp_mvavg();
+  h->d = *desc;
+  h->in_eb = elem_bytes(desc->in.W);
+  h->out_eb = elem_bytes(desc->out.W);
+  if (hipMalloc((void **)&h->d_coeffs, (size_t)desc->taps * sizeof(int64_t)) != hipSuccess) {
+    delete h;
+    return fail(ACDSP_EHIP, "mv_avg: coefficient allocation failed");
+  }
+  *out = h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_mvavg_destroy(acdsp_mvavg_t h) {
+  if (!h) { return ACDSP_OK; }
+  (void)hipSetDevice(h->d.device);
+  if (h->d_coeffs) { (void)hipFree(h->d_coeffs); }
+  h->st.destroy();
+  delete h;
+  return ACDSP_OK;
+}
+
+int32_t acdsp_mvavg_set_coeffs(acdsp_mvavg_t h, const int64_t *coeffs) {
+  if (!h || !coeffs) { return fail(ACDSP_EINVAL, "null argument"); }
+  const DFmt cf = make_dfmt(h->d.coeff);
+  for (int i = 0; i < h->d.taps; i++) {
+    if (coeffs[i] < cf.lo || coeffs[i] > cf.hi) { return fail(ACDSP_EINVAL, "coefficient %d = %lld is not a COEFF_TYPE raw word", i, (long long)coeffs[i]); }
+  }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, (size_t)h->d.taps * sizeof(int64_t), hipMemcpyHostToDevice));
+  h->coeffs_set = true;
+  return ACDSP_OK;
+}
+
+int64_t acdsp_mvavg_out_per_frame(acdsp_mvavg_t h, int64_t n_sample) {
+  if (!h || n_sample < 1 || n_sample > h->d.max_sample) { return -1; }
+  if (h->d.win_mode == ACDSP_WIN_PLAIN) { return n_sample >= h->d.taps ? n_sample - h->d.taps + 1 : 0; }
+  return n_sample;
+}
+
+int32_t acdsp_mvavg_run(acdsp_mvavg_t h, const void *d_in, int64_t in_stride, int64_t n_sample, int64_t n_frames, void *d_out,
+                        int64_t out_stride, int64_t *n_out, void *stream) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  if (!h->coeffs_set) { return fail(ACDSP_ESTATE, "mvavg_run before acdsp_mvavg_set_coeffs"); }
+  const int64_t opf = acdsp_mvavg_out_per_frame(h, n_sample);
+  if (opf < 0) { return fail(ACDSP_EINVAL, "mv_avg: n_sample=%lld outside 1..MAX_SAMPLE=%d (the reference's frame loop would lose alignment)", (long long)n_sample, h->d.max_sample); }
+  if (n_frames < 0 || n_frames > (int64_t(1) << 40) / n_sample) { return fail(ACDSP_EINVAL, "mv_avg: bad frame count"); }
+  const int64_t no = opf * n_frames;
+  if (n_out) { *n_out = no; }
+  if (n_frames == 0) { return ACDSP_OK; }
+  if (!d_in || in_stride < n_sample * n_frames) { return fail(ACDSP_EINVAL, "mv_avg run: bad input arguments"); }
+  if (no > 0 && (!d_out || out_stride < no)) { return fail(ACDSP_EINVAL, "mv_avg run: output buffer too small for %lld outputs", (long long)no); }
+  const acdsp_mvavg_desc_t &d = h->d;
+  int rc = check_device(d.device);
+  if (rc) { return rc; }
+  MvAvgParams p;
+  memset(&p, 0, sizeof p);
+  p.taps = d.taps; p.win_mode = d.win_mode; p.n_obj = d.n_objects;
+  p.in = make_dfmt(d.in); p.cf = make_dfmt(d.coeff); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
+  p.in_eb = h->in_eb; p.out_eb = h->out_eb;
+  p.fast = !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && d.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && p.cf.F >= 0 &&
+           p.cf.F < 62 && d.acc.W + d.coeff.W <= 62;
+  p.n_sample = n_sample; p.n_frames = n_frames; p.out_per_frame = opf; p.in_stride = in_stride; p.out_stride = out_stride;
+  p.x = d_in; p.y = d_out; p.coeffs = h->d_coeffs;
+  hipError_t e = launch_mv_avg(p, (hipStream_t)stream);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "mv_avg kernel launch failed: %s", hipGetErrorString(e)); }
+  return ACDSP_OK;
+}
+
+int32_t acdsp_mvavg_run_host(acdsp_mvavg_t h, const void *h_in, int64_t n_sample, int64_t n_frames, void *h_out, int64_t out_cap,
+                             int64_t *n_out) {
+  if (!h) { return fail(ACDSP_EINVAL, "null handle"); }
+  const int64_t opf = acdsp_mvavg_out_per_frame(h, n_sample);
+  if (opf < 0 || n_frames < 0) { return fail(ACDSP_EINVAL, "mv_avg run_host: bad n_sample / n_frames"); }
+  const int64_t ni = n_sample * n_frames, no = opf * n_frames;
+  if (n_out) { *n_out = no; }
+  if (n_frames == 0) { return ACDSP_OK; }
+  if (!h_in || (no > 0 && (!h_out || out_cap < no))) { return fail(ACDSP_EINVAL, "mv_avg run_host: bad buffers"); }
+  int rc = check_device(h->d.device);
+  if (rc) { return rc; }
+  const size_t nobj = (size_t)h->d.n_objects;
+  if ((rc = h->st.ensure(nobj * ni * h->in_eb, nobj * (no > 0 ? no : 1) * h->out_eb))) { return rc; }
+  HIP_TRY(hipMemcpy(h->st.d_in, h_in, nobj * ni * h->in_eb, hipMemcpyHostToDevice));
+  if ((rc = acdsp_mvavg_run(h, h->st.d_in, ni, n_sample, n_frames, h->st.d_out, no > 0 ? no : 1, nullptr, nullptr))) { return rc; }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  if (no > 0) {
+    HIP_TRY(hipMemcpy2D(h_out, (size_t)out_cap * h->out_eb, h->st.d_out, (size_t)no * h->out_eb, (size_t)no * h->out_eb, nobj, hipMemcpyDeviceToHost));
+  }
+  return ACDSP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
 // state save / restore (SURVEY 8b export list, section 5 checkpoint / resume hook)
 // ---------------------------------------------------------------------------------------------
 namespace {

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, PolyIntrDesc, IntgDumpDesc, StreamHdr, FTYPES, KINDS, PATHS
+from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, PolyIntrDesc, IntgDumpDesc, MvAvgDesc, StreamHdr, FTYPES, KINDS, PATHS
 
 
 def device_count():
@@ -366,6 +366,49 @@ class IntgDump:
     def close(self):
         if getattr(self, "_h", None):
             lib.acdsp_intgdump_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+WIN_MODES = {"WIN": 0, "MIRROR": 1, "CLIP": 2}   # AC_WIN / AC_MIRROR / AC_CLIP
+
+
+class MvAvg:
+    """n_objects independent ac_mv_avg<MAX_SAMPLE, TAPS, WIN_TYPE, ...> objects (C ABI acdsp_mvavg_*): rows hold n_frames
+    frames of n_sample inputs back to back; run() is one run() call of every object."""
+
+    def __init__(self, max_sample, taps, win_mode, fin, fcoeff, facc, fout, n_objects=1, device=0, force_generic=False):
+        self.fin, self.fout, self.n_objects, self.taps = fin, fout, n_objects, taps
+        d = MvAvgDesc(max_sample, taps, WIN_MODES[win_mode] if isinstance(win_mode, str) else win_mode, n_objects, fin, fcoeff, facc,
+                      fout, device, _lib.FLAG_FORCE_GENERIC if force_generic else 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_mvavg_create(C.byref(d), C.byref(self._h)))
+
+    def set_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert c.shape == (self.taps,)
+        check(lib.acdsp_mvavg_set_coeffs(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def out_per_frame(self, n_sample):
+        return lib.acdsp_mvavg_out_per_frame(self._h, n_sample)
+
+    def run(self, x, n_sample, out=None):
+        assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_objects and x.stride(1) == 1 and x.shape[1] % n_sample == 0
+        assert x.dtype == torch_dtype_for(self.fin), (x.dtype, self.fin)
+        n_frames = x.shape[1] // n_sample
+        no = max(self.out_per_frame(n_sample), 0) * n_frames
+        if out is None:
+            out = torch.empty((self.n_objects, max(no, 1)), dtype=torch_dtype_for(self.fout), device=x.device)
+        n_out = C.c_int64()
+        check(lib.acdsp_mvavg_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), n_sample, n_frames, C.c_void_p(out.data_ptr()), out.stride(0),
+                                  C.byref(n_out), _stream_ptr(x)))
+        return out[:, :n_out.value]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.acdsp_mvavg_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -119,6 +119,18 @@ typedef struct {
   int32_t flags;
 } acdsp_intgdump_desc_t;
 
+/* ac_mv_avg<MAX_SAMPLE, TAPS, WIN_TYPE, IN, OUT, ACC, COEFF, S_TYPE> (reference include/ac_dsp/ac_mv_avg.h:135) */
+enum { ACDSP_WIN_PLAIN = 0 /* AC_WIN */, ACDSP_WIN_MIRROR = 1 /* AC_MIRROR */, ACDSP_WIN_CLIP = 2 /* AC_CLIP */ };
+typedef struct {
+  int32_t max_sample;         /* MAX_SAMPLE: longest frame the object accepts */
+  int32_t taps;               /* TAPS: window length, odd (the reference's MAC loop reads coeffs[TAPS] on even values) */
+  int32_t win_mode;           /* ACDSP_WIN_* */
+  int32_t n_objects;          /* independent ac_mv_avg objects (rows of the buffers) */
+  acdsp_fmt_t in, coeff, acc, out;
+  int32_t device;
+  int32_t flags;
+} acdsp_mvavg_desc_t;
+
 /* Raw-integer stream file / wire format: this 64-byte little-endian header, then n_channels rows of `stride` containers
  * (two's-complement raw words, acdsp_elem_bytes(W) bytes each) -- the [channel][time] layout the kernels take. */
 typedef struct {
@@ -136,6 +148,7 @@ typedef struct acdsp_cic *acdsp_cic_t;
 typedef struct acdsp_ddc *acdsp_ddc_t;
 typedef struct acdsp_polyintr *acdsp_polyintr_t;
 typedef struct acdsp_intgdump *acdsp_intgdump_t;
+typedef struct acdsp_mvavg *acdsp_mvavg_t;
 
 /* ---- general ---- */
 int32_t acdsp_abi_version(void);
@@ -250,6 +263,21 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
 int32_t acdsp_intgdump_run_host(acdsp_intgdump_t h, const void *h_in, const int64_t *n_sample, int64_t n_blocks, void *h_out,
                                 int64_t out_cap, int64_t *n_out);
 int32_t acdsp_intgdump_reset(acdsp_intgdump_t h);
+
+/* ---- moving average (reference ac_mv_avg.h:93-196) ----
+ * One run() = one run() call of every object: n_frames frames of n_sample input samples each, back to back in the row (the
+ * reference reads n_sample once per call, :155, and loops `while (data_in.available(1))` over frames).  A frame yields
+ * n_sample outputs in the boundary modes and n_sample - TAPS + 1 (or none) under AC_WIN.  The window class behind it,
+ * ac_window_1d_flag, is not part of ac_dsp: see include/ac_types/ac_window.h for the semantics assumed.  No state crosses
+ * calls (the reference constructs its core object inside run(), :154); coefficients are bound like ac_fir_const_coeffs'. */
+int32_t acdsp_mvavg_create(const acdsp_mvavg_desc_t *desc, acdsp_mvavg_t *out);
+int32_t acdsp_mvavg_destroy(acdsp_mvavg_t h);
+int32_t acdsp_mvavg_set_coeffs(acdsp_mvavg_t h, const int64_t *coeffs);   /* raw COEFF_TYPE words [TAPS] */
+int64_t acdsp_mvavg_out_per_frame(acdsp_mvavg_t h, int64_t n_sample);     /* -1: n_sample outside 1..MAX_SAMPLE */
+int32_t acdsp_mvavg_run(acdsp_mvavg_t h, const void *d_in, int64_t in_stride, int64_t n_sample, int64_t n_frames, void *d_out,
+                        int64_t out_stride, int64_t *n_out, void *stream);
+int32_t acdsp_mvavg_run_host(acdsp_mvavg_t h, const void *h_in, int64_t n_sample, int64_t n_frames, void *h_out, int64_t out_cap,
+                             int64_t *n_out);
 
 /* ---- state save / restore (checkpoint / resume, moving a stream to another GPU) ----
  * The reference's filter state is plain object members (shift register / reg_trans: ac_fir_const_coeffs.h:124-127;

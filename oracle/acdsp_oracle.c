@@ -685,6 +685,102 @@ int64_t orc_intg_dump_run(int64_t *temp, int32_t ns, int32_t chn, const orc_fmt_
   return k;
 }
 
+/* ------------------------------------------------------------------ */
+/* moving average (row f4 of SURVEY 8: reference include/ac_dsp/ac_mv_avg.h:93-196)                       */
+/* ------------------------------------------------------------------ */
+/* ac_window_1d_flag<IN_TYPE, TAPS, WIN_TYPE> as ac_mv_avg drives it (write / valid / operator[], :111-123), kept as the
+ * literal shift register plus the sol / eol flags travelling with the samples.  The class belongs to ac_types, which is not
+ * in the image: the boundary behaviour is restated from its documented modes -- PARITY UNPINNED (acdsp_oracle.h). */
+typedef struct {
+  int taps, mode;
+  int64_t data[ORC_MVAVG_MAX_TAPS];
+  uint8_t sol[ORC_MVAVG_MAX_TAPS], eol[ORC_MVAVG_MAX_TAPS], live[ORC_MVAVG_MAX_TAPS];
+} mv_window_t;
+
+static void win_write(mv_window_t *w, int64_t v, int sol, int eol) {
+  for (int i = 0; i + 1 < w->taps; i++) { w->data[i] = w->data[i + 1]; w->sol[i] = w->sol[i + 1]; w->eol[i] = w->eol[i + 1]; w->live[i] = w->live[i + 1]; }
+  const int last = w->taps - 1;
+  w->data[last] = v; w->sol[last] = (uint8_t)sol; w->eol[last] = (uint8_t)eol; w->live[last] = 1;
+}
+/* slot of the current line's first sample (or -1: it has left the window) and of its last sample (or -1: not seen yet),
+ * looking outwards from the centre slot c: the line of the centre sample starts at the nearest sol at or left of c */
+static void win_line(const mv_window_t *w, int *first, int *last, int *centre_ok) {
+  const int c = w->taps / 2;
+  *first = -1; *last = -1; *centre_ok = w->live[c];
+  for (int i = c; i >= 0; i--) {
+    if (!w->live[i]) { break; }                                            /* never written: the line starts to the right of it */
+    if (i < c && w->eol[i]) { *first = i + 1; *centre_ok = 0; break; }   /* the centre is filler written after a closed line */
+    if (w->sol[i]) { *first = i; break; }
+  }
+  for (int i = c; i < w->taps; i++) {
+    if (w->eol[i]) { *last = i; break; }
+    if (i > c && w->sol[i]) { *last = i - 1; break; }
+  }
+}
+static int win_valid(const mv_window_t *w) {
+  int first, last, ok;
+  win_line(w, &first, &last, &ok);
+  if (!ok) { return 0; }
+  if (w->mode == ORC_WIN_PLAIN) {   /* every slot belongs to the centre's line */
+    const int lo = first < 0 ? 0 : first, hi = last < 0 ? w->taps - 1 : last;
+    if (!w->live[0]) { return 0; }
+    return lo == 0 && hi == w->taps - 1;
+  }
+  return 1;
+}
+static int64_t win_at(const mv_window_t *w, int j) {
+  const int c = w->taps / 2;
+  int first, last, ok;
+  win_line(w, &first, &last, &ok);
+  int i = c + j;
+  if (w->mode != ORC_WIN_PLAIN) {
+    /* first / last = -1 means the boundary is outside the window: nothing to fold on that side */
+    for (int guard = 0; guard < 4 * w->taps; guard++) {
+      if (first >= 0 && i < first) { i = (w->mode == ORC_WIN_CLIP) ? first : 2 * first - i; continue; }
+      if (last >= 0 && i > last) { i = (w->mode == ORC_WIN_CLIP) ? last : 2 * last - i; continue; }
+      break;
+    }
+    if (first >= 0 && last >= 0 && first == last) { i = first; }
+  }
+  if (i < 0) { i = 0; }
+  if (i >= w->taps) { i = w->taps - 1; }
+  return w->data[i];
+}
+
+/* One run() call of one ac_mv_avg object (ac_mv_avg.h:146-190): n_frames frames of n_sample inputs each (the n_sample
+ * word read at :155 applies to every frame of the call); a fresh core object per call (:154), so nothing carries over.
+ * Per valid window position (:113-121):  acc = 0; for j = -TAPS/2 .. TAPS/2: acc = ACC(acc + ACC(w[j]) * c[j + TAPS/2]);
+ * out = OUT(acc).  Returns the outputs written, -1 on parameters the reference cannot run (even TAPS read c[TAPS]). */
+int64_t orc_mv_avg_run(int32_t taps, int32_t win_mode, const orc_fmt_t *in, const orc_fmt_t *coeff, const orc_fmt_t *acc,
+                       const orc_fmt_t *out, const int64_t *c, const int64_t *x, int64_t n_sample, int64_t n_frames, int64_t *y) {
+  if (taps < 1 || taps > ORC_MVAVG_MAX_TAPS || !(taps & 1) || n_sample < 1) { return -1; }
+  const int fi = in->W - in->I, fc = coeff->W - coeff->I, fa = acc->W - acc->I;
+  const int h = taps / 2;
+  mv_window_t w;
+  memset(&w, 0, sizeof w);
+  w.taps = taps; w.mode = win_mode;
+  int64_t k = 0, pos = 0;
+  for (int64_t f = 0; f < n_frames; f++) {
+    const int64_t sample = (win_mode == ORC_WIN_PLAIN) ? n_sample : n_sample + h;   /* :158-162 */
+    int64_t data_in_t = 0;
+    for (int64_t cnt = 0; cnt < sample; cnt++) {
+      if (cnt < n_sample) { data_in_t = x[pos++]; }                                  /* :174-176 */
+      win_write(&w, data_in_t, cnt == 0, cnt == n_sample - 1);                       /* :177-180, :112 */
+      if (win_valid(&w)) {
+        int64_t a = 0;
+        for (int j = -h; j <= h; j++) {
+          const int64_t xq = requant((i128)win_at(&w, j), fi, acc);                  /* (ACC_TYPE) w[j] */
+          int f_sum;
+          const i128 sum = add_aligned((i128)a, fa, (i128)xq * (i128)c[j + h], fa + fc, &f_sum);
+          a = requant(sum, f_sum, acc);
+        }
+        y[k++] = requant((i128)a, fa, out);
+      }
+    }
+  }
+  return k;
+}
+
 uint64_t orc_splitmix64(uint64_t seed, uint64_t index) {
   uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

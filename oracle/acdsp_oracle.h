@@ -113,6 +113,16 @@ int64_t orc_polyintr_run(orc_polyintr_t *f, const int64_t *coeffs, const uint8_t
 int64_t orc_intg_dump_run(int64_t *temp, int32_t ns, int32_t chn, const orc_fmt_t *in, const orc_fmt_t *acc, const orc_fmt_t *out,
                           const int64_t *n_sample, int64_t n_blocks, const int64_t *x, int64_t *y, int64_t *used);
 
+/* ---- moving average (row f4 of SURVEY 8: reference include/ac_dsp/ac_mv_avg.h:93-196) ----
+ * PARITY UNPINNED for the window class: ac_mv_avg is built on ac_window_1d_flag (ac_types' <ac_window.h>), which is absent
+ * from the image and from the reference tree; its boundary behaviour is restated from the documented meaning of the modes
+ * (AC_WIN none, AC_CLIP replicate the edge sample, AC_MIRROR reflect about it) and from how ac_mv_avg.h drives it.  The
+ * MAC loop, its cast and its order are the reference's (:113-121). */
+#define ORC_MVAVG_MAX_TAPS 1025
+enum { ORC_WIN_PLAIN = 0, ORC_WIN_MIRROR = 1, ORC_WIN_CLIP = 2 };
+int64_t orc_mv_avg_run(int32_t taps, int32_t win_mode, const orc_fmt_t *in, const orc_fmt_t *coeff, const orc_fmt_t *acc,
+                       const orc_fmt_t *out, const int64_t *c, const int64_t *x, int64_t n_sample, int64_t n_frames, int64_t *y);
+
 /* ---- synthetic stimulus shared with the GPU generator ---- */
 uint64_t orc_splitmix64(uint64_t seed, uint64_t index);
 /* raw sample for (channel, t): low `bits` bits of the hash, sign-extended */

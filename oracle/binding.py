@@ -76,6 +76,8 @@ lib.orc_polyintr_run.restype = C.c_int64
 lib.orc_polyintr_run.argtypes = [C.c_void_p, _i64p, _u8p, _u8p, _i64p, C.c_int64, _i64p]
 lib.orc_intg_dump_run.restype = C.c_int64
 lib.orc_intg_dump_run.argtypes = [_i64p, C.c_int32, C.c_int32] + [C.POINTER(Fmt)] * 3 + [_i64p, C.c_int64, _i64p, _i64p, _i64p]
+lib.orc_mv_avg_run.restype = C.c_int64
+lib.orc_mv_avg_run.argtypes = [C.c_int32, C.c_int32] + [C.POINTER(Fmt)] * 4 + [_i64p, _i64p, C.c_int64, C.c_int64, _i64p]
 lib.orc_stimulus.restype = C.c_int64
 lib.orc_stimulus.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]
 lib.orc_splitmix64.restype = C.c_uint64
@@ -267,5 +269,35 @@ class OracleIntgDump:
                                       _p(x[o]), _p(y), _p(used))
             assert used[0] <= x.shape[1], "stream shorter than the blocks need"
             self.temp[o] = t
+            outs.append(y[:k].copy())
+        return np.stack(outs)
+
+
+WIN_MODES = {"WIN": 0, "MIRROR": 1, "CLIP": 2}
+
+
+class OracleMvAvg:
+    """ac_mv_avg objects (reference ac_mv_avg.h:93-196), one per row; run() = one run() call of n_frames frames of
+    n_sample inputs.  Nothing carries across calls (the reference builds a fresh core object per call, :154)."""
+
+    def __init__(self, taps, win_mode, fin, fcoeff, facc, fout, n_obj=1):
+        self.taps, self.n_obj = taps, n_obj
+        self.mode = WIN_MODES[win_mode] if isinstance(win_mode, str) else win_mode
+        self.fmts = (fin, fcoeff, facc, fout)
+
+    def out_per_frame(self, n_sample):
+        return max(0, n_sample - self.taps + 1) if self.mode == 0 else n_sample
+
+    def run(self, coeffs, x, n_sample):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64)
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert c.shape == (self.taps,) and x.shape[1] % n_sample == 0
+        n_frames = x.shape[1] // n_sample
+        outs = []
+        for o in range(self.n_obj):
+            y = np.empty(n_frames * n_sample + 1, dtype=np.int64)
+            k = lib.orc_mv_avg_run(self.taps, self.mode, *[C.byref(f) for f in self.fmts], _p(c), _p(x[o]), n_sample, n_frames, _p(y))
+            if k < 0:
+                raise ValueError("oracle: parameters the reference cannot run (even TAPS / empty frame)")
             outs.append(y[:k].copy())
         return np.stack(outs)

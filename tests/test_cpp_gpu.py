@@ -23,11 +23,11 @@ def run(exe):
 
 @pytest.fixture(scope="module", autouse=True)
 def built():
-    if not all(os.path.exists(os.path.join(BIN, t)) for t in ("tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump")):
+    if not all(os.path.exists(os.path.join(BIN, t)) for t in ("tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
 
 
-@pytest.mark.parametrize("tb", ["tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump"])
+@pytest.mark.parametrize("tb", ["tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg"])
 def test_own_cpp_testbench(tb):
     rc, out = run(os.path.join(BIN, tb))
     assert rc == 0 and "Test PASSED." in out, out

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import golden_cases as G
-from oracle import Fmt, OracleFir, OracleCic, OraclePolyDec, OraclePolyIntr, OracleIntgDump
+from oracle import Fmt, OracleFir, OracleCic, OraclePolyDec, OraclePolyIntr, OracleIntgDump, OracleMvAvg
 
 FIR = G.load(("const", "load", "prog"))
 RS = G.load(("reg_share",))
@@ -13,6 +13,7 @@ CIC = G.load(("cic_dec", "cic_intr"))
 PDEC = G.load(("poly_dec",))
 PINT = G.load(("poly_intr",))
 IDMP = G.load(("intg_dump",))
+MVA = G.load(("mv_avg",))
 
 
 def F(a):
@@ -98,3 +99,35 @@ def test_intg_dump_oracle_matches_reference_header(c):
         bp += nb
     assert xp == len(x)
     assert np.array_equal(np.concatenate(ys), G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("c", MVA, ids=G.ids(MVA))
+def test_mv_avg_oracle_matches_reference_header(c):
+    """The reference's run() / mvAvgCore() source over include/ac_types/ac_window.h (index arithmetic) against the oracle's
+    register-and-flags window: frame loop, flush iterations, ACC cast and MAC order are the reference's; the boundary rules
+    are this repo's reading of ac_window_1d_flag on both sides (parity unpinned for those)."""
+    o = OracleMvAvg(c["taps"], c["win_mode"], F(c["in"]), F(c["coeff"]), F(c["acc"]), F(c["out"]))
+    y = o.run(G.arr(c, "coeffs"), G.arr(c, "x"), c["n_sample"])[0]
+    assert np.array_equal(y, G.arr(c, "y"))
+
+
+def test_mv_avg_known_answers():
+    """Hand-derived: x = 1..10, c = [1, 2, 4, 8, 16] (oldest sample first), exact types."""
+    f, a = Fmt(16, 8), Fmt(32, 16)
+    c = np.array([1, 2, 4, 8, 16], dtype=np.int64) * 256
+    x = np.arange(1, 11, dtype=np.int64) * 256
+    want = {"WIN": [129, 160, 191, 222, 253, 284],
+            "MIRROR": [75, 100, 129, 160, 191, 222, 253, 284, 283, 266],     # x[-k] = x[k], x[9+k] = x[9-k]
+            "CLIP": [71, 99, 129, 160, 191, 222, 253, 284, 299, 306]}        # edge sample replicated
+    for mode, w in want.items():
+        y = OracleMvAvg(5, mode, f, f, a, a).run(c, x, 10)[0]
+        assert (y // 65536).tolist() == w and not (y % 65536).any(), mode
+        y2 = OracleMvAvg(5, mode, f, f, a, a).run(c, np.concatenate([x, x]), 10)[0]       # frames are independent
+        assert np.array_equal(y2, np.concatenate([y, y]))
+    # frames shorter than the window: the mirror bounces, the clip repeats
+    assert (OracleMvAvg(5, "MIRROR", f, f, a, a).run(c, x[:2], 2)[0] // 65536).tolist() == [41, 52]
+    assert (OracleMvAvg(5, "CLIP", f, f, a, a).run(c, x[:2], 2)[0] // 65536).tolist() == [55, 59]
+    assert (OracleMvAvg(5, "MIRROR", f, f, a, a).run(c, x[:1], 1)[0] // 65536).tolist() == [31]
+    assert OracleMvAvg(5, "WIN", f, f, a, a).run(c, x[:4], 4).shape == (1, 0)
+    with pytest.raises(ValueError):
+        OracleMvAvg(4, "WIN", f, f, a, a).run(c[:4], x, 10)                               # even TAPS: coeffs[TAPS] is read

@@ -17,6 +17,7 @@ CIC = G.load(("cic_dec", "cic_intr"))
 PDEC = G.load(("poly_dec",))
 PINT = G.load(("poly_intr",))
 IDMP = G.load(("intg_dump",))
+MVA = G.load(("mv_avg",))
 NCH = 3
 
 
@@ -130,3 +131,16 @@ def test_intg_dump_engine_matches_reference_header(c):
         bp += nb
     got = np.concatenate(ys) if ys else np.zeros(0, dtype=np.int64)
     assert np.array_equal(got, G.arr(c, "y"))
+
+
+@pytest.mark.parametrize("force_generic", [False, True], ids=["fast", "generic"])
+@pytest.mark.parametrize("c", MVA, ids=G.ids(MVA))
+def test_mv_avg_engine_matches_reference_header(c, force_generic):
+    fin = F(c["in"])
+    eng = A.MvAvg(c["max_sample"], c["taps"], c["win_mode"], fin, F(c["coeff"]), F(c["acc"]), F(c["out"]), n_objects=NCH, force_generic=force_generic)
+    eng.set_coeffs(G.arr(c, "coeffs"))
+    y = eng.run(dev(G.arr(c, "x"), fin), c["n_sample"])
+    want = G.arr(c, "y")
+    assert y.shape[1] == len(want)
+    if len(want):
+        assert np.array_equal(host(y), want)

@@ -16,5 +16,6 @@ $CXX -DGEN_INTR "$R/tools/gen_golden/gen_cic.cpp" -o "$B/gen_cic_intr"
 $CXX "$R/tools/gen_golden/gen_reg_share.cpp" -o "$B/gen_reg_share"
 $CXX "$R/tools/gen_golden/gen_poly_dec.cpp" -o "$B/gen_poly_dec"
 $CXX "$R/tools/gen_golden/gen_poly_intr.cpp" -o "$B/gen_poly_intr"
-for g in gen_fir gen_cic_dec gen_cic_intr gen_reg_share gen_poly_dec gen_poly_intr; do "$B/$g" "$OUT"; done
+$CXX "$R/tools/gen_golden/gen_mv_avg.cpp" -o "$B/gen_mv_avg"
+for g in gen_fir gen_cic_dec gen_cic_intr gen_reg_share gen_poly_dec gen_poly_intr gen_mv_avg; do "$B/$g" "$OUT"; done
 ls -la "$OUT"
