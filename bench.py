@@ -69,51 +69,25 @@ def cpu_baseline_fir(n_taps, coeffs, fin, fc, fa, fo, seed):
                       "(ctypes releases the GIL), %.1f s wall" % (cores, n, reps, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "cic_intr", "ddc", "polydec", "polyintr", "intgdump"])
-    ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
-    ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pad", type=int, default=0, help="extra elements per row (row stride = samples + pad)")
-    ap.add_argument("--stim-bits", type=int, default=0, help="diagnostic: amplitude of the FIR stimulus in bits (default: full 16)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the HIP engine)")
-    if os.environ.get("ACDSP_BENCH_ONE_GPU"):      # self-test of the multi-rank path on a 1-GPU box: every rank on device 0, gloo
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("ACDSP_BENCH_ONE_GPU"):
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch one process per GPU"
-
+def build_workload(workload, args, world, rank, local_rank):
+    """Allocate one workload's engine handle and device buffers (per-rank channel slice) and return its description:
+    step() = one pass of the hot path over the resident [channels][samples] block."""
     import ac_dsp_amd as A
     dev = torch.device("cuda", local_rank)
     seed = 0xACD5
-
-    if args.workload in ("fir255", "fir255_dense", "fir255_wide", "fir1023"):
-        n_taps = 1023 if args.workload == "fir1023" else 255
+    coeffs = n_taps = fin = fc = fa = fo = None
+    if workload in ("fir255", "fir255_dense", "fir255_wide", "fir1023"):
+        n_taps = 1023 if workload == "fir1023" else 255
         ch_per_gpu = args.channels or 1024
         n = args.samples or (1 << 20)
         fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
         fo = A.Fmt(16, 2, True, "RND", "SAT")
-        if args.workload == "fir1023":     # BASELINE configs[3]: ac_fir_prog_coeffs, 1023 taps, ACC <42,14>, 1024 ch per GPU
+        if workload == "fir1023":     # BASELINE configs[3]: ac_fir_prog_coeffs, 1023 taps, ACC <42,14>, 1024 ch per GPU
             fa = A.Fmt(42, 14)
             coeffs = windowed_sinc_raw(n_taps, 0.05, fc.F)
-        elif args.workload in ("fir255", "fir255_wide"):
+        elif workload in ("fir255", "fir255_wide"):
             coeffs = windowed_sinc_raw(n_taps, 0.1, fc.F)  # SURVEY 8(d): symmetric windowed sinc, sum|c| < 2
-            if args.workload == "fir255_wide":             # SURVEY 8(d) second row: OUT_TYPE = ACC_TYPE, 8-byte containers
+            if workload == "fir255_wide":             # SURVEY 8(d) second row: OUT_TYPE = ACC_TYPE, 8-byte containers
                 fo = fa
         else:  # every Toeplitz byte-plane block populated
             coeffs = np.random.default_rng(1).integers(-32768, 32640, size=n_taps, dtype=np.int64)
@@ -127,9 +101,9 @@ def main():
         macs_per_sample = 4.0 * 32 * eng_nb(n_taps)  # int8 MACs issued: 4 byte-plane products x padded band
         name = "ac_fir_load_coeffs 255-tap ac_fixed<16,2> -> <16,2,RND,SAT>, ACC <40,12>, %d ch x %d samples per GPU " \
                "(BASELINE configs[1])" % (ch_per_gpu, n)
-        if args.workload == "fir255_wide":
+        if workload == "fir255_wide":
             name = name.replace("-> <16,2,RND,SAT>", "-> OUT = ACC <40,12> (int64 containers)").replace("(BASELINE configs[1])", "(BASELINE configs[1], wide-output row)")
-        if args.workload == "fir1023":
+        if workload == "fir1023":
             name = "ac_fir_prog_coeffs 1023-tap ac_fixed<16,2> -> <16,2,RND,SAT>, ACC <42,14>, %d ch x %d samples per GPU " \
                    "(BASELINE configs[3])" % (ch_per_gpu, n)
         dtype = "int16 (exact: int8-split MFMA, int32 accumulate)"
@@ -138,7 +112,7 @@ def main():
             eng.run(x, y)
         path = eng.path
         samples_per_step = (hi - lo) * n
-    elif args.workload == "polydec":
+    elif workload == "polydec":
         # ac_poly_dec, 16 taps per branch x DF = 8 (128-tap decimate-by-8), ac_fixed<16,2>
         ch_per_gpu = args.channels or 1024
         n = args.samples or (1 << 22)
@@ -161,7 +135,7 @@ def main():
             eng.run(x, y)
         samples_per_step = (hi - lo) * n
         path = "polydec"
-    elif args.workload == "polyintr":
+    elif workload == "polyintr":
         # ac_poly_intr FOLD_EVEN, 16 taps x IF = 8, ac_fixed<16,2>; 8 outputs per input sample
         ch_per_gpu = args.channels or 1024
         n = args.samples or (1 << 18)
@@ -182,7 +156,7 @@ def main():
             eng.run(x)
         samples_per_step = (hi - lo) * n
         path = "polyintr"
-    elif args.workload == "intgdump":
+    elif workload == "intgdump":
         # ac_intg_dump, 4 interleaved channels per object, dumps every 64 rounds
         ch_per_gpu = args.channels or 1024
         n = args.samples or (1 << 20)            # interleaved samples per object
@@ -202,7 +176,7 @@ def main():
             eng.run(x, n_sample)
         samples_per_step = (hi - lo) * n
         path = "intgdump"
-    elif args.workload == "cic_intr":
+    elif workload == "cic_intr":
         # ac_cic_intr_full N=5 R=8 on ac_fixed<32,16> (named in north_star; no BASELINE config): 8 outputs per input
         ch_per_gpu = args.channels or 1024
         n = args.samples or (1 << 18)
@@ -225,7 +199,7 @@ def main():
             eng.run(x, y)
         samples_per_step = (hi - lo) * n
         path = "cic_intr_" + eng.path
-    elif args.workload == "ddc":
+    elif workload == "ddc":
         # BASELINE configs[4]: CIC R=16 N=5 on ac_fixed<16,1> -> lossless INT <36,21> -> 127-tap FIR (IN <36,21>,
         # COEFF <16,1>); I and Q are separate real streams, 2048 complex = 4096 real streams per GPU
         ch_per_gpu = args.channels or 4096
@@ -272,11 +246,16 @@ def main():
         path = "cic_dec"
         samples_per_step = (hi - lo) * n
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    return {"workload": workload, "name": name, "dtype": dtype, "step": step, "path": path, "samples_per_step": samples_per_step,
+            "bytes_per_sample": bytes_per_sample, "macs_per_sample": macs_per_sample, "coeffs": coeffs, "eng": eng, "x": x, "n": n,
+            "ch_per_gpu": ch_per_gpu, "n_taps": n_taps, "fmts": (fin, fc, fa, fo), "seed": seed}
 
-    for _ in range(args.warmup):
+
+def measure(w, steps, warmup, barrier):
+    """W untimed steps, then exactly `steps` timed steps bracketed by barrier + synchronize.  Returns wall seconds, the
+    dominant kernel's (avg, min) duration from HIP events on the launch stream, and the whole-step event time (ms)."""
+    step, eng = w["step"], w["eng"]
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     barrier()
@@ -284,21 +263,95 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     ev1.record()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1) / steps
     if hasattr(eng, "kernel_stats"):
-        k_avg, k_min = eng.kernel_stats(min(args.steps, 64))   # HIP events around the dominant kernel, launch stream
-    else:                                                     # poly_dec handle: events around the whole step on the launch stream
-        k_avg = k_min = ev0.elapsed_time(ev1) / args.steps
+        k_avg, k_min = eng.kernel_stats(min(steps, 64))   # HIP events around the dominant kernel, on the stream it is launched on
+    else:                                                # handles without a kernel timer: events around the whole step
+        k_avg = k_min = ev_ms
+    return dt, k_avg, k_min, ev_ms
+
+
+PROFILE_TAGS = {"fir255": "fir255", "fir255_dense": "fir255_dense", "fir255_wide": "fir255_wide", "fir1023": "fir1023", "cic_dec": "cic_dec",
+                "ddc": "ddc", "polydec": "polydec"}
+
+
+def roofline_of(w, k_avg, k_min, ev_ms):
+    """roofline object of one workload: algorithmic bytes per launch / the dominant kernel's average duration (kernel only:
+    the per-step state-update kernel and any staging copy are in `frac_step`, which divides by the whole step's event time)."""
+    nbytes = w["bytes_per_sample"] * w["samples_per_step"]
+    ach = nbytes / (k_avg * 1e-3) / 1e9
+    xb = w["x"].element_size()
+    traffic, src = pmc_traffic(PROFILE_TAGS.get(w["workload"], "none"))
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "basis": "dominant kernel only, HIP events on its launch stream",
+            "frac_step": nbytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes_per_launch": nbytes, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
+            "algorithmic_bytes_per_sample": w["bytes_per_sample"],
+            # north_star's wording "HBM-read roofline": input bytes only (SURVEY 8d asks for both views)
+            "read_only": {"bytes_per_sample": float(xb), "achieved": xb * w["samples_per_step"] / (k_avg * 1e-3) / 1e9,
+                          "frac": xb * w["samples_per_step"] / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+
+def mfma_roofline_of(w, k_avg):
+    tops = 2.0 * w["macs_per_sample"] * w["samples_per_step"] / (k_avg * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": tops, "peak": I8_MFMA_PEAK_TOPS,
+            "unit": "TOP/s (int8 ops of the dense 4-byte-plane Toeplitz formulation; all-zero high-byte blocks of the "
+                    "coefficient set are skipped, so fewer are issued)", "frac": tops / I8_MFMA_PEAK_TOPS}
+
+
+# the other BASELINE configurations, measured in the same process after the headline (N = 1 only)
+SECONDARY = ["fir255_dense", "fir1023", "cic_dec", "ddc"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "cic_intr", "ddc", "polydec", "polyintr", "intgdump"])
+    ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
+    ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs after the headline workload")
+    ap.add_argument("--pad", type=int, default=0, help="extra elements per row (row stride = samples + pad)")
+    ap.add_argument("--stim-bits", type=int, default=0, help="diagnostic: amplitude of the FIR stimulus in bits (default: full 16)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the HIP engine)")
+    if os.environ.get("ACDSP_BENCH_ONE_GPU"):      # self-test of the multi-rank path on a 1-GPU box: every rank on device 0
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        # Channels are independent filter objects: the data path has no exchange step, so no RCCL communicator is built.
+        # The timing contract (barrier, MAX of the times, SUM of the samples) runs over gloo on host scalars.
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    assert world == args.gpus or world == 1, "launch one process per GPU"
+
+    w = build_workload(args.workload, args, world, rank, local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    dt, k_avg, k_min, ev_ms = measure(w, args.steps, args.warmup, barrier)
+    samples_per_step = w["samples_per_step"]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([float(samples_per_step)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(samples_per_step)], dtype=torch.float64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_samples_per_step = float(tot.item())
     else:
@@ -306,33 +359,40 @@ def main():
 
     if rank == 0:
         value = total_samples_per_step * args.steps / dt / 1e6
-        ach = bytes_per_sample * samples_per_step / (k_avg * 1e-3) / 1e9
         out = {
             "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic (on-device splitmix64 counter hash, seed 0xACD5)",
-            "config": {"workload": name, "kernel_path": path, "channels_per_gpu": ch_per_gpu, "samples_per_step": n,
+            "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic (on-device splitmix64 counter hash, seed 0xACD5)",
+            "config": {"workload": w["name"], "kernel_path": w["path"], "channels_per_gpu": w["ch_per_gpu"], "samples_per_step": w["n"],
                        "parallelism": "channel-slice x%d, no collectives" % world},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic({"fir255": "r1_fir255", "fir255_dense": "r1_fir255_dense", "fir255_wide": "r1_fir255_wide", "fir1023": "r1_fir1023", "cic_dec": "r1_cic_dec", "ddc": "r1_ddc", "polydec": "r1_polydec"}.get(args.workload, "none")),
-                         "algorithmic_bytes_per_launch": bytes_per_sample * samples_per_step, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
-                         "algorithmic_bytes_per_sample": bytes_per_sample,
-                         # north_star's wording "HBM-read roofline": input bytes only (SURVEY 8d asks for both views)
-                         "read_only": {"bytes_per_sample": float(x.element_size()),
-                                       "achieved": x.element_size() * samples_per_step / (k_avg * 1e-3) / 1e9,
-                                       "frac": x.element_size() * samples_per_step / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-            "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
+            "roofline": roofline_of(w, k_avg, k_min, ev_ms),
+            "event_ms_per_step": ev_ms,
         }
-        if macs_per_sample:
-            tops = 2.0 * macs_per_sample * samples_per_step / (k_avg * 1e-3) / 1e12
-            out["mfma_roofline"] = {"bound": "mfma", "achieved": tops, "peak": I8_MFMA_PEAK_TOPS,
-                                    "unit": "TOP/s (int8 ops of the dense 4-byte-plane Toeplitz formulation; all-zero high-byte "
-                                            "blocks of the coefficient set are skipped, so fewer are issued)",
-                                    "frac": tops / I8_MFMA_PEAK_TOPS}
-        if world == 1 and not args.no_cpu_baseline and coeffs is not None:
-            out["cpu_baseline"] = cpu_baseline_fir(n_taps, coeffs, fin, fc, fa, fo, seed)
+        if w["macs_per_sample"]:
+            out["mfma_roofline"] = mfma_roofline_of(w, k_avg)
+        fin, fc, fa, fo = w["fmts"]
+        if world == 1 and not args.no_cpu_baseline and w["coeffs"] is not None:
+            out["cpu_baseline"] = cpu_baseline_fir(w["n_taps"], w["coeffs"], fin, fc, fa, fo, w["seed"])
         elif world == 1 and not args.no_cpu_baseline and args.workload == "cic_dec":
-            out["cpu_baseline"] = cpu_baseline_cic(fin, fo, seed)
+            out["cpu_baseline"] = cpu_baseline_cic(fin, fo, w["seed"])
+        if world == 1 and not args.no_secondary and args.workload == "fir255" and not (args.channels or args.samples or args.stim_bits):
+            # every other BASELINE config in the same process, 5 timed steps each (one resident workload at a time:
+            # config 3 alone holds 86 GB)
+            del w
+            torch.cuda.empty_cache()
+            sec = {}
+            for name in SECONDARY:
+                w2 = build_workload(name, args, 1, 0, local_rank)
+                dt2, ka2, km2, ev2 = measure(w2, 5, 2, lambda: None)
+                r2 = roofline_of(w2, ka2, km2, ev2)
+                sec[name] = {"workload": w2["name"], "kernel_path": w2["path"], "ms_per_step": dt2 / 5 * 1e3,
+                             "Msamples_per_s": w2["samples_per_step"] * 5 / dt2 / 1e6, "kernel_ms_avg": ka2,
+                             "roofline_frac": r2["frac"], "roofline_frac_step": r2["frac_step"], "achieved_GBps": r2["achieved"]}
+                if w2["macs_per_sample"]:
+                    sec[name]["mfma_frac"] = mfma_roofline_of(w2, ka2)["frac"]
+                del w2
+                torch.cuda.empty_cache()
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -361,26 +421,28 @@ def host_cores():
 
 
 def pmc_traffic(tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of the same
-    command (profiles/<tag>_rocprof.txt): FETCH_SIZE (KB, x2 on gfx950 for 16-byte streaming reads, see
-    MI355X_MICROARCH.md) + WRITE_SIZE (KB).  None when no summary has been committed for this workload."""
-    path = os.path.join(ROOT, "profiles", tag + "_rocprof.txt")
-    try:
-        vals = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
-        seen = set()
-        kernel = None
-        for line in open(path):
-            if line.startswith("void ") or line.startswith("acdsp::"):
-                kernel = line.strip()
-            f = line.split()
-            if len(f) == 3 and f[0] in vals and kernel and any(k in kernel for k in ("fir_mfma", "fir_gen", "cascade_kernel", "cic_kernel<")):
-                vals[f[0]] += float(f[2])      # summed over the data-path kernels of one step (the DDC has two)
-                seen.add(f[0])
-        if len(seen) == 2:
-            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    except OSError:
-        pass
-    return None
+    """(HBM bytes per launch of the dominant kernel, source) from the committed rocprofv3 --pmc summary of the same command
+    (profiles/r<round>_<tag>_rocprof.txt, newest round first): FETCH_SIZE (KB, x2 on gfx950 for 16-byte streaming reads, see
+    MI355X_MICROARCH.md) + WRITE_SIZE (KB).  A static value from the profile of the same binary, NOT measured in this run
+    (the PMC passes are separate rocprofv3 invocations); (None, None) when no summary has been committed."""
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_rocprof.txt" % (rnd, tag))
+        try:
+            vals = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+            seen = set()
+            kernel = None
+            for line in open(path):
+                if line.startswith("void ") or line.startswith("acdsp::"):
+                    kernel = line.strip()
+                f = line.split()
+                if len(f) == 3 and f[0] in vals and kernel and any(k in kernel for k in ("fir_mfma", "fir_gen", "cascade_kernel", "cic_kernel<")):
+                    vals[f[0]] += float(f[2])      # summed over the data-path kernels of one step (the DDC has two)
+                    seen.add(f[0])
+            if len(seen) == 2:
+                return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "static: profiles/%s_%s_rocprof.txt (separate rocprofv3 --pmc passes of this command)" % (rnd, tag)
+        except OSError:
+            pass
+    return None, None
 
 
 def timed_threads(work, cores, set_reps):
