@@ -128,6 +128,7 @@ SYMBOLS = {
     "acdsp_polyintr_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64), _vp]),
     "acdsp_polyintr_run_host": (_i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "acdsp_polyintr_reset": (_i32, [_vp]),
+    "acdsp_polyintr_path": (_i32, [_vp]),
     "acdsp_intgdump_create": (_i32, [C.POINTER(IntgDumpDesc), C.POINTER(_vp)]),
     "acdsp_intgdump_destroy": (_i32, [_vp]),
     "acdsp_intgdump_counts": (_i32, [_vp, C.POINTER(_i64), _i64, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -1245,8 +1245,67 @@ struct acdsp_polyintr {
   int64_t t_total = 0;
   int64_t *d_coeffs = nullptr;
   uint8_t *d_sign = nullptr, *d_corr = nullptr;
+  // exact-accumulation class on the matrix cores (fir_up.hip): folded per-phase taps of the current control words
+  bool up_ok = false;
+  FirUpPlan up_plan;
+  uint32_t up_shmask = 0;
+  int64_t up_max_abs = -1;      // bound on |z| of the folded taps (enables the 32-bit epilogue)
+  uint32_t *d_upfrag = nullptr;
+  int64_t *d_upcorr = nullptr;
+  int last_path = ACDSP_PATH_GENERIC;
   Staging st;
 };
+
+namespace {
+
+// Per-phase taps of ac_poly_intr as one linear filter of the input (host side; see fir_up.hip).  E[j][k] multiplies
+// x[n - k] in the output group of input sample n.  Returns false when the control words make the cores non-linear in the
+// input (a phase with sign[j] = 0 negates samples in IN_TYPE: -min(IN_TYPE) is not representable).
+bool polyintr_linear_taps(const acdsp_polyintr_desc_t &d, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr,
+                          std::vector<int64_t> *E, int *nt, uint32_t *sh_mask, __int128 *max_abs_sum) {
+  const int N = d.n_taps, L = d.ifac;
+  std::vector<std::vector<__int128>> sub((size_t)L, std::vector<__int128>((size_t)N, 0));   // sub-filter sums acc_n[j] = sum_k sub[j][k] x[n-k]
+  for (int j = 0; j < L; j++) {
+    if (d.ftype == ACDSP_POLY_FOLD_ANTI) {
+      for (int i = 0; i < N; i++) { sub[j][i] = coeffs[i + N * j]; }                           // ac_poly_intr.h:246-256
+      continue;
+    }
+    if (!sign[j]) { return false; }
+    if (d.ftype == ACDSP_POLY_FOLD_EVEN) {                                                      // :141-151
+      for (int i = 0; i < N / 2; i++) { const int64_t c = coeffs[i + j * N / 2]; sub[j][i] += c; sub[j][N - 1 - i] += c; }
+    } else {                                                                                    // :194-209
+      const int mid = (N - 1) / 2;
+      for (int i = 0; i <= mid; i++) {
+        const int64_t c = coeffs[i + (N / 2 + 1) * j];
+        sub[j][i] += c;
+        if (i != mid) { sub[j][N - 1 - i] += c; }
+      }
+    }
+  }
+  *max_abs_sum = 0;
+  for (int j = 0; j < L; j++) {
+    __int128 sa = 0;
+    for (int k = 0; k < N; k++) { sa += sub[j][k] < 0 ? -sub[j][k] : sub[j][k]; }
+    if (sa > *max_abs_sum) { *max_abs_sum = sa; }
+  }
+  const int lag = d.ftype == ACDSP_POLY_FOLD_ANTI ? 0 : 1;   // banks: the sums of sample n-1 leave with sample n (:153-175)
+  *nt = N + lag;
+  *sh_mask = 0;
+  E->assign((size_t)L * (size_t)*nt, 0);
+  for (int j = 0; j < L; j++) {
+    const int cj = d.ftype == ACDSP_POLY_FOLD_ANTI ? j : corr[j];
+    for (int k = 0; k < N; k++) {
+      __int128 g = sub[j][k];
+      if (cj != j) { g -= sub[cj][k]; }                      // (t1 + ACC(-t2)) >> 1 with sign[j] set (:164-172)
+      if (g < INT64_MIN / 4 || g > INT64_MAX / 4) { return false; }
+      (*E)[(size_t)j * *nt + k + lag] = (int64_t)g;
+    }
+    if (cj != j) { *sh_mask |= 1u << j; }
+  }
+  return true;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1260,10 +1319,14 @@ int32_t acdsp_polyintr_destroy(acdsp_polyintr_t h) {
   if (h->d_coeffs) { (void)hipFree(h->d_coeffs); }
   if (h->d_sign) { (void)hipFree(h->d_sign); }
   if (h->d_corr) { (void)hipFree(h->d_corr); }
+  if (h->d_upfrag) { (void)hipFree(h->d_upfrag); }
+  if (h->d_upcorr) { (void)hipFree(h->d_upcorr); }
   h->st.destroy();
   delete h;
   return ACDSP_OK;
 }
+
+int32_t acdsp_polyintr_path(acdsp_polyintr_t h) { return h ? h->last_path : -1; }
 
 int32_t acdsp_polyintr_create(const acdsp_polyintr_desc_t *desc, acdsp_polyintr_t *out) {
   if (!desc || !out) { return fail(ACDSP_EINVAL, "null argument"); }
@@ -1330,6 +1393,43 @@ int32_t acdsp_polyintr_set_ctrl(acdsp_polyintr_t h, const int64_t *coeffs, const
   HIP_TRY(hipMemcpy(h->d_sign, sign, (size_t)d.ifac, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_corr, corr, (size_t)d.ifac, hipMemcpyHostToDevice));
   h->ctrl_set = true;
+  // matrix-core path: exact-accumulation class, int16 samples, control words that keep the cores linear, and an
+  // accumulator that cannot wrap (the symmetric-pair halving (t1 -/+ t2) >> 1 does not commute with a wrap)
+  h->up_ok = false;
+  static const bool no_gen = getenv("ACDSP_NO_GEN") != nullptr;
+  const int fi = d.in.W - d.in.I, fc = d.coeff.W - d.coeff.I, fa = d.acc.W - d.acc.I, ls = fa - fi - fc;
+  const bool lossless = d.in.S && d.acc.S && d.acc.O == ACDSP_WRAP && ls >= 0 && ls < 64 && fa >= fi && d.acc.I >= d.in.I + 1 && d.acc.W <= 63;
+  if (lossless && !no_gen && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && d.in.W <= 16 && h->in_eb == 2 && d.ifac <= 32) {
+    std::vector<int64_t> E;
+    int nt = 0;
+    uint32_t shm = 0;
+    __int128 sa = 0;
+    std::vector<uint32_t> frag;
+    std::vector<int64_t> ucorr;
+    FirUpPlan pl;
+    if (polyintr_linear_taps(d, coeffs, sign, corr, &E, &nt, &shm, &sa) &&
+        // |acc| <= sum|taps| * 2^(W_in - 1) << ls must stay inside ACC_TYPE; a pair sum then fits one more bit
+        (sa << (d.in.W - 1 + ls)) < ((__int128)1 << (d.acc.W - 1)) &&
+        fir_up_plan(E.data(), d.ifac, nt, 2, &pl, &frag, &ucorr) && fir_up_shape_ok(h->in_eb, 2, pl.nb, d.ifac, h->out_eb)) {
+      if (h->d_upfrag) { (void)hipFree(h->d_upfrag); h->d_upfrag = nullptr; }
+      if (h->d_upcorr) { (void)hipFree(h->d_upcorr); h->d_upcorr = nullptr; }
+      HIP_TRY(hipMalloc((void **)&h->d_upfrag, frag.size() * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc((void **)&h->d_upcorr, ucorr.size() * sizeof(int64_t)));
+      HIP_TRY(hipMemcpy(h->d_upfrag, frag.data(), frag.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(h->d_upcorr, ucorr.data(), ucorr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+      h->up_plan = pl; h->up_shmask = shm; h->up_ok = true;
+      {  // |z| <= max_j sum_k |E_j[k]| * 2^(W_in - 1)
+        __int128 worst = 0;
+        for (int j = 0; j < d.ifac; j++) {
+          __int128 sj = 0;
+          for (int k = 0; k < nt; k++) { const int64_t v = E[(size_t)j * nt + k]; sj += v < 0 ? -(__int128)v : (__int128)v; }
+          if (sj > worst) { worst = sj; }
+        }
+        worst <<= (d.in.W - 1);
+        h->up_max_abs = worst < ((__int128)1 << 62) ? (int64_t)worst : -1;
+      }
+    }
+  }
   return ACDSP_OK;
 }
 
@@ -1368,8 +1468,39 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
   p.in_stride = in_stride; p.out_stride = out_stride; p.n = n_in; p.n_out = no;
   p.x = d_in; p.y = d_out; p.hist = h->d_hist[h->cur];
   p.coeffs = h->d_coeffs; p.sign = h->d_sign; p.corr = h->d_corr; p.saved = h->d_saved[h->cur];
-  hipError_t e = launch_polyintr(p, h->d_saved[h->cur ^ 1], s);
-  if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_intr kernel launch failed: %s", hipGetErrorString(e)); }
+  p.o_begin = 0; p.o_end = no;
+  hipError_t e = hipSuccess;
+  // Complete steps of 32 input slots go to the matrix-core kernel; the head (history, the saved sums of the previous call)
+  // and the ragged tail stay on the VALU kernels.
+  int64_t o_a = 0, o_b = 0;   // outputs [o_a, o_b) are produced by fir_up
+  h->last_path = p.lossless ? ACDSP_PATH_LOSSLESS64 : ACDSP_PATH_GENERIC;
+  if (h->up_ok && p.lossless) {
+    const int L = d.ifac;
+    const int64_t out_off = -(int64_t)p.skip * L, slot_a = h->up_plan.hs;
+    const int64_t n_steps = (n_in / 16 - slot_a) / 32;
+    const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0) && ((uintptr_t)d_out % 8 == 0) &&
+                         ((out_stride * h->out_eb) % 8 == 0) && ((out_off * h->out_eb) % 8 == 0);
+    if (aligned && n_steps > 0) {
+      FirParams k;
+      memset(&k, 0, sizeof k);
+      k.n_ch = d.n_channels; k.in = p.in; k.cf = p.cf; k.acc = p.acc; k.out = p.out; k.in_eb = h->in_eb; k.out_eb = h->out_eb;
+      k.lossless_shift = p.lossless_shift; k.in_stride = in_stride; k.out_stride = out_stride; k.n = n_in; k.x = d_in; k.y = d_out;
+      e = launch_fir_up(k, h->up_plan, 2, h->d_upfrag, h->d_upcorr, 0, 0, 0, h->up_shmask, h->up_max_abs, slot_a, n_steps, out_off, s);
+      if (e == hipSuccess) {
+        o_a = 16 * slot_a * L + out_off; o_b = 16 * (slot_a + 32 * n_steps) * L + out_off;
+        h->last_path = ACDSP_PATH_MFMA_GEN;
+      } else if (e != hipErrorNotSupported) {
+        return fail(ACDSP_EHIP, "poly_intr matrix-core kernel launch failed: %s", hipGetErrorString(e));
+      }
+    }
+  }
+  if (o_b > o_a) {
+    p.o_begin = 0; p.o_end = o_a;
+    e = launch_polyintr(p, nullptr, s);
+    if (e == hipSuccess) { p.o_begin = o_b; p.o_end = no; e = launch_polyintr(p, h->d_saved[h->cur ^ 1], s); }
+  } else {
+    e = launch_polyintr(p, h->d_saved[h->cur ^ 1], s);
+  }
   FirParams k;
   memset(&k, 0, sizeof k);
   k.n_ch = d.n_channels; k.in = p.in; k.in_eb = h->in_eb; k.hl = h->hl; k.in_stride = in_stride; k.n = n_in; k.x = d_in; k.hist = p.hist;

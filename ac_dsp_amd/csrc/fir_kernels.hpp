@@ -72,6 +72,20 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
 hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint32_t *d_fragA, int w_int, int64_t first,
                           const FirParams &pb, const FirGenPlan &plb, const uint32_t *d_fragB, int64_t n_out, hipStream_t s);
 
+// Interpolating polyphase FIR on the matrix cores (fir_up.hip): z[n L + j] = sum_k E_j[k] x[n - k] mod 2^64.
+struct FirUpPlan {
+  int32_t L, nt, pc, nb, hs;   // up factor, taps per phase, coefficient digit planes, 32-sample K blocks, history slots (2 nb - 1)
+};
+// E = [L][nt] taps; builds the Toeplitz fragments [RG][nb][3][64][4] and the per-phase re-bias correction [L] for px input
+// byte planes.  false: L does not divide 32, more than 3 digits per tap, or a window of more than 2 K blocks (nt > 49).
+bool fir_up_plan(const int64_t *E, int L, int nt, int px, FirUpPlan *pl, std::vector<uint32_t> *frag, std::vector<int64_t> *corr);
+bool fir_up_shape_ok(int in_eb, int px, int nb, int L, int out_eb);   // is this shape compiled in?
+// mode 0: poly_intr epilogue ((V << p.lossless_shift) >> sh_j, p.acc.F -> p.out);  mode 1: CIC epilogue (wrap to w_int, p.in.F -> p.out).
+// Covers input slots [slot0, slot0 + 32 n_steps) (16 samples each, slot0 >= pl.hs, rows 16-byte aligned); output element of
+// (input n, phase j) = n L + j + out_off (8-byte aligned runs).  hipErrorNotSupported: shape not compiled in.
+hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const uint32_t *d_frag, const int64_t *d_corr, int mode, int w_int,
+                         int out_simple, uint32_t sh_mask, int64_t max_abs_v, int64_t slot0, int64_t n_steps, int64_t out_off, hipStream_t s);
+
 // Polyphase interpolator (polyintr.hip): ftype 0 FOLD_EVEN, 1 FOLD_ODD, 2 FOLD_ANTI (ac_poly_intr.h:71)
 struct PolyIntrParams {
   int32_t n_taps, coeff_sz, ifac, ftype, n_ch;
@@ -80,6 +94,7 @@ struct PolyIntrParams {
   int32_t skip;               // 1: the stream's very first sample is in this call and emits nothing (folded cores)
   int32_t lossless, lossless_shift;   // exact-accumulation class: int64 dot products, shift = F_acc - F_in - F_coeff
   int64_t in_stride, out_stride, n, n_out;   // n inputs -> n_out outputs per channel
+  int64_t o_begin, o_end;     // outputs [o_begin, o_end) of the call are produced by this launch (the rest: fir_up.hip)
   const void *x; void *y; const void *hist;
   const int64_t *coeffs;      // [coeff_sz]
   const uint8_t *sign, *corr; // [ifac]

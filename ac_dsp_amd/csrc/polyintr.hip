@@ -93,8 +93,8 @@ __device__ int64_t polyintr_acc_fast(const PolyIntrParams &p, int ch, int64_t m,
 
 __global__ void polyintr_kernel(PolyIntrParams p) {
   const int ch = blockIdx.y;
-  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // output index of this call
-  if (o >= p.n_out) { return; }
+  const int64_t o = p.o_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // output index of this call
+  if (o >= p.o_end) { return; }
   const int IF = p.ifac;
   const int j = (int)(o % IF);
   const int64_t grp = o / IF + p.skip;                                 // local index of the sample that emits this group
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) polyintr_fast_kernel(PolyIntrParams p, ui
   unsigned char *sgn = (unsigned char *)(xw + n_win_max), *cor = sgn + 256;   // [IF] each
   const int ch = blockIdx.y;
   const int IF = p.ifac, N = p.n_taps;
-  const int64_t o0 = (int64_t)blockIdx.x * kPiTile;
+  const int64_t o0 = p.o_begin + (int64_t)blockIdx.x * kPiTile;
   const int64_t g0 = o0 / IF;                      // wave-uniform, once
   const int rem0 = (int)(o0 - g0 * IF);
   const int lag = FT == 2 ? 0 : 1;            // the folded cores emit the sums of the previous sample
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) polyintr_fast_kernel(PolyIntrParams p, ui
   };
   for (int it = 0; it < kPiTile / 256; it++) {
     const int64_t o = o0 + threadIdx.x + 256 * it;
-    if (o >= p.n_out) { return; }
+    if (o >= p.o_end) { return; }
     const unsigned t = (unsigned)rem0 + threadIdx.x + 256u * it;     // < IF + kPiTile < 2^16
     const unsigned dg = IF == 1 ? t : __umulhi(t, rcp);              // ceil(2^32 / 1) does not fit the 32-bit reciprocal
     const int j = (int)(t - dg * (unsigned)IF);
@@ -211,11 +211,12 @@ __global__ void polyintr_save_kernel(PolyIntrParams p, int64_t *saved_next) {
 }
 
 hipError_t launch_polyintr(const PolyIntrParams &p, int64_t *saved_next, hipStream_t s) {
-  if (p.n_out > 0) {
+  const int64_t span = p.o_end - p.o_begin;
+  if (span > 0) {
     const int n_win_max = p.n_taps + kPiTile / p.ifac + 4;
     const size_t lds = ((size_t)p.coeff_sz + 2 + (size_t)n_win_max) * sizeof(int64_t) + 512;
     if (p.lossless && lds <= 60 * 1024) {
-      dim3 grid((unsigned)((p.n_out + kPiTile - 1) / kPiTile), (unsigned)p.n_ch);
+      dim3 grid((unsigned)((span + kPiTile - 1) / kPiTile), (unsigned)p.n_ch);
       const uint32_t rcp = (uint32_t)((0x100000000ull + p.ifac - 1) / p.ifac);
       const bool narrow = p.in.W <= 30 && p.cf.W <= 32;
 #define ACDSP_PI_LAUNCH(NV, FV) hipLaunchKernelGGL((polyintr_fast_kernel<NV, FV>), grid, dim3(256), lds, s, p, rcp, n_win_max)
@@ -226,13 +227,13 @@ hipError_t launch_polyintr(const PolyIntrParams &p, int64_t *saved_next, hipStre
       }
 #undef ACDSP_PI_LAUNCH
     } else {
-      dim3 grid((unsigned)((p.n_out + 255) / 256), (unsigned)p.n_ch);
+      dim3 grid((unsigned)((span + 255) / 256), (unsigned)p.n_ch);
       hipLaunchKernelGGL(polyintr_kernel, grid, dim3(256), 0, s, p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { return e; }
   }
-  if (p.ftype != 2 && p.n > 0) {
+  if (p.ftype != 2 && p.n > 0 && saved_next) {
     dim3 grid((unsigned)((p.ifac + 63) / 64), (unsigned)p.n_ch);
     hipLaunchKernelGGL(polyintr_save_kernel, grid, dim3(64), 0, s, p, saved_next);
     return hipGetLastError();

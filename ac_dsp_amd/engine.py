@@ -321,6 +321,11 @@ class PolyIntr:
                                      out.stride(0), C.byref(n_out), _stream_ptr(x)))
         return out[:, :n_out.value]
 
+    @property
+    def path(self):
+        """kernel family of the last run(): "generic", "lossless64" (tiled int64 VALU kernel) or "mfma_gen" (fir_up.hip)"""
+        return PATHS[lib.acdsp_polyintr_path(self._h)]
+
     def reset(self):
         check(lib.acdsp_polyintr_reset(self._h))
 

@@ -155,7 +155,8 @@ def build_workload(workload, args, world, rank, local_rank):
         def step():
             eng.run(x)
         samples_per_step = (hi - lo) * n
-        path = "polyintr"
+        step()
+        path = "polyintr_" + eng.path
     elif workload == "intgdump":
         # ac_intg_dump, 4 interleaved channels per object, dumps every 64 rounds
         ch_per_gpu = args.channels or 1024

@@ -249,6 +249,7 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
                            int64_t *n_out, void *stream);
 int32_t acdsp_polyintr_run_host(acdsp_polyintr_t h, const void *h_in, int64_t n_in, void *h_out, int64_t out_cap, int64_t *n_out);
 int32_t acdsp_polyintr_reset(acdsp_polyintr_t h);
+int32_t acdsp_polyintr_path(acdsp_polyintr_t h);   /* kernel family of the last run(): ACDSP_PATH_GENERIC, _LOSSLESS64 or _MFMA_GEN */
 
 /* ---- integrate and dump (reference ac_intg_dump.h:93-147) ----
  * Rows = objects; a row is the interleaved stream the reference reads from data_in (round-major, channel-minor).

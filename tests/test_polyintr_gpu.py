@@ -124,3 +124,58 @@ def test_lossless_class_int64_kernel(ftype, n_taps, in_o):
     orc = OraclePolyIntr(n_taps, csz, 4, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fa), n_ch=2)
     y = eng.run(torch.from_numpy(x).to(torch.int16).cuda()).cpu().numpy().astype(np.int64)
     assert np.array_equal(y, orc.run(c, sign, corr, x))
+
+
+# ---- matrix-core path (fir_up.hip): exact-accumulation class, int16 samples, all phases with sign set ----
+
+def check_up(n_taps, ifac, ftype, fo, n_ch=3, n=16 * 33 * 3 + 80, splits=None, seed=0, pairs=True, coeff_bits=13, expect="mfma_gen", sign=None,
+             fa=A.Fmt(40, 12)):
+    fin, fc = A.Fmt(16, 2), A.Fmt(16, 2)
+    rng = np.random.default_rng(seed)
+    csz = table_size(n_taps, ifac, ftype) + 1
+    c = rng.integers(-(1 << (coeff_bits - 1)), 1 << (coeff_bits - 1), size=csz, dtype=np.int64)
+    sg = np.ones(ifac, dtype=np.int64) if sign is None else np.asarray(sign)
+    corr = (ifac - 1 - np.arange(ifac)) if pairs else np.arange(ifac)
+    x = rand_raw(rng, fin, (n_ch, n))
+    x[0, :40] = -32768                                      # the most negative word everywhere in one window
+    eng = A.PolyIntr(n_taps, csz, ifac, ftype, fin, fc, fa, fo, n_channels=n_ch)
+    eng.set_ctrl(c, sg, corr)
+    orc = OraclePolyIntr(n_taps, csz, ifac, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    bounds = [0] + list(splits or []) + [n]
+    seen = set()
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        xd = torch.from_numpy(x[:, a:b].copy()).to(torch.int16).cuda()
+        y = eng.run(xd).cpu().numpy().astype(np.int64)
+        seen.add(eng.path)
+        yo = orc.run(c, sg, corr, x[:, a:b])
+        assert y.shape == yo.shape, (y.shape, yo.shape)
+        bad = np.argwhere(y != yo)
+        assert bad.size == 0, "%d mismatches, first at %s: got %d want %d" % (len(bad), bad[0], y[tuple(bad[0])], yo[tuple(bad[0])])
+    if expect:
+        assert expect in seen, seen
+    return eng
+
+
+@pytest.mark.parametrize("ftype,n_taps", [("FOLD_EVEN", 16), ("FOLD_ODD", 15), ("FOLD_ANTI", 16), ("FOLD_EVEN", 12), ("FOLD_ODD", 9), ("FOLD_EVEN", 40)])
+@pytest.mark.parametrize("ifac", [4, 8, 16])
+def test_matrix_core_path_all_cores(ftype, n_taps, ifac):
+    fo = A.Fmt(16, 2, True, "RND", "SAT")
+    check_up(n_taps, ifac, ftype, fo, seed=n_taps + ifac, pairs=True)
+    check_up(n_taps, ifac, ftype, fo, seed=n_taps + ifac + 1, pairs=False, splits=[8, 8 + 16 * 36, 8 + 16 * 72 + 3], n=16 * 33 * 3 + 160)   # state carry, ragged and unaligned bursts
+
+
+@pytest.mark.parametrize("fo", [A.Fmt(40, 12), A.Fmt(16, 2, True, "TRN", "WRAP"), A.Fmt(24, 6, True, "RND_CONV", "SAT_SYM"), A.Fmt(12, 4, False, "RND", "SAT")])
+def test_matrix_core_path_output_types(fo):
+    check_up(16, 8, "FOLD_EVEN", fo, seed=5, n=16 * 33 * 5)
+    check_up(15, 8, "FOLD_ODD", fo, seed=6, n=16 * 33 * 2 + 8, pairs=False)
+
+
+def test_matrix_core_path_is_left_when_the_cores_are_not_linear():
+    fo = A.Fmt(16, 2, True, "RND", "SAT")
+    # a phase with sign = 0 negates samples in IN_TYPE (-min wraps): stays on the VALU kernel, results still exact
+    check_up(16, 8, "FOLD_EVEN", fo, seed=7, sign=[1, 1, 0, 1, 1, 1, 1, 1], expect="lossless64")
+    # an accumulator that can wrap (34 bits for sums of up to 2^35): the pair halving does not commute with the wrap
+    check_up(16, 8, "FOLD_EVEN", fo, seed=8, coeff_bits=16, expect="lossless64", fa=A.Fmt(34, 6))
+    check_up(16, 8, "FOLD_EVEN", fo, seed=8, coeff_bits=16, fa=A.Fmt(40, 12))
+    # unaligned rows / odd interpolation factors fall back as well
+    check_up(16, 5, "FOLD_EVEN", fo, seed=9, expect="lossless64")

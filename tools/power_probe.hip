@@ -98,6 +98,24 @@ __global__ void __launch_bounds__(64, OCC) probe(const v4i *__restrict__ frag, c
   }
 }
 
+struct Ctx;
+// write-only stream with W-byte stores per lane (W = 4, 8, 16), a wave's stores forming one contiguous run: what a
+// store-bound kernel (the interpolators: 8 output words per input word) can expect from narrower stores
+template <int W>
+__global__ void __launch_bounds__(256) wprobe(char *__restrict__ y, long bytes_per_block) {
+  char *base = y + (long)blockIdx.x * bytes_per_block;
+  const int tid = threadIdx.x;
+  for (long off = 0; off < bytes_per_block; off += 256 * W * 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      char *p = base + off + u * 256 * W + tid * W;
+      if (W == 16) { *(v4i *)p = (v4i){tid, u, 3, 4}; }
+      else if (W == 8) { *(long *)p = (long)tid * 77 + u; }
+      else { *(int *)p = tid + u; }
+    }
+  }
+}
+
 static uint64_t sm64(uint64_t &s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -109,6 +127,23 @@ struct Ctx {
   v4i *d_frag; short *d_x, *d_y; long *d_dbg; long stride; int n_ch; long n; int reps;
   std::vector<long> h_dbg;
 };
+
+template <int W> static void run_w(Ctx &c, size_t bytes) {
+  const long per_block = 1 << 20;
+  const unsigned blocks = (unsigned)(bytes / per_block);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(wprobe<W>, dim3(blocks), dim3(256), 0, 0, (char *)c.d_y, per_block);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < c.reps; r++) { hipLaunchKernelGGL(wprobe<W>, dim3(blocks), dim3(256), 0, 0, (char *)c.d_y, per_block); }
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= c.reps;
+  printf("write-only, %2d-byte stores per lane (256-thread blocks, 1 MiB per block): %7.3f ms  %6.0f GB/s\n", W, ms, bytes / (ms * 1e-3) / 1e9);
+}
 
 template <int NM, bool LOADS, bool STORES, int kU = 4, int OCC = 2>
 static void run(Ctx &c, const char *label, int data) {
@@ -201,5 +236,6 @@ int main(int argc, char **argv) {
   run<28, true, true, 4, 4>(c, "stream+mfma", 0);
   run<28, true, false, 4, 4>(c, "read+mfma", 2);
   run<28, false, true, 4, 4>(c, "write+mfma", 2);
+  run_w<16>(c, bytes); run_w<8>(c, bytes); run_w<4>(c, bytes);
   return 0;
 }
