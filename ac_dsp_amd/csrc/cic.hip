@@ -270,7 +270,8 @@ __global__ void __launch_bounds__(256) cic_intr_fir_kernel(CicParams p, const in
   XW *xw = (XW *)(lds_raw + (size_t)((n_taps + 1) / 2 * 2) * 4);
   const int ch = blockIdx.y;
   const int64_t lo = p.q_begin > p.q_skip ? p.q_begin : p.q_skip;    // first emitted iteration of this call
-  const int64_t q0 = lo + (int64_t)blockIdx.x * kIntrTile;           // a block owns kIntrTile consecutive outputs
+  const int64_t q_stop = p.q_to > p.q_from ? p.q_to : p.q_end;       // this launch: [q_from, q_to) (or the whole call)
+  const int64_t q0 = (p.q_to > p.q_from ? p.q_from : lo) + (int64_t)blockIdx.x * kIntrTile;   // a block owns kIntrTile consecutive outputs
   const int R = p.R;
   const int64_t n_base = q0 / R;                                      // wave-uniform 64-bit division, once
   const int r0 = (int)(q0 - n_base * R);
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(256) cic_intr_fir_kernel(CicParams p, const in
 #pragma unroll 2
   for (int i = 0; i < kIntrTile / 256; i++) {
     const int64_t q = q0 + threadIdx.x + 256 * i;                     // consecutive lanes = consecutive outputs
-    if (q >= p.q_end) { return; }
+    if (q >= q_stop) { return; }
     const unsigned t = (unsigned)r0 + threadIdx.x + 256u * i;         // < R + kIntrTile < 2^16
     const unsigned dn = __umulhi(t, rcp);                             // t / R (exact for t < 2^16)
     const int r = (int)(t - dn * (unsigned)R);
@@ -310,9 +311,10 @@ __global__ void __launch_bounds__(256) cic_intr_fir_kernel(CicParams p, const in
 }
 
 hipError_t launch_cic_intr_fir(const CicParams &p, const int64_t *d_taps, int n_taps, hipStream_t s) {
-  const int64_t lo = p.q_begin > p.q_skip ? p.q_begin : p.q_skip;
-  if (p.q_end <= lo) { return hipSuccess; }
-  dim3 grid((unsigned)((p.q_end - lo + kIntrTile - 1) / kIntrTile), (unsigned)p.n_ch);
+  const int64_t lo = p.q_to > p.q_from ? p.q_from : (p.q_begin > p.q_skip ? p.q_begin : p.q_skip);
+  const int64_t hi = p.q_to > p.q_from ? p.q_to : p.q_end;
+  if (hi <= lo) { return hipSuccess; }
+  dim3 grid((unsigned)((hi - lo + kIntrTile - 1) / kIntrTile), (unsigned)p.n_ch);
   const uint32_t rcp = (uint32_t)((0x100000000ull + p.R - 1) / p.R);
   const int kmax = (n_taps + p.R - 1) / p.R;
   const size_t lds = (size_t)((n_taps + 1) / 2 * 2) * 4 + (size_t)(kmax + (kIntrTile - 1) / p.R + 2) * 8;

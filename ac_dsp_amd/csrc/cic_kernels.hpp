@@ -27,6 +27,9 @@ struct CicParams {
   // interpolator: iteration window [q_begin, q_end) of this call in global iteration numbers,
   // inputs consumed by earlier calls, and the number of start-up iterations that are never emitted
   int64_t q_begin, q_end, t_prev, q_skip;
+  // interpolator, FIR-identity kernels: iterations [q_from, q_to) are produced by this launch (0, 0: the whole call);
+  // the output index stays q - max(q_begin, q_skip)
+  int64_t q_from, q_to;
 };
 
 hipError_t launch_cic(const CicParams &p, hipStream_t s);

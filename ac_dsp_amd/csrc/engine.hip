@@ -177,6 +177,12 @@ struct acdsp_cic {
   FirGenPlan gen_plan[16];
   uint32_t *d_gfrag = nullptr;   // [16][3*8*64*4]
   int64_t *d_taps = nullptr;     // interpolator: the identity's taps for the polyphase kernel
+  // interpolator on the matrix cores (fir_up.hip): per-phase taps E_r[k] = h[r + R k]
+  bool up_ok = false;
+  int up_px = 0;
+  FirUpPlan up_plan;
+  uint32_t *d_upfrag = nullptr;
+  int64_t *d_upcorr = nullptr;
   int last_path = 0;
   int64_t t_total = 0;  // inputs consumed so far (all calls)
   void *d_hist[2] = {nullptr, nullptr};
@@ -682,6 +688,23 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
     if (e == hipSuccess && desc->interp && !no_gen) {   // interpolator: polyphase FIR kernel reads the taps themselves
       e = hipMalloc((void **)&h->d_taps, h->h_taps.size() * sizeof(int64_t));
       if (e == hipSuccess) { e = hipMemcpy(h->d_taps, h->h_taps.data(), h->h_taps.size() * sizeof(int64_t), hipMemcpyHostToDevice); }
+      // ... and, where the shape is compiled in, the same identity phase by phase on the matrix cores
+      const int R = desc->R, n_taps = (int)h->h_taps.size(), kmax = (n_taps + R - 1) / R;
+      const int px = (desc->in.W + (desc->in.S ? 0 : 1) + 7) / 8;
+      if (e == hipSuccess && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) && ((px <= 2 && h->in_eb == 2) || (px <= 4 && h->in_eb == 4)) && R <= 32) {
+        std::vector<int64_t> E((size_t)R * kmax, 0);
+        for (int r = 0; r < R; r++) { for (int k = 0; k < kmax; k++) { if (r + R * k < n_taps) { E[(size_t)r * kmax + k] = h->h_taps[(size_t)(r + R * k)]; } } }
+        std::vector<uint32_t> frag;
+        std::vector<int64_t> ucorr;
+        FirUpPlan pl;
+        if (fir_up_plan(E.data(), R, kmax, h->in_eb, &pl, &frag, &ucorr) && pl.pc <= 2 && pl.nb == 1 && fir_up_shape_ok(h->in_eb, h->in_eb, pl.nb, R, h->out_eb)) {
+          e = hipMalloc((void **)&h->d_upfrag, frag.size() * sizeof(uint32_t));
+          if (e == hipSuccess) { e = hipMalloc((void **)&h->d_upcorr, ucorr.size() * sizeof(int64_t)); }
+          if (e == hipSuccess) { e = hipMemcpy(h->d_upfrag, frag.data(), frag.size() * sizeof(uint32_t), hipMemcpyHostToDevice); }
+          if (e == hipSuccess) { e = hipMemcpy(h->d_upcorr, ucorr.data(), ucorr.size() * sizeof(int64_t), hipMemcpyHostToDevice); }
+          h->up_plan = pl; h->up_px = h->in_eb; h->up_ok = e == hipSuccess;
+        }
+      }
     }
     h->gen_ok = e == hipSuccess && !desc->interp && !no_gen && (desc->in.W + (desc->in.S ? 0 : 1) + 7) / 8 <= h->in_eb &&
                 fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), desc->R, 15, &probe, &fr) &&   // worst-case window offset
@@ -701,6 +724,8 @@ int32_t acdsp_cic_destroy(acdsp_cic_t h) {
   (void)hipSetDevice(h->d.device);
   if (h->d_gfrag) { (void)hipFree(h->d_gfrag); }
   if (h->d_taps) { (void)hipFree(h->d_taps); }
+  if (h->d_upfrag) { (void)hipFree(h->d_upfrag); }
+  if (h->d_upcorr) { (void)hipFree(h->d_upcorr); }
   for (int i = 0; i < 2; i++) {
     if (h->d_hist[i]) { (void)hipFree(h->d_hist[i]); }
   }
@@ -777,6 +802,7 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
   hipStream_t s = (hipStream_t)stream;
   CicParams p;
   cic_window(h, n_in, &p);
+  p.q_from = p.q_to = 0;
   p.interp = d.interp; p.R = d.R; p.me = h->me; p.N = d.N; p.n_ch = d.n_channels;
   p.w_int = h->it.W;
   p.in = make_dfmt(d.in); p.out = make_dfmt(d.out);
@@ -823,7 +849,38 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
     k.x = d_in; k.y = d_out; k.hist = h->d_hist[h->cur];
     e = launch_fir_gen(k, gpl, gfrag, 1, h->it.W, p.first, no, s);
   } else if (use_intr_fir) {
-    e = launch_cic_intr_fir(p, h->d_taps, (int)h->h_taps.size(), s);
+    // whole steps of 32 input slots on the matrix cores; the head (history, earlier-call phase) and the tail (the call's
+    // last input emits only its first iteration, ac_cic_intr_full.h:200-205) on the polyphase VALU kernel
+    int64_t q_a = 0, q_b = 0;
+    const int64_t lo = p.q_begin > p.q_skip ? p.q_begin : p.q_skip;
+    p.q_from = p.q_to = 0;
+    static const bool cic_up = getenv("ACDSP_CIC_UP") != nullptr;   // slower than the VALU kernel so far (store pattern): opt-in
+    if (h->up_ok && p.vec_ok && cic_up) {
+      const int64_t slot_a = h->up_plan.hs, n_steps = ((n_in - 1) / 16 - slot_a) / 32;
+      const int64_t out_off = (int64_t)d.R * p.t_prev - lo;
+      const bool out_ok = ((uintptr_t)d_out % 8 == 0) && ((out_stride * h->out_eb) % 8 == 0) && ((out_off * h->out_eb) % 8 == 0);
+      if (n_steps > 0 && out_ok && (int64_t)d.R * (p.t_prev + 16 * slot_a) >= lo) {
+        FirParams k;
+        memset(&k, 0, sizeof k);
+        k.n_ch = d.n_channels; k.in = p.in; k.out = p.out; k.acc = p.out; k.cf = p.in;
+        k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.in_stride = in_stride; k.out_stride = out_stride; k.n = n_in; k.x = d_in; k.y = d_out;
+        e = launch_fir_up(k, h->up_plan, h->up_px, h->d_upfrag, h->d_upcorr, 1, h->it.W, p.out_simple, 0, -1, slot_a, n_steps, out_off, s);
+        if (e == hipSuccess) {
+          q_a = (int64_t)d.R * (p.t_prev + 16 * slot_a); q_b = (int64_t)d.R * (p.t_prev + 16 * (slot_a + 32 * n_steps));
+          h->last_path = ACDSP_PATH_MFMA_GEN;
+        } else if (e != hipErrorNotSupported) {
+          return fail(ACDSP_EHIP, "CIC interpolator matrix-core kernel launch failed: %s", hipGetErrorString(e));
+        }
+      }
+    }
+    if (q_b > q_a) {
+      e = hipSuccess;
+      if (q_a > lo) { p.q_from = lo; p.q_to = q_a; e = launch_cic_intr_fir(p, h->d_taps, (int)h->h_taps.size(), s); }
+      if (e == hipSuccess && p.q_end > q_b) { p.q_from = q_b; p.q_to = p.q_end; e = launch_cic_intr_fir(p, h->d_taps, (int)h->h_taps.size(), s); }
+      p.q_from = p.q_to = 0;
+    } else {
+      e = launch_cic_intr_fir(p, h->d_taps, (int)h->h_taps.size(), s);
+    }
   } else {
     e = launch_cic(p, s);
   }

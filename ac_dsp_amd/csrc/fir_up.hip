@@ -26,6 +26,7 @@
 // the speed: every row group (or, for 2-byte outputs, four of them) is converted into a padded LDS tile holding the
 // outputs of each column as one contiguous run, and leaves as 8-byte-per-lane stores that form 256-byte runs
 // (tools/power_probe: full-wave contiguous stores reach 5.8 - 5.9 TB/s at 4, 8 and 16 bytes per lane alike).
+#include <type_traits>
 #include <vector>
 
 #include "fir_kernels.hpp"
@@ -63,13 +64,18 @@ struct UpArgs {
   int32_t w_int, out_simple;
   uint32_t sh_mask;           // mode 0: bit j set = phase j is a symmetric pair: halve
   const int64_t *corr;        // [L] re-bias correction per phase (mod 2^64)
-  // EPI 1 (mode 0, every intermediate inside int32, AC_TRN / AC_RND into AC_WRAP / AC_SAT): out = clamp((V + rnd_j) >> (rs + sh_j))
-  int32_t e_rs, e_rnd, e_sat, e_lo, e_hi, e_w;
+  // EPI 1 (mode 0, every intermediate inside int32, AC_TRN / AC_RND into AC_WRAP / AC_SAT):
+  //   q = (V + (rnd << sh_j)) >> (rs + sh_j);  q = clamp(q, lo, hi);  q = ((q << w) >> w) & mask       (all branch-free)
+  // EPI 2 (mode 1, OUT_TYPE has INT_TYPE's fraction and AC_WRAP):  v = (y << w) >> w;  o = ((v << rs) >> rs) & mask
+  int32_t e_rs, e_rnd, e_lo, e_hi, e_w;
+  uint64_t e_mask;
 };
 
-// EPI 0: 64-bit recombination + the generic conversions.  EPI 1: poly_intr with every intermediate inside int32 and a
-// shift / clamp conversion (host-checked): five VALU operations per output instead of ~80.
-template <typename TIN, int PX, int NBT, int L, int OEB, int EPI>
+// EPI 0: 64-bit recombination + the generic conversions (any Q / O mode; uniform branches per output).
+// EPI 1: poly_intr with every intermediate inside int32 and a shift / clamp / wrap conversion (host-checked).
+// EPI 2: CIC with a bit-field wrap conversion.  1 and 2 are branch-free: the step loop stays one basic block.
+// PCT: coefficient digit planes compiled in (2 or 3; the fragment array always has 3 per K block).
+template <typename TIN, int PX, int PCT, int NBT, int L, int OEB, int EPI>
 __global__ void __launch_bounds__(64, 2) fir_up_kernel(UpArgs a, const v4i *__restrict__ frag) {
   constexpr int RG = (16 * L + 31) / 32;                      // row groups per column
   constexpr int HS = 2 * NBT - 1;                             // history slots in front of a column's own slot
@@ -78,7 +84,7 @@ __global__ void __launch_bounds__(64, 2) fir_up_kernel(UpArgs a, const v4i *__re
   constexpr int FG = (RG < 256 / (32 * OEB)) ? RG : (256 / (32 * OEB) > 0 ? 256 / (32 * OEB) : 1);   // row groups per write-out
   constexpr int RUN = FG * 32 * OEB;                          // contiguous output bytes of one column per write-out
   constexpr int RUNP = RUN + (OEB == 2 ? 8 : 16);             // padded column pitch of the tile (conflict-free stores)
-  constexpr int NACC = PX + kUpMaxPC - 1;
+  constexpr int NACC = PX + PCT - 1;
   constexpr int TS = up_tab_size<L>();
   static_assert(32 % L == 0 || L == 32, "phase tables assume L divides 32");
   static_assert(RG % FG == 0, "row groups per write-out must divide the row groups");
@@ -89,13 +95,13 @@ __global__ void __launch_bounds__(64, 2) fir_up_kernel(UpArgs a, const v4i *__re
   const int c = lane & 31, h = lane >> 5;
   const int ch = blockIdx.y;
 
-  v4i A[RG][NBT][kUpMaxPC];
+  v4i A[RG][NBT][PCT];
 #pragma unroll
   for (int rg = 0; rg < RG; rg++) {
 #pragma unroll
     for (int b = 0; b < NBT; b++) {
 #pragma unroll
-      for (int q = 0; q < kUpMaxPC; q++) { A[rg][b][q] = frag[(((size_t)rg * NBT + b) * kUpMaxPC + q) * 64 + lane]; }
+      for (int q = 0; q < PCT; q++) { A[rg][b][q] = frag[(((size_t)rg * NBT + b) * kUpMaxPC + q) * 64 + lane]; }
     }
   }
   // phase-dependent constants of this lane's accumulator registers
@@ -147,11 +153,31 @@ __global__ void __launch_bounds__(64, 2) fir_up_kernel(UpArgs a, const v4i *__re
     }
   };
 
-  if (st0 < st1) { fetch(st0); }
-  for (int64_t st = st0; st < st1; st++) {
+  // write-out of one finished unit (FG row groups of one step): 32 columns x RUN contiguous bytes, 8 bytes per lane and
+  // instruction.  e_unit = output element (before out_off) of column 0, first row of the unit.
+  auto flush = [&](int64_t e_unit) {
+#pragma unroll
+    for (int k = 0; k < 32 * RUN / 512; k++) {
+      const int lin = (k * 64 + lane) * 8;
+      const int cc = lin / RUN, w = lin % RUN;
+      const long val = *(const long *)(tile + cc * RUNP + w);
+#ifdef UP_ABLATE_STORES
+      if (a.n_steps < 0)
+#endif
+      *(long *)(yrow + (e_unit + (int64_t)cc * 16 * L) * OEB + w) = val;
+    }
+  };
+  // One step.  VMEM program order: [wait for this step's slots] -> stores of the previous step's last unit -> loads of the
+  // next step -> (per unit) stores of the unit before.  hipcc waits vmcnt(0) at the top of the loop (its entry path has
+  // the loads as the youngest operations), so every store a step issues AFTER its loads is waited for at the next top:
+  // those are the units 0 .. last-1, written out one unit behind the arithmetic -- they had a unit's time or more to land.
+  auto body = [&](int64_t st, auto first_c) {
+    constexpr bool FIRST = decltype(first_c)::value;
     // (single-wave workgroup: the LDS operations of a wave execute in order, no barrier needed)
     stage();
+    if (!FIRST) { flush(16 * (a.slot0 + 32 * (st - 1)) * (int64_t)L + 32 * (RG - FG)); }
     fetch(st + 1 < st1 ? st + 1 : st);
+    __builtin_amdgcn_sched_barrier(0);
     v4i X[NBT][PX];
 #pragma unroll
     for (int b = 0; b < NBT; b++) {
@@ -161,6 +187,7 @@ __global__ void __launch_bounds__(64, 2) fir_up_kernel(UpArgs a, const v4i *__re
     const int64_t e_col = 16 * (a.slot0 + 32 * st) * (int64_t)L;   // output element (before out_off) of column 0, row 0
 #pragma unroll
     for (int g0 = 0; g0 < RG; g0 += FG) {
+      if (g0 > 0) { flush(e_col + 32 * (g0 - FG)); }
 #pragma unroll
       for (int gl = 0; gl < FG; gl++) {
         const int rg = g0 + gl;
@@ -170,7 +197,7 @@ __global__ void __launch_bounds__(64, 2) fir_up_kernel(UpArgs a, const v4i *__re
 #pragma unroll
         for (int b = 0; b < NBT; b++) {
 #pragma unroll
-          for (int q = 0; q < kUpMaxPC; q++) {
+          for (int q = 0; q < PCT; q++) {
 #pragma unroll
             for (int pp = 0; pp < PX; pp++) {
               acc[pp + q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[rg][b][q], X[b][pp], acc[pp + q], 0, 0, 0);
@@ -192,25 +219,43 @@ __global__ void __launch_bounds__(64, 2) fir_up_kernel(UpArgs a, const v4i *__re
             for (int m = 0; m < (NACC + 1) / 2; m++) {
               pr[m] = (2 * m + 1 < NACC) ? (int)(((unsigned)acc[2 * m + 1][r] << 8) + (unsigned)acc[2 * m][r]) : acc[2 * m][r];
             }
-            if (EPI == 1) {
+            if constexpr (EPI == 1) {
               static_assert(EPI != 1 || NACC <= 4, "32-bit epilogue: two accumulator pairs");
+              // branch-free (a uniform branch per output would split the step loop into hundreds of basic blocks, each
+              // with its own s_waitcnt vmcnt(0) on the write-out stores): clamp bounds are the int32 range when OUT_TYPE
+              // wraps, the wrap shift is 0 for full-width containers
               const int y32 = (int)(((unsigned)pr[(NACC + 1) / 2 - 1] << 16) + (unsigned)pr[0]) + corr32_t[t];
               int q = y32 >> shift_t[t];
-              if (a.e_sat) { q = q < a.e_lo ? a.e_lo : (q > a.e_hi ? a.e_hi : q); }
-              else if (a.e_w < 32) { q = p.out.S ? (int)((unsigned)q << (32 - a.e_w)) >> (32 - a.e_w) : (int)((unsigned)q & ((1u << a.e_w) - 1u)); }
+              q = q < a.e_lo ? a.e_lo : (q > a.e_hi ? a.e_hi : q);
+              q = (int)(((unsigned)((int)((unsigned)q << a.e_w) >> a.e_w)) & (unsigned)a.e_mask);
               o32[rr] = q;
-              continue;
-            }
-            uint64_t y = (uint64_t)corr_t[t];
-#pragma unroll
-            for (int m = 0; m < (NACC + 1) / 2; m++) { y += (uint64_t)(int64_t)pr[m] << (16 * m); }
-            if (a.mode == 1) {
-              if (a.out_simple == 2) { o[rr] = wrap64((int64_t)y, a.w_int, 1); }
-              else if (a.out_simple == 1) { o[rr] = wrap64(wrap64((int64_t)y, a.w_int, 1), p.out.W, p.out.S); }
-              else { o[rr] = requant64(wrap64((int64_t)y, a.w_int, 1), p.in.F, p.out); }
             } else {
-              const int64_t v = (int64_t)(y << p.lossless_shift) >> ((sh_t >> t) & 1u);
-              o[rr] = requant64(v, p.acc.F, p.out);
+              // y = corr + sum_m sext(pr[m]) << 16 m, in 32-bit halves (carry chains instead of 64-bit shifts)
+              uint64_t y;
+              {
+                unsigned lo = (unsigned)corr_t[t], hi = (unsigned)((uint64_t)corr_t[t] >> 32);
+#pragma unroll
+                for (int m = 0; m < (NACC + 1) / 2; m++) {
+                  if (m == 0) { const unsigned s0 = lo + (unsigned)pr[0]; hi += (unsigned)(pr[0] >> 31) + (s0 < lo); lo = s0; }
+                  else if (m == 1) { const unsigned t1 = (unsigned)pr[1] << 16, s1 = lo + t1; hi += (unsigned)(pr[1] >> 16) + (s1 < lo); lo = s1; }
+                  else if (m == 2) { hi += (unsigned)pr[2]; }
+                  else { hi += (unsigned)pr[3] << 16; }
+                }
+                y = ((uint64_t)hi << 32) | lo;
+              }
+              if constexpr (EPI == 2) {
+                // CIC: wrap to INT_TYPE, then to OUT_TYPE (same fraction, AC_WRAP); both are wider than 32 bits (host-checked),
+                // so the wraps are bit-field extracts of the high word (64-bit shifts run at a quarter of the 32-bit rate)
+                int hi = (int)(y >> 32);
+                hi = (int)((unsigned)hi << a.e_w) >> a.e_w;
+                hi = (int)((unsigned)((int)((unsigned)hi << a.e_rs) >> a.e_rs) & (unsigned)a.e_mask);
+                o[rr] = (int64_t)(((uint64_t)(unsigned)hi << 32) | (uint32_t)y);
+              } else if (a.mode == 1) {
+                o[rr] = requant64(wrap64((int64_t)y, a.w_int, 1), p.in.F, p.out);
+              } else {
+                const int64_t v = (int64_t)(y << p.lossless_shift) >> ((sh_t >> t) & 1u);
+                o[rr] = requant64(v, p.acc.F, p.out);
+              }
             }
           }
           unsigned char *dst = tile + c * RUNP + (gl * 32 + 8 * g + 4 * h) * OEB;
@@ -232,17 +277,16 @@ __global__ void __launch_bounds__(64, 2) fir_up_kernel(UpArgs a, const v4i *__re
             *(v4s *)dst = (v4s){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
           }
         }
-      }
-      // write-out: 32 columns x RUN contiguous bytes, 8 bytes per lane and instruction
-#pragma unroll
-      for (int k = 0; k < 32 * RUN / 512; k++) {
-        const int lin = (k * 64 + lane) * 8;
-        const int cc = lin / RUN, w = lin % RUN;
-        const long val = *(const long *)(tile + cc * RUNP + w);
-        *(long *)(yrow + (e_col + (int64_t)cc * 16 * L + 32 * g0) * OEB + w) = val;
+        // keep the row groups apart: interleaved, their accumulators and 64-bit temporaries exceed the register file
+        if constexpr (EPI != 1) { __builtin_amdgcn_sched_barrier(0); }
       }
     }
-  }
+  };
+  if (st0 >= st1) { return; }
+  fetch(st0);
+  body(st0, std::integral_constant<bool, true>());
+  for (int64_t st = st0 + 1; st < st1; st++) { body(st, std::integral_constant<bool, false>()); }
+  flush(16 * (a.slot0 + 32 * (st1 - 1)) * (int64_t)L + 32 * (RG - FG));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -305,35 +349,42 @@ bool fir_up_plan(const int64_t *E, int L, int nt, int px, FirUpPlan *pl, std::ve
 }
 
 bool fir_up_shape_ok(int in_eb, int px, int nb, int L, int out_eb) {
-  if (nb < 1 || nb > 2) { return false; }
-  if (in_eb == 2 && px == 2) { return (L == 4 || L == 8 || L == 16) && (out_eb == 2 || out_eb == 8 || (out_eb == 4 && L == 8)); }
-  if (in_eb == 4 && px == 4) { return nb == 1 && (L == 4 || L == 8 || L == 16) && out_eb == 8; }
+  if (nb < 1 || nb > 2 || (L != 8 && L != 16)) { return false; }
+  if (in_eb == 2 && px == 2) { return out_eb == 2 || out_eb == 8; }
+  if (in_eb == 4 && px == 4) { return nb == 1 && out_eb == 8; }
   return false;
 }
 
-template <typename TIN, int PX, int NBT, int L>
+// compiled shapes: poly_intr = int16 samples, 3 digit planes (the pair taps E_j - E_cj have 17 bits), 2- or 8-byte outputs;
+// CIC = int16 / int32 samples, 2 digit planes (boxcar^N taps of the BASELINE shapes fit 16 bits), 8-byte outputs (2-byte ones
+// for int16 samples)
+template <typename TIN, int PX, int PCT, int NBT, int L>
 static hipError_t launch_up_oeb(const UpArgs &a, const uint32_t *d_frag, int out_eb, int epi, dim3 grid, hipStream_t s) {
-  if (out_eb == 8) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, NBT, L, 8, 0>), grid, dim3(64), 0, s, a, (const v4i *)d_frag); }
-  else if (out_eb == 2) {
+  const v4i *f = (const v4i *)d_frag;
+  if (out_eb == 8) {
+    if (epi == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 2>), grid, dim3(64), 0, s, a, f); }
+    else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 0>), grid, dim3(64), 0, s, a, f); }
+  } else if (out_eb == 2) {
     if constexpr (sizeof(TIN) == 2) {
-      if (epi == 1) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, NBT, L, 2, 1>), grid, dim3(64), 0, s, a, (const v4i *)d_frag); }
-      else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, NBT, L, 2, 0>), grid, dim3(64), 0, s, a, (const v4i *)d_frag); }
+      if (epi == 1) {
+        if constexpr (PCT == 3) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 1>), grid, dim3(64), 0, s, a, f); }
+        else { return hipErrorNotSupported; }
+      } else if (epi == 2) {
+        if constexpr (PCT == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 2>), grid, dim3(64), 0, s, a, f); }
+        else { return hipErrorNotSupported; }
+      } else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 0>), grid, dim3(64), 0, s, a, f); }
     } else { return hipErrorNotSupported; }
   } else {
-    if constexpr (sizeof(TIN) == 2 && L == 8) {
-      if (epi == 1) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, NBT, L, 4, 1>), grid, dim3(64), 0, s, a, (const v4i *)d_frag); }
-      else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, NBT, L, 4, 0>), grid, dim3(64), 0, s, a, (const v4i *)d_frag); }
-    } else { return hipErrorNotSupported; }
+    return hipErrorNotSupported;
   }
   return hipGetLastError();
 }
 
-template <typename TIN, int PX, int NBT>
+template <typename TIN, int PX, int PCT, int NBT>
 static hipError_t launch_up_l(const UpArgs &a, const uint32_t *d_frag, int L, int out_eb, int epi, dim3 grid, hipStream_t s) {
   switch (L) {
-    case 4: return launch_up_oeb<TIN, PX, NBT, 4>(a, d_frag, out_eb, epi, grid, s);
-    case 8: return launch_up_oeb<TIN, PX, NBT, 8>(a, d_frag, out_eb, epi, grid, s);
-    case 16: return launch_up_oeb<TIN, PX, NBT, 16>(a, d_frag, out_eb, epi, grid, s);
+    case 8: return launch_up_oeb<TIN, PX, PCT, NBT, 8>(a, d_frag, out_eb, epi, grid, s);
+    case 16: return launch_up_oeb<TIN, PX, PCT, NBT, 16>(a, d_frag, out_eb, epi, grid, s);
     default: return hipErrorNotSupported;
   }
 }
@@ -346,20 +397,31 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
   UpArgs a;
   a.p = p; a.slot0 = slot0; a.n_steps = n_steps; a.out_off = out_off; a.mode = mode; a.w_int = w_int; a.out_simple = out_simple;
   a.sh_mask = sh_mask; a.corr = d_corr;
-  a.e_rs = a.e_rnd = a.e_sat = a.e_lo = a.e_hi = 0; a.e_w = 32;
-  // 32-bit epilogue: poly_intr, no left shift into ACC_TYPE, |V| (+ rounding constant) inside int32, shift / clamp conversion
+  a.e_rs = a.e_rnd = a.e_w = 0; a.e_lo = INT32_MIN; a.e_hi = INT32_MAX; a.e_mask = ~uint64_t(0);
   int epi = 0;
   const int rs = p.acc.F - p.out.F;
-  if (mode == 0 && px == 2 && p.lossless_shift == 0 && rs >= 0 && rs <= 30 && p.out.W <= 32 && (p.out_eb == 2 || p.out_eb == 4) &&
+  if (mode == 0 && px == 2 && p.lossless_shift == 0 && rs >= 0 && rs <= 30 && p.out.W <= 32 && p.out_eb == 2 &&
       (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
       max_abs_v >= 0 && max_abs_v < (int64_t(1) << 30)) {
+    // 32-bit epilogue: poly_intr, no left shift into ACC_TYPE, |V| (+ rounding constant) inside int32
     epi = 1;
     a.e_rs = rs;
     a.e_rnd = (p.out.Q == ACDSP_RND && rs > 0) ? (1 << (rs - 1)) : 0;
-    a.e_sat = p.out.O == ACDSP_SAT;
-    a.e_lo = (int32_t)p.out.lo; a.e_hi = (int32_t)(p.out.hi > INT32_MAX ? INT32_MAX : p.out.hi);
-    a.e_w = p.out.W;
-    if (!a.e_sat && p.out.W == 32) { a.e_w = 32; }
+    if (p.out.O == ACDSP_SAT) { a.e_lo = (int32_t)p.out.lo; a.e_hi = (int32_t)p.out.hi; }
+    else {
+      a.e_w = 32 - p.out.W;
+      if (!p.out.S) { a.e_mask = (uint64_t)((uint32_t)(-1) >> (32 - p.out.W)); }
+    }
+  } else if (mode == 1 && out_simple >= 1) {
+    // bit-field wraps of the high word: to INT_TYPE, then (out_simple 1) to an OUT_TYPE of the same fraction with AC_WRAP
+    if (w_int > 32 && (out_simple == 2 || p.out.W > 32)) {
+      epi = 2;
+      a.e_w = 64 - w_int;
+      if (out_simple == 1) {
+        a.e_rs = 64 - p.out.W;
+        if (!p.out.S) { a.e_mask = (uint64_t)(~uint32_t(0) >> (64 - p.out.W)); }
+      }
+    }
   }
   // >= ~8192 waves when the problem allows it
   int64_t spw = (n_steps * p.n_ch + 8191) / 8192;
@@ -367,9 +429,15 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
   a.steps_per_wave = spw;
   dim3 grid((unsigned)((n_steps + spw - 1) / spw), (unsigned)p.n_ch);
   if (p.in_eb == 2) {
-    return pl.nb == 1 ? launch_up_l<int16_t, 2, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s) : launch_up_l<int16_t, 2, 2>(a, d_frag, pl.L, p.out_eb, epi, grid, s);
+    if (mode == 0) {
+      return pl.nb == 1 ? launch_up_l<int16_t, 2, 3, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s)
+                        : launch_up_l<int16_t, 2, 3, 2>(a, d_frag, pl.L, p.out_eb, epi, grid, s);
+    }
+    if (pl.pc > 2 || pl.nb != 1) { return hipErrorNotSupported; }
+    return launch_up_l<int16_t, 2, 2, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s);
   }
-  return launch_up_l<int32_t, 4, 1>(a, d_frag, pl.L, p.out_eb, 0, grid, s);
+  if (pl.pc > 2 || pl.nb != 1) { return hipErrorNotSupported; }
+  return launch_up_l<int32_t, 4, 2, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s);
 }
 
 }  // namespace acdsp
