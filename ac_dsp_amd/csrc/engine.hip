@@ -854,8 +854,8 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
     int64_t q_a = 0, q_b = 0;
     const int64_t lo = p.q_begin > p.q_skip ? p.q_begin : p.q_skip;
     p.q_from = p.q_to = 0;
-    static const bool cic_up = getenv("ACDSP_CIC_UP") != nullptr;   // slower than the VALU kernel so far (store pattern): opt-in
-    if (h->up_ok && p.vec_ok && cic_up) {
+    static const bool no_up = getenv("ACDSP_NO_CIC_UP") != nullptr;   // A/B knob: polyphase VALU kernel only
+    if (h->up_ok && p.vec_ok && !no_up) {
       const int64_t slot_a = h->up_plan.hs, n_steps = ((n_in - 1) / 16 - slot_a) / 32;
       const int64_t out_off = (int64_t)d.R * p.t_prev - lo;
       const bool out_ok = ((uintptr_t)d_out % 8 == 0) && ((out_stride * h->out_eb) % 8 == 0) && ((out_off * h->out_eb) % 8 == 0);

@@ -141,7 +141,9 @@ class Cic:
         n_in = x.shape[1]
         no = self.out_count(n_in)
         if out is None:
-            out = torch.empty((self.n_channels, max(no, 1)), dtype=torch_dtype_for(self.fout), device=x.device)
+            dt = torch_dtype_for(self.fout)
+            per64 = 64 // torch.empty((), dtype=dt).element_size()       # rows start on 64-byte boundaries (vector stores)
+            out = torch.empty((self.n_channels, (max(no, 1) + per64 - 1) // per64 * per64), dtype=dt, device=x.device)
         assert out.dtype == torch_dtype_for(self.fout) and out.stride(1) == 1 and out.shape[1] >= no
         n_out = C.c_int64()
         check(lib.acdsp_cic_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), n_in, C.c_void_p(out.data_ptr()),

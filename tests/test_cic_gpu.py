@@ -178,3 +178,54 @@ def test_long_runs_take_the_branch_free_kernel(q, o):
     y = run_engine(cic, x)
     assert cic.path == "mfma_gen"
     assert np.array_equal(y, run_oracle(False, 16, 1, 5, fin, fout, x))
+
+
+# ---- interpolator on the matrix cores (fir_up.hip): whole steps of 512 inputs; head and tail on the polyphase VALU kernel ----
+
+@pytest.mark.parametrize("R,M,N,fin,fout", [
+    (8, 1, 5, A.Fmt(32, 16), None),                               # bench shape: INT_TYPE <44,28> out (bit-field wrap epilogue)
+    (8, 1, 5, A.Fmt(32, 16), A.Fmt(40, 24)),                      # narrower signed OUT_TYPE, still wider than 32 bits
+    (8, 1, 5, A.Fmt(32, 16), A.Fmt(36, 20, False)),               # unsigned OUT_TYPE narrower than INT_TYPE (mask)
+    (8, 1, 5, A.Fmt(32, 16), A.Fmt(50, 34, False)),               # unsigned and wider than INT_TYPE: generic conversion
+    (8, 1, 5, A.Fmt(32, 16), A.Fmt(24, 8, True, "RND", "SAT")),   # 4-byte containers: not compiled in, VALU kernel
+    (16, 1, 4, A.Fmt(16, 1), None),                               # int16 samples, R = 16
+    (8, 1, 5, A.Fmt(16, 1), A.Fmt(16, 1, True, "TRN", "WRAP")),   # int16 samples into 2-byte containers (generic conversion)
+    (16, 1, 4, A.Fmt(16, 1), A.Fmt(16, 1, True, "RND", "SAT")),   # N - 1 = 3 skipped 2-byte outputs: unaligned runs, VALU kernel
+    (4, 2, 5, A.Fmt(16, 4), None),                                # R = 4, differential delay 2
+    (8, 2, 4, A.Fmt(30, 10, False), None),                        # unsigned input: 31-bit signed planes
+])
+def test_interpolator_matrix_core_path(R, M, N, fin, fout):
+    rng = np.random.default_rng(R * 100 + N)
+    probe = A.Cic(True, R, M, N, fin, fin)
+    it = probe.int_type
+    fo = fout if fout is not None else A.Fmt(it.W, it.I)
+    n = 16 * 34 + 512 * 2 + 48                                   # rows of whole 16-byte pieces
+    x = rand_raw(rng, fin, (3, n))
+    x[1, :64] = (1 << (fin.W - 1)) - 1 if fin.S else (1 << fin.W) - 1
+    x[2, :64] = -(1 << (fin.W - 1)) if fin.S else 0
+    want_mfma = A.torch_dtype_for(fo) in (torch.int64,) or (A.torch_dtype_for(fo) == torch.int16 and A.torch_dtype_for(fin) == torch.int16 and N == 5)
+    for splits in (None, [600], [16, 1200], [5, 1205]):
+        cic = A.Cic(True, R, M, N, fin, fo, n_channels=3)
+        y = run_engine(cic, x, splits)
+        yo = run_oracle(True, R, M, N, fin, fo, x, splits)
+        assert y.shape == yo.shape
+        bad = np.argwhere(y != yo)
+        assert bad.size == 0, "%d mismatches, first at %s" % (len(bad), bad[0])
+        if splits is None:
+            assert cic.path == ("mfma_gen" if want_mfma else "fir_identity"), cic.path
+
+
+def test_interpolator_both_kernels_agree(monkeypatch):
+    fin = A.Fmt(32, 16)
+    fo = A.Fmt(44, 28)
+    x = stimulus(5, 4, 16 * 34 + 512 * 5, 32)
+    xa = torch.from_numpy(x).to(torch.int32).cuda()
+    c1 = A.Cic(True, 8, 1, 5, fin, fo, n_channels=4)
+    y1 = c1.run(xa).cpu().numpy()
+    assert c1.path == "mfma_gen"
+    big = torch.zeros((4, x.shape[1] + 16), dtype=torch.int32, device="cuda")
+    big[:, 1:1 + x.shape[1]] = xa
+    c2 = A.Cic(True, 8, 1, 5, fin, fo, n_channels=4)
+    y2 = c2.run(big[:, 1:1 + x.shape[1]]).cpu().numpy()      # unaligned rows: polyphase VALU kernel
+    assert c2.path == "fir_identity"
+    assert np.array_equal(y1, y2)
