@@ -1721,6 +1721,10 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
   p.in_eb = h->in_eb; p.out_eb = h->out_eb; p.in_stride = in_stride; p.out_stride = out_stride;
   p.lossless = d.acc.O == ACDSP_WRAP && p.acc.F >= p.in.F && p.acc.F - p.in.F < 64 - d.in.W;
   p.tile_ok = p.lossless && !h->pending && grp == n_blocks;
+  if (p.tile_ok) {
+    p.uni_rounds = blk[(size_t)n_blocks];
+    for (int64_t b = 1; b < n_blocks && p.uni_rounds > 0; b++) { if (blk[(size_t)(n_blocks + b)] != p.uni_rounds) { p.uni_rounds = 0; } }
+  }
   p.x = d_in; p.y = d_out; p.temp = h->d_temp[h->cur];
   p.blk_off = h->d_blk; p.blk_rounds = h->d_blk + n_blocks; p.blk_out = h->d_blk + 2 * n_blocks; p.blk_chain = h->d_chain;
   hipError_t e = launch_intg_dump(p, h->d_temp[h->cur ^ 1], s);

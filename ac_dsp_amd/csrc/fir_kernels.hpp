@@ -108,6 +108,7 @@ struct IntgDumpParams {
   int32_t chn, n_obj, n_blocks;
   int32_t lossless;           // ACC_TYPE is AC_WRAP with F_acc >= F_in: integer sums mod 2^W
   int32_t tile_ok;            // lossless, every block of the call dumps and the handle carries no undumped sum in
+  int64_t uni_rounds;         // > 0: tile_ok and every block has this many rounds (streaming kernel)
   DFmt in, acc, out;
   int32_t in_eb, out_eb;
   int64_t in_stride, out_stride;

@@ -6,6 +6,11 @@
 // and dumps nothing: its sums carry into the next block.  Here one thread owns one (object, block, channel): it starts
 // from the handle's temp[] (first chain of the call) or 0, replays the rounds of its carry chain in order and writes
 // the block's output; one more thread per (object, channel) leaves the trailing, undumped sum in the handle.
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
 #include "fir_kernels.hpp"
 
 namespace acdsp {
@@ -105,12 +110,268 @@ __global__ void __launch_bounds__(256) intg_dump_tile_kernel(IntgDumpParams p, i
   store_raw(p.y, (int64_t)obj * p.out_stride + p.blk_out[b] * p.chn + i, p.out_eb, requant64(acc, p.acc.F, p.out));
 }
 
+// Streaming kernel for the common shape: lossless class, every block dumps the same number of rounds, CHN divides the
+// elements of a 16-byte load and a block is a whole number of loads.  No LDS: a lane adds the elements of its loads into CHN
+// partial sums (element j of any load belongs to channel j % CHN, because blocks and loads start on channel 0), the lanes
+// of a block (GS = 1 .. 64 of them; blocks longer than a wave's 1 KB accumulate LPR loads per lane first) combine with DPP
+// adds (quad_perm, row_half_mirror, row_mirror: every lane of a 16-lane row ends with the row's sum; row_bcast15 / 31 carry
+// it into the last row of a 32- / 64-lane group), and the last min(GS, 16) lanes of the group convert and store one
+// channel each.  Eight independent 16-byte loads per lane are in flight per batch; a wave streams a contiguous span of
+// one object's row.  (First version: ds_bpermute butterfly + the general 128-bit requant inlined per load: 0.59 ms on the
+// bench row, a third of the wave time waiting on the five dependent LDS round trips.)
+struct IdConv {               // branch-free ACC -> OUT conversion (host-checked: AC_TRN / AC_RND into AC_WRAP / AC_SAT, < 2^62)
+  int32_t ok, sh, ka, rs, ls2, ko;
+  uint64_t am, om;            // masks after the sign-extending wraps (all ones for signed types)
+  int64_t rnd, lo, hi;
+};
+
+template <int CTRL, int ROWMASK>
+__device__ inline int dpp_get(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xF, false); }
+template <int CTRL, int ROWMASK>
+__device__ inline int64_t dpp_get(int64_t x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), CTRL, ROWMASK, 0xF, false);
+  return (int64_t)(((uint64_t)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int CTRL, int ROWMASK>
+__device__ inline int dpp_sum(int x) { return x + __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xF, false); }
+template <int CTRL, int ROWMASK>
+__device__ inline int64_t dpp_sum(int64_t x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), CTRL, ROWMASK, 0xF, false);
+  return x + (int64_t)(((uint64_t)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+// all-reduce steps that leave every lane of the group with the group's sum
+template <typename TS> __device__ inline TS id_xor16_sum(TS t) {
+  if constexpr (sizeof(TS) == 4) { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)t, (unsigned)t, false, false); return (TS)(r[0] + r[1]); }
+  else {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)t, (unsigned)t, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)((uint64_t)t >> 32), (unsigned)((uint64_t)t >> 32), false, false);
+    return (TS)((((uint64_t)hi[0] << 32) | lo[0]) + (((uint64_t)hi[1] << 32) | lo[1]));
+  }
+}
+template <typename TS> __device__ inline TS id_xor32_sum(TS t) {
+  if constexpr (sizeof(TS) == 4) { const auto r = __builtin_amdgcn_permlane32_swap((unsigned)t, (unsigned)t, false, false); return (TS)(r[0] + r[1]); }
+  else {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)t, (unsigned)t, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)((uint64_t)t >> 32), (unsigned)((uint64_t)t >> 32), false, false);
+    return (TS)((((uint64_t)hi[0] << 32) | lo[0]) + (((uint64_t)hi[1] << 32) | lo[1]));
+  }
+}
+
+// SCAT (CHN 2 or 4, groups of >= CHN lanes): the first one / two butterfly levels are a reduce-scatter -- a lane keeps half of
+// its channels and receives the partner's partial sums of those -- so the remaining levels move one value per lane instead
+// of CHN.  The half a lane keeps is chosen by lane bit 0 / 1 XOR lane bit 2, which makes the assignment symmetric under the
+// lane reversals of row_half_mirror and row_mirror; lanes 0 .. CHN-1 of a group end with channel 2 * bit0 + bit1 (CHN 4) or
+// bit0 (CHN 2) and store it.
+template <typename TIN, int CHN, bool SGN, bool SCAT>
+__global__ void __launch_bounds__(256) intg_dump_stream_kernel(IntgDumpParams p, IdConv cv, int gs, int lpr, int64_t reds_per_wave, int64_t n_reds) {
+  typedef typename std::conditional<sizeof(TIN) == 2, int, int64_t>::type TS;   // int16: rounds < 2^15 keep the sums inside int32
+  constexpr int EPV = 16 / (int)sizeof(TIN);
+#ifndef ID_BATCH
+#define ID_BATCH 8
+#endif
+  constexpr int BATCH = ID_BATCH;
+  static_assert(!SCAT || CHN == 2 || CHN == 4, "reduce-scatter levels exist for 2 and 4 channels");
+  const int lane = threadIdx.x & 63;
+  const int obj = blockIdx.y;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar address math
+  const int64_t r0 = wave * reds_per_wave;
+  const int64_t r1 = (r0 + reds_per_wave < n_reds) ? r0 + reds_per_wave : n_reds;
+  if (r0 >= r1) { return; }
+  const int bpr = 64 / gs;                                      // blocks per reduce
+  const bool b0 = ((lane ^ (lane >> 2)) & 1) != 0, b1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
+  // writer lanes and their channel
+  const int i_grp = lane & (gs - 1);
+  const int nwl = SCAT ? CHN : (gs < 16 ? gs : 16);             // plain butterfly: the group's last nwl lanes (row_bcast steps)
+  const int wl = SCAT ? i_grp : i_grp - (gs - nwl);
+  const int my_ch = SCAT ? (CHN == 4 ? 2 * (lane & 1) + ((lane >> 1) & 1) : (lane & 1)) : 0;
+  TS acc[CHN];
+#pragma unroll
+  for (int c = 0; c < CHN; c++) { acc[c] = 0; }
+  const int64_t q0 = r0 * lpr, q1 = r1 * lpr;                   // 1 KB wave-loads of this wave
+  const v4i_t *src = (const v4i_t *)((const TIN *)p.x + (int64_t)obj * p.in_stride) + 64 * q0 + lane;
+  int k_in_red = 0;
+  int64_t red = r0;
+  for (int64_t q = q0; q < q1; q += BATCH, src += 64 * BATCH) {
+    const int rem = (int)(q1 - q < BATCH ? q1 - q : BATCH);
+    v4i_t v[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; k++) { v[k] = src[64 * (k < rem ? k : rem - 1)]; }
+#pragma unroll
+    for (int k = 0; k < BATCH; k++) {
+      if (k >= rem) { break; }
+      const unsigned d[4] = {(unsigned)v[k].x, (unsigned)v[k].y, (unsigned)v[k].z, (unsigned)v[k].w};
+      if constexpr (sizeof(TIN) == 2 && CHN <= 4) {
+        // pairs of elements of one channel -> one dword (v_perm_b32) -> v_dot2 with (1, 1) adds both, sign- or zero-extended
+        typedef short v2s __attribute__((ext_vector_type(2)));
+        typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          // CHN 4: (e_c, e_c+4), c = m;  CHN 2: (e_c, e_c+2) and (e_c+4, e_c+6), c = m & 1;  CHN 1: the dwords as they are
+          unsigned w;
+          if (CHN == 4) { w = __builtin_amdgcn_perm(d[2 + (m >> 1)], d[m >> 1], (m & 1) ? 0x07060302u : 0x05040100u); }
+          else if (CHN == 2) { w = __builtin_amdgcn_perm(d[2 * (m >> 1) + 1], d[2 * (m >> 1)], (m & 1) ? 0x07060302u : 0x05040100u); }
+          else { w = d[m]; }
+          const int c = CHN == 4 ? m : (CHN == 2 ? (m & 1) : 0);
+          if (SGN) { acc[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, w), (v2s){1, 1}, acc[c], false); }
+          else { acc[c] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2us, w), (v2us){1, 1}, (unsigned)acc[c], false); }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < EPV; j++) {
+          TS e;
+          if constexpr (sizeof(TIN) == 2) {
+            const unsigned w = d[j >> 1];
+            e = (j & 1) ? (SGN ? (int)w >> 16 : (int)(w >> 16)) : (SGN ? (int)(short)w : (int)(w & 0xffffu));
+          } else {
+            e = SGN ? (int64_t)(int)d[j] : (int64_t)d[j];
+          }
+          acc[j % CHN] += e;
+        }
+      }
+      if (++k_in_red == lpr) {
+        k_in_red = 0;
+        TS mine;
+        if constexpr (SCAT) {
+          TS t;
+          if constexpr (CHN == 4) {
+            TS kx = b0 ? acc[2] : acc[0], ky = b0 ? acc[3] : acc[1];
+            const TS sx = b0 ? acc[0] : acc[2], sy = b0 ? acc[1] : acc[3];
+            kx += dpp_get<0xB1, 0xF>(sx); ky += dpp_get<0xB1, 0xF>(sy);
+            t = b1 ? ky : kx;
+            const TS st = b1 ? kx : ky;
+            t += dpp_get<0x4E, 0xF>(st);
+          } else {
+            t = b0 ? acc[1] : acc[0];
+            const TS st = b0 ? acc[0] : acc[1];
+            t += dpp_get<0xB1, 0xF>(st);
+            if (gs >= 4) { t = dpp_sum<0x4E, 0xF>(t); }
+          }
+          if (gs >= 8) { t = dpp_sum<0x141, 0xF>(t); }           // row_half_mirror
+          if (gs >= 16) { t = dpp_sum<0x140, 0xF>(t); }          // row_mirror
+          if (gs >= 32) { t = id_xor16_sum(t); }
+          if (gs >= 64) { t = id_xor32_sum(t); }
+          mine = t;
+        } else {
+#pragma unroll
+          for (int c = 0; c < CHN; c++) {
+            TS t = acc[c];
+            if (gs >= 2) { t = dpp_sum<0xB1, 0xF>(t); }            // quad_perm [1,0,3,2]
+            if (gs >= 4) { t = dpp_sum<0x4E, 0xF>(t); }            // quad_perm [2,3,0,1]
+            if (gs >= 8) { t = dpp_sum<0x141, 0xF>(t); }           // row_half_mirror (the quads are uniform by now)
+            if (gs >= 16) { t = dpp_sum<0x140, 0xF>(t); }          // row_mirror
+            if (gs >= 32) { t = dpp_sum<0x142, 0xA>(t); }          // row_bcast15 into rows 1 and 3
+            if (gs >= 64) { t = dpp_sum<0x143, 0xC>(t); }          // row_bcast31 into rows 2 and 3
+            acc[c] = t;
+          }
+          mine = acc[0];
+        }
+        const int64_t b = red * bpr + lane / gs;
+#pragma unroll
+        for (int pi = 0; pi < (SCAT ? 1 : CHN); pi++) {
+          if (pi * nwl >= CHN) { break; }
+          int cch = my_ch;
+          if constexpr (!SCAT) {
+            cch = pi * nwl + wl;
+#pragma unroll
+            for (int c = 1; c < CHN; c++) { mine = (cch == c) ? acc[c] : mine; }
+          }
+          if (wl >= 0 && wl < nwl && cch < CHN) {
+            const int64_t a = (int64_t)(((uint64_t)((int64_t)((uint64_t)(int64_t)mine << (cv.sh + cv.ka)) >> cv.ka)) & cv.am);   // wrap to ACC_TYPE
+            int64_t qv = (int64_t)((uint64_t)((a + cv.rnd) >> cv.rs) << cv.ls2);
+            qv = qv < cv.lo ? cv.lo : (qv > cv.hi ? cv.hi : qv);
+            const int64_t o = (int64_t)(((uint64_t)((int64_t)((uint64_t)qv << cv.ko) >> cv.ko)) & cv.om);
+            store_raw(p.y, (int64_t)obj * p.out_stride + b * CHN + cch, p.out_eb, o);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CHN; c++) { acc[c] = 0; }
+        red++;
+      }
+    }
+  }
+}
+
+template <typename TIN, int CHN>
+static bool launch_stream(const IntgDumpParams &p, int gs, int lpr, int64_t rpw, int64_t n_reds, dim3 grid, hipStream_t s) {
+  // ACC -> OUT as shifts, a clamp and bit-field wraps where the modes allow it
+  IdConv cv;
+  memset(&cv, 0, sizeof cv);
+  cv.sh = p.acc.F - p.in.F;
+  const int rs = p.acc.F - p.out.F;
+  cv.ka = 64 - p.acc.W; cv.am = p.acc.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.acc.W));
+  cv.rs = rs > 0 ? rs : 0; cv.ls2 = rs < 0 ? -rs : 0;
+  cv.rnd = (p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0;
+  if (p.out.O == ACDSP_SAT) { cv.lo = p.out.lo; cv.hi = p.out.hi; cv.ko = 0; cv.om = ~uint64_t(0); }
+  else { cv.lo = INT64_MIN; cv.hi = INT64_MAX; cv.ko = 64 - p.out.W; cv.om = p.out.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.out.W)); }
+  cv.ok = (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && p.acc.W <= 61 && cv.rs <= 60 &&
+          p.acc.W + cv.ls2 <= 61 && p.out.W <= 62;               // neither the rounding add nor the left shift can leave int64
+  if (!cv.ok) { return false; }                                   // other modes: the tiled kernel and its general requant
+  if constexpr (CHN == 2 || CHN == 4) {
+    if (gs >= CHN) {
+      if (p.in.S) { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, true, true>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds); }
+      else { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, false, true>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds); }
+      return true;
+    }
+  }
+  if (p.in.S) { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, true, false>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds); }
+  else { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, false, false>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds); }
+  return true;
+}
+
+// true: launched.  Shape conditions of the streaming kernel (see above); rows must start on 16-byte boundaries.
+static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
+  if (!p.tile_ok || p.uni_rounds <= 0 || p.uni_rounds >= 32768 || (p.in_eb != 2 && p.in_eb != 4)) { return false; }
+  const int epv = 16 / p.in_eb;
+  if (p.chn < 1 || p.chn > epv || epv % p.chn != 0) { return false; }
+  const int64_t be = p.uni_rounds * p.chn;                     // elements per block
+  if (be % epv != 0 || ((uintptr_t)p.x % 16) != 0 || (p.in_stride * p.in_eb) % 16 != 0) { return false; }
+  const int64_t lpb = be / epv;                                // lane-loads per block
+  int gs, lpr;
+  if (lpb <= 64) { if (lpb & (lpb - 1)) { return false; } gs = (int)lpb; lpr = 1; }
+  else { if (lpb % 64) { return false; } gs = 64; lpr = (int)(lpb / 64); }
+  const int bpr = 64 / gs;
+  if (p.n_blocks % bpr != 0) { return false; }                 // (a ragged last reduce would read past the call's samples)
+  const int64_t n_reds = p.n_blocks / bpr;
+  // ~64 KB per wave, >= ~16 K waves when the problem allows it
+  int64_t rpw = (64 + lpr - 1) / lpr;
+  while (rpw > 1 && (n_reds / rpw) * p.n_obj < 16384) { rpw /= 2; }
+  static const char *rpw_env = getenv("ACDSP_INTG_RPW");   // tuning knob: reduces per wave
+  if (rpw_env && atoi(rpw_env) > 0) { rpw = atoi(rpw_env); }
+  const int64_t waves = (n_reds + rpw - 1) / rpw;
+  dim3 grid((unsigned)((waves + 3) / 4), (unsigned)p.n_obj);
+  if (p.in_eb == 2) {
+    switch (p.chn) {
+      case 1: return launch_stream<int16_t, 1>(p, gs, lpr, rpw, n_reds, grid, s);
+      case 2: return launch_stream<int16_t, 2>(p, gs, lpr, rpw, n_reds, grid, s);
+      case 4: return launch_stream<int16_t, 4>(p, gs, lpr, rpw, n_reds, grid, s);
+      default: return launch_stream<int16_t, 8>(p, gs, lpr, rpw, n_reds, grid, s);
+    }
+  } else {
+    switch (p.chn) {
+      case 1: return launch_stream<int32_t, 1>(p, gs, lpr, rpw, n_reds, grid, s);
+      case 2: return launch_stream<int32_t, 2>(p, gs, lpr, rpw, n_reds, grid, s);
+      default: return launch_stream<int32_t, 4>(p, gs, lpr, rpw, n_reds, grid, s);
+    }
+  }
+}
+
 __global__ void intg_dump_zero_kernel(int64_t *temp_next, int64_t n) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) { temp_next[t] = 0; }
 }
 
 hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStream_t s) {
+  static const bool no_stream = getenv("ACDSP_NO_INTG_STREAM") != nullptr;   // A/B knob
+  if (!no_stream && try_stream(p, s)) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { return e; }
+    const int64_t nt = (int64_t)p.n_obj * p.chn;
+    hipLaunchKernelGGL(intg_dump_zero_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, temp_next, nt);   // every block dumped: temp[] = 0
+    return hipGetLastError();
+  }
   if (p.tile_ok && p.chn <= 256) {
     const int bpw = 256 / p.chn;
     const int lds_elems = (47 * 1024) / p.in_eb;   // + one pad dword per 512 bytes stays inside the 48 KB

@@ -53,3 +53,19 @@ def test_rejects_short_buffers():
     x = torch.zeros((1, 8), dtype=torch.int16, device="cuda")
     with pytest.raises(AssertionError):
         eng.run(x, [5])                      # needs 10 samples
+
+
+# ---- streaming kernel: every block dumps the same number of rounds, CHN divides a 16-byte load ----
+
+@pytest.mark.parametrize("ns,chn,rounds,n_blk,fin,fa,fo", [
+    (64, 4, 64, 96, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)),                       # bench shape: 32 lanes per block
+    (64, 4, 64, 96, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(12, 6, True, "RND", "SAT")),    # narrowing, saturating OUT_TYPE
+    (64, 8, 2, 128, A.Fmt(16, 8, False), A.Fmt(20, 12, False), A.Fmt(20, 12, False)),  # unsigned, 2 lanes per block
+    (8, 1, 8, 256, A.Fmt(13, 3), A.Fmt(30, 20), A.Fmt(30, 20)),                        # one lane per block, CHN = 1, F_acc > F_in
+    (1024, 2, 1024, 6, A.Fmt(16, 2), A.Fmt(27, 13), A.Fmt(27, 13)),                    # blocks of 4 KB: four loads per lane and reduce
+    (256, 4, 256, 16, A.Fmt(32, 16), A.Fmt(44, 28), A.Fmt(44, 28)),                    # int32 containers, 64-bit sums
+    (64, 2, 64, 32, A.Fmt(24, 8, False), A.Fmt(34, 18, False), A.Fmt(15, 9, False, "TRN", "WRAP")),
+    (48, 4, 48, 64, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)),                       # 24 lanes per block: not a power of two -> tiled kernel
+])
+def test_streaming_kernel_shapes(ns, chn, rounds, n_blk, fin, fa, fo):
+    check(ns, chn, fin, fa, fo, [[rounds] * n_blk, [rounds] * (n_blk // 2)], n_obj=5, seed=ns + chn)
