@@ -27,7 +27,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int kSteps = 64;   // 1024-sample steps per wave (as the product kernel at config 2)
 
 // kU: load ring (loads run kU-1 steps ahead; must divide kSteps); OCC: waves per SIMD the register budget is held to
-template <int NM, bool LOADS, bool STORES, int kU = 4, int OCC = 2>
+template <int NM, bool LOADS, bool STORES, int kU = 4, int OCC = 2, int AREUSE = 2>
 __global__ void __launch_bounds__(64, OCC) probe(const v4i *__restrict__ frag, const short *__restrict__ x, short *__restrict__ y,
                                                 long stride, long *__restrict__ dbg, int sink_flag) {
   static_assert(kSteps % kU == 0, "ring depth must divide the steps per wave");
@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(64, OCC) probe(const v4i *__restrict__ frag, c
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NM; i++) {
-        acc[i & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[(i >> 1) & 3], R[u][i & 1], acc[i & 3], 0, 0, 0);
+        // AREUSE consecutive MFMAs share the A operand (register-blocking depth of the product kernels); B walks the ring
+        acc[i & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[(i / AREUSE) & 3], R[AREUSE == 2 ? u : (u + (i >> 1)) % kU][i & 1], acc[i & 3], 0, 0, 0);
       }
       if (NM > 0) {
         o0 = (v4i){acc[0][0], acc[1][1], acc[2][2], acc[3][3]};
@@ -145,7 +146,7 @@ template <int W> static void run_w(Ctx &c, size_t bytes) {
   printf("write-only, %2d-byte stores per lane (256-thread blocks, 1 MiB per block): %7.3f ms  %6.0f GB/s\n", W, ms, bytes / (ms * 1e-3) / 1e9);
 }
 
-template <int NM, bool LOADS, bool STORES, int kU = 4, int OCC = 2>
+template <int NM, bool LOADS, bool STORES, int kU = 4, int OCC = 2, int AREUSE = 2>
 static void run(Ctx &c, const char *label, int data) {
   // operand fill: 0 = zeros, 1 = small (|v| < 4, like the high-byte plane of a low-pass set), 2 = random bytes
   std::vector<uint32_t> h(16 * 64 * 4);
@@ -162,10 +163,10 @@ static void run(Ctx &c, const char *label, int data) {
   const long n_waves = (long)grid.x * grid.y;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 2; w++) { hipLaunchKernelGGL((probe<NM, LOADS, STORES, kU, OCC>), grid, dim3(64), lds, 0, c.d_frag, c.d_x, c.d_y, c.stride, c.d_dbg, 0); }
+  for (int w = 0; w < 2; w++) { hipLaunchKernelGGL((probe<NM, LOADS, STORES, kU, OCC, AREUSE>), grid, dim3(64), lds, 0, c.d_frag, c.d_x, c.d_y, c.stride, c.d_dbg, 0); }
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));
-  for (int r = 0; r < c.reps; r++) { hipLaunchKernelGGL((probe<NM, LOADS, STORES, kU, OCC>), grid, dim3(64), lds, 0, c.d_frag, c.d_x, c.d_y, c.stride, c.d_dbg, 0); }
+  for (int r = 0; r < c.reps; r++) { hipLaunchKernelGGL((probe<NM, LOADS, STORES, kU, OCC, AREUSE>), grid, dim3(64), lds, 0, c.d_frag, c.d_x, c.d_y, c.stride, c.d_dbg, 0); }
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -178,7 +179,7 @@ static void run(Ctx &c, const char *label, int data) {
   const double gbs = ((LOADS ? 2.0 : 0.0) + (STORES ? 2.0 : 0.0)) * samples / (ms * 1e-3) / 1e9;
   const double tops = 2.0 * NM * 32768.0 * (samples / 1024.0) / (ms * 1e-3) / 1e12;
   int occ = 0;
-  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, probe<NM, LOADS, STORES, kU, OCC>, 64, lds));
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, probe<NM, LOADS, STORES, kU, OCC, AREUSE>, 64, lds));
   printf("%-14s NM=%2d ahead=%d waves/SIMD=%d data=%-6s  %7.3f ms  %7.0f cyc/step  clock %.3f GHz  %6.0f GB/s  %6.0f TOP/s\n", label, NM, kU - 1, occ / 4,
          data == 0 ? "zero" : data == 1 ? "small" : "random", ms, sc / n_waves / kSteps, sc / sr * 0.1, gbs, tops);
   fflush(stdout);
@@ -208,6 +209,21 @@ int main(int argc, char **argv) {
   }
   printf("# power_probe: %d ch x %ld samples, %ld single-wave workgroups, %d timed launches per row\n", c.n_ch, c.n, n_waves, c.reps);
   printf("# target: 70 %% of 8 TB/s on 4 B/sample = %.3f ms per launch\n", 4.0 * c.n_ch * c.n / 5.6e12 * 1e3);
+  if (argc > 4 && atoi(argv[4]) == 1023) {   // envelope of the 1023-tap kernel: 76 MFMAs per step with the config-4 set's band skip, 132 dense
+    printf("# A-operand reuse sweep (consecutive MFMAs sharing A): 1, 4, 8, 76\n");
+    run<76, false, false, 4, 2, 1>(c, "mfma-only", 2);
+    run<76, false, false, 4, 2, 4>(c, "mfma-only", 2);
+    run<76, false, false, 4, 2, 8>(c, "mfma-only", 2);
+    run<76, false, false, 4, 2, 76>(c, "mfma-only", 2);
+    printf("# default reuse 2\n");
+    run<76, false, false>(c, "mfma-only", 0);
+    run<76, false, false>(c, "mfma-only", 2);
+    run<132, false, false>(c, "mfma-only", 2);
+    run<76, true, true, 4, 2>(c, "stream+mfma", 2);
+    run<76, true, true, 4, 4>(c, "stream+mfma", 2);
+    run<132, true, true, 4, 2>(c, "stream+mfma", 2);
+    return 0;
+  }
   run<28, false, false>(c, "mfma-only", 0);
   run<28, false, false>(c, "mfma-only", 1);
   run<28, false, false>(c, "mfma-only", 2);
