@@ -331,21 +331,65 @@ __global__ void __launch_bounds__(64, 2) fir_gen_fast_kernel(FirParams p, const 
   const int64_t s0 = ((int64_t)blockIdx.x + a.chunk0) * a.steps_per_wave;
   const int64_t s1 = s0 + a.steps_per_wave;            // the launch covers complete chunks only
 
+  // Loads are coalesced over the window, not over a lane's slot: load k of a lane is 16-byte piece lane + 64 k of the step's
+  // window (a slot of 16 samples is S = sizeof(TIN) pieces), so one instruction reads 1 KB contiguous instead of 64 pieces
+  // 16 S bytes apart (that form touched every 128-byte line of the window S times: 5.3 TB/s on config 3 where a plain
+  // 4 : 1 read / write stream reaches 5.8, tools/copy_probe).  The byte planes of a piece are 16 / S bytes each.
+  constexpr int S = (int)sizeof(TIN);
+  constexpr bool COAL = S <= 4;
+  constexpr int NPC = SPL * S;                                // pieces (COAL) per lane and step
   v4i pre[SPL][sizeof(TIN)];
   int sl_of[SPL], ps_of[SPL];
+  int pc_off[COAL ? NPC : 1], pc_ps[COAL ? NPC : 1];         // COAL: sample offset of the piece in the window, LDS byte offset of its planes
 #pragma unroll
   for (int j = 0; j < SPL; j++) {
     sl_of[j] = (lane + 64 * j < a.n_slots) ? lane + 64 * j : a.n_slots - 1;   // surplus lanes repeat the last slot
     ps_of[j] = phys_slot(sl_of[j], a) * 16;
   }
+  if constexpr (COAL) {
+#pragma unroll
+    for (int k = 0; k < NPC; k++) {
+      int slot = (lane + 64 * k) / S;
+      const int sub = lane % S;
+      if (slot >= a.n_slots) { slot = a.n_slots - 1; }         // surplus pieces repeat a piece of the last slot
+      pc_off[k] = 16 * slot + (16 / S) * sub;
+      pc_ps[k] = phys_slot(slot, a) * 16 + (16 / S) * sub;
+    }
+  }
   auto fetch = [&](int64_t st) {
     const int64_t W0 = a.first + st * 256 * R - a.pl.off;
+    if constexpr (COAL) {
 #pragma unroll
-    for (int j = 0; j < SPL; j++) {
-      const int64_t t = W0 + 16 * (int64_t)sl_of[j];
-      const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
+      for (int k = 0; k < NPC; k++) {
+        const int64_t t = W0 + pc_off[k];
+        const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
+        pre[k / S][k % S] = *(const v4i *)src;
+      }
+    } else {
 #pragma unroll
-      for (int q = 0; q < (int)sizeof(TIN); q++) { pre[j][q] = ((const v4i *)src)[q]; }
+      for (int j = 0; j < SPL; j++) {
+        const int64_t t = W0 + 16 * (int64_t)sl_of[j];
+        const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
+#pragma unroll
+        for (int q = 0; q < (int)sizeof(TIN); q++) { pre[j][q] = ((const v4i *)src)[q]; }
+      }
+    }
+  };
+  // COAL: byte plane pp of one 16-byte piece -> 16 / S bytes
+  auto stage_piece = [&](const v4i &v, int ps) {
+#pragma unroll
+    for (int pp = 0; pp < PX; pp++) {
+      if constexpr (S == 2) {
+        const unsigned sel = pp == 0 ? 0x06040200u : 0x07050301u;
+        unsigned lo = __builtin_amdgcn_perm((unsigned)v.y, (unsigned)v.x, sel), hi = __builtin_amdgcn_perm((unsigned)v.w, (unsigned)v.z, sel);
+        if (pp < PX - 1) { lo ^= 0x80808080u; hi ^= 0x80808080u; }
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        *(v2u *)(lds + pp * plane_bytes + ps) = (v2u){lo, hi};
+      } else {
+        unsigned w = gather4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w, pp);
+        if (pp < PX - 1) { w ^= 0x80808080u; }
+        *(unsigned *)(lds + pp * plane_bytes + ps) = w;
+      }
     }
   };
   auto stage_slot = [&](const v4i (&raw)[sizeof(TIN)], int ps16) {
@@ -403,8 +447,13 @@ __global__ void __launch_bounds__(64, 2) fir_gen_fast_kernel(FirParams p, const 
   // s_waitcnt in front of the next staging waits for loads that are the youngest VMEM operations, and the stores get a
   // whole step to drain.
   auto body = [&](int64_t st, auto first_c) {
+    if constexpr (COAL) {
 #pragma unroll
-    for (int j = 0; j < SPL; j++) { stage_slot(pre[j], ps_of[j]); }
+      for (int k = 0; k < NPC; k++) { stage_piece(pre[k / S][k % S], pc_ps[k]); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SPL; j++) { stage_slot(pre[j], ps_of[j]); }
+    }
     if (!decltype(first_c)::value) { flush(st - 1); }
     fetch(st + 1 < s1 ? st + 1 : st);   // the last step re-fetches itself: no branch in the loop
 

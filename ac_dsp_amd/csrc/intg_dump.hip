@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) intg_dump_stream_kernel(IntgDumpParams p,
     const int rem = (int)(q1 - q < BATCH ? q1 - q : BATCH);
     v4i_t v[BATCH];
 #pragma unroll
-    for (int k = 0; k < BATCH; k++) { v[k] = src[64 * (k < rem ? k : rem - 1)]; }
+    for (int k = 0; k < BATCH; k++) { v[k] = __builtin_nontemporal_load(src + 64 * (k < rem ? k : rem - 1)); }   // read once: streaming policy (6.05 -> 6.75 TB/s in tools/copy_probe)
 #pragma unroll
     for (int k = 0; k < BATCH; k++) {
       if (k >= rem) { break; }
