@@ -673,35 +673,35 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   const int64_t s0 = ((int64_t)blockIdx.x + a.chunk0) * a.steps_per_wave;
   const int64_t s1 = GUARD ? ((s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps) : s0 + a.steps_per_wave;
 
-  v4i pre[SPLA][sizeof(TIN)];
-  int sl_of[SPLA], ps_of[SPLA];
+  // window loads coalesced over 16-byte pieces (8 samples; a slot is two pieces), as in fir_gen_fast_kernel
+  constexpr int NPCA = SPLA * 2;
+  v4i pre[NPCA];
+  int pc_off[NPCA], pc_ps[NPCA];
 #pragma unroll
-  for (int j = 0; j < SPLA; j++) {
-    sl_of[j] = (lane + 64 * j < a.n_slots) ? lane + 64 * j : a.n_slots - 1;
-    ps_of[j] = phys_slot(sl_of[j], a) * 16;
+  for (int k = 0; k < NPCA; k++) {
+    int slot = (lane + 64 * k) / 2;
+    const int sub = lane & 1;
+    if (slot >= a.n_slots) { slot = a.n_slots - 1; }
+    pc_off[k] = 16 * slot + 8 * sub;
+    pc_ps[k] = phys_slot(slot, a) * 16 + 8 * sub;
   }
   auto fetch = [&](int64_t st) {
     const int64_t W0 = a.first + st * 256 * R - a.pl.off;
 #pragma unroll
-    for (int j = 0; j < SPLA; j++) {
-      const int64_t t = W0 + 16 * (int64_t)sl_of[j];
+    for (int k = 0; k < NPCA; k++) {
+      const int64_t t = W0 + pc_off[k];
       const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
-#pragma unroll
-      for (int q = 0; q < (int)sizeof(TIN); q++) { pre[j][q] = ((const v4i *)src)[q]; }
+      pre[k] = *(const v4i *)src;
     }
   };
-  auto stage_slot = [&](const v4i (&raw)[sizeof(TIN)], int ps16) {
-    union { v4i v[sizeof(TIN)]; unsigned d[4 * sizeof(TIN)]; } u;
-#pragma unroll
-    for (int q = 0; q < (int)sizeof(TIN); q++) { u.v[q] = raw[q]; }
+  auto stage_piece = [&](const v4i &v, int ps) {
 #pragma unroll
     for (int pp = 0; pp < PXA; pp++) {
       const unsigned sel = pp == 0 ? 0x06040200u : 0x07050301u;
-      v4i o;
-      o.x = (int)__builtin_amdgcn_perm(u.d[1], u.d[0], sel); o.y = (int)__builtin_amdgcn_perm(u.d[3], u.d[2], sel);
-      o.z = (int)__builtin_amdgcn_perm(u.d[5], u.d[4], sel); o.w = (int)__builtin_amdgcn_perm(u.d[7], u.d[6], sel);
-      if (pp < PXA - 1) { o ^= (v4i){(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u}; }
-      *(v4i *)(lds + pp * plane_bytes + ps16) = o;
+      unsigned lo = __builtin_amdgcn_perm((unsigned)v.y, (unsigned)v.x, sel), hi = __builtin_amdgcn_perm((unsigned)v.w, (unsigned)v.z, sel);
+      if (pp < PXA - 1) { lo ^= 0x80808080u; hi ^= 0x80808080u; }
+      typedef unsigned v2u __attribute__((ext_vector_type(2)));
+      *(v2u *)(lds + pp * plane_bytes + ps) = (v2u){lo, hi};
     }
   };
   int xs_of[NBA];
@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   auto body = [&](int64_t st, auto warm_c, auto flush_c) {
     constexpr bool WARM = decltype(warm_c)::value, FLUSH = decltype(flush_c)::value;
 #pragma unroll
-    for (int j = 0; j < SPLA; j++) { stage_slot(pre[j], ps_of[j]); }
+    for (int k = 0; k < NPCA; k++) { stage_piece(pre[k], pc_ps[k]); }
     if (FLUSH && !GUARD) { flush(st - 1); }
     fetch(st + 1 < s1 ? st + 1 : st);
 
