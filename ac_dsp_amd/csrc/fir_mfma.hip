@@ -573,13 +573,32 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       __builtin_amdgcn_sched_barrier(0);
       constexpr int dummy = 0; (void)dummy;
       const int cb = (PAR * NG + g) & 1, nb_ = cb ^ 1;
+      // ACDSP_ABL_*: timing-only ablation builds (wrong results) behind the table in profiles/r2_fir255_clock.txt (d)
+#ifndef ACDSP_ABL_STAGE
       if (NG == 1 && g == gS) { stage(nbuf); }
+#endif
+#ifdef ACDSP_ABL_BREAD
+      if (g == 0) {
+#endif
       if (g + 1 < NG) { read_group(buf, g + 1, Bh[nb_], Bl[nb_]); }
       else { read_group(nbuf, 0, Bh[nb_], Bl[nb_]); }          // first group of the next step (staged in group 0)
+#ifdef ACDSP_ABL_BREAD
+      }
+#endif
+#ifndef ACDSP_ABL_STAGE
       if (NG > 1 && g == gS) { stage(nbuf); }
+#endif
+#ifndef ACDSP_ABL_LOAD
       if (g == gL) { issue_loads_in(T0 + 2048); }
+#endif
+#ifndef ACDSP_ABL_EMIT
       if (PREV && g == gE1) { emit(wide_c, T0 - 1024, ph, pm, pl); }
+#else
+      if (PREV && g == gE1) { asm volatile("" :: "v"(ph[0]), "v"(pm[0]), "v"(pl[0])); }   // keeps the MFMAs of the step alive
+#endif
+#ifndef ACDSP_ABL_FLUSH
       if (PREV && g == gE2) { flush(T0 - 1024); }
+#endif
 #pragma unroll
       for (int i = 0; i < GS; i++) {
         const int b = g * GS + i;
