@@ -29,7 +29,11 @@ __global__ void __launch_bounds__(256) probe(const v4i *__restrict__ x, v4i *__r
       for (int u = 0; u < U; u++) {
         const long j = i + u * n_thr;
         if (RW == 1) { acc += v[u]; }
-        else if (RW == 3) { acc += v[u]; if ((u & 3) == 3 && j < n_vec) { if (NT) { __builtin_nontemporal_store(acc, y + (j >> 2)); } else { y[j >> 2] = acc; } } }
+        else if (RW == 3) {   // one 16-byte store per four loads, lane-contiguous
+          acc += v[u];
+          const long o = ((j - tid) / n_thr / 4) * n_thr + tid;
+          if ((u & 3) == 3 && j < n_vec) { if (NT) { __builtin_nontemporal_store(acc, y + o); } else { y[o] = acc; } }
+        }
         else if (j < n_vec) { if (NT) { __builtin_nontemporal_store(v[u], y + j); } else { y[j] = v[u]; } }
       }
     }
@@ -48,7 +52,11 @@ __global__ void __launch_bounds__(256) probe(const v4i *__restrict__ x, v4i *__r
       for (int u = 0; u < U; u++) {
         const long j = i + 64 * u;
         if (RW == 1) { acc += v[u]; }
-        else if (RW == 3) { acc += v[u]; if ((u & 3) == 3 && j < e) { if (NT) { __builtin_nontemporal_store(acc, y + (j >> 2)); } else { y[j >> 2] = acc; } } }
+        else if (RW == 3) {
+          acc += v[u];
+          const long o = b / 4 + 64 * ((j - b - lane) / 64 / 4) + lane;
+          if ((u & 3) == 3 && j < e) { if (NT) { __builtin_nontemporal_store(acc, y + o); } else { y[o] = acc; } }
+        }
         else if (j < e) { if (NT) { __builtin_nontemporal_store(v[u], y + j); } else { y[j] = v[u]; } }
       }
     }
