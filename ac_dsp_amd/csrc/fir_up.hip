@@ -439,7 +439,7 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
   a.e_rs = a.e_rnd = a.e_w = 0; a.e_lo = INT32_MIN; a.e_hi = INT32_MAX; a.e_mask = ~uint64_t(0);
   int epi = 0;
   const int rs = p.acc.F - p.out.F;
-  if (mode == 0 && px == 2 && p.lossless_shift == 0 && rs >= 0 && rs <= 30 && p.out_eb == 2 &&
+  if (mode == 0 && px == 2 && p.lossless_shift == 0 && rs >= 0 && rs <= 28 && p.out_eb == 2 &&
       (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_SAT || (p.out.O == ACDSP_WRAP && p.out.W == 16)) &&
       max_abs_v >= 0 && max_abs_v < (int64_t(1) << 30)) {
     // 32-bit epilogue: poly_intr, no left shift into ACC_TYPE, |V| (+ rounding constant) inside int32; AC_SAT clamps, AC_WRAP at
