@@ -147,6 +147,9 @@ SYMBOLS = {
     "acdsp_cic_state_size": (_i64, [_vp]),
     "acdsp_cic_state_get": (_i32, [_vp, _vp, C.c_uint64]),
     "acdsp_cic_state_set": (_i32, [_vp, _vp, C.c_uint64]),
+    "acdsp_ddc_state_size": (_i64, [_vp]),
+    "acdsp_ddc_state_get": (_i32, [_vp, _vp, C.c_uint64]),
+    "acdsp_ddc_state_set": (_i32, [_vp, _vp, C.c_uint64]),
     "acdsp_stream_write": (_i32, [C.c_char_p, C.POINTER(StreamHdr), _vp]),
     "acdsp_stream_read_header": (_i32, [C.c_char_p, C.POINTER(StreamHdr)]),
     "acdsp_stream_read": (_i32, [C.c_char_p, _vp, C.c_uint64]),

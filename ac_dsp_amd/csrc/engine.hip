@@ -1903,7 +1903,8 @@ namespace {
 struct StateHdr {
   char magic[8];            // "ACDSPST1"
   uint32_t version;         // 1
-  uint32_t kind;            // 1: FIR input history, 2: FIR reg_trans partial sums, 3: CIC input history + input count
+  uint32_t kind;            // 1: FIR input history, 2: FIR reg_trans partial sums, 3: CIC input history + input count,
+                            // 4: fused DDC input history + input count, 5: two-kernel DDC (CIC blob + FIR blob follow)
   uint32_t n_channels;
   uint32_t elem_bytes;      // bytes per state word (IN container, or 8 for reg_trans)
   uint64_t per_channel;     // state words per channel
@@ -2013,6 +2014,67 @@ int32_t acdsp_cic_state_set(acdsp_cic_t h, const void *buf, uint64_t bytes) {
   HIP_TRY(hipMemcpy(h->d_hist[h->cur], (const char *)buf + sizeof s, state_payload(mine), hipMemcpyHostToDevice));
   h->t_total = s.t_total;
   return ACDSP_OK;
+}
+
+// DDC cascade.  Fused mode: the input history + input count are the whole state (stage B's window is recomputed from it):
+// one kind-4 blob.  Two-kernel mode: a kind-5 header followed by the stage blobs (CIC, then FIR).
+static StateHdr ddc_state_hdr(const acdsp_ddc *h) {
+  StateHdr s;
+  memset(&s, 0, sizeof s);
+  memcpy(s.magic, kStateMagic, 8);
+  s.version = 1;
+  s.kind = h->fused ? 4 : 5;
+  s.n_channels = (uint32_t)h->cic->d.n_channels;
+  s.p0 = (uint32_t)h->cic->d.R; s.p1 = (uint32_t)h->cic->d.M; s.p2 = (uint32_t)h->cic->d.N; s.p3 = (uint32_t)h->fir->d.n_taps;
+  if (h->fused) { s.elem_bytes = (uint32_t)h->cic->in_eb; s.per_channel = (uint64_t)h->hl; s.t_total = h->t_total; }
+  else {   // payload = the two stage blobs; per_channel x elem_bytes x n_channels must give its size
+    s.elem_bytes = 1; s.n_channels = 1;
+    s.per_channel = (uint64_t)(acdsp_cic_state_size(h->cic) + acdsp_fir_state_size(h->fir));
+    s.reserved = (uint64_t)h->cic->d.n_channels;
+  }
+  return s;
+}
+
+int64_t acdsp_ddc_state_size(acdsp_ddc_t h) { return h ? (int64_t)(sizeof(StateHdr) + state_payload(ddc_state_hdr(h))) : -1; }
+
+int32_t acdsp_ddc_state_get(acdsp_ddc_t h, void *buf, uint64_t cap_bytes) {
+  if (!h || !buf) { return fail(ACDSP_EINVAL, "null argument"); }
+  const StateHdr s = ddc_state_hdr(h);
+  const uint64_t pay = state_payload(s);
+  if (cap_bytes < sizeof s + pay) { return fail(ACDSP_EINVAL, "ddc_state_get: buffer of %llu bytes, state needs %llu", (unsigned long long)cap_bytes, (unsigned long long)(sizeof s + pay)); }
+  int rc = check_device(h->cic->d.device);
+  if (rc) { return rc; }
+  memcpy(buf, &s, sizeof s);
+  if (h->fused) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy((char *)buf + sizeof s, h->d_hist[h->cur], pay, hipMemcpyDeviceToHost));
+    return ACDSP_OK;
+  }
+  const uint64_t nc = (uint64_t)acdsp_cic_state_size(h->cic);
+  if ((rc = acdsp_cic_state_get(h->cic, (char *)buf + sizeof s, nc))) { return rc; }
+  return acdsp_fir_state_get(h->fir, (char *)buf + sizeof s + nc, pay - nc);
+}
+
+int32_t acdsp_ddc_state_set(acdsp_ddc_t h, const void *buf, uint64_t bytes) {
+  if (!h || !buf) { return fail(ACDSP_EINVAL, "null argument"); }
+  const StateHdr mine = ddc_state_hdr(h);
+  StateHdr s;
+  if (bytes < sizeof s) { return fail(ACDSP_EINVAL, "ddc_state_set: blob shorter than its header"); }
+  memcpy(&s, buf, sizeof s);
+  if (!state_compatible(s, mine) || s.reserved != mine.reserved || bytes != sizeof s + state_payload(mine) || s.t_total < 0) {
+    return fail(ACDSP_EINVAL, "ddc_state_set: blob does not belong to a cascade of these parameters / channel count / kernel mode");
+  }
+  int rc = check_device(h->cic->d.device);
+  if (rc) { return rc; }
+  if (h->fused) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->d_hist[h->cur], (const char *)buf + sizeof s, state_payload(mine), hipMemcpyHostToDevice));
+    h->t_total = s.t_total;
+    return ACDSP_OK;
+  }
+  const uint64_t nc = (uint64_t)acdsp_cic_state_size(h->cic);
+  if ((rc = acdsp_cic_state_set(h->cic, (const char *)buf + sizeof s, nc))) { return rc; }
+  return acdsp_fir_state_set(h->fir, (const char *)buf + sizeof s + nc, state_payload(mine) - nc);
 }
 
 }  // extern "C"

@@ -272,6 +272,15 @@ class Ddc:
                                 C.byref(n_out), _stream_ptr(x)))
         return out[:, :n_out.value]
 
+    def state(self):
+        """Versioned state blob (bytes) of the cascade (acdsp_ddc_state_get)."""
+        buf = (C.c_char * lib.acdsp_ddc_state_size(self._h))()
+        check(lib.acdsp_ddc_state_get(self._h, buf, len(buf)))
+        return bytes(buf)
+
+    def set_state(self, blob):
+        check(lib.acdsp_ddc_state_set(self._h, C.c_char_p(blob), len(blob)))
+
     def reset(self):
         check(lib.acdsp_ddc_reset(self._h))
 

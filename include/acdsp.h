@@ -297,6 +297,11 @@ int32_t acdsp_fir_state_set(acdsp_fir_t h, const void *h_buf, uint64_t bytes);
 int64_t acdsp_cic_state_size(acdsp_cic_t h);
 int32_t acdsp_cic_state_get(acdsp_cic_t h, void *h_buf, uint64_t cap_bytes);
 int32_t acdsp_cic_state_set(acdsp_cic_t h, const void *h_buf, uint64_t bytes);
+/* cascade (acdsp_ddc_*): the input history and input count of the fused kernel (its FIR window is recomputed from them), or
+ * the two stage blobs behind one header when the handle runs the stages as two kernels */
+int64_t acdsp_ddc_state_size(acdsp_ddc_t h);
+int32_t acdsp_ddc_state_get(acdsp_ddc_t h, void *h_buf, uint64_t cap_bytes);
+int32_t acdsp_ddc_state_set(acdsp_ddc_t h, const void *h_buf, uint64_t bytes);
 
 /* ---- raw-integer stream files (host side; no device needed) ---- */
 int32_t acdsp_stream_write(const char *path, const acdsp_stream_hdr_t *hdr, const void *data);

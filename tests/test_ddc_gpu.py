@@ -105,3 +105,35 @@ def test_rejects_a_lossy_middle():
         out = C.c_void_p()
         from ac_dsp_amd._lib import check
         check(h(C.byref(cd), C.byref(fd), C.byref(out)))
+
+
+def test_state_round_trip_fused_and_two_kernels():
+    """acdsp_ddc_state_get / _set: run -> get -> fresh handle -> set -> continue == the uninterrupted stream == the oracle cascade."""
+    rng = np.random.default_rng(23)
+    cases = [
+        (CFG5["R"], CFG5["cin"], 127, CFG5["fc"], CFG5["fa"], A.Fmt(24, 9, True, "RND", "SAT"), "fused", 16 * 700, 16 * 900),
+        (8, A.Fmt(32, 16), 63, A.Fmt(16, 1), A.Fmt(64, 31), A.Fmt(32, 16, True, "RND", "SAT"), "two_kernels", 8 * 1000 + 3, 8 * 1200),
+    ]
+    for R, cin, n_taps, fc, fa, fo, path, n1, n2 in cases:
+        lo, hi = -(1 << (cin.W - 1)), 1 << (cin.W - 1)
+        x = rng.integers(lo, hi, size=(3, n1 + n2))
+        c = windowed_sinc(n_taps, 0.2, fc)
+        a = A.Ddc(R, 1, 5, cin, n_taps, "SHIFT_REG", fc, fa, fo, n_channels=3)
+        a.set_coeffs(c)
+        assert a.path == path
+        yo = oracle_cascade(R, 1, 5, cin, a.int_type, n_taps, "SHIFT_REG", fc, fa, fo, c, x, [n1])
+        y1 = run_ddc(a, x[:, :n1])
+        blob = a.state()
+        assert blob[:8] == b"ACDSPST1" and len(blob) == A.lib.acdsp_ddc_state_size(a._h)
+        b = A.Ddc(R, 1, 5, cin, n_taps, "SHIFT_REG", fc, fa, fo, n_channels=3)
+        b.set_coeffs(c)
+        b.set_state(blob)
+        y2 = run_ddc(b, x[:, n1:])
+        assert np.array_equal(np.concatenate([y1, y2], axis=1), yo)
+        assert np.array_equal(run_ddc(a, x[:, n1:]), y2)
+        other = A.Ddc(R, 1, 5, cin, n_taps, "SHIFT_REG", fc, fa, fo, n_channels=2)
+        other.set_coeffs(c)
+        with pytest.raises(A.AcdspError):
+            other.set_state(blob)
+        with pytest.raises(A.AcdspError):
+            b.set_state(blob[:-1])
