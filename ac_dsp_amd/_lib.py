@@ -139,6 +139,7 @@ SYMBOLS = {
     "acdsp_mvavg_destroy": (_i32, [_vp]),
     "acdsp_mvavg_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
     "acdsp_mvavg_out_per_frame": (_i64, [_vp, _i64]),
+    "acdsp_mvavg_path": (_i32, [_vp]),
     "acdsp_mvavg_run": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, C.POINTER(_i64), _vp]),
     "acdsp_mvavg_run_host": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64)]),
     "acdsp_fir_state_size": (_i64, [_vp]),

@@ -1779,6 +1779,8 @@ struct acdsp_mvavg {
   int in_eb, out_eb;
   bool coeffs_set = false;
   int64_t *d_coeffs = nullptr;
+  std::vector<int64_t> h_coeffs;
+  int last_path = 0;
   Staging st;
 };
 
@@ -1831,9 +1833,12 @@ int32_t acdsp_mvavg_set_coeffs(acdsp_mvavg_t h, const int64_t *coeffs) {
   if (rc) { return rc; }
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, (size_t)h->d.taps * sizeof(int64_t), hipMemcpyHostToDevice));
+  h->h_coeffs.assign(coeffs, coeffs + h->d.taps);
   h->coeffs_set = true;
   return ACDSP_OK;
 }
+
+int32_t acdsp_mvavg_path(acdsp_mvavg_t h) { return h ? h->last_path : -1; }
 
 int64_t acdsp_mvavg_out_per_frame(acdsp_mvavg_t h, int64_t n_sample) {
   if (!h || n_sample < 1 || n_sample > h->d.max_sample) { return -1; }
@@ -1861,11 +1866,12 @@ int32_t acdsp_mvavg_run(acdsp_mvavg_t h, const void *d_in, int64_t in_stride, in
   p.taps = d.taps; p.win_mode = d.win_mode; p.n_obj = d.n_objects;
   p.in = make_dfmt(d.in); p.cf = make_dfmt(d.coeff); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
   p.in_eb = h->in_eb; p.out_eb = h->out_eb;
-  p.fast = !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && d.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && p.cf.F >= 0 &&
+  p.force_generic = (d.flags & ACDSP_FLAG_FORCE_GENERIC) != 0;
+  p.fast = !p.force_generic && d.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && p.cf.F >= 0 &&
            p.cf.F < 62 && d.acc.W + d.coeff.W <= 62;
   p.n_sample = n_sample; p.n_frames = n_frames; p.out_per_frame = opf; p.in_stride = in_stride; p.out_stride = out_stride;
-  p.x = d_in; p.y = d_out; p.coeffs = h->d_coeffs;
-  hipError_t e = launch_mv_avg(p, (hipStream_t)stream);
+  p.x = d_in; p.y = d_out; p.coeffs = h->d_coeffs; p.h_coeffs = h->h_coeffs.data();
+  hipError_t e = launch_mv_avg(p, (hipStream_t)stream, &h->last_path);
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "mv_avg kernel launch failed: %s", hipGetErrorString(e)); }
   return ACDSP_OK;
 }

@@ -122,14 +122,16 @@ hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStre
 // Moving average (mv_avg.hip).  win_mode 0 AC_WIN, 1 AC_MIRROR, 2 AC_CLIP; rows = objects, frames of n_sample inputs back to back
 struct MvAvgParams {
   int32_t taps, win_mode, n_obj;
+  int32_t force_generic;      // ACDSP_FLAG_FORCE_GENERIC: exact-order kernel only
   int32_t fast;               // AC_TRN / AC_RND + AC_WRAP accumulator, F_coeff >= 0, products within 63 bits: order-free int64 sums
   DFmt in, cf, acc, out;
   int32_t in_eb, out_eb;
   int64_t n_sample, n_frames, out_per_frame, in_stride, out_stride;
   const void *x; void *y;
   const int64_t *coeffs;      // [taps]
+  const int64_t *h_coeffs;    // host copy (the streaming kernel takes its coefficients as kernel arguments)
 };
-hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s);
+hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s, int *path);   // *path: 0 exact order, 1 int64 sums, 2 streaming kernel
 
 // Polyphase decimator, exact per-MAC order (polydec.hip); p.coeffs = STR_COEFF_TYPE array [ntaps*df], p.n = inputs used
 hipError_t launch_polydec_generic(const FirParams &p, int ntaps, int df, int64_t n_out, hipStream_t s);

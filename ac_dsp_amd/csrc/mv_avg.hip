@@ -12,6 +12,9 @@
 // Two arithmetic classes: per-tap requantisation in 128 bits (any Q / O), and, for AC_TRN / AC_RND + AC_WRAP accumulators
 // whose products fit 63 bits, the order-free form acc = sum_j ((xq_j * c_j + rnd) >> F_c) mod 2^W_acc in int64.
 // Streaming op: 2 + 2 bytes per sample at 16-bit containers; bound by HBM for short windows.
+#include <cstdlib>
+#include <cstring>
+
 #include "fir_kernels.hpp"
 
 namespace acdsp {
@@ -77,10 +80,277 @@ __global__ void __launch_bounds__(kTile) mv_avg_kernel(MvAvgParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming kernel for the common class: 16-bit samples and 16-bit coefficients whose absolute values sum to < 2^15, a
+// wrapping AC_TRN / AC_RND accumulator that holds the cast of a sample exactly (F_acc >= F_in, enough integer bits).  Then
+//     acc = wrap( sum_j floor((x_j * 2^d * c_j + rnd) / 2^sh) ),   d = F_acc - F_in,  sh = F_coeff
+// and every term fits int32:   d >= sh ("linear"):  x_j * c_j * 2^(d - sh)      -> v_dot2_i32_i16 on sample / coefficient pairs
+//                              d <  sh ("per tap"): (x_j * c_j + r) >> (sh - d) -> mad / shift / add per tap.
+// A wave owns runs of 512-output tiles of the (object, frame) rows: one coalesced 16-byte load per lane (+ a partial one
+// for the window reach) goes to a wave-private LDS image of the tile, the frame-edge positions of AC_CLIP / AC_MIRROR are
+// patched in from their source samples, every lane reads its 8 + TAPS - 1 window samples back with (unaligned) 16-byte
+// reads, computes 8 consecutive outputs -- coefficients sit in SGPRs -- converts them (32-bit shift / clamp when nothing
+// can wrap, else the 64-bit branch-free form) and stores 16 bytes per instruction.  The loads of the next tile are issued
+// before the arithmetic of the current one.  No workgroup barrier: waves never share data.
+struct MvStreamArgs {
+  int16_t c16[34];            // coefficients, zero padded (pairs (c[2q], c[2q+1]) are the v_dot2 operands)
+  int32_t taps, h, hb, off, mode, nxg;
+  int32_t linear, ls, e, rnd_e;
+  int32_t cv32, s32, r32, lo32, hi32, ko32;   // 32-bit epilogue: q = (S + r32) >> s32, clamp, wrap (ko32 = 32 - W_out or 0)
+  int32_t ka, rs, ls2, ko;    // 64-bit epilogue (see IdConv in intg_dump.hip)
+  uint64_t am, om;
+  int64_t rnd, lo, hi;
+  int32_t out_eb, vec_ok;
+  int64_t n_sample, n_frames, opf, in_stride, out_stride, tpf, n_tiles, tiles_per_wave;
+  const int16_t *x;
+  void *y;
+};
+
+typedef short v2s_t __attribute__((ext_vector_type(2)));
+
+template <int NR, bool LINEAR, bool CV32, bool EDGE>
+__global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
+  constexpr int REGION = 512 + 8 * NR;          // samples of one wave's LDS image
+  constexpr int NQ = 4 * NR - 3;                // coefficient pairs covering 8 NR - 7 taps (+ a zero)
+  __shared__ __attribute__((aligned(16))) int16_t sm[4][REGION];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int16_t *img = sm[wave];
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * a.tiles_per_wave;
+  const int64_t t_end = (t0 + a.tiles_per_wave < a.n_tiles) ? t0 + a.tiles_per_wave : a.n_tiles;
+  if (t0 >= t_end) { return; }
+  const int n_my = (int)(t_end - t0);
+  const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.c16);
+
+  // Tiles are fetched two ahead into alternating register sets.  (object, frame, tile) of the tile being fetched: one
+  // division per wave, then counted up; past the wave's last tile the fetch repeats that tile (branch-free loop body, so
+  // the waits in front of the LDS writes are counted vmcnt's on the older set only).
+  struct Tile { uint4 mv, ev; int16_t fxl, fxr; int64_t ti, fr, obj; };
+  const int64_t pair0 = t0 / a.tpf;
+  int64_t f_ti = t0 - pair0 * a.tpf, f_obj = pair0 / a.n_frames, f_fr = pair0 - f_obj * a.n_frames;
+  int f_left = n_my;   // tiles not fetched yet
+  auto fetch = [&](Tile &T) {   // aligned 8-sample groups: whole groups lie inside or outside the frame
+    const int16_t *row = a.x + f_obj * a.in_stride + f_fr * a.n_sample;
+    const int64_t n = a.n_sample, g = f_ti * 512 - a.hb + 8 * lane;
+    T.ti = f_ti; T.fr = f_fr; T.obj = f_obj;
+    // every load is unconditional (addresses clamped into the frame; what the clamped lanes fetch is never used), so
+    // the loop body has no load under a branch and the waits stay counted
+    const int64_t gc = g < 0 ? 0 : (g < n ? g : n - 8);
+    T.mv = *reinterpret_cast<const uint4 *>(row + gc);
+    const int64_t g2 = f_ti * 512 - a.hb + 512 + 8 * (lane < a.nxg ? lane : 0);
+    T.ev = *reinterpret_cast<const uint4 *>(row + (g2 < n ? g2 : n - 8));
+    if constexpr (EDGE) {   // frame-edge patches of AC_CLIP / AC_MIRROR: the source samples of positions -1 - lane and n + lane
+      const int l = lane < a.h ? lane : 0;
+      T.fxl = row[a.mode == 2 ? 0 : 1 + l];
+      T.fxr = row[a.mode == 2 ? n - 1 : n - 2 - l];
+    }
+    if (f_left > 1) {
+      f_left--;
+      if (++f_ti == a.tpf) {
+        f_ti = 0;
+        if (++f_fr == a.n_frames) { f_fr = 0; f_obj++; }
+      }
+    }
+  };
+  auto process = [&](Tile &T) {
+    const int64_t ti = T.ti, fr = T.fr, obj = T.obj, p0 = ti * 512 - a.hb;
+    *reinterpret_cast<uint4 *>(img + 8 * lane) = T.mv;
+    if (lane < a.nxg) { *reinterpret_cast<uint4 *>(img + 512 + 8 * lane) = T.ev; }
+    if constexpr (EDGE) {   // positions outside [0, n) take the clipped / mirrored source sample
+      if (lane < a.h) {
+        if (ti == 0) { img[a.hb - 1 - lane] = T.fxl; }
+        const int64_t idx = a.n_sample + lane - p0;
+        if (idx < REGION) { img[idx] = T.fxr; }
+      }
+    }
+    fetch(T);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t R[4 * NR + 1];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      uint4 v;
+      __builtin_memcpy(&v, img + 8 * lane + a.off + 8 * r, 16);   // 2-byte aligned: the LDS takes unaligned b128 reads
+      R[4 * r] = v.x; R[4 * r + 1] = v.y; R[4 * r + 2] = v.z; R[4 * r + 3] = v.w;
+    }
+    R[4 * NR] = 0;
+    int S[8];
+    if constexpr (LINEAR) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        int sum = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const uint32_t w = (i & 1) ? __builtin_amdgcn_alignbit(R[i / 2 + q + 1], R[i / 2 + q], 16) : R[i / 2 + q];
+          sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s_t, w), __builtin_bit_cast(v2s_t, cp[q]), sum, false);
+        }
+        S[i] = sum;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8 * NR - 7; j++) {
+          const int k = i + j;
+          const int xs = (k & 1) ? ((int)R[k / 2] >> 16) : (int)(int16_t)R[k / 2];
+          sum += (xs * (int)a.c16[j] + a.rnd_e) >> a.e;
+        }
+        S[i] = sum;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // every lane has its window: the image may be overwritten
+    const int64_t k0 = ti * 512 + 8 * lane;
+    if (k0 < a.opf) {
+      const int64_t yb = obj * a.out_stride + fr * a.opf + k0;
+      if constexpr (CV32) {
+        int o[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          int q = (S[i] + a.r32) >> a.s32;
+          q = q < a.lo32 ? a.lo32 : (q > a.hi32 ? a.hi32 : q);
+          o[i] = (int)((uint32_t)q << a.ko32) >> a.ko32;
+          if (a.om != ~uint64_t(0)) { o[i] = (int)((uint32_t)o[i] & (uint32_t)a.om); }
+        }
+        if (a.vec_ok) {
+          if (a.out_eb == 2) {
+            uint4 v;
+            v.x = ((uint32_t)o[0] & 0xFFFFu) | ((uint32_t)o[1] << 16); v.y = ((uint32_t)o[2] & 0xFFFFu) | ((uint32_t)o[3] << 16);
+            v.z = ((uint32_t)o[4] & 0xFFFFu) | ((uint32_t)o[5] << 16); v.w = ((uint32_t)o[6] & 0xFFFFu) | ((uint32_t)o[7] << 16);
+            *reinterpret_cast<uint4 *>((int16_t *)a.y + yb) = v;
+          } else if (a.out_eb == 4) {
+            uint4 *d = reinterpret_cast<uint4 *>((int32_t *)a.y + yb);
+            d[0] = make_uint4(o[0], o[1], o[2], o[3]); d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+          } else {
+            // unsigned OUT: the masked word zero-extends; signed: sign-extends
+            int64_t *d = (int64_t *)a.y + yb;
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+              const int64_t e0 = a.om != ~uint64_t(0) ? (int64_t)(uint32_t)o[i] : (int64_t)o[i];
+              const int64_t e1 = a.om != ~uint64_t(0) ? (int64_t)(uint32_t)o[i + 1] : (int64_t)o[i + 1];
+              *reinterpret_cast<ulonglong2 *>(d + i) = make_ulonglong2((uint64_t)e0, (uint64_t)e1);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            if (k0 + i < a.opf) { store_raw(a.y, yb + i, a.out_eb, a.om != ~uint64_t(0) ? (int64_t)(uint32_t)o[i] : (int64_t)o[i]); }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int64_t acc = (int64_t)(((uint64_t)((int64_t)((uint64_t)(int64_t)S[i] << (a.ls + a.ka)) >> a.ka)) & a.am);   // wrap to ACC_TYPE
+          int64_t qv = (int64_t)((uint64_t)((acc + a.rnd) >> a.rs) << a.ls2);
+          qv = qv < a.lo ? a.lo : (qv > a.hi ? a.hi : qv);
+          const int64_t o = (int64_t)(((uint64_t)((int64_t)((uint64_t)qv << a.ko) >> a.ko)) & a.om);
+          if (k0 + i < a.opf) { store_raw(a.y, yb + i, a.out_eb, o); }
+        }
+      }
+    }
+  };
+  Tile A, B;
+  A.mv = A.ev = B.mv = B.ev = make_uint4(0, 0, 0, 0);
+  A.fxl = A.fxr = B.fxl = B.fxr = 0;
+  fetch(A);
+  fetch(B);
+  for (int it = 0; it < n_my; it += 2) {
+    process(A);
+    if (it + 1 < n_my) { process(B); }
+  }
+}
+
 }  // namespace
 
-hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s) {
+// true: launched.  Class and shape conditions of the streaming kernel (see above).
+static bool try_stream(const MvAvgParams &p, hipStream_t s) {
+  static const bool off = getenv("ACDSP_NO_MVAVG_STREAM") != nullptr;   // A/B knob
+  if (off || p.force_generic || !p.h_coeffs || p.taps > 33 || p.in_eb != 2 || !(p.in.S || p.in.W <= 15)) { return false; }
+  if (p.n_sample < p.taps || p.n_sample % 8 != 0 || p.in_stride % 8 != 0 || ((uintptr_t)p.x % 16) != 0) { return false; }
+  // the cast (ACC_TYPE) w[j] is exact and the accumulator wraps
+  const int d = p.acc.F - p.in.F, sh = p.cf.F;
+  const int i_in = p.in.W - p.in.F, i_acc = p.acc.W - p.acc.F;
+  if (d < 0 || sh < 0 || p.acc.O != ACDSP_WRAP || (p.acc.Q != ACDSP_TRN && p.acc.Q != ACDSP_RND)) { return false; }
+  if (p.in.S ? (!p.acc.S || i_acc < i_in) : (i_acc < i_in + (p.acc.S ? 1 : 0))) { return false; }
+  int64_t sum_abs = 0;
+  for (int i = 0; i < p.taps; i++) {
+    if (p.h_coeffs[i] < -32768 || p.h_coeffs[i] > 32767) { return false; }
+    sum_abs += p.h_coeffs[i] < 0 ? -p.h_coeffs[i] : p.h_coeffs[i];
+  }
+  if (sum_abs > 32767) { return false; }            // |sum of products| < 2^30: every intermediate stays inside int32
+  MvStreamArgs a;
+  memset(&a, 0, sizeof a);
+  for (int i = 0; i < p.taps; i++) { a.c16[i] = (int16_t)p.h_coeffs[i]; }
+  a.taps = p.taps; a.h = p.taps / 2; a.mode = p.win_mode;
+  a.hb = p.win_mode == 0 ? 0 : 8 * ((a.h + 7) / 8);
+  a.off = p.win_mode == 0 ? 0 : a.hb - a.h;
+  a.nxg = (a.off + p.taps - 1 + 7) / 8;
+  a.linear = d >= sh;
+  a.ls = a.linear ? d - sh : 0;
+  a.e = a.linear ? 0 : sh - d;
+  if (a.e > 30 || a.ls > 62) { return false; }
+  a.rnd_e = (!a.linear && p.acc.Q == ACDSP_RND) ? (1 << (a.e - 1)) : 0;
+  if (p.acc.W > 61 || a.ls >= p.acc.W) { return false; }
+  // ACC -> OUT
+  if ((p.out.Q != ACDSP_TRN && p.out.Q != ACDSP_RND) || (p.out.O != ACDSP_WRAP && p.out.O != ACDSP_SAT) || p.out.W > 62) { return false; }
+  const int rs = p.acc.F - p.out.F;
+  a.ka = 64 - p.acc.W; a.am = p.acc.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.acc.W));
+  a.rs = rs > 0 ? rs : 0; a.ls2 = rs < 0 ? -rs : 0;
+  if (a.rs > 60 || p.acc.W + a.ls2 > 61) { return false; }
+  a.rnd = (p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0;
+  if (p.out.O == ACDSP_SAT) { a.lo = p.out.lo; a.hi = p.out.hi; a.ko = 0; a.om = ~uint64_t(0); }
+  else { a.lo = INT64_MIN; a.hi = INT64_MAX; a.ko = 64 - p.out.W; a.om = p.out.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.out.W)); }
+  // 32-bit form: the accumulator cannot wrap (signed, W_acc >= 31 + ls) and the output shift swallows ls
+  a.cv32 = p.acc.S && p.acc.W >= 31 + a.ls && rs >= a.ls && rs - a.ls <= 30 && (p.out.S || p.out.W <= 31);
+  if (a.cv32) {
+    a.s32 = rs - a.ls;
+    a.r32 = (p.out.Q == ACDSP_RND && a.s32 > 0) ? (1 << (a.s32 - 1)) : 0;
+    a.lo32 = INT32_MIN; a.hi32 = INT32_MAX; a.ko32 = 0;
+    if (p.out.O == ACDSP_SAT) {
+      if (p.out.lo > INT32_MIN) { a.lo32 = (int32_t)p.out.lo; }
+      if (p.out.hi < INT32_MAX) { a.hi32 = (int32_t)p.out.hi; }
+    } else if (p.out.W < 32) { a.ko32 = 32 - p.out.W; }
+  }
+  a.out_eb = p.out_eb;
+  a.vec_ok = p.out_per_frame % 8 == 0 && p.out_stride % 8 == 0 && ((uintptr_t)p.y % 16) == 0;
+  a.n_sample = p.n_sample; a.n_frames = p.n_frames; a.opf = p.out_per_frame; a.in_stride = p.in_stride; a.out_stride = p.out_stride;
+  a.tpf = (p.out_per_frame + 511) / 512;
+  a.n_tiles = (int64_t)p.n_obj * p.n_frames * a.tpf;
+  a.tiles_per_wave = 32;
+  while (a.tiles_per_wave > 1 && a.n_tiles / a.tiles_per_wave < 16384) { a.tiles_per_wave /= 2; }
+  static const char *tpw_env = getenv("ACDSP_MVAVG_TPW");   // tuning knob: tiles per wave
+  if (tpw_env && atoi(tpw_env) > 0) { a.tiles_per_wave = atoi(tpw_env); }
+  a.x = (const int16_t *)p.x; a.y = p.y;
+  const int64_t waves = (a.n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
+  const int64_t blocks = (waves + 3) / 4;
+  if (blocks > 0x7FFFFFFF) { return false; }
+  dim3 grid((unsigned)blocks);
+  const int nr = p.taps <= 9 ? 2 : (p.taps <= 17 ? 3 : (p.taps <= 25 ? 4 : 5));
+#define ACDSP_MV_LAUNCH2(NR_, LIN_, CV_)                                                                                           \
+  if (a.mode != 0) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true>), grid, dim3(256), 0, s, a); }                  \
+  else { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, false>), grid, dim3(256), 0, s, a); }
+#define ACDSP_MV_LAUNCH(NR_)                                                                                                       \
+  if (a.linear) {                                                                                                                   \
+    if (a.cv32) { ACDSP_MV_LAUNCH2(NR_, true, true) } else { ACDSP_MV_LAUNCH2(NR_, true, false) }                                  \
+  } else {                                                                                                                          \
+    if (a.cv32) { ACDSP_MV_LAUNCH2(NR_, false, true) } else { ACDSP_MV_LAUNCH2(NR_, false, false) }                                \
+  }
+  switch (nr) {
+    case 2: ACDSP_MV_LAUNCH(2) break;
+    case 3: ACDSP_MV_LAUNCH(3) break;
+    case 4: ACDSP_MV_LAUNCH(4) break;
+    default: ACDSP_MV_LAUNCH(5) break;
+  }
+#undef ACDSP_MV_LAUNCH2
+#undef ACDSP_MV_LAUNCH
+  return true;
+}
+
+hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s, int *path) {
   if (p.out_per_frame <= 0 || p.n_frames <= 0) { return hipSuccess; }
+  if (try_stream(p, s)) { *path = 2; return hipGetLastError(); }
+  *path = p.fast ? 1 : 0;
   const int64_t pairs = (int64_t)p.n_obj * p.n_frames;
   dim3 grid((unsigned)((p.out_per_frame + kTile - 1) / kTile), (unsigned)(pairs < 65535 ? pairs : 65535));
   const size_t lds = (size_t)(kTile + 2 * p.taps - 1) * sizeof(int64_t);

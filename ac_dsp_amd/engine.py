@@ -410,6 +410,11 @@ class MvAvg:
     def out_per_frame(self, n_sample):
         return lib.acdsp_mvavg_out_per_frame(self._h, n_sample)
 
+    @property
+    def path(self):
+        """kernel family of the last run()"""
+        return {0: "exact_order", 1: "int64_sums", 2: "stream"}[lib.acdsp_mvavg_path(self._h)]
+
     def run(self, x, n_sample, out=None):
         assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_objects and x.stride(1) == 1 and x.shape[1] % n_sample == 0
         assert x.dtype == torch_dtype_for(self.fin), (x.dtype, self.fin)

@@ -177,6 +177,29 @@ def build_workload(workload, args, world, rank, local_rank):
             eng.run(x, n_sample)
         samples_per_step = (hi - lo) * n
         path = "intgdump"
+    elif workload == "mvavg":
+        # ac_mv_avg, TAPS = 9, AC_MIRROR, frames of 1024 samples (S_TYPE ac_int<11,false>), ac_fixed<16,8>
+        ch_per_gpu = args.channels or 1024
+        n = args.samples or (1 << 20)            # samples per object = 1024 frames x 1024
+        fin, fc, fa, fo = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18), A.Fmt(16, 8, True, "RND", "SAT")
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        eng = A.MvAvg(1024, 9, "MIRROR", fin, fc, fa, fo, n_objects=hi - lo, device=local_rank)
+        wts = np.round(np.hanning(11)[1:-1] / np.hanning(11).sum() * 2.0 ** fc.F).astype(np.int64)
+        eng.set_coeffs(wts)
+        x = torch.empty((hi - lo, n), dtype=torch.int16, device=dev)
+        A.fill_stimulus(x, seed, 16, ch0=lo)
+        y = torch.empty((hi - lo, n), dtype=torch.int16, device=dev)
+        bytes_per_sample = 2.0 + 2.0
+        macs_per_sample = 0.0
+        name = "ac_mv_avg TAPS=9 AC_MIRROR ac_fixed<16,8> -> <16,8,RND,SAT>, ACC <40,18>, %d objects x %d frames x 1024 samples per GPU (SURVEY 8 f4)" % (ch_per_gpu, n // 1024)
+        dtype = "int32 (exact: weights sum below 2^15, ACC <40,18> cannot wrap)"
+        coeffs = None
+
+        def step():
+            eng.run(x, 1024, out=y)
+        samples_per_step = (hi - lo) * n
+        step()
+        path = "mvavg_" + eng.path
     elif workload == "cic_intr":
         # ac_cic_intr_full N=5 R=8 on ac_fixed<32,16> (named in north_star; no BASELINE config): 8 outputs per input
         ch_per_gpu = args.channels or 1024
@@ -316,7 +339,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "cic_intr", "ddc", "polydec", "polyintr", "intgdump"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "cic_intr", "ddc", "polydec", "polyintr", "intgdump", "mvavg"])
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")

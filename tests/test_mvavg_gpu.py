@@ -16,10 +16,10 @@ def rand_raw(rng, fmt, shape):
     return rng.integers(lo, hi + 1, size=shape, dtype=np.int64)
 
 
-def check(taps, mode, fin, fc, fa, fo, n_sample, n_frames, n_obj=3, seed=0, force_generic=False, max_sample=None):
+def check(taps, mode, fin, fc, fa, fo, n_sample, n_frames, n_obj=3, seed=0, force_generic=False, max_sample=None, coeffs=None, path=None):
     rng = np.random.default_rng(seed)
     x = rand_raw(rng, fin, (n_obj, n_sample * n_frames))
-    c = rand_raw(rng, fc, (taps,))
+    c = rand_raw(rng, fc, (taps,)) if coeffs is None else np.asarray(coeffs, dtype=np.int64)
     eng = A.MvAvg(max_sample or max(n_sample, 1), taps, mode, fin, fc, fa, fo, n_objects=n_obj, force_generic=force_generic)
     eng.set_coeffs(c)
     y = eng.run(torch.from_numpy(x).to(A.torch_dtype_for(fin)).cuda(), n_sample).cpu().numpy().astype(np.int64)
@@ -27,6 +27,8 @@ def check(taps, mode, fin, fc, fa, fo, n_sample, n_frames, n_obj=3, seed=0, forc
     assert y.shape == yo.shape, (y.shape, yo.shape)
     bad = np.argwhere(y != yo)
     assert bad.size == 0, "%d mismatches, first at %s" % (len(bad), bad[0])
+    if path is not None:
+        assert eng.path == path, eng.path
 
 
 MODES = ["WIN", "MIRROR", "CLIP"]
@@ -71,3 +73,64 @@ def test_argument_checks():
         eng.run(x, 65)                                        # n_sample > MAX_SAMPLE
     assert eng.run(x[:, :128], 64).shape == (1, 128)
     assert eng.out_per_frame(0) == -1 and eng.out_per_frame(64) == 64
+
+
+def small_coeffs(rng, taps, total=32767):
+    """TAPS signed 16-bit weights whose absolute values sum to <= total (the streaming kernel's int32 bound)."""
+    c = rng.integers(-total // taps, total // taps + 1, size=taps, dtype=np.int64)
+    c[taps // 2] += (total - np.abs(c).sum()) * (1 if rng.integers(0, 2) else -1)
+    assert np.abs(c).sum() <= total
+    return c
+
+
+STREAM_ACC = [
+    (A.Fmt(40, 18), "linear, d = sh"),                  # F_acc = F_in + F_coeff: exact products
+    (A.Fmt(48, 20), "linear, d > sh"),                  # products shifted left
+    (A.Fmt(32, 16), "per tap, TRN"),                    # F_acc < F_in + F_coeff: every product loses bits
+    (A.Fmt(32, 16, True, "RND"), "per tap, RND"),
+    (A.Fmt(30, 14, True, "RND"), "per tap, 64-bit epilogue"),   # W_acc < 31: the accumulator may wrap
+]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("taps", [1, 3, 9, 11, 17, 25, 33])
+def test_stream_kernel_classes(mode, taps):
+    """16-bit samples / weights with sum |c| < 2^15, frames aligned to 16 bytes: the streaming kernel (path 'stream')."""
+    rng = np.random.default_rng(100 + taps)
+    fin, fc = A.Fmt(16, 8), A.Fmt(16, 2)
+    for k, (fa, _) in enumerate(STREAM_ACC):
+        for fo in (A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(24, 10, True, "TRN", "WRAP"), A.Fmt(40, 18), A.Fmt(12, 6, False, "RND", "SAT")):
+            check(taps, mode, fin, fc, fa, fo, 1024, 3, n_obj=2, seed=200 + k, coeffs=small_coeffs(rng, taps), path="stream")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_stream_kernel_shapes(mode):
+    """Frame lengths around the 512-output tile, single-tile frames, many frames per wave, unaligned output frames."""
+    rng = np.random.default_rng(7)
+    fin, fc, fa, fo = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18), A.Fmt(16, 8, True, "RND", "SAT")
+    for n in (8, 16, 40, 504, 512, 520, 1016, 1024, 1032, 2048, 4096 + 8):
+        for taps in (5, 9):
+            if n >= taps:
+                check(taps, mode, fin, fc, fa, fo, n, 5, n_obj=3, seed=n, coeffs=small_coeffs(rng, taps), path="stream", max_sample=8192)
+    check(9, mode, fin, fc, fa, fo, 64, 700, n_obj=5, seed=1, coeffs=small_coeffs(rng, 9), path="stream")       # runs of tiles cross frames and objects
+    check(33, mode, fin, fc, fa, A.Fmt(40, 18), 256, 9, n_obj=2, seed=2, coeffs=small_coeffs(rng, 33), path="stream")
+    # extreme samples and weights: the int32 bound is tight
+    c = np.zeros(9, dtype=np.int64)
+    c[4] = 32767
+    check(9, mode, A.Fmt(16, 8), fc, fa, fo, 1024, 2, coeffs=c, seed=3, path="stream")
+    c[:] = [-4095, 4095, -4095, 4095, -4095, 4095, -4095, 4095, -7]
+    check(9, mode, A.Fmt(16, 8), fc, fa, fo, 1024, 2, coeffs=c, seed=4, path="stream")
+
+
+def test_stream_kernel_fallbacks():
+    """Shapes / types outside the streaming class run on the general kernels with the same results."""
+    rng = np.random.default_rng(9)
+    fin, fc, fa, fo = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18), A.Fmt(16, 8, True, "RND", "SAT")
+    c = small_coeffs(rng, 9)
+    check(9, "MIRROR", fin, fc, fa, fo, 1020, 3, coeffs=c, seed=1, path="int64_sums")                 # frames not 16-byte aligned
+    check(9, "MIRROR", fin, fc, fa, fo, 1024, 3, coeffs=[12000, -9000] * 4 + [30000], seed=2, path="int64_sums")             # sum |c| >= 2^15
+    check(9, "MIRROR", fin, fc, A.Fmt(40, 18, True, "TRN", "SAT"), fo, 1024, 3, coeffs=c, seed=3, path="exact_order")
+    check(9, "MIRROR", fin, fc, A.Fmt(20, 4), fo, 1024, 3, coeffs=c, seed=4, path="int64_sums")       # the cast to ACC wraps
+    check(9, "WIN", A.Fmt(16, 8, False), fc, fa, fo, 1024, 3, coeffs=c, seed=5, path="int64_sums")    # unsigned 16-bit samples
+    check(9, "WIN", A.Fmt(15, 8, False), fc, fa, fo, 1024, 3, coeffs=c, seed=6, path="stream")        # unsigned 15-bit: fits int16
+    check(5, "WIN", fin, fc, fa, fo, 1024, 3, coeffs=small_coeffs(rng, 5), seed=7, path="stream")      # 1020 outputs per frame: element stores
