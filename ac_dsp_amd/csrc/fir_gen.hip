@@ -26,6 +26,7 @@
 // padded by slot/R so that the 16 columns of a read hit 16 different 16-byte bank groups.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -62,9 +63,10 @@ bool fir_gen_plan(const int64_t *h, int n_taps, int R, int first_mod16, FirGenPl
   const int nb = (off + 15 * R + 1 + 63) / 64;
   if (nb > kGenMaxNB) { return false; }
   pl->pc = pc; pl->nb = nb; pl->off = off; pl->R = R;
-  __int128 sum = 0;
-  for (int k = 0; k < n_taps; k++) { sum += (__int128)h[k]; }
+  __int128 sum = 0, sum_abs = 0;
+  for (int k = 0; k < n_taps; k++) { sum += (__int128)h[k]; sum_abs += h[k] < 0 ? -(__int128)h[k] : (__int128)h[k]; }
   pl->sum_h = (int64_t)(unsigned long long)sum;  // mod 2^64
+  pl->sum_abs_h = sum_abs < ((__int128)1 << 62) ? (int64_t)sum_abs : (int64_t(1) << 62);
   frag->assign((size_t)pc * nb * 64 * 4, 0u);
   for (int q = 0; q < pc; q++) {
     for (int b = 0; b < nb; b++) {
@@ -110,6 +112,11 @@ struct GenArgs {
   int32_t e_ls, e_ka, e_rs, e_ls2, e_ko;
   int64_t e_rnd, e_lo, e_hi;
   int32_t out_vec_ok;         // output rows are 16-byte aligned: whole steps leave as 1 KB-per-instruction stores
+  // 32-bit limb epilogues of the cascade kernel (host-verified bounds, see launch_cascade): the constant of the
+  // recombination (re-bias correction + rounding) enters as balanced base-256 digits = the initial accumulator values
+  int32_t dig[8];
+  int32_t l_hb_lo, l_hb_hi;   // stage B, AC_SAT: clamp of the high limb in front of the funnel shift
+  int32_t l_lo, l_hi, l_w;    // stage B: OUT range (AC_SAT) / OUT width (AC_WRAP: l_lo = l_hi = 0)
 };
 
 __device__ inline int phys_slot(int s, const GenArgs &a) {
@@ -644,7 +651,10 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
 // input history instead of being carried, so the handle keeps 256*R + window input samples per channel.
 // Against the two-kernel path this saves writing and re-reading the 8-byte intermediate (config 5: 14.0 -> 9.7 GB).
 //   GUARD: chunks with incomplete steps (ragged end of the call): element-wise guarded stores.
-template <int PXA, int PCA, int NBA, int SPLA, int PXB, int PCB, int NBB, bool GUARD>
+#ifndef ACDSP_CASC_BARRIER
+#define ACDSP_CASC_BARRIER 1
+#endif
+template <int PXA, int PCA, int NBA, int SPLA, int PXB, int PCB, int NBB, bool GUARD, bool LIMB>
 __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams pb, const v4i *__restrict__ fragA,
                                                        const v4i *__restrict__ fragB, GenArgs a, GenArgs b) {
   typedef int16_t TIN;
@@ -685,13 +695,29 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
     pc_off[k] = 16 * slot + 8 * sub;
     pc_ps[k] = phys_slot(slot, a) * 16 + 8 * sub;
   }
-  auto fetch = [&](int64_t st) {
+  // Interior chunks (every window of the chunk lies inside the call's samples: all but a row's first and last chunk) address
+  // their pieces as uniform base + 16 bytes x lane + 1024 bytes x k -- no per-piece 64-bit selects; only the last two pieces,
+  // whose surplus lanes repeat the last slot, keep an offset register.  (A per-step uniform branch instead of two loops
+  // was measured: no gain over the general form -- the split loop body schedules worse.)
+  const int64_t W_first = a.first + (s0 - 1) * 256 * R - a.pl.off, W_last = a.first + (s1 - 1) * 256 * R - a.pl.off;
+  const bool interior = !GUARD && W_first >= 0 && W_last + 16 * a.n_slots <= a.n16;
+  const unsigned lane16 = 16u * (unsigned)lane;
+  auto fetch = [&](int64_t st, auto fast_c) {
     const int64_t W0 = a.first + st * 256 * R - a.pl.off;
+    if constexpr (decltype(fast_c)::value) {
+      const char *base = (const char *)(xrow + W0);
 #pragma unroll
-    for (int k = 0; k < NPCA; k++) {
-      const int64_t t = W0 + pc_off[k];
-      const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
-      pre[k] = *(const v4i *)src;
+      for (int k = 0; k < NPCA; k++) {
+        const unsigned off = k < NPCA - 2 ? lane16 + 1024u * k : 2u * (unsigned)pc_off[k];
+        pre[k] = *(const v4i *)(base + off);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NPCA; k++) {
+        const int64_t t = W0 + pc_off[k];
+        const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
+        pre[k] = *(const v4i *)src;
+      }
     }
   };
   auto stage_piece = [&](const v4i &v, int ps) {
@@ -714,17 +740,29 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
     *(v4i *)(yrow + st * 1024 + 16 * lane) = val;
   };
   // One step.  WARM: stage A only (fills the ring for the chunk's first stage-B step).  FLUSH: step st-1 waits in the tile.
-  auto body = [&](int64_t st, auto warm_c, auto flush_c) {
+  auto body = [&](int64_t st, auto warm_c, auto flush_c, auto fast_c) {
     constexpr bool WARM = decltype(warm_c)::value, FLUSH = decltype(flush_c)::value;
 #pragma unroll
-    for (int k = 0; k < NPCA; k++) { stage_piece(pre[k], pc_ps[k]); }
+    for (int k = 0; k < NPCA; k++) {
+      if constexpr (LIMB) {   // LDS offsets recomputed per piece (3 - 5 VALU) instead of ten resident registers: the loop must not spill
+        int slot = (lane >> 1) + 32 * k;
+        if (k >= NPCA - 2 && slot >= a.n_slots) { slot = a.n_slots - 1; }
+        stage_piece(pre[k], phys_slot(slot, a) * 16 + 8 * (lane & 1));
+      } else {
+        stage_piece(pre[k], pc_ps[k]);
+      }
+    }
     if (FLUSH && !GUARD) { flush(st - 1); }
-    fetch(st + 1 < s1 ? st + 1 : st);
+    fetch(st + 1 < s1 ? st + 1 : st, fast_c);
+    // The next step's loads must leave before this step's arithmetic: left alone, the scheduler sinks them to the end of the
+    // step and the wave eats the whole HBM latency at the top of the next one.  A compiler-level memory barrier pins them
+    // between the staging writes above and the fragment reads below; ALU work stays free to move.
+    if (ACDSP_CASC_BARRIER) { asm volatile("" ::: "memory"); }
 
     // ---- stage A: 256 outputs of the decimating FIR, wrapped to the INT_TYPE width ----
     v4i accA[PXA + PCA - 1];
 #pragma unroll
-    for (int w = 0; w < PXA + PCA - 1; w++) { accA[w] = (v4i){0, 0, 0, 0}; }
+    for (int w = 0; w < PXA + PCA - 1; w++) { accA[w] = LIMB ? (v4i){a.dig[w], a.dig[w], a.dig[w], a.dig[w]} : (v4i){0, 0, 0, 0}; }
 #pragma unroll
     for (int bb = 0; bb < NBA; bb++) {
       v4i X[PXA];
@@ -736,29 +774,52 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
         for (int pp = 0; pp < PXA; pp++) { accA[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(AA[bb][q], X[pp], accA[pp + q], 0, 0, 0); }
       }
     }
-    unsigned lo[4], hi[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      uint64_t y = (uint64_t)a.corr;
-#pragma unroll
-      for (int w = 0; w < PXA + PCA - 1; w++) { y += (uint64_t)(int64_t)accA[w][r] << (8 * w); }
-      const int64_t v = (int64_t)(y << a.e_ka) >> a.e_ka;        // INT_TYPE word (signed, w_int bits)
-      lo[r] = (unsigned)v; hi[r] = (unsigned)((uint64_t)v >> 32);
-    }
     // byte planes of the four words of this lane -> ring slot (st * 16 + n_col) & 31, bytes 4 kg .. 4 kg + 3
     const int wslot = (((int)(st & 1) * 16 + n_col) & 31) * 16 + 4 * kg;
+    if constexpr (LIMB) {
+      // y = sum_w acc_w 2^(8w) is the exact word (constant folded into the accumulators): a byte carry chain in 32-bit
+      // registers gives its bytes -- u_w = acc_w + (u_{w-1} >> 8), byte w = u_w & 255, the last u holds y >> 8 (NW - 1)
+      static_assert(PXA + PCA - 1 == 4 && PXB == 5, "limb epilogue: four weight classes into five byte planes");
+      int u[4][4];
 #pragma unroll
-    for (int pp = 0; pp < PXB; pp++) {
-      unsigned d = pp < 4 ? gather4(lo[0], lo[1], lo[2], lo[3], pp) : gather4(hi[0], hi[1], hi[2], hi[3], pp - 4);
-      if (pp < PXB - 1) { d ^= 0x80808080u; }
-      *(unsigned *)(ring + pp * 512 + wslot) = d;
+      for (int r = 0; r < 4; r++) {
+        u[0][r] = accA[0][r];
+#pragma unroll
+        for (int w = 1; w < 4; w++) { u[w][r] = accA[w][r] + (u[w - 1][r] >> 8); }
+      }
+#pragma unroll
+      for (int pp = 0; pp < 4; pp++) {
+        const unsigned d = gather4((unsigned)u[pp][0], (unsigned)u[pp][1], (unsigned)u[pp][2], (unsigned)u[pp][3], 0) ^ 0x80808080u;
+        *(unsigned *)(ring + pp * 512 + wslot) = d;
+      }
+      // top plane: bits 32 .. w_int - 1 of the word, sign-extended (the wrap to INT_TYPE)
+      unsigned tb[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) { tb[r] = (unsigned)__builtin_amdgcn_sbfe(u[3][r], 8, a.w_int - 32); }
+      *(unsigned *)(ring + 4 * 512 + wslot) = gather4(tb[0], tb[1], tb[2], tb[3], 0);
+    } else {
+      unsigned lo[4], hi[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        uint64_t y = (uint64_t)a.corr;
+#pragma unroll
+        for (int w = 0; w < PXA + PCA - 1; w++) { y += (uint64_t)(int64_t)accA[w][r] << (8 * w); }
+        const int64_t v = (int64_t)(y << a.e_ka) >> a.e_ka;        // INT_TYPE word (signed, w_int bits)
+        lo[r] = (unsigned)v; hi[r] = (unsigned)((uint64_t)v >> 32);
+      }
+#pragma unroll
+      for (int pp = 0; pp < PXB; pp++) {
+        unsigned d = pp < 4 ? gather4(lo[0], lo[1], lo[2], lo[3], pp) : gather4(hi[0], hi[1], hi[2], hi[3], pp - 4);
+        if (pp < PXB - 1) { d ^= 0x80808080u; }
+        *(unsigned *)(ring + pp * 512 + wslot) = d;
+      }
     }
     if (WARM) { return; }
 
     // ---- stage B: 256 outputs of the FIR on ring slots st*16 - 8 .. st*16 + 18 ----
     v4i accB[PXB + PCB - 1];
 #pragma unroll
-    for (int w = 0; w < PXB + PCB - 1; w++) { accB[w] = (v4i){0, 0, 0, 0}; }
+    for (int w = 0; w < PXB + PCB - 1; w++) { accB[w] = LIMB ? (v4i){b.dig[w], b.dig[w], b.dig[w], b.dig[w]} : (v4i){0, 0, 0, 0}; }
     const int rbase = (int)(st & 1) * 16 - 8 + n_col + kg;
 #pragma unroll
     for (int bb = 0; bb < NBB; bb++) {
@@ -772,16 +833,36 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
       }
     }
     int o[4];
+    if constexpr (LIMB) {
+      // z = sum_w acc_w 2^(8w) (exact; correction and rounding constant folded in) as two 32-bit limbs through 16-bit
+      // carries; OUT = clamp(z >> rs): the high limb is clamped first so that the funnel shift cannot leave int32
+      static_assert(PXB + PCB - 1 == 6, "limb epilogue: six weight classes");
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      uint64_t y = (uint64_t)b.corr;
+      for (int r = 0; r < 4; r++) {
+        const int p01 = accB[0][r] + (int)((unsigned)accB[1][r] << 8);
+        const int p23 = accB[2][r] + (int)((unsigned)accB[3][r] << 8);
+        const int p45 = accB[4][r] + (int)((unsigned)accB[5][r] << 8);
+        const int v1 = p23 + (p01 >> 16);
+        int H = p45 + (v1 >> 16);                                                      // z >> 32
+        const unsigned L = __builtin_amdgcn_perm((unsigned)v1, (unsigned)p01, 0x05040100u);   // z mod 2^32
+        // AC_SAT: both clamps act; AC_WRAP: the host sets them to the int32 range and the bit-field extract wraps
+        H = H < b.l_hb_lo ? b.l_hb_lo : (H > b.l_hb_hi ? b.l_hb_hi : H);
+        int q = (int)__builtin_amdgcn_alignbit((unsigned)H, L, (unsigned)b.e_rs);
+        q = q < b.l_lo ? b.l_lo : (q > b.l_hi ? b.l_hi : q);
+        o[r] = __builtin_amdgcn_sbfe(q, 0, b.l_w);
+      }
+    } else {
 #pragma unroll
-      for (int w = 0; w < PXB + PCB - 1; w++) { y += (uint64_t)(int64_t)accB[w][r] << (8 * w); }
-      int64_t v = (int64_t)(y << b.e_ls);
-      v = (int64_t)((uint64_t)v << b.e_ka) >> b.e_ka;
-      v = (int64_t)((uint64_t)((v + b.e_rnd) >> b.e_rs) << b.e_ls2);
-      v = v < b.e_lo ? b.e_lo : (v > b.e_hi ? b.e_hi : v);
-      o[r] = (int)((int64_t)((uint64_t)v << b.e_ko) >> b.e_ko);
+      for (int r = 0; r < 4; r++) {
+        uint64_t y = (uint64_t)b.corr;
+#pragma unroll
+        for (int w = 0; w < PXB + PCB - 1; w++) { y += (uint64_t)(int64_t)accB[w][r] << (8 * w); }
+        int64_t v = (int64_t)(y << b.e_ls);
+        v = (int64_t)((uint64_t)v << b.e_ka) >> b.e_ka;
+        v = (int64_t)((uint64_t)((v + b.e_rnd) >> b.e_rs) << b.e_ls2);
+        v = v < b.e_lo ? b.e_lo : (v > b.e_hi ? b.e_hi : v);
+        o[r] = (int)((int64_t)((uint64_t)v << b.e_ko) >> b.e_ko);
+      }
     }
     if (GUARD) {
 #pragma unroll
@@ -796,10 +877,17 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   };
   typedef std::integral_constant<bool, true> T;
   typedef std::integral_constant<bool, false> F;
-  fetch(s0 - 1);
-  body(s0 - 1, T(), F());
-  body(s0, F(), F());
-  for (int64_t st = s0 + 1; st < s1; st++) { body(st, F(), T()); }
+  if (interior) {
+    fetch(s0 - 1, T());
+    body(s0 - 1, T(), F(), T());
+    body(s0, F(), F(), T());
+    for (int64_t st = s0 + 1; st < s1; st++) { body(st, F(), T(), T()); }
+  } else {
+    fetch(s0 - 1, F());
+    body(s0 - 1, T(), F(), F());
+    body(s0, F(), F(), F());
+    for (int64_t st = s0 + 1; st < s1; st++) { body(st, F(), T(), F()); }
+  }
   if (!GUARD) { flush(s1 - 1); }
 }
 
@@ -810,6 +898,7 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
                           const FirParams &pb, const FirGenPlan &plb, const uint32_t *d_fragB, int64_t n_out, hipStream_t s) {
   if (n_out <= 0) { return hipSuccess; }
   GenArgs a, b;
+  memset(&a, 0, sizeof a); memset(&b, 0, sizeof b);
   a.pl = pla; b.pl = plb;
   a.px = (pa.in.W + (pa.in.S ? 0 : 1) + 7) / 8;
   b.px = (w_int + 7) / 8;
@@ -832,6 +921,8 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   a.n_steps = (n_out + 255) / 256;
   int64_t spw = (a.n_steps * pa.n_ch + 16383) / 16384;
   if (spw < 8) { spw = 8; }                  // one warm-up step per chunk: keep it <= 12 % of the work
+  static const char *cspw_env = getenv("ACDSP_CASC_SPW");   // tuning knob: steps per wave of the fused cascade
+  if (cspw_env && atoi(cspw_env) > 0) { spw = atoi(cspw_env); }
   a.steps_per_wave = spw;
   a.n16 = (pa.n + 15) / 16 * 16;
   a.out_vec_ok = 1; a.chunk0 = 0;
@@ -843,22 +934,54 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   const size_t lds_bytes = (size_t)a.obuf_off + 5 * 512 + 1024;
   const int64_t n_chunks = (a.n_steps + spw - 1) / spw, fast_chunks = n_out / (spw * 256);
   const v4i *fa = (const v4i *)d_fragA, *fb = (const v4i *)d_fragB;
+
+  // 32-bit limb epilogues: the exact stage results are small enough that byte / 16-bit carry chains in 32-bit registers
+  // reproduce them (no 64-bit arithmetic per output).  Conditions: the true |y| of both stages bounded well inside int64
+  // (sum |h| x the input range), no ACC_TYPE wrap in stage B, a right shift of 0..31 bits into an OUT_TYPE of <= 31 bits,
+  // and for AC_SAT an OUT range that reaches into the high limb.
+  static const bool no_limb = getenv("ACDSP_NO_LIMB") != nullptr;   // A/B knob
+  bool limb = !no_limb && w_int >= 33 && w_int <= 40 && pla.sum_abs_h < (int64_t(1) << 38) && plb.sum_abs_h < (int64_t(1) << 20);
+  const int64_t bound_b = limb ? plb.sum_abs_h * (int64_t(1) << (w_int - 1)) + b.e_rnd : 0;   // |stage-B dot product + rounding constant|
+  limb = limb && b.e_ls == 0 && b.e_ls2 == 0 && b.e_rs <= 31 && pb.out.W <= 31 && bound_b < (int64_t(1) << 61) &&
+         (pb.acc.W >= 63 || bound_b < (int64_t(1) << (pb.acc.W - 1)));
+  if (limb) {
+    auto digits = [](int64_t c, int nw, int32_t *dig) {   // balanced base-256 digits, the last one takes the rest
+      for (int w = 0; w < nw - 1; w++) {
+        int lo = (int)(((c % 256) + 256) % 256);
+        if (lo >= 128) { lo -= 256; }
+        dig[w] = lo;
+        c = (c - lo) / 256;
+      }
+      dig[nw - 1] = (int32_t)c;
+      return c > -(int64_t(1) << 20) && c < (int64_t(1) << 20);
+    };
+    limb = digits(a.corr, 4, a.dig) && digits(b.corr + b.e_rnd, 6, b.dig);
+    if (pb.out.O == ACDSP_SAT) {
+      const int hb = pb.out.W - 1 + b.e_rs - 32;           // OUT range in units of the high limb: [-2^hb, 2^hb)
+      limb = limb && hb >= 0 && hb <= 29;
+      b.l_hb_lo = -(1 << (hb < 0 ? 0 : hb)) - 1; b.l_hb_hi = 1 << (hb < 0 ? 0 : hb);
+      b.l_lo = (int32_t)b.e_lo; b.l_hi = (int32_t)b.e_hi; b.l_w = pb.out.W;
+    } else {
+      b.l_hb_lo = b.l_lo = INT32_MIN; b.l_hb_hi = b.l_hi = INT32_MAX; b.l_w = pb.out.W;
+    }
+  }
   hipError_t e;
+#define ACDSP_CASCADE_LAUNCH(GUARD_, LIMB_, GRID_)                                                                                   \
+  e = hipFuncSetAttribute((const void *)cascade_kernel<2, 3, 6, 5, 5, 2, 3, GUARD_, LIMB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)lds_bytes);                                                                                           \
+  if (e != hipSuccess) { return e; }                                                                                                 \
+  hipLaunchKernelGGL((cascade_kernel<2, 3, 6, 5, 5, 2, 3, GUARD_, LIMB_>), GRID_, dim3(64), lds_bytes, s, pa, pb, fa, fb, a, b);      \
+  if ((e = hipGetLastError()) != hipSuccess) { return e; }
   if (fast_chunks > 0) {
-    e = hipFuncSetAttribute((const void *)cascade_kernel<2, 3, 6, 5, 5, 2, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { return e; }
-    hipLaunchKernelGGL((cascade_kernel<2, 3, 6, 5, 5, 2, 3, false>), dim3((unsigned)fast_chunks, (unsigned)pa.n_ch), dim3(64), lds_bytes, s,
-                       pa, pb, fa, fb, a, b);
-    if ((e = hipGetLastError()) != hipSuccess) { return e; }
+    const dim3 grid((unsigned)fast_chunks, (unsigned)pa.n_ch);
+    if (limb) { ACDSP_CASCADE_LAUNCH(false, true, grid) } else { ACDSP_CASCADE_LAUNCH(false, false, grid) }
   }
   if (fast_chunks < n_chunks) {
     a.chunk0 = (int32_t)fast_chunks;
-    e = hipFuncSetAttribute((const void *)cascade_kernel<2, 3, 6, 5, 5, 2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { return e; }
-    hipLaunchKernelGGL((cascade_kernel<2, 3, 6, 5, 5, 2, 3, true>), dim3((unsigned)(n_chunks - fast_chunks), (unsigned)pa.n_ch), dim3(64), lds_bytes,
-                       s, pa, pb, fa, fb, a, b);
-    if ((e = hipGetLastError()) != hipSuccess) { return e; }
+    const dim3 grid((unsigned)(n_chunks - fast_chunks), (unsigned)pa.n_ch);
+    if (limb) { ACDSP_CASCADE_LAUNCH(true, true, grid) } else { ACDSP_CASCADE_LAUNCH(true, false, grid) }
   }
+#undef ACDSP_CASCADE_LAUNCH
   return hipSuccess;
 }
 

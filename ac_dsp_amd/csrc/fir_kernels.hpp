@@ -57,6 +57,7 @@ enum { kRsShiftReg = 16, kRsFoldEven = 17, kRsFoldEvenAnti = 18, kRsFoldOdd = 19
 struct FirGenPlan {
   int32_t pc, nb, off, R;   // coefficient byte planes, 64-sample K blocks, T_n - W_n, decimation
   int64_t sum_h;            // sum of the taps mod 2^64 (re-bias correction)
+  int64_t sum_abs_h;        // sum of |taps|, saturating at 2^62 (bounds of the 32-bit limb epilogues)
 };
 // y[m] = sum_k h[k] x[first + m R - k] mod 2^64.  Builds the A fragments for first % 16 == first_mod16;
 // false if the taps need more than 3 byte planes or more than 8 K blocks.
