@@ -302,7 +302,7 @@ def measure(w, steps, warmup, barrier):
 
 
 PROFILE_TAGS = {"fir255": "fir255", "fir255_dense": "fir255_dense", "fir255_wide": "fir255_wide", "fir1023": "fir1023", "cic_dec": "cic_dec",
-                "ddc": "ddc", "polydec": "polydec"}
+                "ddc": "ddc", "polydec": "polydec", "cic_intr": "cic_intr", "polyintr": "polyintr", "intgdump": "intgdump", "mvavg": "mvavg"}
 
 
 def roofline_of(w, k_avg, k_min, ev_ms):
@@ -330,8 +330,9 @@ def mfma_roofline_of(w, k_avg):
                     "coefficient set are skipped, so fewer are issued)", "frac": tops / I8_MFMA_PEAK_TOPS}
 
 
-# the other BASELINE configurations, measured in the same process after the headline (N = 1 only)
-SECONDARY = ["fir255_dense", "fir1023", "cic_dec", "ddc"]
+# every other workload, measured in the same process after the headline (N = 1 only): the other BASELINE configurations
+# first, then the SURVEY 8 (f) rows
+SECONDARY = ["fir255_dense", "fir255_wide", "fir1023", "cic_dec", "ddc", "cic_intr", "polydec", "polyintr", "intgdump", "mvavg"]
 
 
 def main():
@@ -400,8 +401,8 @@ def main():
         elif world == 1 and not args.no_cpu_baseline and args.workload == "cic_dec":
             out["cpu_baseline"] = cpu_baseline_cic(fin, fo, w["seed"])
         if world == 1 and not args.no_secondary and args.workload == "fir255" and not (args.channels or args.samples or args.stim_bits):
-            # every other BASELINE config in the same process, 5 timed steps each (one resident workload at a time:
-            # config 3 alone holds 86 GB)
+            # every other workload in the same process, 5 timed steps each (one resident workload at a time: config 3
+            # alone holds 86 GB)
             del w
             torch.cuda.empty_cache()
             sec = {}
@@ -459,7 +460,7 @@ def pmc_traffic(tag):
                 if line.startswith("void ") or line.startswith("acdsp::"):
                     kernel = line.strip()
                 f = line.split()
-                if len(f) == 3 and f[0] in vals and kernel and any(k in kernel for k in ("fir_mfma", "fir_gen", "cascade_kernel", "cic_kernel<")):
+                if len(f) == 3 and f[0] in vals and kernel and any(k in kernel for k in ("fir_mfma", "fir_gen", "cascade_kernel", "cic_kernel<", "fir_up_kernel", "intg_dump_stream", "mv_avg_stream")):
                     vals[f[0]] += float(f[2])      # summed over the data-path kernels of one step (the DDC has two)
                     seen.add(f[0])
             if len(seen) == 2:

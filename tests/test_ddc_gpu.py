@@ -38,7 +38,7 @@ CFG5 = dict(R=16, M=1, N=5, cin=A.Fmt(16, 1), n_taps=127, fc=A.Fmt(16, 1), fa=A.
 
 # 32-bit limb epilogues (OUT <= 31 bits, shift <= 31: AC_SAT with the clamp in the high limb, AC_WRAP) and the 64-bit form (32-bit OUT)
 @pytest.mark.parametrize("fo", [A.Fmt(24, 9, True, "RND", "SAT"), A.Fmt(24, 9, True, "TRN", "WRAP"), A.Fmt(32, 12, True, "RND", "WRAP"),
-                                A.Fmt(16, 3, True, "TRN", "SAT"), A.Fmt(31, 12, True, "RND", "SAT"), A.Fmt(12, 11, True, "RND", "SAT"),
+                                A.Fmt(20, 3, True, "TRN", "SAT"), A.Fmt(31, 12, True, "RND", "SAT"), A.Fmt(18, 17, True, "RND", "SAT"),
                                 A.Fmt(30, 29, True, "RND", "WRAP")])
 def test_config5_fused_cascade_matches_the_oracle_cascade(fo):
     g = CFG5

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 RND=${ACDSP_ROUND:-r2}
 cd "$R"
 mkdir -p gpurun_out
-WL=${*:-fir255 fir255_dense fir255_wide fir1023 cic_dec cic_intr ddc polydec polyintr intgdump}
+WL=${*:-fir255 fir255_dense fir255_wide fir1023 cic_dec cic_intr ddc polydec polyintr intgdump mvavg}
 python -m pytest tests -q -m gpu 2>&1 | tail -3 > gpurun_out/gpu_tests.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> gpurun_out/gpu_tests.txt 2>&1
 for w in $WL; do
