@@ -214,3 +214,37 @@ def test_poly_dec_and_intr_random_shapes(seed):
         y = pi.run(torch.from_numpy(x).to(A.torch_dtype_for(fin)).cuda()).cpu().numpy().astype(np.int64)
         yo = oi.run(ci, sign, corr, x)
         assert y.shape == yo.shape and np.array_equal(y, yo), ("intr", seed, ftype, n_taps, ifac)
+
+
+MV_ACC = [A.Fmt(40, 18), A.Fmt(48, 20), A.Fmt(32, 16), A.Fmt(32, 16, True, "RND"), A.Fmt(30, 14, True, "RND"), A.Fmt(36, 14, False),
+          A.Fmt(24, 4), A.Fmt(40, 18, True, "RND_CONV", "SAT")]
+MV_OUT = [A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(24, 10, True, "TRN", "WRAP"), A.Fmt(40, 18), A.Fmt(12, 6, False, "RND", "SAT"),
+          A.Fmt(33, 20, True, "RND", "SAT"), A.Fmt(16, 8, True, "RND_INF", "SAT_SYM"), A.Fmt(9, 3, False, "TRN", "WRAP")]
+
+
+@pytest.mark.parametrize("seed", range(CASES))
+def test_mv_avg_random_shapes(seed):
+    """ac_mv_avg: streaming kernel (aligned frames, small weights) and the general kernels, picked by the shapes / types drawn."""
+    from oracle import OracleMvAvg
+    rng = np.random.default_rng(6000 + seed)
+    fin = [A.Fmt(16, 8), A.Fmt(14, 3), A.Fmt(15, 8, False), A.Fmt(16, 8, False), A.Fmt(24, 12)][rng.integers(5)]
+    fc = [A.Fmt(16, 2), A.Fmt(12, 1), A.Fmt(16, 16), A.Fmt(10, 0, False)][rng.integers(4)]
+    fa, fo = MV_ACC[rng.integers(len(MV_ACC))], MV_OUT[rng.integers(len(MV_OUT))]
+    taps = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 17, 23, 25, 31, 33, 35]))
+    mode = ["WIN", "MIRROR", "CLIP"][rng.integers(3)]
+    n_sample = int(rng.choice([8, 16, 24, 64, 200, 504, 512, 520, 1000, 1024, 1032, 2056]))
+    n_frames, n_obj = int(rng.choice([1, 2, 3, 17])), int(rng.choice([1, 2, 5]))
+    x = rand_raw(rng, fin, (n_obj, n_sample * n_frames))
+    c = rand_raw(rng, fc, (taps,))
+    if rng.integers(3):                                   # mostly: weights small enough for the int32 class
+        c = c // int(max(1, (np.abs(c).sum() >> 14) + 1))
+    lead = int(rng.choice([0, 0, 8, 3]))
+    eng = A.MvAvg(4096, taps, mode, fin, fc, fa, fo, n_objects=n_obj)
+    eng.set_coeffs(c)
+    xv = padded_view(x, A.torch_dtype_for(fin), lead, int(rng.integers(0, 9)))
+    y = eng.run(xv, n_sample).cpu().numpy().astype(np.int64)
+    yo = OracleMvAvg(taps, mode, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_obj=n_obj).run(c, x, n_sample)
+    assert y.shape == yo.shape, (y.shape, yo.shape)
+    bad = np.argwhere(y != yo)
+    assert bad.size == 0, "seed %d: %d mismatches, first %s (path %s, taps %d %s n %d x %d obj %d, %s %s %s %s)" % (
+        seed, len(bad), bad[0], eng.path, taps, mode, n_sample, n_frames, n_obj, fin, fc, fa, fo)
