@@ -99,3 +99,34 @@ def test_config5_full_size_per_gpu():
         yo = OracleFir(NT, "SHIFT_REG", ofmt(mid), ofmt(fc), ofmt(fa), ofmt(fo)).run(c, u)[0][(t0 - ta) // R:]
         got = y[ch, t0 // R:(t0 + w) // R].cpu().numpy().astype(np.int64)
         assert np.array_equal(got, yo), (ch, t0)
+
+
+def test_mv_avg_bench_size():
+    """ac_mv_avg TAPS 9 AC_MIRROR at the bench row's size (1024 objects x 1024 frames x 1024 samples): sampled frames against
+    the oracle (frames are independent: no state crosses them), frame independence as a property (the same frame data placed at
+    another (object, frame) position gives the same outputs), and linearity with the lossless OUT = ACC on full rows."""
+    from oracle import OracleMvAvg
+    fin, fc, fa, fo = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18), A.Fmt(16, 8, True, "RND", "SAT")
+    n_obj, n_frames, ns, taps = 1024, 1024, 1024, 9
+    wts = np.round(np.hanning(11)[1:-1] / np.hanning(11).sum() * 2.0 ** fc.F).astype(np.int64)
+    x = torch.empty((n_obj, n_frames * ns), dtype=torch.int16, device="cuda")
+    A.fill_stimulus(x, SEED, 16)
+    eng = A.MvAvg(ns, taps, "MIRROR", fin, fc, fa, fo, n_objects=n_obj)
+    eng.set_coeffs(wts)
+    y = eng.run(x, ns)
+    torch.cuda.synchronize()
+    assert eng.path == "stream" and y.shape == x.shape
+    orc = OracleMvAvg(taps, "MIRROR", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_obj=1)
+    for obj, fr in ((0, 0), (0, 1023), (1, 1), (511, 512), (1023, 0), (1023, 1023), (700, 333)):
+        xs = x[obj:obj + 1, fr * ns:(fr + 1) * ns].cpu().numpy().astype(np.int64)
+        assert np.array_equal(y[obj, fr * ns:(fr + 1) * ns].cpu().numpy().astype(np.int64), orc.run(wts, xs, ns)[0]), (obj, fr)
+    # frame independence: rows rolled by whole frames give rolled outputs
+    e16 = A.MvAvg(ns, taps, "MIRROR", fin, fc, fa, fo, n_objects=16)
+    e16.set_coeffs(wts)
+    xr = torch.roll(x[:16], shifts=5 * ns, dims=1).contiguous()
+    assert torch.equal(e16.run(xr, ns), torch.roll(y[:16], shifts=5 * ns, dims=1))
+    # linearity of the exact accumulator (OUT = ACC <40,18>: no rounding, no saturation)
+    ew = A.MvAvg(ns, taps, "MIRROR", fin, fc, fa, fa, n_objects=16)
+    ew.set_coeffs(wts)
+    x1, x2 = x[:16] >> 1, x[16:32] >> 1
+    assert torch.equal(ew.run(x1 + x2, ns), ew.run(x1, ns) + ew.run(x2, ns))
