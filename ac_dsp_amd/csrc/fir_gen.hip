@@ -316,8 +316,11 @@ __global__ void __launch_bounds__(64, SMALL ? 3 : 2) fir_gen_kernel(FirParams p,
 // ~1500 basic blocks and an s_waitcnt vmcnt(0) in front of every MFMA group -- the prefetch never overlapped anything.
 //   PCT / NBT: coefficient digits / K blocks compiled in (fragments beyond the plan's pc / nb are zero)
 //   SPL: slots per lane (exact)        OEB: output container bytes
+#ifndef ACDSP_GEN_FAST_WAVES
+#define ACDSP_GEN_FAST_WAVES 2
+#endif
 template <typename TIN, int PX, int PCT, int NBT, int SPL, int OEB>
-__global__ void __launch_bounds__(64, 2) fir_gen_fast_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
+__global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [PX][phys slots][16] + output tile
   const int lane = threadIdx.x;
   const int n_col = lane & 15, kg = lane >> 4;
@@ -619,7 +622,8 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   const int slots_alloc = 15 * pl.R + 4 * phys_nb;
   const int phys = a.pad ? slots_alloc + slots_alloc / pl.R : slots_alloc;
   a.obuf_off = a.px * (phys + 1) * 16;
-  const size_t lds_bytes = (size_t)a.obuf_off + 2048;
+  static const char *lds_pad_env = getenv("ACDSP_GEN_LDS_PAD");   // diagnostic: extra LDS bytes per wave (lowers the occupancy)
+  const size_t lds_bytes = (size_t)a.obuf_off + 2048 + (lds_pad_env ? (size_t)atoi(lds_pad_env) : 0);
   const int64_t n_chunks = (a.n_steps + spw - 1) / spw;
   const int64_t fast_chunks = (nbt && conv_ok && a.out_vec_ok) ? n_out / (spw * 256) : 0;   // chunks made of complete steps only
   const v4i *fr = (const v4i *)d_frag;
