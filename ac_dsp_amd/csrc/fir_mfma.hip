@@ -160,7 +160,9 @@ constexpr int kGroupSize = ACDSP_GS, kOccupancy = ACDSP_OCC;
 //        32-bit epilogue (epi32).   EPI 2: the same with O = SAT (v_cvt_pk_i16_i32 clamps and packs).
 // EPI 3: OUT container int64, signed, Q in {TRN, RND}, O = WRAP, no accumulator wrap possible (the OUT = ACC row
 //        of config 2): 64-bit shift-and-wrap epilogue, stored straight from registers; pipelined body only.
-// HS:    compile-time band [HS, NB-1-HS] of K-blocks whose high-byte Toeplitz plane is non-zero.
+// HS:    compile-time band of K-blocks whose high-byte Toeplitz plane is non-zero: HS = lo + 16 hi skips the first `lo` and the
+//        last `hi` blocks (0: none; the band of a linear-phase set is centred on tap (N-1)/2, which is not a block centre, so the
+//        two sides differ: config 2's set needs blocks 3 .. 6 of 9).
 // WAVES: 8 = ping-pong workgroup (see header), 1 = single-wave workgroup.
 // FAST:  the chunk is interior: all loads/stores are full vectors, so the loop has no divergent branch
 //        around VMEM and the compiler counts outstanding operations exactly (vmcnt(k), not vmcnt(0)).
@@ -300,7 +302,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
         const int b = g * GS + i;
         if (b < NB) {
           // a Toeplitz block whose high-byte plane is all zero contributes nothing to hh / mid
-          if (HS == 0 || (b >= HS && b <= NB - 1 - HS)) {
+          if (HS == 0 || (b >= (HS & 15) && b <= NB - 1 - (HS >> 4))) {
             hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bh[g & 1][i], hh, 0, 0, 0);
             mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[g & 1][i], mid, 0, 0, 0);
           }
@@ -603,7 +605,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       for (int i = 0; i < GS; i++) {
         const int b = g * GS + i;
         if (b < NB) {
-          if (HS == 0 || (b >= HS && b <= NB - 1 - HS)) {
+          if (HS == 0 || (b >= (HS & 15) && b <= NB - 1 - (HS >> 4))) {
             hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bh[cb][i], hh, 0, 0, 0);
             mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[cb][i], mid, 0, 0, 0);
           }
@@ -685,23 +687,29 @@ static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const
 // whatever the pairing; kept selectable for the record.
 constexpr int kSmallWaves = 1;
 
-// Largest instantiated band skip hs (0, 2 or 3) such that every non-zero high-byte block lies in [hs, NB-1-hs].
+// Band skip code (HS = lo + 16 hi) for the non-zero high-byte blocks: each side skips 2 or 3 blocks when the set allows it
+// (instantiated: both sides >= 2), else nothing is skipped.
 static int pick_hs(int nb, uint64_t hi_mask) {
-  const int cand[2] = {3, 2};
-  for (int hs : cand) {
-    if (2 * hs >= nb) { continue; }
-    uint64_t band = 0;
-    for (int b = hs; b <= nb - 1 - hs; b++) { band |= uint64_t(1) << b; }
-    if ((hi_mask & ~band) == 0) { return hs; }
-  }
-  return 0;
+  if (hi_mask == 0) { return nb >= 7 ? 3 + 16 * 3 : (nb >= 5 ? 2 + 16 * 2 : 0); }
+  int lo = 0, hi = 0;
+  while (lo < nb && !((hi_mask >> lo) & 1)) { lo++; }
+  while (hi < nb && !((hi_mask >> (nb - 1 - hi)) & 1)) { hi++; }
+  lo = lo > 3 ? 3 : lo; hi = hi > 3 ? 3 : hi;
+  if (nb < 7) { lo = lo > 2 ? 2 : lo; hi = hi > 2 ? 2 : hi; }
+  if (nb < 5 || lo < 2 || hi < 2) { return 0; }
+  return lo + 16 * hi;
 }
 
 template <int NB>
 static hipError_t launch_nb(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   const int hs = epi ? pick_hs(NB, a.hi_mask) : 0;
-  if (NB >= 7 && hs == 3) { return launch_nb_hs<NB, (NB >= 7 ? 3 : 0), kSmallWaves>(p, d_frag, a, epi, grid, s); }
-  if (NB >= 5 && hs == 2) { return launch_nb_hs<NB, (NB >= 5 ? 2 : 0), kSmallWaves>(p, d_frag, a, epi, grid, s); }
+  if (NB >= 7) {
+    constexpr int H33 = NB >= 7 ? 3 + 16 * 3 : 0, H32 = NB >= 7 ? 3 + 16 * 2 : 0, H23 = NB >= 7 ? 2 + 16 * 3 : 0;
+    if (hs == 3 + 16 * 3) { return launch_nb_hs<NB, H33, kSmallWaves>(p, d_frag, a, epi, grid, s); }
+    if (hs == 3 + 16 * 2) { return launch_nb_hs<NB, H32, kSmallWaves>(p, d_frag, a, epi, grid, s); }
+    if (hs == 2 + 16 * 3) { return launch_nb_hs<NB, H23, kSmallWaves>(p, d_frag, a, epi, grid, s); }
+  }
+  if (NB >= 5 && hs == 2 + 16 * 2) { return launch_nb_hs<NB, (NB >= 5 ? 2 + 16 * 2 : 0), kSmallWaves>(p, d_frag, a, epi, grid, s); }
   return launch_nb_hs<NB, 0, kSmallWaves>(p, d_frag, a, epi, grid, s);
 }
 

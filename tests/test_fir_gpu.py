@@ -123,6 +123,30 @@ def test_mfma_path_tap_counts(n_taps):
                splits=[77, 512], expect_path="mfma_i8", seed=n_taps, coeffs=c)
 
 
+@pytest.mark.parametrize("n_taps,big", [
+    (255, (160, 64)),          # high-byte blocks 3 and 6 of 9: skip 3 low / 2 high
+    (255, (192, 96)),          # blocks 2 and 5: skip 2 / 3
+    (255, (160, 96)),          # blocks 3 .. 5: skip 3 / 3
+    (255, (192, 64)),          # blocks 2 .. 6: skip 2 / 2
+    (255, (224, 127)),         # block 1: no skip on the low side -> dense kernel
+    (255, ()),                 # no high bytes at all
+    (193, (128, 64)),          # NB = 7: blocks 2 and 4: skip 2 / 2
+    (193, (96,)),              # NB = 7: block 3 only: skip 3 / 3
+    (130, (64,)),              # NB = 6
+])
+@pytest.mark.parametrize("fo", [A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(40, 12)])
+def test_mfma_high_byte_band_variants(n_taps, big, fo):
+    """Coefficient sets whose high-byte Toeplitz planes are non-zero in chosen K-blocks only: every instantiated band skip
+    (asymmetric ones included) against the oracle, interior (pipelined) and edge chunks."""
+    rng = np.random.default_rng(n_taps + len(big))
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
+    c = rng.integers(-100, 101, size=n_taps, dtype=np.int64)
+    for t in big:
+        c[t] = int(rng.integers(3000, 20000)) * (1 if rng.integers(2) else -1)
+    check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=5, n=1024 * 70 + 333, kind="load", coeffs=c, expect_path="mfma_i8",
+               splits=[1024 * 33 + 5], seed=7)
+
+
 @pytest.mark.parametrize("ftype", FTYPES6)
 def test_mfma_path_ftypes_and_wide_output(ftype):
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12)
