@@ -396,28 +396,30 @@ def main():
         if w["macs_per_sample"]:
             out["mfma_roofline"] = mfma_roofline_of(w, k_avg)
         fin, fc, fa, fo = w["fmts"]
-        if world == 1 and not args.no_cpu_baseline and w["coeffs"] is not None:
-            out["cpu_baseline"] = cpu_baseline_fir(w["n_taps"], w["coeffs"], fin, fc, fa, fo, w["seed"])
-        elif world == 1 and not args.no_cpu_baseline and args.workload == "cic_dec":
-            out["cpu_baseline"] = cpu_baseline_cic(fin, fo, w["seed"])
+        cpu_args = (w["n_taps"], w["coeffs"], fin, fc, fa, fo, w["seed"])
         if world == 1 and not args.no_secondary and args.workload == "fir255" and not (args.channels or args.samples or args.stim_bits):
-            # every other workload in the same process, 5 timed steps each (one resident workload at a time: config 3
-            # alone holds 86 GB)
+            # every other workload in the same process, 10 timed steps each behind 5 warm-up steps (one resident workload at a
+            # time: config 3 alone holds 86 GB); measured BEFORE the CPU baseline, whose 10 s leave the GPU idle and in a low
+            # power state (the first workload behind it measured 15 % slow)
             del w
             torch.cuda.empty_cache()
             sec = {}
             for name in SECONDARY:
                 w2 = build_workload(name, args, 1, 0, local_rank)
-                dt2, ka2, km2, ev2 = measure(w2, 5, 2, lambda: None)
+                dt2, ka2, km2, ev2 = measure(w2, 10, 5, lambda: None)
                 r2 = roofline_of(w2, ka2, km2, ev2)
-                sec[name] = {"workload": w2["name"], "kernel_path": w2["path"], "ms_per_step": dt2 / 5 * 1e3,
-                             "Msamples_per_s": w2["samples_per_step"] * 5 / dt2 / 1e6, "kernel_ms_avg": ka2,
+                sec[name] = {"workload": w2["name"], "kernel_path": w2["path"], "ms_per_step": dt2 / 10 * 1e3,
+                             "Msamples_per_s": w2["samples_per_step"] * 10 / dt2 / 1e6, "kernel_ms_avg": ka2,
                              "roofline_frac": r2["frac"], "roofline_frac_step": r2["frac_step"], "achieved_GBps": r2["achieved"]}
                 if w2["macs_per_sample"]:
                     sec[name]["mfma_frac"] = mfma_roofline_of(w2, ka2)["frac"]
                 del w2
                 torch.cuda.empty_cache()
             out["secondary"] = sec
+        if world == 1 and not args.no_cpu_baseline and cpu_args[1] is not None:
+            out["cpu_baseline"] = cpu_baseline_fir(*cpu_args)
+        elif world == 1 and not args.no_cpu_baseline and args.workload == "cic_dec":
+            out["cpu_baseline"] = cpu_baseline_cic(fin, fo, cpu_args[6])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
