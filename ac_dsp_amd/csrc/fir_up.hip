@@ -390,7 +390,7 @@ bool fir_up_shape_ok(int in_eb, int px, int nb, int L, int out_eb) {
   return false;
 }
 
-// compiled shapes: poly_intr = int16 samples, 3 digit planes (the pair taps E_j - E_cj have 17 bits), 2- or 8-byte outputs;
+// compiled shapes: poly_intr = int16 samples, 3 digit planes (the pair taps E_j - E_cj have 17 bits) or 2 when the set allows it, 2- or 8-byte outputs;
 // CIC = int16 / int32 samples, 2 digit planes (boxcar^N taps of the BASELINE shapes fit 16 bits), 8-byte outputs (2-byte ones
 // for int16 samples)
 template <typename TIN, int PX, int PCT, int NBT, int L>
@@ -402,7 +402,7 @@ static hipError_t launch_up_oeb(const UpArgs &a, const uint32_t *d_frag, int out
   } else if (out_eb == 2) {
     if constexpr (sizeof(TIN) == 2) {
       if (epi == 1) {
-        if constexpr (PCT == 3) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 1>), grid, dim3(64), 0, s, a, f); }
+        if constexpr (PCT == 3 || NBT == 1) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 1>), grid, dim3(64), 0, s, a, f); }
         else { return hipErrorNotSupported; }
       } else if (epi == 2) {
         if constexpr (PCT == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 2>), grid, dim3(64), 0, s, a, f); }
@@ -467,6 +467,9 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
   dim3 grid((unsigned)((n_steps + spw - 1) / spw), (unsigned)p.n_ch);
   if (p.in_eb == 2) {
     if (mode == 0) {
+      // poly_intr: the pair taps E_j -+ E_cj can have 17 bits = 3 digit planes; sets whose folded taps stay inside two planes
+      // (|tap| < 2^15: e.g. any low-pass with sum |c| < 2) skip the third plane's MFMAs and its accumulator
+      if (pl.nb == 1 && pl.pc <= 2) { return launch_up_l<int16_t, 2, 2, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s); }
       return pl.nb == 1 ? launch_up_l<int16_t, 2, 3, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s)
                         : launch_up_l<int16_t, 2, 3, 2>(a, d_frag, pl.L, p.out_eb, epi, grid, s);
     }

@@ -164,6 +164,16 @@ def test_matrix_core_path_all_cores(ftype, n_taps, ifac):
     check_up(n_taps, ifac, ftype, fo, seed=n_taps + ifac + 1, pairs=False, splits=[8, 8 + 16 * 36, 8 + 16 * 72 + 3], n=16 * 33 * 3 + 160)   # state carry, ragged and unaligned bursts
 
 
+@pytest.mark.parametrize("ftype,n_taps", [("FOLD_EVEN", 16), ("FOLD_ODD", 15), ("FOLD_ANTI", 16), ("FOLD_EVEN", 40)])
+@pytest.mark.parametrize("ifac", [4, 8, 16])
+@pytest.mark.parametrize("coeff_bits", [15, 16])
+def test_matrix_core_path_three_digit_planes(ftype, n_taps, ifac, coeff_bits):
+    """Full-range coefficients: the folded pair taps need 17 bits = three digit planes (the 13-bit sets above stay inside two and
+    run the two-plane instantiation)."""
+    for fo in (A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(40, 12)):
+        check_up(n_taps, ifac, ftype, fo, seed=100 + n_taps + ifac, coeff_bits=coeff_bits, splits=[8 + 16 * 36], n=16 * 33 * 3 + 160)
+
+
 @pytest.mark.parametrize("fo", [A.Fmt(40, 12), A.Fmt(16, 2, True, "TRN", "WRAP"), A.Fmt(24, 6, True, "RND_CONV", "SAT_SYM"), A.Fmt(12, 4, False, "RND", "SAT")])
 def test_matrix_core_path_output_types(fo):
     want = "mfma_gen" if fo.W <= 16 or fo.W > 32 else "lossless64"          # 4-byte output containers are not compiled in
