@@ -294,10 +294,132 @@ __global__ void __launch_bounds__(256) intg_dump_stream_kernel(IntgDumpParams p,
   }
 }
 
-template <typename TIN, int CHN>
-static bool launch_stream(const IntgDumpParams &p, int gs, int lpr, int64_t rpw, int64_t n_reds, dim3 grid, hipStream_t s) {
-  // ACC -> OUT as shifts, a clamp and bit-field wraps where the modes allow it
-  IdConv cv;
+// Batched form of the streaming kernel for int16 rows whose blocks fit one 1 KB wave-load (LPR = 1).  The eight loads of a
+// batch leave 8 * CHN partial sums in every lane, and the GS lanes of a block combine them with a reduce-scatter: at each
+// butterfly level a lane keeps half of its values and receives the partner's partial sums of those (2 selects + 1 DPP add
+// per surviving value; the 16- and 32-lane levels are one v_permlane*_swap + 1 add), so every (load, block, channel) sum
+// ends in exactly one lane of its group (in GS / (8 CHN) lanes when the group is larger than the batch's value count,
+// the last levels being plain all-reduce steps).  One ACC -> OUT conversion and one store instruction per batch on all 64
+// lanes -- a 256-byte run of int32 outputs for 8 * CHN = GS -- instead of one of each per load on 8 lanes: the per-load
+// kernel above spends 59 VALU instructions per KB (profiles/r2_intgdump_rocprof.txt), this one about 25.
+// The half kept at level l is chosen by keep bit k_l of the lane number: k0 = b0 ^ b2, k1 = b1 ^ b2, k_l = b_l above, which
+// is symmetric under the lane reversal of row_half_mirror (level 2); levels 0, 1, 3 are the XOR partners quad_perm
+// [1,0,3,2], [2,3,0,1] and row_ror:8.
+template <int L> __device__ inline int id_partner(int x) {
+  static_assert(L >= 0 && L < 4, "DPP levels");
+  constexpr int CTRL = L == 0 ? 0xB1 : (L == 1 ? 0x4E : (L == 2 ? 0x141 : 0x128));
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
+}
+// lanes [31:16] of a trade places with lanes [15:0] of b (L = 4), or the wave halves (L = 5): r[0] + r[1] is a's pair sum
+// in the lower half of each lane pair's span and b's in the upper half
+template <int L> __device__ inline int id_swap_sum(int a, int b) {
+  static_assert(L == 4 || L == 5, "permlane swap levels");
+  if constexpr (L == 4) { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false); return (int)(r[0] + r[1]); }
+  else { const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false); return (int)(r[0] + r[1]); }
+}
+__device__ inline bool id_keep_bit(int level, int lane) {
+  return level < 2 ? (((lane >> level) ^ (lane >> 2)) & 1) != 0 : ((lane >> level) & 1) != 0;
+}
+template <int L, int LG, int N, int VMAX>
+__device__ inline void id_reduce_levels(int (&v)[VMAX], int lane) {
+  if constexpr (L < LG) {
+    if constexpr (N > 1) {
+      const bool kb = id_keep_bit(L, lane);
+#pragma unroll
+      for (int j = 0; j < N / 2; j++) {
+        const int a = v[2 * j], b = v[2 * j + 1];
+        if constexpr (L < 4) { v[j] = (kb ? b : a) + id_partner<L>(kb ? a : b); }
+        else { v[j] = id_swap_sum<L>(a, b); }
+      }
+      id_reduce_levels<L + 1, LG, N / 2, VMAX>(v, lane);
+    } else {
+      if constexpr (L < 4) { v[0] += id_partner<L>(v[0]); }
+      else { v[0] = id_swap_sum<L>(v[0], v[0]); }
+      id_reduce_levels<L + 1, LG, 1, VMAX>(v, lane);
+    }
+  }
+}
+constexpr int id_log2(int x) { return x <= 1 ? 0 : 1 + id_log2(x / 2); }
+
+template <int CHN, int GS, bool SGN>
+__global__ void __launch_bounds__(256) intg_dump_batch_kernel(IntgDumpParams p, IdConv cv, int64_t loads_per_wave, int64_t n_loads) {
+  constexpr int BATCH = 8, V = BATCH * CHN, LG = id_log2(GS), LV = id_log2(V);
+  constexpr int NSC = LG < LV ? LG : LV;         // reduce-scatter levels; the remaining LG - NSC levels are all-reduce steps
+  constexpr int NREM = V >> NSC;                 // values a lane ends with
+  constexpr int BPL = 64 / GS;                   // blocks per wave-load
+  typedef short v2s __attribute__((ext_vector_type(2)));
+  typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63;
+  const int obj = blockIdx.y;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t q0 = wave * loads_per_wave;
+  const int64_t q1 = (q0 + loads_per_wave < n_loads) ? q0 + loads_per_wave : n_loads;
+  if (q0 >= q1) { return; }
+  int low = 0;                                   // index bits of the values this lane ends with: its keep bits
+#pragma unroll
+  for (int l = 0; l < NSC; l++) { low |= (id_keep_bit(l, lane) ? 1 : 0) << l; }
+  const bool writer = LG == NSC || ((lane & (GS - 1)) >> NSC) == 0;   // all-reduce levels leave copies: the first sub-group stores
+  const int blk = lane / GS;
+  const v4i_t *src = (const v4i_t *)((const int16_t *)p.x + (int64_t)obj * p.in_stride) + 64 * q0 + lane;
+  const int64_t ybase = (int64_t)obj * p.out_stride;
+  for (int64_t q = q0; q < q1; q += BATCH, src += 64 * BATCH) {
+    const int rem = (int)(q1 - q < BATCH ? q1 - q : BATCH);
+    v4i_t v[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; k++) { v[k] = __builtin_nontemporal_load(src + 64 * (k < rem ? k : rem - 1)); }
+    int vals[V];
+#pragma unroll
+    for (int k = 0; k < BATCH; k++) {
+      const unsigned d[4] = {(unsigned)v[k].x, (unsigned)v[k].y, (unsigned)v[k].z, (unsigned)v[k].w};
+      int acc[CHN];
+#pragma unroll
+      for (int c = 0; c < CHN; c++) { acc[c] = 0; }
+#pragma unroll
+      for (int m = 0; m < 4; m++) {   // as in the per-load kernel: element pairs of one channel -> v_dot2 with (1, 1)
+        unsigned w;
+        if (CHN == 4) { w = __builtin_amdgcn_perm(d[2 + (m >> 1)], d[m >> 1], (m & 1) ? 0x07060302u : 0x05040100u); }
+        else if (CHN == 2) { w = __builtin_amdgcn_perm(d[2 * (m >> 1) + 1], d[2 * (m >> 1)], (m & 1) ? 0x07060302u : 0x05040100u); }
+        else { w = d[m]; }
+        const int c = CHN == 4 ? m : (CHN == 2 ? (m & 1) : 0);
+        if (SGN) { acc[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, w), (v2s){1, 1}, acc[c], false); }
+        else { acc[c] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2us, w), (v2us){1, 1}, (unsigned)acc[c], false); }
+      }
+#pragma unroll
+      for (int c = 0; c < CHN; c++) { vals[k * CHN + c] = acc[c]; }
+    }
+    id_reduce_levels<0, LG, V, V>(vals, lane);
+#pragma unroll
+    for (int j = 0; j < NREM; j++) {
+      const int idx = (j << NSC) | low, c = idx % CHN, k = idx / CHN;
+      if (writer && k < rem) {
+        const int64_t a = (int64_t)(((uint64_t)((int64_t)((uint64_t)(int64_t)vals[j] << (cv.sh + cv.ka)) >> cv.ka)) & cv.am);   // wrap to ACC_TYPE
+        int64_t qv = (int64_t)((uint64_t)((a + cv.rnd) >> cv.rs) << cv.ls2);
+        qv = qv < cv.lo ? cv.lo : (qv > cv.hi ? cv.hi : qv);
+        const int64_t o = (int64_t)(((uint64_t)((int64_t)((uint64_t)qv << cv.ko) >> cv.ko)) & cv.om);
+        store_raw(p.y, ybase + ((q + k) * BPL + blk) * CHN + c, p.out_eb, o);
+      }
+    }
+  }
+}
+
+template <int CHN, int GS>
+static void launch_batch2(const IntgDumpParams &p, const IdConv &cv, int64_t lpw, int64_t n_loads, dim3 grid, hipStream_t s) {
+  if (p.in.S) { hipLaunchKernelGGL((intg_dump_batch_kernel<CHN, GS, true>), grid, dim3(256), 0, s, p, cv, lpw, n_loads); }
+  else { hipLaunchKernelGGL((intg_dump_batch_kernel<CHN, GS, false>), grid, dim3(256), 0, s, p, cv, lpw, n_loads); }
+}
+template <int CHN>
+static bool launch_batch(const IntgDumpParams &p, const IdConv &cv, int gs, int64_t lpw, int64_t n_loads, dim3 grid, hipStream_t s) {
+  switch (gs) {
+    case 8: launch_batch2<CHN, 8>(p, cv, lpw, n_loads, grid, s); return true;
+    case 16: launch_batch2<CHN, 16>(p, cv, lpw, n_loads, grid, s); return true;
+    case 32: launch_batch2<CHN, 32>(p, cv, lpw, n_loads, grid, s); return true;
+    case 64: launch_batch2<CHN, 64>(p, cv, lpw, n_loads, grid, s); return true;
+    default: return false;
+  }
+}
+
+// ACC -> OUT as shifts, a clamp and bit-field wraps where the modes allow it
+static bool make_conv(const IntgDumpParams &p, IdConv &cv) {
   memset(&cv, 0, sizeof cv);
   cv.sh = p.acc.F - p.in.F;
   const int rs = p.acc.F - p.out.F;
@@ -308,7 +430,13 @@ static bool launch_stream(const IntgDumpParams &p, int gs, int lpr, int64_t rpw,
   else { cv.lo = INT64_MIN; cv.hi = INT64_MAX; cv.ko = 64 - p.out.W; cv.om = p.out.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.out.W)); }
   cv.ok = (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && p.acc.W <= 61 && cv.rs <= 60 &&
           p.acc.W + cv.ls2 <= 61 && p.out.W <= 62;               // neither the rounding add nor the left shift can leave int64
-  if (!cv.ok) { return false; }                                   // other modes: the tiled kernel and its general requant
+  return cv.ok != 0;
+}
+
+template <typename TIN, int CHN>
+static bool launch_stream(const IntgDumpParams &p, int gs, int lpr, int64_t rpw, int64_t n_reds, dim3 grid, hipStream_t s) {
+  IdConv cv;
+  if (!make_conv(p, cv)) { return false; }                        // other modes: the tiled kernel and its general requant
   if constexpr (CHN == 2 || CHN == 4) {
     if (gs >= CHN) {
       if (p.in.S) { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, true, true>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds); }
@@ -335,8 +463,25 @@ static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
   const int bpr = 64 / gs;
   if (p.n_blocks % bpr != 0) { return false; }                 // (a ragged last reduce would read past the call's samples)
   const int64_t n_reds = p.n_blocks / bpr;
-  // ~64 KB per wave, >= ~16 K waves when the problem allows it
-  int64_t rpw = (64 + lpr - 1) / lpr;
+  static const bool no_batch = getenv("ACDSP_NO_INTG_BATCH") != nullptr;   // A/B knob: per-load kernel
+  if (!no_batch && p.in_eb == 2 && lpr == 1 && gs >= 8 && (p.chn == 1 || p.chn == 2 || p.chn == 4)) {
+    IdConv cv;
+    if (!make_conv(p, cv)) { return false; }
+    // 16 KB per wave (multiples of the 8-load batch; 8 / 16 measured alike, 32 and 64 slower by 8 - 12 %), >= ~16 K waves when the problem allows it
+    int64_t lpw = 16;
+    while (lpw > 8 && (n_reds / lpw) * p.n_obj < 16384) { lpw /= 2; }
+    static const char *lpw_env = getenv("ACDSP_INTG_RPW");
+    if (lpw_env && atoi(lpw_env) > 0) { lpw = (atoi(lpw_env) + 7) / 8 * 8; }
+    const int64_t waves_b = (n_reds + lpw - 1) / lpw;
+    dim3 grid_b((unsigned)((waves_b + 3) / 4), (unsigned)p.n_obj);
+    switch (p.chn) {
+      case 1: return launch_batch<1>(p, cv, gs, lpw, n_reds, grid_b, s);
+      case 2: return launch_batch<2>(p, cv, gs, lpw, n_reds, grid_b, s);
+      default: return launch_batch<4>(p, cv, gs, lpw, n_reds, grid_b, s);
+    }
+  }
+  // ~32 KB per wave (8 .. 32 KB measured alike, 64 KB 4 % slower), >= ~16 K waves when the problem allows it
+  int64_t rpw = (32 + lpr - 1) / lpr;
   while (rpw > 1 && (n_reds / rpw) * p.n_obj < 16384) { rpw /= 2; }
   static const char *rpw_env = getenv("ACDSP_INTG_RPW");   // tuning knob: reduces per wave
   if (rpw_env && atoi(rpw_env) > 0) { rpw = atoi(rpw_env); }

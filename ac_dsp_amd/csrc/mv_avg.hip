@@ -94,7 +94,8 @@ __global__ void __launch_bounds__(kTile) mv_avg_kernel(MvAvgParams p) {
 // can wrap, else the 64-bit branch-free form) and stores 16 bytes per instruction.  The loads of the next tile are issued
 // before the arithmetic of the current one.  No workgroup barrier: waves never share data.
 struct MvStreamArgs {
-  int16_t c16[34];            // coefficients, zero padded (pairs (c[2q], c[2q+1]) are the v_dot2 operands)
+  int16_t c16[34];            // coefficients, zero padded (pairs (c[2q], c[2q+1]) are the v_dot2 operands of even outputs)
+  int16_t c16o[34];           // the same behind one zero: pairs (c[2q-1], c[2q]) for odd outputs, whose windows start in a high half
   int32_t taps, h, hb, off, mode, nxg;
   int32_t linear, ls, e, rnd_e;
   int32_t cv32, s32, r32, lo32, hi32, ko32;   // 32-bit epilogue: q = (S + r32) >> s32, clamp, wrap (ko32 = 32 - W_out or 0)
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   const int64_t t_end = (t0 + a.tiles_per_wave < a.n_tiles) ? t0 + a.tiles_per_wave : a.n_tiles;
   if (t0 >= t_end) { return; }
   const int n_my = (int)(t_end - t0);
-  const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.c16);
+  const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.c16), *cpo = reinterpret_cast<const uint32_t *>(a.c16o);
 
   // Tiles are fetched two ahead into alternating register sets.  (object, frame, tile) of the tile being fetched: one
   // division per wave, then counted up; past the wave's last tile the fetch repeats that tile (branch-free loop body, so
@@ -176,21 +177,24 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     }
     R[4 * NR] = 0;
     int S[8];
+    const int s_init = CV32 ? a.r32 : 0;   // the 32-bit epilogue's rounding constant rides in the sum (|sum| < 2^30, r32 <= 2^29)
     if constexpr (LINEAR) {
+      // output i of the lane starts at sample i of its dwords: even outputs pair (x[i+2q], x[i+2q+1]) = dword i/2 + q with
+      // (c[2q], c[2q+1]); odd outputs pair the same aligned dwords with the coefficient pairs shifted by one tap,
+      // (c[2q-1], c[2q]) with c[-1] = 0 -- no realignment of the samples
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        int sum = 0;
+        int sum = s_init;
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-          const uint32_t w = (i & 1) ? __builtin_amdgcn_alignbit(R[i / 2 + q + 1], R[i / 2 + q], 16) : R[i / 2 + q];
-          sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s_t, w), __builtin_bit_cast(v2s_t, cp[q]), sum, false);
+          sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s_t, R[i / 2 + q]), __builtin_bit_cast(v2s_t, (i & 1) ? cpo[q] : cp[q]), sum, false);
         }
         S[i] = sum;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        int sum = 0;
+        int sum = s_init;
 #pragma unroll
         for (int j = 0; j < 8 * NR - 7; j++) {
           const int k = i + j;
@@ -208,16 +212,17 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
         int o[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-          int q = (S[i] + a.r32) >> a.s32;
+          int q = S[i] >> a.s32;
           q = q < a.lo32 ? a.lo32 : (q > a.hi32 ? a.hi32 : q);
-          o[i] = (int)((uint32_t)q << a.ko32) >> a.ko32;
+          o[i] = q;
+          if (a.ko32) { o[i] = (int)((uint32_t)q << a.ko32) >> a.ko32; }
           if (a.om != ~uint64_t(0)) { o[i] = (int)((uint32_t)o[i] & (uint32_t)a.om); }
         }
         if (a.vec_ok) {
           if (a.out_eb == 2) {
             uint4 v;
-            v.x = ((uint32_t)o[0] & 0xFFFFu) | ((uint32_t)o[1] << 16); v.y = ((uint32_t)o[2] & 0xFFFFu) | ((uint32_t)o[3] << 16);
-            v.z = ((uint32_t)o[4] & 0xFFFFu) | ((uint32_t)o[5] << 16); v.w = ((uint32_t)o[6] & 0xFFFFu) | ((uint32_t)o[7] << 16);
+            v.x = __builtin_amdgcn_perm((uint32_t)o[1], (uint32_t)o[0], 0x05040100u); v.y = __builtin_amdgcn_perm((uint32_t)o[3], (uint32_t)o[2], 0x05040100u);
+            v.z = __builtin_amdgcn_perm((uint32_t)o[5], (uint32_t)o[4], 0x05040100u); v.w = __builtin_amdgcn_perm((uint32_t)o[7], (uint32_t)o[6], 0x05040100u);
             *reinterpret_cast<uint4 *>((int16_t *)a.y + yb) = v;
           } else if (a.out_eb == 4) {
             uint4 *d = reinterpret_cast<uint4 *>((int32_t *)a.y + yb);
@@ -281,7 +286,7 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   if (sum_abs > 32767) { return false; }            // |sum of products| < 2^30: every intermediate stays inside int32
   MvStreamArgs a;
   memset(&a, 0, sizeof a);
-  for (int i = 0; i < p.taps; i++) { a.c16[i] = (int16_t)p.h_coeffs[i]; }
+  for (int i = 0; i < p.taps; i++) { a.c16[i] = (int16_t)p.h_coeffs[i]; a.c16o[i + 1] = (int16_t)p.h_coeffs[i]; }
   a.taps = p.taps; a.h = p.taps / 2; a.mode = p.win_mode;
   a.hb = p.win_mode == 0 ? 0 : 8 * ((a.h + 7) / 8);
   a.off = p.win_mode == 0 ? 0 : a.hb - a.h;

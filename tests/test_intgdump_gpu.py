@@ -69,3 +69,31 @@ def test_rejects_short_buffers():
 ])
 def test_streaming_kernel_shapes(ns, chn, rounds, n_blk, fin, fa, fo):
     check(ns, chn, fin, fa, fo, [[rounds] * n_blk, [rounds] * (n_blk // 2)], n_obj=5, seed=ns + chn)
+
+
+# ---- batched streaming kernel (int16 rows, blocks of 128 B .. 1 KB): reduce-scatter over the lanes of a block ----
+
+@pytest.mark.parametrize("chn", [1, 2, 4])
+@pytest.mark.parametrize("gs", [8, 16, 32, 64])
+def test_batched_kernel_every_group_size(chn, gs):
+    rounds = 8 * gs // chn                      # gs lanes x 8 int16 elements per block
+    per_load = 64 // gs                         # blocks per 1 KB wave-load
+    # 21 and 11 wave-loads per object: batches of 8 with ragged tails, three waves in the first call
+    signed = (gs + chn) % 3 != 0
+    fin = A.Fmt(16, 8, signed)
+    fa = A.Fmt(33, 20, signed)
+    fo = [A.Fmt(33, 20, signed), A.Fmt(12, 6, signed, "RND", "SAT"), A.Fmt(31, 19, signed, "TRN", "WRAP")][(gs // 8 + chn) % 3]
+    check(rounds, chn, fin, fa, fo, [[rounds] * (21 * per_load), [rounds] * (11 * per_load)], n_obj=3, seed=100 * gs + chn)
+
+
+def test_batched_kernel_many_waves_full_scale_inputs():
+    # every sample at the extreme of <16,8>: the int32 lane sums are at their bound (rounds < 2^15)
+    ns, chn, n_obj = 64, 4, 4
+    eng = A.IntgDump(ns, chn, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16), n_objects=n_obj)
+    orc = OracleIntgDump(ns, chn, ofmt(A.Fmt(16, 8)), ofmt(A.Fmt(32, 16)), ofmt(A.Fmt(32, 16)), n_obj=n_obj)
+    n_sample = [ns] * 2048                      # 1024 wave-loads per object
+    x = np.full((n_obj, ns * chn * len(n_sample)), -32768, dtype=np.int64)
+    x[1] = 32767
+    x[2, ::3] = 32767
+    y = eng.run(torch.from_numpy(x).to(torch.int16).cuda(), n_sample).cpu().numpy().astype(np.int64)
+    assert np.array_equal(y, orc.run(x, n_sample))
