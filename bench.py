@@ -462,7 +462,7 @@ def pmc_traffic(tag):
                 if line.startswith("void ") or line.startswith("acdsp::"):
                     kernel = line.strip()
                 f = line.split()
-                if len(f) == 3 and f[0] in vals and kernel and any(k in kernel for k in ("fir_mfma", "fir_gen", "cascade_kernel", "cic_kernel<", "fir_up_kernel", "intg_dump_stream", "mv_avg_stream")):
+                if len(f) == 3 and f[0] in vals and kernel and any(k in kernel for k in ("fir_mfma", "fir_gen", "cascade_kernel", "cic_kernel<", "fir_up_kernel", "intg_dump_stream", "intg_dump_batch", "mv_avg_stream")):
                     vals[f[0]] += float(f[2])      # summed over the data-path kernels of one step (the DDC has two)
                     seen.add(f[0])
             if len(seen) == 2:
