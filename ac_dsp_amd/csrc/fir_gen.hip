@@ -32,6 +32,13 @@
 
 #include "fir_kernels.hpp"
 
+// A/B knob (tools/ab_build.sh ... -DACDSP_GEN_NT): non-temporal policy on the streaming window loads
+#ifdef ACDSP_GEN_NT
+#define ACDSP_GEN_LD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define ACDSP_GEN_LD(ptr) (*(ptr))
+#endif
+
 namespace acdsp {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -373,7 +380,7 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
       for (int k = 0; k < NPC; k++) {
         const int64_t t = W0 + pc_off[k];
         const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
-        pre[k / S][k % S] = *(const v4i *)src;
+        pre[k / S][k % S] = ACDSP_GEN_LD((const v4i *)src);
       }
     } else {
 #pragma unroll
@@ -713,14 +720,14 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
 #pragma unroll
       for (int k = 0; k < NPCA; k++) {
         const unsigned off = k < NPCA - 2 ? lane16 + 1024u * k : 2u * (unsigned)pc_off[k];
-        pre[k] = *(const v4i *)(base + off);
+        pre[k] = ACDSP_GEN_LD((const v4i *)(base + off));
       }
     } else {
 #pragma unroll
       for (int k = 0; k < NPCA; k++) {
         const int64_t t = W0 + pc_off[k];
         const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
-        pre[k] = *(const v4i *)src;
+        pre[k] = ACDSP_GEN_LD((const v4i *)src);
       }
     }
   };

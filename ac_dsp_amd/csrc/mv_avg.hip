@@ -109,6 +109,13 @@ struct MvStreamArgs {
 };
 
 typedef short v2s_t __attribute__((ext_vector_type(2)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+// A/B knob (-DACDSP_MV_NT): non-temporal policy on the tile loads
+#ifdef ACDSP_MV_NT
+#define ACDSP_MV_LD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define ACDSP_MV_LD(ptr) (*(ptr))
+#endif
 
 template <int NR, bool LINEAR, bool CV32, bool EDGE>
 __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
@@ -137,7 +144,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     // every load is unconditional (addresses clamped into the frame; what the clamped lanes fetch is never used), so
     // the loop body has no load under a branch and the waits stay counted
     const int64_t gc = g < 0 ? 0 : (g < n ? g : n - 8);
-    T.mv = *reinterpret_cast<const uint4 *>(row + gc);
+    { const v4u_t t_ = ACDSP_MV_LD(reinterpret_cast<const v4u_t *>(row + gc)); T.mv = make_uint4(t_.x, t_.y, t_.z, t_.w); }
     const int64_t g2 = f_ti * 512 - a.hb + 512 + 8 * (lane < a.nxg ? lane : 0);
     T.ev = *reinterpret_cast<const uint4 *>(row + (g2 < n ? g2 : n - 8));
     if constexpr (EDGE) {   // frame-edge patches of AC_CLIP / AC_MIRROR: the source samples of positions -1 - lane and n + lane

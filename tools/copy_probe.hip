@@ -64,6 +64,52 @@ __global__ void __launch_bounds__(256) probe(const v4i *__restrict__ x, v4i *__r
   if (RW == 1 && flag == acc.x + acc.y + acc.z + acc.w + 12345) { y[tid] = acc; }
 }
 
+// LDS-DMA transport (global_load_lds_dwordx4: 1 KB per wave-instruction, no VGPR on the way in): wave-span geometry, a
+// wave-private double buffer of U KB per half; the batch two ahead is issued before the current one is read back with
+// ds_read_b128.  The asm loads are invisible to hipcc's waitcnt bookkeeping, so the waits are counted by hand: behind the
+// newest U loads (read-only) or the newest U loads + the U stores issued in front of them (copy) everything has landed.
+template <bool NT>
+__device__ __forceinline__ void glds16(const v4i *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  if (NT) { asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory"); }
+  else { asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory"); }
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int RW, int U, bool NT>
+__global__ void __launch_bounds__(256) probe_glds(const v4i *__restrict__ x, v4i *__restrict__ y, long n_vec, long span_vec, int flag) {
+  __shared__ __attribute__((aligned(16))) v4i sm[4][2][U][64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const long gw = (long)blockIdx.x * 4 + wave;
+  const long b = gw * span_vec, e = b + span_vec < n_vec ? b + span_vec : n_vec;   // spans are whole batches (host)
+  v4i acc = {0, 0, 0, 0};
+  if (b < e) {
+    const unsigned base = (unsigned)(uintptr_t)&sm[wave][0][0][0];   // LDS byte address, wave-uniform
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+    for (int u = 0; u < U; u++) { glds16<NT>(x + b + 64 * u + lane, sbase + 1024 * u); }
+    int buf = 0;
+    for (long i = b; i < e; i += 64 * U, buf ^= 1) {
+      const long nx = i + 64 * U < e ? i + 64 * U : i;   // past the end: the last batch again (branch-free body)
+      const unsigned nb = sbase + 1024 * U * (buf ^ 1);
+#pragma unroll
+      for (int u = 0; u < U; u++) { glds16<NT>(x + nx + 64 * u + lane, nb + 1024 * u); }
+      if (RW == 0) { wait_vm<2 * U>(); } else { wait_vm<U>(); }
+      v4i v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { v[u] = sm[wave][buf][u][lane]; }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (RW == 1) { acc += v[u]; }
+        else { y[i + 64 * u + lane] = v[u]; }
+      }
+      asm volatile("" ::: "memory");
+    }
+    wait_vm<0>();
+  }
+  if (RW == 1 && flag == acc.x + acc.y + acc.z + acc.w + 12345) { y[(long)blockIdx.x * 256 + threadIdx.x] = acc; }
+}
+
 struct Ctx { v4i *x, *y; long n_vec; int reps; };
 
 template <int MODE, int RW, int U, bool NT>
@@ -88,6 +134,25 @@ static void run(const Ctx &c, long blocks, long span_kb) {
          bytes / ms / 1e9);
 }
 
+template <int RW, int U, bool NT>
+static void run_glds(const Ctx &c, long span_kb) {
+  const long span_vec = span_kb * 64;
+  const long waves = (c.n_vec + span_vec - 1) / span_vec, nb = (waves + 3) / 4;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 2; w++) { hipLaunchKernelGGL((probe_glds<RW, U, NT>), dim3((unsigned)nb), dim3(256), 0, 0, c.x, c.y, c.n_vec, span_vec, 0); }
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < c.reps; r++) { hipLaunchKernelGGL((probe_glds<RW, U, NT>), dim3((unsigned)nb), dim3(256), 0, 0, c.x, c.y, c.n_vec, span_vec, 0); }
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= c.reps;
+  const double bytes = (double)c.n_vec * 16 * (RW == 0 ? 2.0 : 1.0);
+  printf("%-15s %-11s U=%2d nt=%d blocks=%7ld span=%5ld KB  %8.3f ms  %6.2f TB/s\n", RW == 0 ? "copy 1:1" : "read-only", "lds-dma", U, (int)NT, nb, span_kb, ms, bytes / ms / 1e9);
+}
+
 int main(int argc, char **argv) {
   Ctx c;
   const long gib = argc > 1 ? atol(argv[1]) : 4;
@@ -106,5 +171,10 @@ int main(int argc, char **argv) {
   run<1, 0, 4, false>(c, 0, 64); run<1, 0, 8, false>(c, 0, 64); run<1, 0, 8, false>(c, 0, 16); run<1, 0, 8, false>(c, 0, 256); run<1, 0, 8, true>(c, 0, 64);
   run<1, 1, 8, false>(c, 0, 64); run<1, 1, 8, true>(c, 0, 64); run<1, 2, 4, false>(c, 0, 64); run<1, 2, 4, true>(c, 0, 64);
   run<1, 3, 8, false>(c, 0, 64); run<1, 3, 8, true>(c, 0, 64); run<1, 3, 8, false>(c, 0, 256);
+  // LDS-DMA transport, wave-span geometry
+  run_glds<1, 4, false>(c, 64); run_glds<1, 4, true>(c, 64); run_glds<1, 8, false>(c, 64); run_glds<1, 8, true>(c, 64); run_glds<1, 4, true>(c, 16);
+  run_glds<0, 4, false>(c, 64); run_glds<0, 4, true>(c, 64); run_glds<0, 8, false>(c, 64); run_glds<0, 4, false>(c, 16); run_glds<0, 4, true>(c, 16);
+  // register loads again, behind the LDS-DMA rows (clock / thermal drift check)
+  run<1, 1, 8, true>(c, 0, 64); run<1, 0, 8, false>(c, 0, 16);
   return 0;
 }
