@@ -275,10 +275,29 @@ def build_workload(workload, args, world, rank, local_rank):
             "ch_per_gpu": ch_per_gpu, "n_taps": n_taps, "fmts": (fin, fc, fa, fo), "seed": seed}
 
 
-def measure(w, steps, warmup, barrier):
-    """W untimed steps, then exactly `steps` timed steps bracketed by barrier + synchronize.  Returns wall seconds, the
-    dominant kernel's (avg, min) duration from HIP events on the launch stream, and the whole-step event time (ms)."""
+def settle_clocks(step, seconds):
+    """Untimed pre-conditioning, reported in the JSON line as `clock_settle`: the same step in a loop for `seconds` of wall
+    time BEFORE the W warm-up steps.  The part idles at ~100 MHz and its power management needs 20 - 40 ms of this load to
+    settle the shader clock (tools/dbg/ramp.py: the first 20 steps from idle average 1.42 ms, every later block of 20 steps
+    1.00 ms); W = 3 .. 5 warm-up steps end inside that ramp, so without this the K timed steps measure the DVFS transient of
+    a cold start instead of the streaming engine.  Nothing inside the timed region changes.  Returns the steps run."""
+    n = 0
+    if seconds > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            n += 10
+    return n
+
+
+def measure(w, steps, warmup, barrier, settle_s=0.0):
+    """Optional clock pre-conditioning (settle_clocks), W untimed steps, then exactly `steps` timed steps bracketed by
+    barrier + synchronize.  Returns wall seconds, the dominant kernel's (avg, min) duration from HIP events on the launch
+    stream, and the whole-step event time (ms)."""
     step, eng = w["step"], w["eng"]
+    w["settle_steps"] = settle_clocks(step, settle_s)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -347,6 +366,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs after the headline workload")
     ap.add_argument("--pad", type=int, default=0, help="extra elements per row (row stride = samples + pad)")
     ap.add_argument("--stim-bits", type=int, default=0, help="diagnostic: amplitude of the FIR stimulus in bits (default: full 16)")
+    ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed pre-conditioning steps in front of the warm-up "
+                    "(shader-clock ramp from idle; 0 = cold start, the K timed steps then include the DVFS transient)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -370,7 +391,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    dt, k_avg, k_min, ev_ms = measure(w, args.steps, args.warmup, barrier)
+    dt, k_avg, k_min, ev_ms = measure(w, args.steps, args.warmup, barrier, args.settle)
     samples_per_step = w["samples_per_step"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
@@ -392,6 +413,9 @@ def main():
                        "parallelism": "channel-slice x%d, no collectives" % world},
             "roofline": roofline_of(w, k_avg, k_min, ev_ms),
             "event_ms_per_step": ev_ms,
+            "clock_settle": {"seconds": args.settle, "steps": w["settle_steps"],
+                             "note": "untimed pre-conditioning in front of the W warm-up steps (same step, same data): the shader clock needs "
+                                     "20-40 ms of load to settle from idle; --settle 0 measures the cold-start transient instead"},
         }
         if w["macs_per_sample"]:
             out["mfma_roofline"] = mfma_roofline_of(w, k_avg)
@@ -406,7 +430,7 @@ def main():
             sec = {}
             for name in SECONDARY:
                 w2 = build_workload(name, args, 1, 0, local_rank)
-                dt2, ka2, km2, ev2 = measure(w2, 10, 5, lambda: None)
+                dt2, ka2, km2, ev2 = measure(w2, 10, 5, lambda: None, args.settle)
                 r2 = roofline_of(w2, ka2, km2, ev2)
                 sec[name] = {"workload": w2["name"], "kernel_path": w2["path"], "ms_per_step": dt2 / 10 * 1e3,
                              "Msamples_per_s": w2["samples_per_step"] * 10 / dt2 / 1e6, "kernel_ms_avg": ka2,
