@@ -1618,6 +1618,12 @@ struct acdsp_intgdump {
   int32_t *d_chain = nullptr;   // [cap]
   int64_t blk_cap = 0;
   bool pending = false;         // the last call ended on a block that did not dump: temp[] is non-zero
+  // block table of the last call: a stream that dumps on a fixed schedule passes the same n_sample[] every call, and then
+  // neither the table is rebuilt nor uploaded and run() stays asynchronous (no stream synchronisation)
+  std::vector<int64_t> last_ns;
+  void *last_stream = nullptr;
+  int64_t tbl_grp = 0, tbl_uni_rounds = 0;
+  int32_t tbl_start = 0;
   Staging st;
 };
 
@@ -1698,22 +1704,37 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
     HIP_TRY(hipMalloc((void **)&h->d_blk, (size_t)3 * n_blocks * sizeof(int64_t)));
     HIP_TRY(hipMalloc((void **)&h->d_chain, (size_t)n_blocks * sizeof(int32_t)));
     h->blk_cap = n_blocks;
+    h->last_ns.clear();   // new device arrays: the table has to be uploaded again
   }
-  std::vector<int64_t> blk((size_t)3 * n_blocks);
-  std::vector<int32_t> chain((size_t)n_blocks);
-  int64_t off = 0, grp = 0;
-  int32_t start = 0;
-  for (int64_t b = 0; b < n_blocks; b++) {
-    bool dumps;
-    const int64_t r = intg_rounds(n_sample[b], d.ns, &dumps);
-    blk[(size_t)b] = off; blk[(size_t)(n_blocks + b)] = r; blk[(size_t)(2 * n_blocks + b)] = dumps ? grp : -1;
-    chain[(size_t)b] = start;
-    off += r;
-    if (dumps) { grp++; start = (int32_t)(b + 1); }
+  const bool same_table = h->last_stream == stream && (int64_t)h->last_ns.size() == n_blocks &&
+                          memcmp(h->last_ns.data(), n_sample, (size_t)n_blocks * sizeof(int64_t)) == 0;
+  if (!same_table) {
+    std::vector<int64_t> blk((size_t)3 * n_blocks);
+    std::vector<int32_t> chain((size_t)n_blocks);
+    int64_t off = 0, grp = 0;
+    int32_t start = 0;
+    for (int64_t b = 0; b < n_blocks; b++) {
+      bool dumps;
+      const int64_t r = intg_rounds(n_sample[b], d.ns, &dumps);
+      blk[(size_t)b] = off; blk[(size_t)(n_blocks + b)] = r; blk[(size_t)(2 * n_blocks + b)] = dumps ? grp : -1;
+      chain[(size_t)b] = start;
+      off += r;
+      if (dumps) { grp++; start = (int32_t)(b + 1); }
+    }
+    h->last_ns.clear();                 // (stays empty if the upload fails)
+    // the previous table may still be read by a kernel on another stream: drain the device before overwriting it
+    if (h->last_stream != stream) { HIP_TRY(hipDeviceSynchronize()); }
+    HIP_TRY(hipMemcpyAsync(h->d_blk, blk.data(), blk.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // blk / chain are stack vectors
+    h->tbl_grp = grp; h->tbl_start = start;
+    h->tbl_uni_rounds = blk[(size_t)n_blocks];
+    for (int64_t b = 1; b < n_blocks && h->tbl_uni_rounds > 0; b++) { if (blk[(size_t)(n_blocks + b)] != h->tbl_uni_rounds) { h->tbl_uni_rounds = 0; } }
+    h->last_ns.assign(n_sample, n_sample + n_blocks);
+    h->last_stream = stream;
   }
-  HIP_TRY(hipMemcpyAsync(h->d_blk, blk.data(), blk.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));   // blk / chain are stack vectors
+  const int64_t grp = h->tbl_grp;
+  const int32_t start = h->tbl_start;
   IntgDumpParams p;
   memset(&p, 0, sizeof p);
   p.chn = d.chn; p.n_obj = d.n_objects; p.n_blocks = (int32_t)n_blocks;
@@ -1721,10 +1742,7 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
   p.in_eb = h->in_eb; p.out_eb = h->out_eb; p.in_stride = in_stride; p.out_stride = out_stride;
   p.lossless = d.acc.O == ACDSP_WRAP && p.acc.F >= p.in.F && p.acc.F - p.in.F < 64 - d.in.W;
   p.tile_ok = p.lossless && !h->pending && grp == n_blocks;
-  if (p.tile_ok) {
-    p.uni_rounds = blk[(size_t)n_blocks];
-    for (int64_t b = 1; b < n_blocks && p.uni_rounds > 0; b++) { if (blk[(size_t)(n_blocks + b)] != p.uni_rounds) { p.uni_rounds = 0; } }
-  }
+  if (p.tile_ok) { p.uni_rounds = h->tbl_uni_rounds; }
   p.x = d_in; p.y = d_out; p.temp = h->d_temp[h->cur];
   p.blk_off = h->d_blk; p.blk_rounds = h->d_blk + n_blocks; p.blk_out = h->d_blk + 2 * n_blocks; p.blk_chain = h->d_chain;
   hipError_t e = launch_intg_dump(p, h->d_temp[h->cur ^ 1], s);

@@ -97,3 +97,29 @@ def test_batched_kernel_many_waves_full_scale_inputs():
     x[2, ::3] = 32767
     y = eng.run(torch.from_numpy(x).to(torch.int16).cuda(), n_sample).cpu().numpy().astype(np.int64)
     assert np.array_equal(y, orc.run(x, n_sample))
+
+
+def test_block_table_is_cached_across_calls_and_streams():
+    # the same n_sample[] call after call (table reused, run() stays asynchronous), then other tables, other streams, and a
+    # growing block count (device arrays reallocated): every call against the oracle, which rebuilds everything every time
+    ns, chn, n_obj = 64, 4, 3
+    fin, fa, fo = A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)
+    rng = np.random.default_rng(11)
+    eng = A.IntgDump(ns, chn, fin, fa, fo, n_objects=n_obj)
+    orc = OracleIntgDump(ns, chn, ofmt(fin), ofmt(fa), ofmt(fo), n_obj=n_obj)
+    uniform, ragged = [ns] * 32, [3, ns, 1, 70, 12, ns, ns, 5]
+    side = torch.cuda.Stream()
+    plan = [(uniform, None), (uniform, None), (uniform, side), (ragged, side), (ragged, None), (uniform, None),
+            ([ns] * 96, None), ([ns] * 96, side), (uniform, None)]
+    for n_sample, stream in plan:
+        ni, no = eng.counts(n_sample)
+        x = rand_raw(rng, fin, (n_obj, ni))
+        xd = torch.from_numpy(x).to(torch.int16).cuda()
+        torch.cuda.synchronize()
+        if stream is None:
+            y = eng.run(xd, n_sample)
+        else:
+            with torch.cuda.stream(stream):
+                y = eng.run(xd, n_sample)
+        torch.cuda.synchronize()
+        assert np.array_equal(y.cpu().numpy().astype(np.int64), orc.run(x, n_sample))
