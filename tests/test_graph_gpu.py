@@ -1,0 +1,84 @@
+"""GPU tests: run() calls captured into a HIP graph (torch.cuda.CUDAGraph) and replayed.
+
+Small chunks are launch-bound (a 255-tap step over 256 ch x 4096 samples is ~10 us of GPU work behind two launches), so a
+streaming deployment captures a fixed schedule of run() calls once and replays it.  run() performs no
+allocation, synchronisation or host copy in steady state, so it is capturable; the handle's host-side bookkeeping (the
+double-buffered history: two buffers, flipped per call; the decimation phase) must be the same after the captured sequence
+as before it, i.e. an EVEN number of calls per handle whose samples add up to a multiple of the rate change.  Replays
+continue the stream: the state lives in device memory and is carried from replay to replay exactly as from call to call
+(ac_fir_load_coeffs.h:180-188, ac_cic_full_core.h:71-74)."""
+import numpy as np
+import pytest
+import torch
+
+import ac_dsp_amd as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _capture_and_check(make, x, out_shape, out_dtype, n_replays=3):
+    """make() -> fresh engine; x [nk][nch][cs] device inputs.  Eager reference: one engine fed the chunks in order, n_replays
+    times over; graph: the nk calls captured once, replayed n_replays times."""
+    nk = x.shape[0]
+    ref_eng = make()
+    refs = [torch.stack([ref_eng.run(x[k]).clone() for k in range(nk)]) for _ in range(n_replays)]
+    torch.cuda.synchronize()
+    eng = make()
+    y = torch.zeros((nk,) + out_shape, dtype=out_dtype, device="cuda")
+    eng.run(x[0], out=y[0])            # one-time uploads (fragments per phase) happen outside the capture
+    eng.run(x[1], out=y[1])
+    eng.reset()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+        for k in range(nk):
+            eng.run(x[k], out=y[k])
+    eng.reset()                        # whatever ran during capture set-up: start the stream from the constructed state
+    torch.cuda.synchronize()
+    for r in range(n_replays):
+        y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        got = y[:, :, :refs[r].shape[2]]
+        assert torch.equal(got, refs[r]), "replay %d differs from the eager stream" % r
+
+
+@pytest.mark.parametrize("n_taps", [63, 255, 1023])
+def test_fir_calls_replayed_from_a_graph_continue_the_stream(n_taps):
+    nch, cs, nk = 48, 4096, 4
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14), A.Fmt(16, 2, True, "RND", "SAT")
+    rng = np.random.default_rng(n_taps)
+    coeffs = rng.integers(-1500, 1500, size=n_taps, dtype=np.int64)
+
+    def make():
+        e = A.Fir(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_channels=nch, kind="load")
+        e.set_coeffs(coeffs)
+        return e
+
+    x = torch.from_numpy(rng.integers(-32768, 32768, size=(nk, nch, cs), dtype=np.int16)).cuda()
+    _capture_and_check(make, x, (nch, cs), torch.int16)
+
+
+def test_cic_decimator_calls_replayed_from_a_graph():
+    nch, cs, nk, R = 64, 8192, 2, 8
+    fin = A.Fmt(32, 16)
+    fout = A.Fmt(47, 31)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31, size=(nk, nch, cs), dtype=np.int64).astype(np.int32)).cuda()
+    _capture_and_check(lambda: A.Cic(False, R, 1, 5, fin, fout, n_channels=nch), x, (nch, cs // R), torch.int64)
+
+
+def test_fused_ddc_calls_replayed_from_a_graph():
+    nch, cs, nk = 16, 16 * 256 * 4, 2
+    cin, fc, fa, fo = A.Fmt(16, 1), A.Fmt(16, 1), A.Fmt(60, 30), A.Fmt(24, 9, True, "RND", "SAT")
+    rng = np.random.default_rng(9)
+    c = rng.integers(-3000, 3000, size=127, dtype=np.int64)
+
+    def make():
+        d = A.Ddc(16, 1, 5, cin, 127, "SHIFT_REG", fc, fa, fo, n_channels=nch)
+        d.set_coeffs(c)
+        assert d.path == "fused"
+        return d
+
+    x = torch.from_numpy(rng.integers(-32768, 32768, size=(nk, nch, cs), dtype=np.int16)).cuda()
+    _capture_and_check(make, x, (nch, cs // 16), torch.int32)
