@@ -38,6 +38,10 @@ int fail(int code, const char *fmt, ...) {
     if (e_ != hipSuccess) { return fail(ACDSP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
   } while (0)
 
+// history buffer the state kernel of a call writes: the current one (in place) when the call's input alone defines the new
+// history, else the other one
+static inline int hist_next_index(int cur, bool in_place) { return in_place ? cur : (cur ^ 1); }
+
 // Device check of every entry point.  The architecture test (hipGetDeviceProperties: ~100 us) runs once per device and
 // process; later calls only make `device` the calling thread's current device when it is not already.
 int check_device(int device) {
@@ -554,14 +558,18 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR kernel launch failed: %s", hipGetErrorString(e)); }
   HIP_TRY(hipEventRecord(h->tm.stop(), s));
   h->tm.commit();
-  // state carry into the other buffer, then flip
+  // state carry.  A call of at least hl samples takes the new history from its input alone: written in place behind the
+  // main kernel (same stream), no buffer flip -- the handle's host-side state is then the same after every call, which is what
+  // lets any schedule of such calls be captured into a HIP graph.  Shorter calls (and reg_trans, which reads its old value)
+  // go into the other buffer, then flip.
+  const int nxt = hist_next_index(h->cur, !h->use_rt && k.n >= k.hl);
   if (h->use_rt) {
-    e = launch_fir_rt_update(k, h->d_rt[h->cur ^ 1], s);
+    e = launch_fir_rt_update(k, h->d_rt[nxt], s);
   } else {
-    e = launch_fir_hist_update(k, h->d_hist[h->cur ^ 1], s);
+    e = launch_fir_hist_update(k, h->d_hist[nxt], s);
   }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR state kernel launch failed: %s", hipGetErrorString(e)); }
-  h->cur ^= 1;
+  h->cur = nxt;
   return ACDSP_OK;
 }
 
@@ -887,9 +895,10 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "CIC kernel launch failed: %s", hipGetErrorString(e)); }
   HIP_TRY(hipEventRecord(h->tm.stop(), s));
   h->tm.commit();
-  e = launch_cic_hist_update(p, h->d_hist[h->cur ^ 1], s);
+  const int nxt = hist_next_index(h->cur, p.n_in >= p.hl);
+  e = launch_cic_hist_update(p, h->d_hist[nxt], s);
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "CIC state kernel launch failed: %s", hipGetErrorString(e)); }
-  h->cur ^= 1;
+  h->cur = nxt;
   h->t_total += n_in;
   return ACDSP_OK;
 }
@@ -1057,9 +1066,10 @@ int32_t acdsp_polydec_run(acdsp_polydec_t h, const void *d_in, int64_t in_stride
     e = launch_polydec_generic(k, d.n_taps, d.df, n_out, s);
   }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_dec kernel launch failed: %s", hipGetErrorString(e)); }
-  e = launch_fir_hist_update(k, h->d_hist[h->cur ^ 1], s);
+  const int nxt = hist_next_index(h->cur, k.n >= k.hl);
+  e = launch_fir_hist_update(k, h->d_hist[nxt], s);
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_dec state kernel launch failed: %s", hipGetErrorString(e)); }
-  h->cur ^= 1;
+  h->cur = nxt;
   return ACDSP_OK;
 }
 
@@ -1275,9 +1285,10 @@ int32_t acdsp_ddc_run(acdsp_ddc_t h, const void *d_in, int64_t in_stride, int64_
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "cascade kernel launch failed: %s", hipGetErrorString(e)); }
   HIP_TRY(hipEventRecord(h->tm.stop(), s));
   h->tm.commit();
-  e = launch_fir_hist_update(pa, h->d_hist[h->cur ^ 1], s);
+  const int nxt = hist_next_index(h->cur, pa.n >= pa.hl);
+  e = launch_fir_hist_update(pa, h->d_hist[nxt], s);
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "ddc state kernel launch failed: %s", hipGetErrorString(e)); }
-  h->cur ^= 1;
+  h->cur = nxt;
   h->t_total += n_in;
   return ACDSP_OK;
 }
@@ -1561,7 +1572,7 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
   FirParams k;
   memset(&k, 0, sizeof k);
   k.n_ch = d.n_channels; k.in = p.in; k.in_eb = h->in_eb; k.hl = h->hl; k.in_stride = in_stride; k.n = n_in; k.x = d_in; k.hist = p.hist;
-  e = launch_fir_hist_update(k, h->d_hist[h->cur ^ 1], s);
+  e = launch_fir_hist_update(k, h->d_hist[h->cur ^ 1], s);   // (always the other buffer: the saved sums flip with it)
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_intr state kernel launch failed: %s", hipGetErrorString(e)); }
   h->cur ^= 1;
   h->t_total += n_in;

@@ -2,9 +2,10 @@
 
 Small chunks are launch-bound (a 255-tap step over 256 ch x 4096 samples is ~10 us of GPU work behind two launches), so a
 streaming deployment captures a fixed schedule of run() calls once and replays it.  run() performs no
-allocation, synchronisation or host copy in steady state, so it is capturable; the handle's host-side bookkeeping (the
-double-buffered history: two buffers, flipped per call; the decimation phase) must be the same after the captured sequence
-as before it, i.e. an EVEN number of calls per handle whose samples add up to a multiple of the rate change.  Replays
+allocation, synchronisation or host copy in steady state, so it is capturable; the handle's host-side bookkeeping must be
+the same after the captured sequence as before it: calls of at least N_TAPS - 1 samples (the window of the class) update the
+history in place, so any number of them qualifies as long as their samples add up to a multiple of the rate change (the
+decimation phase); shorter calls flip a double buffer and have to come in pairs (engine.hip: hist_next_index).  Replays
 continue the stream: the state lives in device memory and is carried from replay to replay exactly as from call to call
 (ac_fir_load_coeffs.h:180-188, ac_cic_full_core.h:71-74)."""
 import numpy as np
@@ -45,7 +46,7 @@ def _capture_and_check(make, x, out_shape, out_dtype, n_replays=3):
 
 @pytest.mark.parametrize("n_taps", [63, 255, 1023])
 def test_fir_calls_replayed_from_a_graph_continue_the_stream(n_taps):
-    nch, cs, nk = 48, 4096, 4
+    nch, cs, nk = 48, 4096, 3          # an odd number of calls: long calls update the history in place
     fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14), A.Fmt(16, 2, True, "RND", "SAT")
     rng = np.random.default_rng(n_taps)
     coeffs = rng.integers(-1500, 1500, size=n_taps, dtype=np.int64)
@@ -60,7 +61,7 @@ def test_fir_calls_replayed_from_a_graph_continue_the_stream(n_taps):
 
 
 def test_cic_decimator_calls_replayed_from_a_graph():
-    nch, cs, nk, R = 64, 8192, 2, 8
+    nch, cs, nk, R = 64, 8192, 3, 8
     fin = A.Fmt(32, 16)
     fout = A.Fmt(47, 31)
     rng = np.random.default_rng(5)
@@ -69,7 +70,7 @@ def test_cic_decimator_calls_replayed_from_a_graph():
 
 
 def test_fused_ddc_calls_replayed_from_a_graph():
-    nch, cs, nk = 16, 16 * 256 * 4, 2
+    nch, cs, nk = 16, 16 * 256 * 4, 3
     cin, fc, fa, fo = A.Fmt(16, 1), A.Fmt(16, 1), A.Fmt(60, 30), A.Fmt(24, 9, True, "RND", "SAT")
     rng = np.random.default_rng(9)
     c = rng.integers(-3000, 3000, size=127, dtype=np.int64)
@@ -82,3 +83,20 @@ def test_fused_ddc_calls_replayed_from_a_graph():
 
     x = torch.from_numpy(rng.integers(-32768, 32768, size=(nk, nch, cs), dtype=np.int16)).cuda()
     _capture_and_check(make, x, (nch, cs // 16), torch.int32)
+
+
+def test_short_fir_calls_flip_the_history_and_replay_in_pairs():
+    # 100-sample calls of a 255-tap filter: the new history still holds part of the old one, so the handle flips buffers per
+    # call; a pair of calls restores the parity and the graph replays correctly
+    nch, cs, nk = 8, 100, 2
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14), A.Fmt(16, 2, True, "RND", "SAT")
+    rng = np.random.default_rng(3)
+    coeffs = rng.integers(-1500, 1500, size=255, dtype=np.int64)
+
+    def make():
+        e = A.Fir(255, "SHIFT_REG", fin, fc, fa, fo, n_channels=nch, kind="load")
+        e.set_coeffs(coeffs)
+        return e
+
+    x = torch.from_numpy(rng.integers(-32768, 32768, size=(nk, nch, cs), dtype=np.int16)).cuda()
+    _capture_and_check(make, x, (nch, cs), torch.int16, n_replays=4)
