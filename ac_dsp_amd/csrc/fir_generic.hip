@@ -183,8 +183,24 @@ __global__ void fir_hist_update_kernel(FirParams p, void *hist_next) {
   }
 }
 
+// the same for calls of at least hl samples whose tail is 16-byte aligned: a plain copy of the row tails, 16 bytes per lane
+__global__ void fir_hist_copy16_kernel(const char *__restrict__ x, char *__restrict__ hist_next, int64_t row_bytes, int64_t tail_off, int vecs_per_row) {
+  const int ch = blockIdx.y;
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  const v4i_ *src = (const v4i_ *)(x + (int64_t)ch * row_bytes + tail_off);
+  v4i_ *dst = (v4i_ *)hist_next + (int64_t)ch * vecs_per_row;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < vecs_per_row; j += gridDim.x * blockDim.x) { dst[j] = src[j]; }
+}
+
 hipError_t launch_fir_hist_update(const FirParams &p, void *hist_next, hipStream_t s) {
   if (p.n <= 0 || p.hl <= 0) { return hipSuccess; }
+  const int64_t hb = (int64_t)p.hl * p.in_eb, tail = (int64_t)(p.n - p.hl) * p.in_eb, rb = (int64_t)p.in_stride * p.in_eb;
+  if (p.n >= p.hl && hb >= 4096 && hb % 16 == 0 && tail % 16 == 0 && rb % 16 == 0 && ((uintptr_t)p.x % 16) == 0 && ((uintptr_t)hist_next % 16) == 0) {
+    const int vpr = (int)(hb / 16);
+    dim3 grid((unsigned)((vpr + 255) / 256), (unsigned)p.n_ch);
+    hipLaunchKernelGGL(fir_hist_copy16_kernel, grid, dim3(256), 0, s, (const char *)p.x, (char *)hist_next, rb, tail, vpr);
+    return hipGetLastError();
+  }
   dim3 grid((unsigned)((p.hl + 255) / 256), (unsigned)p.n_ch);
   hipLaunchKernelGGL(fir_hist_update_kernel, grid, dim3(256), 0, s, p, hist_next);
   return hipGetLastError();
