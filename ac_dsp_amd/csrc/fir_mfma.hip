@@ -525,18 +525,28 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     }
     int o[16];
     epi32_t<decltype(wide_c)::value>(hh, mid, ll, rs, o);
+    // A lane holds rows 8 g + 4 h .. + 3 of column n: 8 bytes per g, and the 16 lanes of a ds_write_b64 group share h, so
+    // they can reach only half of the 32 banks (2-way conflict on every store: the 16.6 % SQ_LDS_BANK_CONFLICT of round 1).
+    // v_permlane32_swap trades g-odd of the h = 0 lanes for g-even of the h = 1 lanes: every lane then owns 16 contiguous
+    // bytes (slot P = 4 n + 2 pr + h), written as two ds_write_b128; slot ^ ((n >> 1) & 3) spreads the 8 lanes of a store
+    // group over the 8 slots of a 128-byte bank row and keeps the aligned 4-slot sets flush() reads conflict-free.
+    unsigned d[4][2];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-      v4s pk;
       if (EPI == 2) {
-        typedef short v2s __attribute__((ext_vector_type(2)));
-        const v2s p0 = __builtin_amdgcn_cvt_pk_i16(o[4 * g], o[4 * g + 1]), p1 = __builtin_amdgcn_cvt_pk_i16(o[4 * g + 2], o[4 * g + 3]);
-        pk = (v4s){p0.x, p0.y, p1.x, p1.y};
+        d[g][0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(o[4 * g], o[4 * g + 1]));
+        d[g][1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(o[4 * g + 2], o[4 * g + 3]));
       } else {
-        pk = (v4s){(short)o[4 * g], (short)o[4 * g + 1], (short)o[4 * g + 2], (short)o[4 * g + 3]};
+        d[g][0] = __builtin_amdgcn_perm((unsigned)o[4 * g + 1], (unsigned)o[4 * g], 0x05040100u);
+        d[g][1] = __builtin_amdgcn_perm((unsigned)o[4 * g + 3], (unsigned)o[4 * g + 2], 0x05040100u);
       }
-      const int P = 4 * n_col + g;
-      *(v4s *)(obuf + (((P & ~15) | ((P + (P >> 4)) & 15)) * 16 + 8 * h)) = pk;
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+      const auto a0 = __builtin_amdgcn_permlane32_swap(d[2 * pr][0], d[2 * pr + 1][0], false, false);
+      const auto a1 = __builtin_amdgcn_permlane32_swap(d[2 * pr][1], d[2 * pr + 1][1], false, false);
+      const int P = 4 * n_col + 2 * pr + h;
+      *(v4i *)(obuf + (P ^ ((n_col >> 1) & 3)) * 16) = (v4i){(int)a0[0], (int)a1[0], (int)a0[1], (int)a1[1]};
     }
   };
   // ... and its row-contiguous write-out: two coalesced 16-byte-per-lane stores
@@ -553,7 +563,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       const int P = 64 * half + lane;
-      const v4i val = *(const v4i *)(obuf + ((P & ~15) | ((P + (P >> 4)) & 15)) * 16);
+      const v4i val = *(const v4i *)(obuf + (P ^ ((P >> 3) & 3)) * 16);
       *(v4i *)(yout + T0 + 512 * half + 8 * lane) = val;
     }
   };
@@ -994,6 +1004,8 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
       int o[16];
       if (set == 0) { epi32(h0, m0, l0, rs, o); } else { epi32(h1, m1, l1, rs, o); }
 #pragma unroll
+      // (the permlane32-swap / ds_write_b128 tile of fir_mfma_pipe_body was tried here: conflicts 2.5e7 -> 0 but +0.8 % time,
+      // the phase is not in the shadow of MFMAs)
       for (int g = 0; g < 4; g++) {
         v4s pk;
         if (EPI == 2) {
