@@ -409,7 +409,15 @@ template <int NB, int EPI, int HS>
 __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
                                                    unsigned char *lds) {
   static_assert(EPI >= 1 && EPI <= 3, "fast epilogue classes only");
-  constexpr int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, JN = (NP + 63) / 64, ARR = staged_array_bytes(NC);
+  constexpr int HB = NB - 1, NC = 32 + HB, NP = 4 * NC, JN = (NP + 63) / 64;
+  // The staged byte planes live in a RING of 128 chunk slots (four steps of 32) per [plane][half] array, plus HB mirror
+  // slots [128, 128 + HB) that repeat slots [0, HB): the window of a step with s % 4 == PAR is the linear slot range
+  // [32 PAR, 32 PAR + 32 + HB), so its first HB chunks are the tail the previous step staged -- a step loads and stages only
+  // its own 2 KB of new samples (two 16-byte loads per lane) instead of the whole 2.5 KB window with its 25 % halo.
+  // The wide-output class (EPI 3) keeps two separate windows per step pair: its loop, unrolled by four, ran 2 - 8 % slower
+  // (same-box A/B, profiles/r2_ab_ring.txt) -- that row is bound by its 8-byte stores, not by the input side.
+  constexpr bool RINGED = EPI != 3;
+  constexpr int RING = 128 + HB, ARR = RINGED ? staged_array_bytes(RING) : staged_array_bytes(NC);
   // two accumulator sets + all Toeplitz fragments leave room for GS = 2 only when some high-byte blocks are skipped
   constexpr int GS = (HS == 0 && NB >= 8) ? 1 : 2, NG = (NB + GS - 1) / GS;
   const int lane = threadIdx.x & 63;
@@ -418,7 +426,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   if (ch >= p.n_ch) { ch = p.n_ch - 1; }
   ch = __builtin_amdgcn_readfirstlane(ch);
   const int set = a.frag_per_channel ? ch : 0;
-  unsigned char *obuf = lds + 2 * 4 * ARR;
+  unsigned char *obuf = lds + (RINGED ? 4 : 2 * 4) * ARR;
   unsigned char *dummy = obuf + (EPI == 3 ? 8192 : 2048);   // 1 KB sink for the surplus lanes of stage()
 
   v4i Ah[NB], Al[NB];
@@ -444,16 +452,46 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       R[j] = *(const v4i *)src;
     }
   };
-  auto issue_loads_in = [&](int64_t T0) {      // see fir_mfma_body
+  v4i Q[2];
+  auto issue_loads_new = [&](int64_t T0) {     // the 1024 new samples of a later step; past the chunk: the last step's (never used)
     const int64_t tl = (s1 - 1) * 1024;
-    const char *sb = (const char *)(xrow + ((T0 < tl ? T0 : tl) - 32 * HB));
+    if constexpr (RINGED) {
+      const char *sb = (const char *)(xrow + (T0 < tl ? T0 : tl));
 #pragma unroll
-    for (int j = 0; j < JN; j++) {
-      const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
-      R[j] = *(const v4i *)(sb + (unsigned)(16 * pc));
+      for (int j = 0; j < 2; j++) { Q[j] = *(const v4i *)(sb + (unsigned)(16 * (lane + 64 * j))); }
+    } else {                                   // the whole window of that step (see fir_mfma_body)
+      const char *sb = (const char *)(xrow + ((T0 < tl ? T0 : tl) - 32 * HB));
+#pragma unroll
+      for (int j = 0; j < JN; j++) {
+        const int pc = (lane + 64 * j < NP) ? lane + 64 * j : NP - 1;
+        R[j] = *(const v4i *)(sb + (unsigned)(16 * pc));
+      }
     }
   };
-  auto stage = [&](unsigned char *buf) {
+  typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+  auto stage_ring = [&](auto par_c) {          // Q -> slots [32 (PAR + 1) + HB, + 32) mod 128 of the step after a step of parity PAR
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr int base = (PAR == 3) ? HB : 32 * (PAR + 1) + HB;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int pc = lane + 64 * j;
+      const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
+      const unsigned hi0 = __builtin_amdgcn_perm((unsigned)Q[j].y, (unsigned)Q[j].x, 0x07050301u);
+      const unsigned hi1 = __builtin_amdgcn_perm((unsigned)Q[j].w, (unsigned)Q[j].z, 0x07050301u);
+      const unsigned lo0 = __builtin_amdgcn_perm((unsigned)Q[j].y, (unsigned)Q[j].x, 0x06040200u) ^ 0x80808080u;
+      const unsigned lo1 = __builtin_amdgcn_perm((unsigned)Q[j].w, (unsigned)Q[j].z, 0x06040200u) ^ 0x80808080u;
+      unsigned char *dh = lds + (0 * 2 + hh_) * ARR + (base + c) * 16 + sub * 8;
+      unsigned char *dl = lds + (1 * 2 + hh_) * ARR + (base + c) * 16 + sub * 8;
+      *(v2u_ *)dh = (v2u_){hi0, hi1};
+      *(v2u_ *)dl = (v2u_){lo0, lo1};
+      if (PAR == 2 && j == 1 && HB > 0) {       // slots [128, 128 + HB) also go to [0, HB): the window of parity 0 starts there
+        const bool m = c >= 32 - HB;
+        *(v2u_ *)(m ? dh - 128 * 16 : dummy + lane * 8) = (v2u_){hi0, hi1};
+        *(v2u_ *)(m ? dl - 128 * 16 : dummy + 512 + lane * 8) = (v2u_){lo0, lo1};
+      }
+    }
+  };
+  auto stage = [&](unsigned char *buf) {       // prologue: the whole window of the chunk's first step -> slots [0, NC)
 #pragma unroll
     for (int j = 0; j < JN; j++) {
       // surplus lanes (last j only) store their copy of the last piece into a private dummy slot: no exec-mask branch
@@ -474,6 +512,11 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     }
   };
 
+  auto stage_new = [&](auto par_c) {
+    if constexpr (RINGED) { stage_ring(par_c); }
+    else { stage(lds + ((decltype(par_c)::value & 1) ^ 1) * (4 * ARR)); }
+  };
+
   const int rs = p.in.F + p.cf.F - p.out.F;
   const int c_ll = (int)(a.corr[set] + ((p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0));
   const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
@@ -485,9 +528,9 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   // B fragments: groups of GS K-blocks, double buffered; the group sequence runs on across steps, so the
   // buffer of group g of a step with parity PAR is (PAR * NG + g) & 1.
   v4i Bh[2][GS], Bl[2][GS];
-  auto read_group = [&](const unsigned char *buf, int g, v4i (&dh)[GS], v4i (&dl)[GS]) {
-    const unsigned char *fh = buf + (0 * 2 + h) * ARR + n_col * 16;
-    const unsigned char *fl = buf + (1 * 2 + h) * ARR + n_col * 16;
+  auto read_group = [&](int woff, int g, v4i (&dh)[GS], v4i (&dl)[GS]) {   // woff: byte offset of the step's window
+    const unsigned char *fh = lds + woff + (0 * 2 + h) * ARR + n_col * 16;
+    const unsigned char *fl = lds + woff + (1 * 2 + h) * ARR + n_col * 16;
 #pragma unroll
     for (int i = 0; i < GS; i++) {
       const int b = g * GS + i;
@@ -574,8 +617,8 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     constexpr int PAR = decltype(par_c)::value;
     constexpr bool PREV = decltype(prev_c)::value;
     const int64_t T0 = (s0 + s) * 1024;
-    const unsigned char *buf = lds + PAR * (4 * ARR);
-    unsigned char *nbuf = lds + (PAR ^ 1) * (4 * ARR);
+    // byte offsets of this step's and the next step's window: ring slots 32 PAR, or one of the two separate windows
+    constexpr int buf = RINGED ? 512 * PAR : (PAR & 1) * (4 * ARR), nbuf = RINGED ? 512 * ((PAR + 1) & 3) : ((PAR & 1) ^ 1) * (4 * ARR);
     hh = (v16i){0}; mid = (v16i){0}; ll = ll_init;
     // side work, spread over the first groups: S = stage step s+1, L = fetch step s+2, E1 = epilogue of step
     // s-1 into the LDS tile, E2 = its write-out
@@ -587,7 +630,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       const int cb = (PAR * NG + g) & 1, nb_ = cb ^ 1;
       // ACDSP_ABL_*: timing-only ablation builds (wrong results) behind the table in profiles/r2_fir255_clock.txt (d)
 #ifndef ACDSP_ABL_STAGE
-      if (NG == 1 && g == gS) { stage(nbuf); }
+      if (NG == 1 && g == gS) { stage_new(par_c); }
 #endif
 #ifdef ACDSP_ABL_BREAD
       if (g == 0) {
@@ -598,10 +641,10 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       }
 #endif
 #ifndef ACDSP_ABL_STAGE
-      if (NG > 1 && g == gS) { stage(nbuf); }
+      if (NG > 1 && g == gS) { stage_new(par_c); }
 #endif
 #ifndef ACDSP_ABL_LOAD
-      if (g == gL) { issue_loads_in(T0 + 2048); }
+      if (g == gL) { issue_loads_new(T0 + 2048); }
 #endif
 #ifndef ACDSP_ABL_EMIT
       if (PREV && g == gE1) { emit(wide_c, T0 - 1024, ph, pm, pl); }
@@ -628,29 +671,57 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   };
   using std::integral_constant;
   typedef integral_constant<int, 0> P0; typedef integral_constant<int, 1> P1;
+  typedef integral_constant<int, 2> P2; typedef integral_constant<int, 3> P3;
   typedef integral_constant<bool, true> WithPrev; typedef integral_constant<bool, false> NoPrev;
 
   // prologue: step s0 staged, step s0+1 in flight, first B group read
   issue_loads_first(s0 * 1024);
   stage(lds);
-  issue_loads_in((s0 + 1) * 1024);
-  read_group(lds, 0, Bh[0], Bl[0]);
+  issue_loads_new((s0 + 1) * 1024);
+  read_group(0, 0, Bh[0], Bl[0]);
 
   auto go = [&](auto wide_c) {   // the loop exists once per epilogue shift class: no branch inside it
     v16i hA, mA, lA, hB, mB, lB;
     run_step(wide_c, P0(), NoPrev(), 0, hA, mA, lA, hA, mA, lA);
     int s = 1;
-    for (; s + 1 < nsteps; s += 2) {
-      run_step(wide_c, P1(), WithPrev(), s, hB, mB, lB, hA, mA, lA);
-      run_step(wide_c, P0(), WithPrev(), s + 1, hA, mA, lA, hB, mB, lB);
-    }
-    if (s < nsteps) {
-      run_step(wide_c, P1(), WithPrev(), s, hB, mB, lB, hA, mA, lA);
-      emit(wide_c, (s0 + s) * 1024, hB, mB, lB);
-      flush((s0 + s) * 1024);
+    auto last = [&](int sl, const v16i &h_, const v16i &m_, const v16i &l_) {
+      emit(wide_c, (s0 + sl) * 1024, h_, m_, l_);
+      flush((s0 + sl) * 1024);
+    };
+    if constexpr (!RINGED) {
+      for (; s + 1 < nsteps; s += 2) {
+        run_step(wide_c, P1(), WithPrev(), s, hB, mB, lB, hA, mA, lA);
+        run_step(wide_c, P0(), WithPrev(), s + 1, hA, mA, lA, hB, mB, lB);
+      }
+      if (s < nsteps) {
+        run_step(wide_c, P1(), WithPrev(), s, hB, mB, lB, hA, mA, lA);
+        last(s, hB, mB, lB);
+      } else {
+        last(s - 1, hA, mA, lA);
+      }
     } else {
-      emit(wide_c, (s0 + s - 1) * 1024, hA, mA, lA);
-      flush((s0 + s - 1) * 1024);
+      for (; s + 3 < nsteps; s += 4) {      // ring parity = s % 4, accumulator set = s % 2
+        run_step(wide_c, P1(), WithPrev(), s, hB, mB, lB, hA, mA, lA);
+        run_step(wide_c, P2(), WithPrev(), s + 1, hA, mA, lA, hB, mB, lB);
+        run_step(wide_c, P3(), WithPrev(), s + 2, hB, mB, lB, hA, mA, lA);
+        run_step(wide_c, P0(), WithPrev(), s + 3, hA, mA, lA, hB, mB, lB);
+      }
+      if (s < nsteps) {                     // up to three more steps; each arm ends with the write-out of its own last step
+        run_step(wide_c, P1(), WithPrev(), s, hB, mB, lB, hA, mA, lA);
+        if (s + 1 < nsteps) {
+          run_step(wide_c, P2(), WithPrev(), s + 1, hA, mA, lA, hB, mB, lB);
+          if (s + 2 < nsteps) {
+            run_step(wide_c, P3(), WithPrev(), s + 2, hB, mB, lB, hA, mA, lA);
+            last(s + 2, hB, mB, lB);
+          } else {
+            last(s + 1, hA, mA, lA);
+          }
+        } else {
+          last(s, hB, mB, lB);
+        }
+      } else {
+        last(s - 1, hA, mA, lA);
+      }
     }
   };
   if (EPI == 3 || rs <= 16) { go(integral_constant<bool, false>()); }
@@ -660,7 +731,10 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
 template <int NB, int EPI, int HS, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES, kOccupancy)
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (2 * 4 * staged_array_bytes(32 + NB - 1) + (EPI == 3 ? 8192 : 2048)) + 1024];
+  // WAVES == 1: the pipelined body keeps a 4-step ring of staged planes (4 arrays of 128 + NB - 1 slots), the plain body two windows
+  constexpr int kStaged = (WAVES == 1 && EPI != 0 && EPI != 3 && 4 * staged_array_bytes(128 + NB - 1) > 2 * 4 * staged_array_bytes(32 + NB - 1))
+                              ? 4 * staged_array_bytes(128 + NB - 1) : 2 * 4 * staged_array_bytes(32 + NB - 1);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * (kStaged + (EPI == 3 ? 8192 : 2048)) + 1024];
   const int64_t s0 = (int64_t)blockIdx.x * a.steps_per_wave;
   const int64_t s1 = (s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps;
   // (a lone first step has no in-row window to park the unused prefetch on: see issue_loads_in)
