@@ -622,7 +622,13 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     hh = (v16i){0}; mid = (v16i){0}; ll = ll_init;
     // side work, spread over the first groups: S = stage step s+1, L = fetch step s+2, E1 = epilogue of step
     // s-1 into the LDS tile, E2 = its write-out
-    constexpr int gS = 0, gL = (NG > 1) ? 1 : 0, gE1 = (NG > 1) ? 1 : 0, gE2 = (NG > 2) ? 2 : NG - 1;
+#if defined(ACDSP_GE1)   // A/B builds: where the side work sits among the MFMA groups
+    constexpr int gS = ACDSP_PGS < NG ? ACDSP_PGS : NG - 1, gL = ACDSP_PGL < NG ? ACDSP_PGL : NG - 1, gE1 = ACDSP_GE1 < NG ? ACDSP_GE1 : NG - 1, gE2 = ACDSP_GE2 < NG ? ACDSP_GE2 : NG - 1;
+#else
+    // loads first (longest latency), the epilogue under the widest MFMA groups: same-box A/B of seven placements in
+    // profiles/r2_ab_place.txt (round-2 start: L 1, E1 1, E2 2; this one -1.3 % on config 2, -0.6 % dense, -0.5 % wide)
+    constexpr int gS = 0, gL = 0, gE1 = (NG > 2) ? 2 : NG - 1, gE2 = (NG > 3) ? 3 : NG - 1;
+#endif
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       __builtin_amdgcn_sched_barrier(0);
