@@ -543,7 +543,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   // epilogue of a finished step: 16 outputs per lane -> packed int16 -> swizzled 2 KB LDS tile (fir_mfma_body)
   int64_t *yout64 = (int64_t *)p.y + (int64_t)ch * p.out_stride;
   const int e3_sr = rs > 0 ? rs : 0, e3_wl = 64 - p.out.W, e3_sl = (rs < 0 ? -rs : 0) + e3_wl;
-  auto emit = [&](auto wide_c, int64_t T0, const v16i &hh, const v16i &mid, const v16i &ll) {
+  auto emit = [&](auto wide_c, int64_t T0, const v16i &hh, const v16i &mid, const v16i &ll, int prsel = 2) {
     if constexpr (EPI == 3) {
       // y = wrap_W((V + rnd) >> rs) (or V << -rs), V = 2^16 hh + 2^8 mid + ll.  The 1024 outputs of the step form an
       // 8 KB tile of 16-byte slots (slot = 16 n + 4 g + 2 h + half), XOR-swizzled with the column so that both the
@@ -586,6 +586,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     }
 #pragma unroll
     for (int pr = 0; pr < 2; pr++) {
+      if (prsel != 2 && prsel != pr) { continue; }
       const auto a0 = __builtin_amdgcn_permlane32_swap(d[2 * pr][0], d[2 * pr + 1][0], false, false);
       const auto a1 = __builtin_amdgcn_permlane32_swap(d[2 * pr][1], d[2 * pr + 1][1], false, false);
       const int P = 4 * n_col + 2 * pr + h;
@@ -622,13 +623,12 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     hh = (v16i){0}; mid = (v16i){0}; ll = ll_init;
     // side work, spread over the first groups: S = stage step s+1, L = fetch step s+2, E1 = epilogue of step
     // s-1 into the LDS tile, E2 = its write-out
-#if defined(ACDSP_GE1)   // A/B builds: where the side work sits among the MFMA groups
-    constexpr int gS = ACDSP_PGS < NG ? ACDSP_PGS : NG - 1, gL = ACDSP_PGL < NG ? ACDSP_PGL : NG - 1, gE1 = ACDSP_GE1 < NG ? ACDSP_GE1 : NG - 1, gE2 = ACDSP_GE2 < NG ? ACDSP_GE2 : NG - 1;
-#else
     // loads first (longest latency), the epilogue under the widest MFMA groups: same-box A/B of seven placements in
-    // profiles/r2_ab_place.txt (round-2 start: L 1, E1 1, E2 2; this one -1.3 % on config 2, -0.6 % dense, -0.5 % wide)
-    constexpr int gS = 0, gL = 0, gE1 = (NG > 2) ? 2 : NG - 1, gE2 = (NG > 3) ? 3 : NG - 1;
-#endif
+    // profiles/r2_ab_place.txt (round-2 start: L 1, E1 1, E2 2; this one -1.3 % on config 2, -0.6 % dense, -0.5 % wide).
+    // With five or more groups the int16 epilogue is split over two of them (halves of the tile), write-out one group
+    // later: another -0.9 % (profiles/r2_ab_place.txt, last section).
+    constexpr bool kSplitEmit = NG > 4 && EPI != 3;
+    constexpr int gS = 0, gL = 0, gE1 = (NG > 2) ? 2 : NG - 1, gE2 = kSplitEmit ? 4 : ((NG > 3) ? 3 : NG - 1);
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       __builtin_amdgcn_sched_barrier(0);
@@ -653,7 +653,10 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       if (g == gL) { issue_loads_new(T0 + 2048); }
 #endif
 #ifndef ACDSP_ABL_EMIT
-      if (PREV && g == gE1) { emit(wide_c, T0 - 1024, ph, pm, pl); }
+      if (PREV && kSplitEmit) {
+        if (g == gE1) { emit(wide_c, T0 - 1024, ph, pm, pl, 0); }
+        if (g == gE1 + 1) { emit(wide_c, T0 - 1024, ph, pm, pl, 1); }
+      } else if (PREV && g == gE1) { emit(wide_c, T0 - 1024, ph, pm, pl); }
 #else
       if (PREV && g == gE1) { asm volatile("" :: "v"(ph[0]), "v"(pm[0]), "v"(pl[0])); }   // keeps the MFMAs of the step alive
 #endif
