@@ -153,6 +153,10 @@ __device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16
 #ifndef ACDSP_OCC
 #define ACDSP_OCC 2
 #endif
+// non-temporal accesses of the pipelined body (A/B knob): bit 0 = ring loads, bit 1 = int16 tile stores, bit 2 = wide tile stores
+#ifndef ACDSP_FIR_NT
+#define ACDSP_FIR_NT 7
+#endif
 constexpr int kGroupSize = ACDSP_GS, kOccupancy = ACDSP_OCC;
 
 // EPI 0: any OUT_TYPE / ACC width through requant64.
@@ -458,7 +462,13 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     if constexpr (RINGED) {
       const char *sb = (const char *)(xrow + (T0 < tl ? T0 : tl));
 #pragma unroll
-      for (int j = 0; j < 2; j++) { Q[j] = *(const v4i *)(sb + (unsigned)(16 * (lane + 64 * j))); }
+      for (int j = 0; j < 2; j++) {
+#if ACDSP_FIR_NT & 1   // the ring reads every input byte once: non-temporal loads and stores -2.4 % same box (profiles/r2_ab_nt.txt)
+        Q[j] = __builtin_nontemporal_load((const v4i *)(sb + (unsigned)(16 * (lane + 64 * j))));
+#else
+        Q[j] = *(const v4i *)(sb + (unsigned)(16 * (lane + 64 * j)));
+#endif
+      }
     } else {                                   // the whole window of that step (see fir_mfma_body)
       const char *sb = (const char *)(xrow + ((T0 < tl ? T0 : tl) - 32 * HB));
 #pragma unroll
@@ -600,7 +610,11 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       for (int k = 0; k < 8; k++) {
         const int P = 64 * k + lane;
         const v4i val = *(const v4i *)(obuf + (P ^ ((P >> 4) & 15)) * 16);
+#if ACDSP_FIR_NT & 4
+        __builtin_nontemporal_store(val, (v4i *)((char *)(yout64 + T0) + (unsigned)(16 * P)));
+#else
         *(v4i *)((char *)(yout64 + T0) + (unsigned)(16 * P)) = val;
+#endif
       }
       return;
     }
@@ -608,7 +622,11 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     for (int half = 0; half < 2; half++) {
       const int P = 64 * half + lane;
       const v4i val = *(const v4i *)(obuf + (P ^ ((P >> 3) & 3)) * 16);
+#if ACDSP_FIR_NT & 2
+      __builtin_nontemporal_store(val, (v4i *)(yout + T0 + 512 * half + 8 * lane));
+#else
       *(v4i *)(yout + T0 + 512 * half + 8 * lane) = val;
+#endif
     }
   };
 
