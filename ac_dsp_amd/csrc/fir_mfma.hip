@@ -153,9 +153,10 @@ __device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16
 #ifndef ACDSP_OCC
 #define ACDSP_OCC 2
 #endif
-// non-temporal accesses of the pipelined body (A/B knob): bit 0 = ring loads, bit 1 = int16 tile stores, bit 2 = wide tile stores
+// non-temporal accesses (A/B knob): bit 0 = ring loads, bit 1 = int16 tile stores, bit 2 = wide tile stores of the pipelined body,
+// bit 3 = stores of the double-wide 1023-tap kernel
 #ifndef ACDSP_FIR_NT
-#define ACDSP_FIR_NT 7
+#define ACDSP_FIR_NT 15
 #endif
 constexpr int kGroupSize = ACDSP_GS, kOccupancy = ACDSP_OCC;
 
@@ -1124,7 +1125,11 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
     for (int q = 0; q < 4; q++) {   // 4 KB contiguous: four coalesced 16-byte-per-lane stores
       const int P = 64 * (q & 1) + lane;
       const v4i val = *(const v4i *)(obuf + 2048 * (q >> 1) + ((P & ~15) | ((P + (P >> 4)) & 15)) * 16);
+#if ACDSP_FIR_NT & 8   // -0.4 % same box (profiles/r2_ab_nt.txt)
+      __builtin_nontemporal_store(val, (v4i *)(yout + T0 + 512 * q + 8 * lane));
+#else
       *(v4i *)(yout + T0 + 512 * q + 8 * lane) = val;
+#endif
     }
     if (s + 1 < nsteps) {
       stage();
