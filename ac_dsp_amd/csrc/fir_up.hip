@@ -181,7 +181,11 @@ __global__ void __launch_bounds__(64, (PX * NBT >= 4 ? 2 : 3)) fir_up_kernel(UpA
 #ifdef UP_ABLATE_STORES
       if (a.n_steps < 0)
 #endif
+#if defined(ACDSP_UP_NT) && ACDSP_UP_NT   // A/B knob: the interpolated stream is written once and not read back by this kernel
+      __builtin_nontemporal_store(val, (long *)(yrow + e_unit * OEB + lin));
+#else
       *(long *)(yrow + e_unit * OEB + lin) = val;
+#endif
     }
   };
   // One step.  VMEM program order: [wait for this step's samples] -> loads of the step AHEAD later -> the stores of this step.
