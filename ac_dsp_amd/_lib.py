@@ -103,6 +103,7 @@ SYMBOLS = {
     "acdsp_fir_path": (_i32, [_vp]),
     "acdsp_fir_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "acdsp_fir_kernel_stats": (_i32, [_vp, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "acdsp_fir_mfma_issued": (_i32, [_vp, C.POINTER(C.c_int32)]),
     "acdsp_cic_create": (_i32, [C.POINTER(CicDesc), C.POINTER(_vp)]),
     "acdsp_cic_destroy": (_i32, [_vp]),
     "acdsp_cic_clone": (_i32, [_vp, C.POINTER(_vp)]),

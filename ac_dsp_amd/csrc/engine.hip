@@ -331,7 +331,8 @@ int fir_validate(const acdsp_fir_desc_t &d) {
                     : "FOLD_*_ANTI: the reference run() has no branch for these (output is an unassigned value)");
   }
   if (d.n_taps < 1 || d.n_taps > 2048) { return fail(ACDSP_EUNSUPPORTED, "n_taps=%d outside 1..2048", d.n_taps); }
-  if (d.n_channels < 1 || d.n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", d.n_channels); }
+  if (d.n_channels < 1) { return fail(ACDSP_EINVAL, "n_channels=%d must be positive", d.n_channels); }
+  if (d.n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", d.n_channels); }
   int rc;
   if ((rc = check_fmt(d.in, "IN_TYPE")) || (rc = check_fmt(d.coeff, "COEFF_TYPE")) || (rc = check_fmt(d.acc, "ACC_TYPE")) ||
       (rc = check_fmt(d.out, "OUT_TYPE"))) {
@@ -613,6 +614,21 @@ int32_t acdsp_fir_kernel_stats(acdsp_fir_t h, int32_t last_k, float *avg_ms, flo
   return h->tm.stats(last_k, avg_ms, min_ms);
 }
 
+int32_t acdsp_fir_mfma_issued(acdsp_fir_t h, int32_t *per_1024_samples) {
+  if (!h || !per_1024_samples) { return fail(ACDSP_EINVAL, "null argument"); }
+  if (!h->coeffs_set) { return fail(ACDSP_ESTATE, "acdsp_fir_mfma_issued before acdsp_fir_set_coeffs"); }
+  *per_1024_samples = 0;
+  if (h->path == ACDSP_PATH_MFMA_I8) {
+    const acdsp_fir_desc_t &d = h->d;
+    FirParams k;
+    memset(&k, 0, sizeof k);
+    k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+    k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
+    *per_1024_samples = fir_mfma_issued_per_step(k, h->plan);
+  }
+  return ACDSP_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
@@ -663,7 +679,8 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
   if (desc->R > 256) { return fail(ACDSP_EUNSUPPORTED, "CIC: R=%d > 256 (8-bit rate counter in the reference)", desc->R); }
   if (desc->interp && desc->R < 2) { return fail(ACDSP_EUNSUPPORTED, "CIC interpolator: R=1 never re-arms in the reference (ac_cic_full_core.h:146-158)"); }
   if (desc->interp && desc->N > 255) { return fail(ACDSP_EUNSUPPORTED, "CIC: N too large"); }
-  if (desc->n_channels < 1 || desc->n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "CIC: n_channels=%d outside 1..65535", desc->n_channels); }
+  if (desc->n_channels < 1) { return fail(ACDSP_EINVAL, "CIC: n_channels=%d must be positive", desc->n_channels); }
+  if (desc->n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "CIC: n_channels=%d outside 1..65535", desc->n_channels); }
   if ((rc = check_device(desc->device))) { return rc; }
   acdsp_cic *h = new acdsp_cic();
   h->d = *desc;
@@ -961,7 +978,8 @@ int32_t acdsp_polydec_create(const acdsp_polydec_desc_t *desc, acdsp_polydec_t *
   if (desc->n_taps < 1 || desc->df < 1 || (int64_t)desc->n_taps * desc->df > 2048) {
     return fail(ACDSP_EUNSUPPORTED, "poly_dec: NTAPS*DF = %lld outside 1..2048", (long long)desc->n_taps * desc->df);
   }
-  if (desc->n_channels < 1 || desc->n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", desc->n_channels); }
+  if (desc->n_channels < 1) { return fail(ACDSP_EINVAL, "n_channels=%d must be positive", desc->n_channels); }
+  if (desc->n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", desc->n_channels); }
   int rc;
   if ((rc = check_fmt(desc->in, "IN_TYPE")) || (rc = check_fmt(desc->coeff, "COEFF_TYPE")) || (rc = check_fmt(desc->acc, "ACC_TYPE")) ||
       (rc = check_fmt(desc->out, "OUT_TYPE"))) {
@@ -1403,7 +1421,8 @@ int32_t acdsp_polyintr_create(const acdsp_polyintr_desc_t *desc, acdsp_polyintr_
   if (d.n_taps < 1 || d.n_taps > 2048) { return fail(ACDSP_EUNSUPPORTED, "NTAPS=%d outside 1..2048", d.n_taps); }
   if (d.ifac < 1 || d.ifac > 255) { return fail(ACDSP_EUNSUPPORTED, "IF=%d outside 1..255 (corr[] is ac_int<8,false>)", d.ifac); }
   if (d.coeff_sz < 1 || d.coeff_sz > (1 << 20)) { return fail(ACDSP_EUNSUPPORTED, "COEFFSZ=%d outside 1..2^20", d.coeff_sz); }
-  if (d.n_channels < 1 || d.n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", d.n_channels); }
+  if (d.n_channels < 1) { return fail(ACDSP_EINVAL, "n_channels=%d must be positive", d.n_channels); }
+  if (d.n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", d.n_channels); }
   int rc;
   if ((rc = check_fmt(d.in, "IN_TYPE")) || (rc = check_fmt(d.coeff, "COEFF_TYPE")) || (rc = check_fmt(d.acc, "ACC_TYPE")) ||
       (rc = check_fmt(d.out, "OUT_TYPE"))) {
@@ -1569,6 +1588,7 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
   } else {
     e = launch_polyintr(p, h->d_saved[h->cur ^ 1], s);
   }
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_intr kernel launch failed: %s", hipGetErrorString(e)); }
   FirParams k;
   memset(&k, 0, sizeof k);
   k.n_ch = d.n_channels; k.in = p.in; k.in_eb = h->in_eb; k.hl = h->hl; k.in_stride = in_stride; k.n = n_in; k.x = d_in; k.hist = p.hist;
@@ -1664,7 +1684,8 @@ int32_t acdsp_intgdump_create(const acdsp_intgdump_desc_t *desc, acdsp_intgdump_
   const acdsp_intgdump_desc_t &d = *desc;
   if (d.ns < 1 || d.ns > (1 << 24)) { return fail(ACDSP_EUNSUPPORTED, "NS=%d outside 1..2^24", d.ns); }
   if (d.chn < 1 || d.chn > 4096) { return fail(ACDSP_EUNSUPPORTED, "CHN=%d outside 1..4096", d.chn); }
-  if (d.n_objects < 1 || d.n_objects > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_objects=%d outside 1..65535", d.n_objects); }
+  if (d.n_objects < 1) { return fail(ACDSP_EINVAL, "n_objects=%d must be positive", d.n_objects); }
+  if (d.n_objects > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_objects=%d outside 1..65535", d.n_objects); }
   int rc;
   if ((rc = check_fmt(d.in, "IN_TYPE")) || (rc = check_fmt(d.acc, "ACC_TYPE")) || (rc = check_fmt(d.out, "OUT_TYPE"))) { return rc; }
   if ((rc = check_device(d.device))) { return rc; }

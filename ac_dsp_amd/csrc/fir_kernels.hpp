@@ -46,6 +46,7 @@ int fir_mfma_max_blocks();       // K-blocks the MFMA path can take at all (A fr
 int fir_mfma_max_reg_blocks();   // ... with the A fragments register-resident (needed for per-channel coefficient sets): 9
 // One wave = one channel x a time chunk; fragments and corr are per coefficient set:
 // d_frag[n_sets][2][nb][64][4], d_corr[n_sets]; `plan` carries the worst-case bounds over all sets.
+int fir_mfma_issued_per_step(const FirParams &p, const FirMfmaPlan &plan);
 hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag_per_channel, const uint32_t *d_frag,
                            const int64_t *d_corr, hipStream_t s);
 

@@ -1218,6 +1218,27 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
 
 static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s);
 
+// 32x32x32 int8 MFMAs the selected kernel issues per 1024 samples of one channel: two low-plane products per K-block plus two
+// high-plane products per K-block of the instantiated band (the honest numerator of an MFMA-utilisation figure; the dense
+// formulation would be 4 * nb).
+int fir_mfma_issued_per_step(const FirParams &p, const FirMfmaPlan &plan) {
+  const int epi = fir_mfma_epilogue_class(p, plan), nb = plan.nb;
+  int band = nb;
+  if (nb <= kMaxRegNB) {
+    const int hs = epi ? pick_hs(nb, plan.hi_mask) : 0;
+    band = nb - (hs & 15) - (hs >> 4);
+  } else if (epi) {
+    int b0 = 0, b1 = nb - 1;
+    if (plan.hi_mask == 0) { band = 0; }
+    else {
+      while (!((plan.hi_mask >> b0) & 1)) { b0++; }
+      while (!((plan.hi_mask >> b1) & 1)) { b1--; }
+      band = b1 - b0 + 1;
+    }
+  }
+  return 2 * nb + 2 * band;
+}
+
 hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag_per_channel, const uint32_t *d_frag,
                            const int64_t *d_corr, hipStream_t s) {
   if (p.n <= 0) { return hipSuccess; }
@@ -1271,6 +1292,7 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
 static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   if (nb > kMaxRegNB) { return launch_big(p, d_frag, a, epi, grid, s); }
   switch (nb) {
+#ifndef ACDSP_FIR_DEV_NB9   // development builds: only the 255-tap shape (compile time 3 min -> 35 s)
     case 1: return launch_nb<1>(p, d_frag, a, epi, grid, s);
     case 2: return launch_nb<2>(p, d_frag, a, epi, grid, s);
     case 3: return launch_nb<3>(p, d_frag, a, epi, grid, s);
@@ -1279,6 +1301,7 @@ static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_fr
     case 6: return launch_nb<6>(p, d_frag, a, epi, grid, s);
     case 7: return launch_nb<7>(p, d_frag, a, epi, grid, s);
     case 8: return launch_nb<8>(p, d_frag, a, epi, grid, s);
+#endif
     case 9: return launch_nb<9>(p, d_frag, a, epi, grid, s);
     default: return hipErrorInvalidValue;
   }

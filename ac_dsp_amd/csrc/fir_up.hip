@@ -462,9 +462,8 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
       if (!so) { a.e_mask = (uint64_t)(~uint32_t(0) >> (64 - wo)); }
     }
   }
-  // >= ~8192 waves when the problem allows it
   static const char *spw_env = getenv("ACDSP_UP_SPW");   // tuning knob: 512-sample steps per wave
-  int64_t spw = (n_steps * p.n_ch + 8191) / 8192;
+  int64_t spw = 4;                            // short spans, dispatched in memory order (see launch_fir_gen); 1 step: the prologue dominates
   if (spw_env && atoi(spw_env) > 0) { spw = atoi(spw_env); }
   if (spw < 1) { spw = 1; }
   a.steps_per_wave = spw;

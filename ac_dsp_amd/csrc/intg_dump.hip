@@ -429,7 +429,8 @@ static bool make_conv(const IntgDumpParams &p, IdConv &cv) {
   if (p.out.O == ACDSP_SAT) { cv.lo = p.out.lo; cv.hi = p.out.hi; cv.ko = 0; cv.om = ~uint64_t(0); }
   else { cv.lo = INT64_MIN; cv.hi = INT64_MAX; cv.ko = 64 - p.out.W; cv.om = p.out.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.out.W)); }
   cv.ok = (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && p.acc.W <= 61 && cv.rs <= 60 &&
-          p.acc.W + cv.ls2 <= 61 && p.out.W <= 62;               // neither the rounding add nor the left shift can leave int64
+          p.acc.W + cv.ls2 <= 61 && p.out.W <= 62 &&              // neither the rounding add nor the left shift can leave int64
+          cv.sh >= 0 && cv.sh + cv.ka < 64;                       // the IN -> ACC cast `<< (sh + ka)` stays a defined shift (else: tiled kernel)
   return cv.ok != 0;
 }
 
@@ -467,8 +468,8 @@ static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
   if (!no_batch && p.in_eb == 2 && lpr == 1 && gs >= 8 && (p.chn == 1 || p.chn == 2 || p.chn == 4)) {
     IdConv cv;
     if (!make_conv(p, cv)) { return false; }
-    // 16 KB per wave (multiples of the 8-load batch; 8 / 16 measured alike, 32 and 64 slower by 8 - 12 %), >= ~16 K waves when the problem allows it
-    int64_t lpw = 16;
+    // 8 KB per wave (one 8-load batch; 8: 0.361 ms, 16: 0.373, 32: 0.375 on the bench row, profiles/r3_span_sweep.txt)
+    int64_t lpw = 8;
     while (lpw > 8 && (n_reds / lpw) * p.n_obj < 16384) { lpw /= 2; }
     static const char *lpw_env = getenv("ACDSP_INTG_RPW");
     if (lpw_env && atoi(lpw_env) > 0) { lpw = (atoi(lpw_env) + 7) / 8 * 8; }

@@ -103,6 +103,12 @@ class Fir:
         check(lib.acdsp_fir_kernel_stats(self._h, last_k, C.byref(a), C.byref(m)))
         return a.value, m.value
 
+    def mfma_issued(self):
+        """32x32x32 int8 MFMAs the selected kernel issues per 1024 samples of one channel (0 off the int8 matrix-core path)."""
+        v = C.c_int32()
+        check(lib.acdsp_fir_mfma_issued(self._h, C.byref(v)))
+        return v.value
+
     def close(self):
         if getattr(self, "_h", None):
             lib.acdsp_fir_destroy(self._h)

@@ -98,7 +98,8 @@ def build_workload(workload, args, world, rank, local_rank):
         A.fill_stimulus(x, seed, args.stim_bits or 16, ch0=lo)
         y = torch.empty((hi - lo, n + args.pad), dtype=A.torch_dtype_for(fo), device=dev)[:, :n]
         bytes_per_sample = 2.0 + y.element_size()  # 2 B read + 2 B (8 B for the wide row) written
-        macs_per_sample = 4.0 * 32 * eng_nb(n_taps)  # int8 MACs issued: 4 byte-plane products x padded band
+        macs_per_sample = 4.0 * 32 * eng_nb(n_taps)  # int8 MACs of the DENSE 4-byte-plane Toeplitz formulation (32 MAC per MFMA and sample)
+        issued_macs_per_sample = 32.0 * eng.mfma_issued()   # ... and of the MFMAs the selected kernel really issues (zero blocks skipped)
         name = "ac_fir_load_coeffs 255-tap ac_fixed<16,2> -> <16,2,RND,SAT>, ACC <40,12>, %d ch x %d samples per GPU " \
                "(BASELINE configs[1])" % (ch_per_gpu, n)
         if workload == "fir255_wide":
@@ -270,15 +271,17 @@ def build_workload(workload, args, world, rank, local_rank):
         path = "cic_dec"
         samples_per_step = (hi - lo) * n
 
+    if not macs_per_sample:
+        issued_macs_per_sample = 0.0
     return {"workload": workload, "name": name, "dtype": dtype, "step": step, "path": path, "samples_per_step": samples_per_step,
-            "bytes_per_sample": bytes_per_sample, "macs_per_sample": macs_per_sample, "coeffs": coeffs, "eng": eng, "x": x, "n": n,
+            "bytes_per_sample": bytes_per_sample, "macs_per_sample": macs_per_sample, "issued_macs_per_sample": issued_macs_per_sample, "coeffs": coeffs, "eng": eng, "x": x, "n": n,
             "ch_per_gpu": ch_per_gpu, "n_taps": n_taps, "fmts": (fin, fc, fa, fo), "seed": seed}
 
 
 def settle_clocks(step, seconds):
     """Untimed pre-conditioning, reported in the JSON line as `clock_settle`: the same step in a loop for `seconds` of wall
     time BEFORE the W warm-up steps.  The part idles at ~100 MHz and its power management needs 20 - 40 ms of this load to
-    settle the shader clock (tools/dbg/ramp.py: the first 20 steps from idle average 1.42 ms, every later block of 20 steps
+    settle the shader clock (tools/clock_ramp.py: the first 20 steps from idle average 1.42 ms, every later block of 20 steps
     1.00 ms); W = 3 .. 5 warm-up steps end inside that ramp, so without this the K timed steps measure the DVFS transient of
     a cold start instead of the streaming engine.  Nothing inside the timed region changes.  Returns the steps run."""
     n = 0
@@ -343,10 +346,13 @@ def roofline_of(w, k_avg, k_min, ev_ms):
 
 
 def mfma_roofline_of(w, k_avg):
-    tops = 2.0 * w["macs_per_sample"] * w["samples_per_step"] / (k_avg * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": tops, "peak": I8_MFMA_PEAK_TOPS,
-            "unit": "TOP/s (int8 ops of the dense 4-byte-plane Toeplitz formulation; all-zero high-byte blocks of the "
-                    "coefficient set are skipped, so fewer are issued)", "frac": tops / I8_MFMA_PEAK_TOPS}
+    """Matrix-pipe utilisation from the MFMAs the kernel ISSUES (acdsp_fir_mfma_issued: all-zero high-byte Toeplitz blocks are
+    skipped); the figure of the dense 4-plane formulation is kept beside it, labelled."""
+    tops = 2.0 * w["issued_macs_per_sample"] * w["samples_per_step"] / (k_avg * 1e-3) / 1e12
+    dense = 2.0 * w["macs_per_sample"] * w["samples_per_step"] / (k_avg * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8 ops of the 32x32x32 MFMAs issued)",
+            "frac": tops / I8_MFMA_PEAK_TOPS, "mfma_per_1024_samples": w["issued_macs_per_sample"] / 32.0,
+            "dense_formulation": {"mfma_per_1024_samples": w["macs_per_sample"] / 32.0, "achieved": dense, "frac": dense / I8_MFMA_PEAK_TOPS}}
 
 
 # every other workload, measured in the same process after the headline (N = 1 only): the other BASELINE configurations
@@ -370,6 +376,8 @@ def main():
                     "(shader-clock ramp from idle; 0 = cold start, the K timed steps then include the DVFS transient)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -383,7 +391,10 @@ def main():
         # The timing contract (barrier, MAX of the times, SUM of the samples) runs over gloo on host scalars.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
-    assert world == args.gpus or world == 1, "launch one process per GPU"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one process per GPU; without a launcher bench.py spawns the ranks itself)" % (args.gpus, world))
+    if not os.environ.get("ACDSP_BENCH_ONE_GPU") and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
 
     w = build_workload(args.workload, args, world, rank, local_rank)
 
@@ -391,6 +402,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    cold = None
+    if args.settle > 0 and world == 1:
+        # the same W + K steps from an idle GPU first (what `--settle 0` prints as the headline): the DVFS transient of a cold start
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        cdt, ck, _, _ = measure(w, args.steps, args.warmup, barrier, 0.0)
+        cold = {"ms_per_step": cdt / args.steps * 1e3, "value": w["samples_per_step"] * args.steps / cdt / 1e6, "kernel_ms_avg": ck,
+                "roofline_frac": w["bytes_per_sample"] * w["samples_per_step"] / (ck * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "same W warm-up + K timed steps started 1 s after the GPU went idle, no pre-conditioning"}
     dt, k_avg, k_min, ev_ms = measure(w, args.steps, args.warmup, barrier, args.settle)
     samples_per_step = w["samples_per_step"]
     if world > 1:
@@ -417,6 +437,8 @@ def main():
                              "note": "untimed pre-conditioning in front of the W warm-up steps (same step, same data): the shader clock needs "
                                      "20-40 ms of load to settle from idle; --settle 0 measures the cold-start transient instead"},
         }
+        if cold is not None:
+            out["cold_start"] = cold
         if w["macs_per_sample"]:
             out["mfma_roofline"] = mfma_roofline_of(w, k_avg)
         fin, fc, fa, fo = w["fmts"]
@@ -436,17 +458,69 @@ def main():
                              "Msamples_per_s": w2["samples_per_step"] * 10 / dt2 / 1e6, "kernel_ms_avg": ka2,
                              "roofline_frac": r2["frac"], "roofline_frac_step": r2["frac_step"], "achieved_GBps": r2["achieved"]}
                 if w2["macs_per_sample"]:
-                    sec[name]["mfma_frac"] = mfma_roofline_of(w2, ka2)["frac"]
+                    m2 = mfma_roofline_of(w2, ka2)
+                    sec[name]["mfma_frac"] = m2["frac"]
+                    sec[name]["mfma_per_1024_samples"] = m2["mfma_per_1024_samples"]
                 del w2
                 torch.cuda.empty_cache()
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and cpu_args[1] is not None:
             out["cpu_baseline"] = cpu_baseline_fir(*cpu_args)
+            if args.workload in ("fir255", "fir255_dense"):
+                ref = cpu_baseline_ref_headers()
+                if ref is not None:
+                    out["cpu_baseline_ref_headers"] = ref
         elif world == 1 and not args.no_cpu_baseline and args.workload == "cic_dec":
             out["cpu_baseline"] = cpu_baseline_cic(fin, fo, cpu_args[6])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher (no WORLD_SIZE in the environment): spawn the N ranks -- one process per GPU,
+    the same environment a `torch.distributed.run --nproc-per-node N` launch gives them -- and wait.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    return rc
+
+
+def cpu_baseline_ref_headers():
+    """The reference's own header-only loop (ac_fir_load_coeffs::run -> firShiftReg + MAC, /root/reference/include/ac_dsp/
+    ac_fir_load_coeffs.h:180-188,320-365) timed on this node's host cores: tests/_bin/cref_bench is prebuilt by
+    __graft_entry__.build() in the build container from tools/gen_golden/cref_bench.cpp (the reference's headers compiled where they
+    lie over this repo's include/ac_types subset -- hlslibs/ac_types is not in the image, so this times the reference's loop
+    structure and ac_channel traffic, not Siemens' ac_int arithmetic).  Only the binary travels.  None when it is missing."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "_bin", "cref_bench")
+    if not os.path.isfile(exe):
+        return None
+    cores = host_cores()
+    try:
+        n = 65536
+        out = subprocess.run([exe, str(cores), str(n), "fir"], capture_output=True, text=True, timeout=120).stdout
+        f = [l for l in out.splitlines() if l.startswith("CREF fir")][0].split()
+        if float(f[5]) < 2.0:          # scale the sample to ~8 s of wall time
+            n = int(min(4 << 20, n * 8.0 / max(float(f[5]), 1e-3)))
+            out = subprocess.run([exe, str(cores), str(n), "fir"], capture_output=True, text=True, timeout=300).stdout
+            f = [l for l in out.splitlines() if l.startswith("CREF fir")][0].split()
+        return {"value": float(f[2]), "unit": "Msamples/s", "cores": int(f[3]), "kind": "reference-headers-over-own-ac_types",
+                "sample": "%s filter objects (one per thread) x %s samples of the 255-tap ac_fir_load_coeffs workload (IN/COEFF <16,2>, ACC <40,12>, "
+                          "OUT <16,2,RND,SAT>, SHIFT_REG), %s s wall; g++ -O2 -std=c++11" % (f[3], f[4], f[5])}
+    except (OSError, IndexError, ValueError, subprocess.SubprocessError) as e:
+        return {"error": repr(e), "kind": "reference-headers-over-own-ac_types"}
 
 
 def host_cores():

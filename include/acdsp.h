@@ -194,6 +194,10 @@ int32_t acdsp_fir_path(acdsp_fir_t h);         /* ACDSP_PATH_* chosen for the cu
 int32_t acdsp_fir_last_kernel_ms(acdsp_fir_t h, float *ms);
 /* Average / minimum main-kernel duration over the last `last_k` (<= 64) run() calls. */
 int32_t acdsp_fir_kernel_stats(acdsp_fir_t h, int32_t last_k, float *avg_ms, float *min_ms);
+/* 32x32x32 int8 MFMA instructions the selected kernel issues per 1024 samples of one channel (0 when the current
+ * coefficients do not run on the int8 matrix-core path): the numerator of an MFMA-utilisation figure.  All-zero
+ * high-byte blocks of the coefficient set are not issued, so this is <= 4 * (ceil((n_taps - 1) / 32) + 1). */
+int32_t acdsp_fir_mfma_issued(acdsp_fir_t h, int32_t *per_1024_samples);
 
 /* ---- CIC ---- */
 int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out);

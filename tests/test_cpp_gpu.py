@@ -21,6 +21,12 @@ def run(exe):
     return p.returncode, p.stdout.decode(errors="replace")
 
 
+TBS = ("tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg")
+# tests/_bin arrived prebuilt (the snapshot of a build container that ran __graft_entry__.build()): then the reference's rtest_*
+# binaries must have arrived with it -- a lost binary is a failure there, not a skip
+PREBUILT = all(os.path.exists(os.path.join(BIN, t)) for t in TBS)
+
+
 @pytest.fixture(scope="module", autouse=True)
 def built():
     if not all(os.path.exists(os.path.join(BIN, t)) for t in ("tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg")):
@@ -38,6 +44,7 @@ def test_own_cpp_testbench(tb):
 def test_reference_rtest_binary_unchanged(name):
     exe = os.path.join(BIN, "rtest_" + name)
     if not os.path.exists(exe):
+        assert not PREBUILT, "tests/_bin holds prebuilt testbenches but %s is missing: __graft_entry__.build() did not run with /root/reference" % exe
         pytest.skip("rtest binary not prebuilt (needs /root/reference at build time)")
     rc, out = run(exe)
     assert rc == 0 and "PASSED" in out, out

@@ -1,13 +1,17 @@
 // cref_bench.cpp -- "C-ref" CPU baseline: the REFERENCE's own header-only path
 // (/root/reference/include/ac_dsp, compiled where it lies) over this repo's ac_types subset, one filter object per
 // channel, channels split over the host threads.  Build container only; the numbers go into BASELINE.md.
-//   cref_bench [threads=nproc] [samples per channel=16384]
+//   cref_bench [threads=nproc] [samples per channel=65536] [what: both | fir | cic]
+// Prebuilt by __graft_entry__.build() into tests/_bin/ (binary only: no reference source travels); bench.py runs `cref_bench T N fir`
+// on the GPU node's host cores and reports the "CREF fir <Msamples/s> <threads> <samples> <seconds>" line as
+// cpu_baseline_ref_headers (kind "reference-headers-over-own-ac_types").
 #include <ac_dsp/ac_fir_load_coeffs.h>
 #include <ac_dsp/ac_cic_dec_full.h>
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -35,8 +39,9 @@ struct CicJob { Cic cic; ac_channel<IN32> in; ac_channel<INT47> out; };
 int main(int argc, char **argv) {
   const int threads = argc > 1 ? atoi(argv[1]) : (int)std::thread::hardware_concurrency();
   const int n = argc > 2 ? atoi(argv[2]) : 65536;
+  const std::string what = argc > 3 ? argv[3] : "both";
   std::vector<long long> sink((size_t)threads, 0);
-  {   // BASELINE configs[1]: ac_fir_load_coeffs, 255 taps, SHIFT_REG; stimulus generation is outside the timed region
+  if (what != "cic") {   // BASELINE configs[1]: ac_fir_load_coeffs, 255 taps, SHIFT_REG; stimulus generation is outside the timed region
     std::vector<FirJob> jobs((size_t)threads);
     timed(threads, [&](int id) {
       uint64_t seed = 0xACD5 + id;
@@ -49,8 +54,9 @@ int main(int argc, char **argv) {
     for (int id = 0; id < threads; id++) { while (jobs[(size_t)id].out.available(1)) { sink[(size_t)id] += gg::raw(jobs[(size_t)id].out.read()); } }
     printf("C-ref ac_fir_load_coeffs 255 taps <16,2>, ACC <40,12>, SHIFT_REG: %d threads x %d samples in %.2f s = %.3f Msamples/s\n",
            threads, n, dt, (double)threads * n / dt / 1e6);
+    printf("CREF fir %.6f %d %d %.3f\n", (double)threads * n / dt / 1e6, threads, n, dt);
   }
-  {   // BASELINE configs[2]: ac_cic_dec_full N5 R8 M1 on <32,16>
+  if (what != "fir") {   // BASELINE configs[2]: ac_cic_dec_full N5 R8 M1 on <32,16>
     const int nc = n * 16;
     std::vector<CicJob> jobs((size_t)threads);
     timed(threads, [&](int id) {
@@ -61,6 +67,7 @@ int main(int argc, char **argv) {
     for (int id = 0; id < threads; id++) { while (jobs[(size_t)id].out.available(1)) { sink[(size_t)id] += gg::raw(jobs[(size_t)id].out.read()); } }
     printf("C-ref ac_cic_dec_full N5 R8 M1 <32,16> -> <47,31>: %d threads x %d samples in %.2f s = %.3f Msamples/s\n", threads, nc, dt,
            (double)threads * nc / dt / 1e6);
+    printf("CREF cic %.6f %d %d %.3f\n", (double)threads * nc / dt / 1e6, threads, nc, dt);
   }
   long long t = 0;
   for (long long v : sink) { t += v; }
