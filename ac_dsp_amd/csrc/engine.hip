@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "wide_kernels.hpp"
 #include "cic_kernels.hpp"
 #include "fir_kernels.hpp"
 
@@ -30,6 +31,14 @@ int fail(int code, const char *fmt, ...) {
   va_end(ap);
   g_err = buf;
   return code;
+}
+
+// Is `s` recording a HIP graph?  A replayed graph re-runs the kernels with the HOST-side bookkeeping of capture time baked into
+// their arguments (decimation / interpolation phase, "first call of the stream" special cases), so calls whose bookkeeping would
+// not return to the captured value are refused while capturing instead of replaying the wrong phase silently.
+static bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
 
 #define HIP_TRY(expr)                                                                                  \
@@ -65,16 +74,18 @@ int check_device(int device) {
   return ACDSP_OK;
 }
 
-int check_fmt(const acdsp_fmt_t &f, const char *name) {
-  if (f.W < 1 || f.W > 64) { return fail(ACDSP_EUNSUPPORTED, "%s: W=%d outside 1..64", name, f.W); }
-  if (!f.S && f.W > 63) { return fail(ACDSP_EUNSUPPORTED, "%s: unsigned W=64 not supported", name); }
+// max_w: 64 for IN / COEFF and every class without a wide path; 128 for ACC / OUT of the FIR classes and OUT of the CIC classes
+// (wide.hip).  Unsigned types of the full container width are not representable in the signed raw words and are refused.
+int check_fmt(const acdsp_fmt_t &f, const char *name, int max_w = 64) {
+  if (f.W < 1 || f.W > max_w) { return fail(ACDSP_EUNSUPPORTED, "%s: W=%d outside 1..%d", name, f.W, max_w); }
+  if (!f.S && (f.W == 64 || f.W == 128)) { return fail(ACDSP_EUNSUPPORTED, "%s: unsigned W=%d not supported", name, f.W); }
   if (f.Q < 0 || f.Q > ACDSP_RND_CONV_ODD) { return fail(ACDSP_EINVAL, "%s: bad Q mode %d", name, f.Q); }
   if (f.O < 0 || f.O > ACDSP_SAT_SYM) { return fail(ACDSP_EINVAL, "%s: bad O mode %d", name, f.O); }
   if (f.S != 0 && f.S != 1) { return fail(ACDSP_EINVAL, "%s: S must be 0 or 1", name); }
   return ACDSP_OK;
 }
 
-int elem_bytes(int W) { return W <= 16 ? 2 : (W <= 32 ? 4 : 8); }
+int elem_bytes(int W) { return W <= 16 ? 2 : (W <= 32 ? 4 : (W <= 64 ? 8 : 16)); }
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // HIP-event timing of the main kernel of each run(), recorded on the launch stream.
@@ -153,6 +164,8 @@ struct acdsp_fir {
   acdsp_fir_desc_t d;
   int in_eb, out_eb, hl;
   bool use_rt, lossless, coeffs_set;
+  bool wide = false;   // ACC_TYPE or OUT_TYPE wider than 64 bits: wide.hip (reg_trans words are then 16 bytes)
+  int rt_eb = 8;
   int path;
   void *d_hist[2] = {nullptr, nullptr};
   int64_t *d_rt[2] = {nullptr, nullptr};
@@ -188,6 +201,7 @@ struct acdsp_cic {
   uint32_t *d_upfrag = nullptr;
   int64_t *d_upcorr = nullptr;
   int last_path = 0;
+  bool wide = false;    // INT_TYPE or OUT_TYPE wider than 64 bits: both directions through cic_wide_kernel (wide.hip)
   int64_t t_total = 0;  // inputs consumed so far (all calls)
   void *d_hist[2] = {nullptr, nullptr};
   int cur = 0;
@@ -334,18 +348,21 @@ int fir_validate(const acdsp_fir_desc_t &d) {
   if (d.n_channels < 1) { return fail(ACDSP_EINVAL, "n_channels=%d must be positive", d.n_channels); }
   if (d.n_channels > 65535) { return fail(ACDSP_EUNSUPPORTED, "n_channels=%d outside 1..65535", d.n_channels); }
   int rc;
-  if ((rc = check_fmt(d.in, "IN_TYPE")) || (rc = check_fmt(d.coeff, "COEFF_TYPE")) || (rc = check_fmt(d.acc, "ACC_TYPE")) ||
-      (rc = check_fmt(d.out, "OUT_TYPE"))) {
+  if ((rc = check_fmt(d.in, "IN_TYPE")) || (rc = check_fmt(d.coeff, "COEFF_TYPE")) || (rc = check_fmt(d.acc, "ACC_TYPE", 128)) ||
+      (rc = check_fmt(d.out, "OUT_TYPE", 128))) {
     return rc;
   }
-  // 128-bit exact intermediates must hold: product, aligned sum.
-  int fi = d.in.W - d.in.I, fc = d.coeff.W - d.coeff.I, fa = d.acc.W - d.acc.I;
+  // exact intermediates must hold: product, aligned sum -- 128 bits on the 64-bit paths, 256 bits on the wide path (wide.hip)
+  const bool wide = d.acc.W > 64 || d.out.W > 64;
+  const int limit = wide ? 250 : 125;
+  int fi = d.in.W - d.in.I, fc = d.coeff.W - d.coeff.I, fa = d.acc.W - d.acc.I, fo = d.out.W - d.out.I;
   int wp = d.in.W + d.coeff.W + 2, fp = fi + fc;
   if (is_fold_odd(internal_ftype(d.kind, d.ftype))) { wp = d.acc.W + d.coeff.W + 1; fp = fa + fc; }
   int f = fp > fa ? fp : fa;
-  if (wp + (f - fp) > 125 || d.acc.W + (f - fa) > 125) {
-    return fail(ACDSP_EUNSUPPORTED, "type combination needs more than 128-bit intermediates");
+  if (wp + (f - fp) > limit || d.acc.W + (f - fa) > limit || (wide && d.acc.W + (fo > fa ? fo - fa : 0) > limit)) {
+    return fail(ACDSP_EUNSUPPORTED, "type combination needs more than %d-bit intermediates", wide ? 256 : 128);
   }
+  if (wide && d.kind == ACDSP_FIR_REG_SHARE) { return fail(ACDSP_EUNSUPPORTED, "ac_fir_reg_share: ACC / OUT wider than 64 bits not supported"); }
   return ACDSP_OK;
 }
 
@@ -362,6 +379,8 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   h->d = *desc;
   h->in_eb = elem_bytes(desc->in.W);
   h->out_eb = elem_bytes(desc->out.W);
+  h->wide = desc->acc.W > 64 || desc->out.W > 64;
+  h->rt_eb = h->wide ? 16 : 8;
   h->hl = round_up(desc->n_taps + 15, 32);  // >= n_taps-1 for every kernel, >= n_taps+14 for the 16-aligned windows of fir_gen
   // reg_trans[] carries partial sums computed with the coefficients of their own time; only
   // the const-coefficient class may trade it for an input history.
@@ -369,7 +388,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   const int fi = desc->in.W - desc->in.I, fc = desc->coeff.W - desc->coeff.I, fa = desc->acc.W - desc->acc.I;
   // exact-dot-product class: the kernels compute `sum << (fa - fi - fc)` in 64 bits, so the shift must be 0..63 (formats
   // with I outside [0, W] can ask for more: those stay on the per-tap path)
-  bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && !h->use_rt;
+  bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && !h->use_rt && !h->wide;
   const int ift = internal_ftype(desc->kind, desc->ftype);
   if (is_fold_odd(ift)) {
     // the ACC_TYPE `fold` must also keep every fraction bit of the pre-add (fc < 0 would let fa >= fi + fc pass with fa < fi)
@@ -388,7 +407,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
     e = hipMalloc(&h->d_hist[i], hist_bytes);
     if (e == hipSuccess) { e = hipMemset(h->d_hist[i], 0, hist_bytes); }
     if (e == hipSuccess && h->use_rt) {
-      size_t rb = (size_t)desc->n_channels * desc->n_taps * sizeof(int64_t);
+      size_t rb = (size_t)desc->n_channels * desc->n_taps * h->rt_eb;
       e = hipMalloc((void **)&h->d_rt[i], rb);
       if (e == hipSuccess) { e = hipMemset(h->d_rt[i], 0, rb); }
     }
@@ -488,7 +507,8 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
       h->gen_ok = true;
     }
   }
-  h->path = h->mfma_ok ? ACDSP_PATH_MFMA_I8
+  h->path = h->wide ? ACDSP_PATH_WIDE
+            : h->mfma_ok ? ACDSP_PATH_MFMA_I8
             : h->gen_ok ? ACDSP_PATH_MFMA_GEN
                         : ((h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC)) ? ACDSP_PATH_LOSSLESS64 : ACDSP_PATH_GENERIC);
   h->coeffs_set = true;
@@ -505,7 +525,7 @@ int32_t acdsp_fir_clone(acdsp_fir_t h, acdsp_fir_t *out) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(c->d_hist[0], h->d_hist[h->cur], (size_t)h->d.n_channels * h->hl * h->in_eb, hipMemcpyDeviceToDevice));
   if (h->use_rt) {
-    HIP_TRY(hipMemcpy(c->d_rt[0], h->d_rt[h->cur], (size_t)h->d.n_channels * h->d.n_taps * sizeof(int64_t), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(c->d_rt[0], h->d_rt[h->cur], (size_t)h->d.n_channels * h->d.n_taps * h->rt_eb, hipMemcpyDeviceToDevice));
   }
   c->cur = 0;
   *out = c;
@@ -528,7 +548,9 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   hipStream_t s = (hipStream_t)stream;
   FirParams k;
   k.n_taps = d.n_taps; k.ftype = internal_ftype(d.kind, d.ftype); k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
-  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff);
+  if (h->wide) { memset(&k.acc, 0, sizeof k.acc); memset(&k.out, 0, sizeof k.out); k.acc.F = d.acc.W - d.acc.I; }
+  else { k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out); }
   k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl; k.use_rt = h->use_rt ? 1 : 0;
   k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
   k.in_stride = in_stride; k.out_stride = out_stride; k.n = n;
@@ -536,6 +558,20 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   k.hist = h->d_hist[h->cur]; k.coeffs = h->d_coeffs; k.rt = h->d_rt[h->cur];
 
   int path = h->path;
+  if (h->wide) {
+    FirWideParams kw;
+    kw.p = k; kw.acc = make_wfmt(d.acc); kw.out = make_wfmt(d.out); kw.rt = h->d_rt[h->cur];
+    HIP_TRY(hipEventRecord(h->tm.start(), s));
+    hipError_t ew = launch_fir_wide(kw, s);
+    if (ew != hipSuccess) { return fail(ACDSP_EHIP, "wide FIR kernel launch failed: %s", hipGetErrorString(ew)); }
+    HIP_TRY(hipEventRecord(h->tm.stop(), s));
+    h->tm.commit();
+    const int nxw = hist_next_index(h->cur, !h->use_rt && k.n >= k.hl);
+    ew = h->use_rt ? launch_fir_wide_rt_update(kw, h->d_rt[nxw], s) : launch_fir_hist_update(k, h->d_hist[nxw], s);
+    if (ew != hipSuccess) { return fail(ACDSP_EHIP, "wide FIR state kernel launch failed: %s", hipGetErrorString(ew)); }
+    h->cur = nxw;
+    return ACDSP_OK;
+  }
   if (path == ACDSP_PATH_MFMA_I8 || path == ACDSP_PATH_MFMA_GEN) {
     // The matrix-core kernels read rows with 16-byte vector loads (fir_gen: in whole 16-sample slots).  Rows that are
     // not laid out that way are first copied, on the device, into an aligned staging image (one extra read + write of
@@ -599,7 +635,7 @@ int32_t acdsp_fir_reset(acdsp_fir_t h) {
   HIP_TRY(hipDeviceSynchronize());
   for (int i = 0; i < 2; i++) {
     HIP_TRY(hipMemset(h->d_hist[i], 0, (size_t)h->d.n_channels * h->hl * h->in_eb));
-    if (h->d_rt[i]) { HIP_TRY(hipMemset(h->d_rt[i], 0, (size_t)h->d.n_channels * h->d.n_taps * sizeof(int64_t))); }
+    if (h->d_rt[i]) { HIP_TRY(hipMemset(h->d_rt[i], 0, (size_t)h->d.n_channels * h->d.n_taps * h->rt_eb)); }
   }
   return ACDSP_OK;
 }
@@ -670,10 +706,15 @@ int32_t acdsp_cic_int_type(const acdsp_cic_desc_t *desc, acdsp_fmt_t *it) {
 int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
   if (!desc || !out) { return fail(ACDSP_EINVAL, "null argument"); }
   int rc;
-  if ((rc = check_fmt(desc->in, "IN_TYPE")) || (rc = check_fmt(desc->out, "OUT_TYPE"))) { return rc; }
+  if ((rc = check_fmt(desc->in, "IN_TYPE")) || (rc = check_fmt(desc->out, "OUT_TYPE", 128))) { return rc; }
   acdsp_fmt_t it;
   if ((rc = cic_int_type(*desc, &it))) { return rc; }
-  if (it.W > 64) { return fail(ACDSP_EUNSUPPORTED, "CIC: intermediate type needs %d bits (> 64)", it.W); }
+  // INT_TYPE (reference ac_cic_dec_full.h:116-137, ac_cic_intr_full.h:107-127) of up to 128 bits; more than 64 -> wide.hip
+  if (it.W > 128) { return fail(ACDSP_EUNSUPPORTED, "CIC: intermediate type needs %d bits (> 128)", it.W); }
+  {
+    const int fo = desc->out.W - desc->out.I, fi = desc->in.W - desc->in.I;
+    if (it.W + (fo > fi ? fo - fi : 0) > 250) { return fail(ACDSP_EUNSUPPORTED, "CIC: OUT_TYPE conversion needs more than 256-bit intermediates"); }
+  }
   if (desc->N > kCicMaxN) { return fail(ACDSP_EUNSUPPORTED, "CIC: N=%d > %d", desc->N, kCicMaxN); }
   // rate counters are ac_int<8,false> in the reference (ac_cic_full_core.h:72-73)
   if (desc->R > 256) { return fail(ACDSP_EUNSUPPORTED, "CIC: R=%d > 256 (8-bit rate counter in the reference)", desc->R); }
@@ -688,6 +729,7 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
   h->in_eb = elem_bytes(desc->in.W);
   h->out_eb = elem_bytes(desc->out.W);
   h->me = desc->M < 2 ? desc->M : 2;  // effective comb delay of the reference's delay line, see cic.hip
+  h->wide = it.W > 64 || desc->out.W > 64;
   const int64_t mem = desc->interp ? (int64_t)desc->N * h->me + 1 : (int64_t)desc->N * desc->R * h->me - 1;
   h->hl = round_up((int)(mem > 1 ? mem : 1) + 16, kCicTile);   // + 16: the 16-aligned input windows of fir_gen
   const size_t hb = (size_t)desc->n_channels * h->hl * h->in_eb;
@@ -710,13 +752,13 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
     FirGenPlan probe;
     std::vector<uint32_t> fr;
     static const bool no_gen = getenv("ACDSP_NO_GEN") != nullptr;
-    if (e == hipSuccess && desc->interp && !no_gen) {   // interpolator: polyphase FIR kernel reads the taps themselves
+    if (e == hipSuccess && ((desc->interp && !no_gen) || h->wide)) {   // interpolator (and wide.hip): polyphase FIR kernel reads the taps themselves
       e = hipMalloc((void **)&h->d_taps, h->h_taps.size() * sizeof(int64_t));
       if (e == hipSuccess) { e = hipMemcpy(h->d_taps, h->h_taps.data(), h->h_taps.size() * sizeof(int64_t), hipMemcpyHostToDevice); }
       // ... and, where the shape is compiled in, the same identity phase by phase on the matrix cores
       const int R = desc->R, n_taps = (int)h->h_taps.size(), kmax = (n_taps + R - 1) / R;
       const int px = (desc->in.W + (desc->in.S ? 0 : 1) + 7) / 8;
-      if (e == hipSuccess && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) && ((px <= 2 && h->in_eb == 2) || (px <= 4 && h->in_eb == 4)) && R <= 32) {
+      if (e == hipSuccess && desc->interp && !h->wide && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) && ((px <= 2 && h->in_eb == 2) || (px <= 4 && h->in_eb == 4)) && R <= 32) {
         std::vector<int64_t> E((size_t)R * kmax, 0);
         for (int r = 0; r < R; r++) { for (int k = 0; k < kmax; k++) { if (r + R * k < n_taps) { E[(size_t)r * kmax + k] = h->h_taps[(size_t)(r + R * k)]; } } }
         std::vector<uint32_t> frag;
@@ -731,7 +773,7 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
         }
       }
     }
-    h->gen_ok = e == hipSuccess && !desc->interp && !no_gen && (desc->in.W + (desc->in.S ? 0 : 1) + 7) / 8 <= h->in_eb &&
+    h->gen_ok = e == hipSuccess && !desc->interp && !h->wide && !no_gen && (desc->in.W + (desc->in.S ? 0 : 1) + 7) / 8 <= h->in_eb &&
                 fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), desc->R, 15, &probe, &fr) &&   // worst-case window offset
                 fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), desc->R, 0, &probe, &fr);
     if (h->gen_ok) { e = hipMalloc((void **)&h->d_gfrag, (size_t)16 * 3 * 8 * 64 * 4 * sizeof(uint32_t)); }
@@ -825,12 +867,22 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
   int rc = check_device(d.device);
   if (rc) { return rc; }
   hipStream_t s = (hipStream_t)stream;
+  if (stream_is_capturing(s)) {
+    if (!d.interp && n_in % d.R != 0) {
+      return fail(ACDSP_ESTATE, "cic_run under graph capture: n_in = %lld is not a multiple of R = %d (a replay would repeat the captured decimation phase)",
+                  (long long)n_in, d.R);
+    }
+    if (d.interp && h->t_total == 0) {
+      return fail(ACDSP_ESTATE, "cic_run under graph capture: the interpolator's first call drops its start-up outputs and cannot be replayed; run it before capturing");
+    }
+  }
   CicParams p;
   cic_window(h, n_in, &p);
   p.q_from = p.q_to = 0;
   p.interp = d.interp; p.R = d.R; p.me = h->me; p.N = d.N; p.n_ch = d.n_channels;
   p.w_int = h->it.W;
-  p.in = make_dfmt(d.in); p.out = make_dfmt(d.out);
+  p.in = make_dfmt(d.in);
+  if (h->wide) { memset(&p.out, 0, sizeof p.out); } else { p.out = make_dfmt(d.out); }
   p.in_eb = h->in_eb; p.out_eb = h->out_eb;
   p.hl = h->hl; p.warm_tiles = h->hl / kCicTile;
   p.vec_ok = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0);
@@ -860,11 +912,15 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
     }
     if (use_gen) { gfrag = h->d_gfrag + (size_t)fm * 3 * 8 * 64 * 4; gpl = h->gen_plan[fm]; }
   }
-  const bool use_intr_fir = d.interp && h->d_taps != nullptr;
-  h->last_path = use_gen ? ACDSP_PATH_MFMA_GEN : (use_intr_fir ? ACDSP_PATH_LOSSLESS64 : 0);
+  const bool use_intr_fir = d.interp && h->d_taps != nullptr && !h->wide;
+  h->last_path = h->wide ? ACDSP_PATH_WIDE : (use_gen ? ACDSP_PATH_MFMA_GEN : (use_intr_fir ? ACDSP_PATH_LOSSLESS64 : 0));
   HIP_TRY(hipEventRecord(h->tm.start(), s));
   hipError_t e;
-  if (use_gen) {
+  if (h->wide) {
+    CicWideParams pw;
+    pw.p = p; pw.out = make_wfmt(d.out);
+    e = launch_cic_wide(pw, h->d_taps, (int)h->h_taps.size(), no, s);
+  } else if (use_gen) {
     FirParams k;
     memset(&k, 0, sizeof k);
     k.n_ch = d.n_channels;
@@ -1277,6 +1333,10 @@ int32_t acdsp_ddc_run(acdsp_ddc_t h, const void *d_in, int64_t in_stride, int64_
     return fail(ACDSP_EUNSUPPORTED, "ddc_run (fused): rows must be 16-byte aligned and readable up to a multiple of 16 samples");
   }
   const int R = cd.R;
+  if (stream_is_capturing((hipStream_t)stream) && n_in % R != 0) {
+    return fail(ACDSP_ESTATE, "ddc_run under graph capture: n_in = %lld is not a multiple of R = %d (a replay would repeat the captured decimation phase)",
+                (long long)n_in, R);
+  }
   const int64_t first = (R - h->t_total % R) % R;
   const int fm = (int)(first % 16);
   if (!h->haveA[fm]) {
@@ -1536,6 +1596,9 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
   if (n_out) { *n_out = no; }
   if (n_in == 0) { return ACDSP_OK; }
   if (no > 0 && (!d_out || out_stride < no)) { return fail(ACDSP_EINVAL, "poly_intr run: output buffer too small for %lld outputs", (long long)no); }
+  if (stream_is_capturing((hipStream_t)stream) && h->d.ftype != ACDSP_POLY_FOLD_ANTI && h->t_total == 0) {
+    return fail(ACDSP_ESTATE, "poly_intr run under graph capture: the stream's first call emits one group less and cannot be replayed; run it before capturing");
+  }
   const acdsp_polyintr_desc_t &d = h->d;
   int rc = check_device(d.device);
   if (rc) { return rc; }
@@ -1962,7 +2025,7 @@ struct StateHdr {
   uint32_t kind;            // 1: FIR input history, 2: FIR reg_trans partial sums, 3: CIC input history + input count,
                             // 4: fused DDC input history + input count, 5: two-kernel DDC (CIC blob + FIR blob follow)
   uint32_t n_channels;
-  uint32_t elem_bytes;      // bytes per state word (IN container, or 8 for reg_trans)
+  uint32_t elem_bytes;      // bytes per state word (IN container; reg_trans: 8, or 16 for an ACC_TYPE wider than 64 bits)
   uint64_t per_channel;     // state words per channel
   int64_t t_total;          // CIC: inputs consumed so far (decimation / interpolation phase); 0 for FIR
   uint32_t p0, p1, p2, p3;  // FIR: n_taps, ftype, class, 0;  CIC: R, M, N, interp
@@ -1978,7 +2041,7 @@ StateHdr fir_state_hdr(const acdsp_fir *h) {
   s.version = 1;
   s.kind = h->use_rt ? 2 : 1;
   s.n_channels = (uint32_t)h->d.n_channels;
-  s.elem_bytes = h->use_rt ? 8 : (uint32_t)h->in_eb;
+  s.elem_bytes = h->use_rt ? (uint32_t)h->rt_eb : (uint32_t)h->in_eb;
   s.per_channel = h->use_rt ? (uint64_t)h->d.n_taps : (uint64_t)h->hl;
   s.p0 = (uint32_t)h->d.n_taps; s.p1 = (uint32_t)h->d.ftype; s.p2 = (uint32_t)h->d.kind;
   return s;

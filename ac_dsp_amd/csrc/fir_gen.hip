@@ -605,12 +605,12 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   a.corr = gen_rebias_corr(a.px, pl.sum_h);
   a.first = first; a.n_out = n_out;
   a.n_steps = (n_out + 255) / 256;
-  // Chunk length: ~32 KB of input per wave.  Workgroups are dispatched in memory order (chunk index fastest), so the bytes the
-  // resident waves touch form a compact window that advances through both streams; short spans keep that window small (DRAM
-  // page locality: tools/copy_probe2.hip -- 16 - 32 KB spans copy at 5.8 - 6.1 TB/s, 128+ KB spans at 5.2).  The former rule
-  // (>= 16384 waves, i.e. 0.5 - 4 MB spans on the BASELINE shapes) ran cic_dec 6 %, polydec 11 % slower (profiles/r3_span_sweep.txt).
-  int64_t spw = 32768 / ((int64_t)256 * pl.R * p.in_eb);
-  if (spw < 2) { spw = 2; }
+  // Chunk length: four steps per wave (16 - 32 KB of input on the BASELINE shapes).  Workgroups are dispatched in memory order
+  // (chunk index fastest), so the bytes the resident waves touch form a compact window that advances through both streams; short
+  // spans keep that window small (DRAM page locality: tools/copy_probe2.hip -- 16 - 32 KB spans copy at 5.8 - 6.1 TB/s, 128+ KB
+  // spans at 5.2).  The former rule (>= 16384 waves, i.e. 0.5 - 4 MB spans on the BASELINE shapes) ran cic_dec 6 %, polydec 11 %
+  // slower; 3 - 4 steps measured best on both, 1 - 2 and 8+ lose 2 - 4 % (profiles/r3_span_sweep.txt).
+  int64_t spw = 4;
   static const char *spw_env = getenv("ACDSP_GEN_SPW");   // tuning knob: steps (of 256 outputs) per wave
   if (spw_env && atoi(spw_env) > 0) { spw = atoi(spw_env); }
   a.steps_per_wave = spw;
@@ -934,7 +934,7 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   b.corr = gen_rebias_corr(b.px, plb.sum_h);
   a.first = first; a.n_out = n_out; b.first = 0; b.n_out = n_out;
   a.n_steps = (n_out + 255) / 256;
-  int64_t spw = 8;                           // one warm-up step per chunk (<= 12 % of the work); short spans: see launch_fir_gen
+  int64_t spw = 6;                           // short spans (see launch_fir_gen) against one warm-up step per chunk: 4: 0.600, 6: 0.637, 8: 0.629, 12: 0.608 of the roofline
   static const char *cspw_env = getenv("ACDSP_CASC_SPW");   // tuning knob: steps per wave of the fused cascade
   if (cspw_env && atoi(cspw_env) > 0) { spw = atoi(cspw_env); }
   a.steps_per_wave = spw;

@@ -58,6 +58,7 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 constexpr int kMaxRegNB = 9;  // register-resident Toeplitz fragments: up to 32*8+1 = 257 taps
 constexpr int kMaxNB = 33;    // Toeplitz fragments in LDS (shared coefficient set): up to 1025 taps
 
+static bool use_reg33(int nb, uint64_t hi_mask, int epi);
 int fir_mfma_max_blocks() { return kMaxNB; }
 int fir_mfma_max_reg_blocks() { return kMaxRegNB; }
 
@@ -495,8 +496,8 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       unsigned char *dl = lds + (1 * 2 + hh_) * ARR + (base + c) * 16 + sub * 8;
       *(v2u_ *)dh = (v2u_){hi0, hi1};
       *(v2u_ *)dl = (v2u_){lo0, lo1};
-      if (PAR == 2 && j == 1 && HB > 0) {       // slots [128, 128 + HB) also go to [0, HB): the window of parity 0 starts there
-        const bool m = c >= 32 - HB;
+      if (PAR == 2 && HB > 0 && 16 * (j + 1) > 32 - HB) {   // slots [128, 128 + HB) also go to [0, HB): the window of parity 0 starts there
+        const bool m = c >= 32 - HB;                        // (chunks 32 - HB .. 31 of the step: both loads when HB > 16, i.e. NB = 33)
         *(v2u_ *)(m ? dh - 128 * 16 : dummy + lane * 8) = (v2u_){hi0, hi1};
         *(v2u_ *)(m ? dl - 128 * 16 : dummy + 512 + lane * 8) = (v2u_){lo0, lo1};
       }
@@ -756,8 +757,10 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   else { go(integral_constant<bool, true>()); }
 }
 
+// NB > kMaxRegNB (the 1023-tap shape, NB = 33): one wave per SIMD with the whole 512-entry register file -- 2 * 33 Toeplitz
+// fragments are 264 registers (fewer with a high-byte band), next to two accumulator sets and the B-fragment double buffer.
 template <int NB, int EPI, int HS, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, kOccupancy)
+__global__ void __launch_bounds__(64 * WAVES, (NB > kMaxRegNB ? 1 : kOccupancy))
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   // WAVES == 1: the pipelined body keeps a 4-step ring of staged planes (4 arrays of 128 + NB - 1 slots), the plain body two windows
   constexpr int kStaged = (WAVES == 1 && EPI != 0 && EPI != 3 && 4 * staged_array_bytes(128 + NB - 1) > 2 * 4 * staged_array_bytes(32 + NB - 1))
@@ -788,7 +791,9 @@ static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const
   const dim3 blk(64 * WAVES);
   if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   else if (epi == 2) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
-  else if (epi == 3 && WAVES == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 3, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
+  else if (epi == 3 && WAVES == 1 && NB <= kMaxRegNB) {
+    if constexpr (NB <= kMaxRegNB) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 3, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
+  }
   else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 0, 0, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   return hipGetLastError();
 }
@@ -825,6 +830,28 @@ static hipError_t launch_nb(const FirParams &p, const uint32_t *d_frag, const Mf
   return launch_nb_hs<NB, 0, kSmallWaves>(p, d_frag, a, epi, grid, s);
 }
 
+
+// NB = 33 (993 .. 1025 taps): the register-resident kernel at one wave per SIMD, for coefficient sets whose high-byte band leaves
+// 12 or 14 K-blocks free on either side (any unit-gain low-pass in <16,2>: |c| >= 128 only within ~40 taps of the centre, a
+// 5-block band -- BASELINE config 4 issues 76 instead of 132 MFMAs per step).  Fragments that would all be live (dense sets: 264
+// registers + two accumulator sets) spill; those sets stay on the LDS-resident kernels below.
+// Same-box A/B on config 4 (profiles/r3_fir1023_reg33.txt): 2.32 -> 2.10 ms, 0.45 -> 0.50 of the int8 peak in MFMAs issued.
+static int reg33_band_code(uint64_t hi_mask, int epi) {
+  if (epi != 1 && epi != 2) { return 0; }
+  int lo = 0, hi = 0;
+  if (hi_mask == 0) { lo = hi = 16; }
+  else {
+    while (lo < 33 && !((hi_mask >> lo) & 1)) { lo++; }
+    while (hi < 33 && !((hi_mask >> (32 - hi)) & 1)) { hi++; }
+  }
+  if (lo >= 14 && hi >= 14) { return 14 + 16 * 14; }
+  if (lo >= 12 && hi >= 12) { return 12 + 16 * 12; }
+  return 0;
+}
+static hipError_t launch_nb33(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  if (reg33_band_code(a.hi_mask, epi) == 14 + 16 * 14) { return launch_nb_hs<33, 14 + 16 * 14, 1>(p, d_frag, a, epi, grid, s); }
+  return launch_nb_hs<33, 12 + 16 * 12, 1>(p, d_frag, a, epi, grid, s);
+}
 
 // =============================================================================================
 // Large tap counts (NB = 10 .. 33, e.g. the 1023-tap configuration): the 2*NB Toeplitz fragments no
@@ -1229,12 +1256,13 @@ int fir_mfma_issued_per_step(const FirParams &p, const FirMfmaPlan &plan) {
     band = nb - (hs & 15) - (hs >> 4);
   } else if (epi) {
     int b0 = 0, b1 = nb - 1;
-    if (plan.hi_mask == 0) { band = 0; }
+    if (plan.hi_mask == 0) { band = 0; b0 = nb; b1 = -1; }
     else {
       while (!((plan.hi_mask >> b0) & 1)) { b0++; }
       while (!((plan.hi_mask >> b1) & 1)) { b1--; }
       band = b1 - b0 + 1;
     }
+    if (use_reg33(nb, plan.hi_mask, epi)) { const int code = reg33_band_code(plan.hi_mask, epi); band = nb - (code & 15) - (code >> 4); }
   }
   return 2 * nb + 2 * band;
 }
@@ -1259,7 +1287,7 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   a.lo_mask = plan.lo_mask;
   a.nb = plan.nb; a.hb0 = 0; a.hb1 = plan.nb - 1; a.step0 = 0;
   a.corr = d_corr;
-  const int wpb = plan.nb > kMaxRegNB ? 8 : kSmallWaves;   // channels (waves) per workgroup
+  const int wpb = (plan.nb > kMaxRegNB && !use_reg33(plan.nb, plan.hi_mask, epi)) ? 8 : kSmallWaves;   // channels (waves) per workgroup
   dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)((p.n_ch + wpb - 1) / wpb));
   a.dbg = nullptr;
   static const bool dbg_clock = getenv("ACDSP_DEBUG_CLOCK") != nullptr;
@@ -1289,7 +1317,13 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   return rc;
 }
 
+static bool use_reg33(int nb, uint64_t hi_mask, int epi) {
+  static const bool off = getenv("ACDSP_NO_REG33") != nullptr;   // A/B knob: LDS-resident fragments (fir_mfma_big2_kernel) for NB = 33 too
+  return nb == 33 && !off && reg33_band_code(hi_mask, epi) != 0;
+}
+
 static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  if (use_reg33(nb, a.hi_mask, epi)) { return launch_nb33(p, d_frag, a, epi, grid, s); }
   if (nb > kMaxRegNB) { return launch_big(p, d_frag, a, epi, grid, s); }
   switch (nb) {
 #ifndef ACDSP_FIR_DEV_NB9   // development builds: only the 255-tap shape (compile time 3 min -> 35 s)

@@ -63,7 +63,8 @@ enum {
 #define ACDSP_FLAG_FORCE_GENERIC 1 /* never pick the MFMA / fast kernels (parity tests) */
 
 /* which kernel family a FIR handle resolved to (acdsp_fir_path) */
-enum { ACDSP_PATH_GENERIC = 0, ACDSP_PATH_LOSSLESS64 = 1, ACDSP_PATH_MFMA_I8 = 2, ACDSP_PATH_MFMA_GEN = 3 };
+enum { ACDSP_PATH_GENERIC = 0, ACDSP_PATH_LOSSLESS64 = 1, ACDSP_PATH_MFMA_I8 = 2, ACDSP_PATH_MFMA_GEN = 3,
+       ACDSP_PATH_WIDE = 4 /* a format wider than 64 bits: exact-order kernels on 128-bit words, 256-bit intermediates */ };
 
 typedef struct {
   int32_t kind;               /* ACDSP_FIR_*: which reference class this mirrors (informational) */

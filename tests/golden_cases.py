@@ -8,12 +8,15 @@ import os
 import numpy as np
 
 HDR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_hdr")
+# ac_mv_avg: the reference's run() / mvAvgCore() loops compiled over this repo's OWN restatement of ac_window_1d_flag (the class
+# lives in the absent hlslibs/ac_types): these vectors pin the MAC loop, not the window's boundary rules -- kept apart and named so.
+HDR_UNPINNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_hdr_window_unpinned")
 
 
 def load(kind):
     """All cases whose "class" is one of `kind` (tuple), as (id, dict) pairs in file order."""
     out = []
-    for f in sorted(glob.glob(os.path.join(HDR, "*.json"))):
+    for f in sorted(glob.glob(os.path.join(HDR, "*.json"))) + sorted(glob.glob(os.path.join(HDR_UNPINNED, "*.json"))):
         for c in json.load(open(f))["cases"]:
             if c["class"] in kind:
                 out.append(c)

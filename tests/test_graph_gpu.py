@@ -3,9 +3,10 @@
 Small chunks are launch-bound (a 255-tap step over 256 ch x 4096 samples is ~10 us of GPU work behind two launches), so a
 streaming deployment captures a fixed schedule of run() calls once and replays it.  run() performs no
 allocation, synchronisation or host copy in steady state, so it is capturable; the handle's host-side bookkeeping must be
-the same after the captured sequence as before it: calls of at least N_TAPS - 1 samples (the window of the class) update the
-history in place, so any number of them qualifies as long as their samples add up to a multiple of the rate change (the
-decimation phase); shorter calls flip a double buffer and have to come in pairs (engine.hip: hist_next_index).  Replays
+the same after the captured sequence as before it: calls of at least `hl` samples (the handle's history length: N_TAPS - 1
+rounded up to a multiple of 32, the window of the class for CIC / DDC) update the history in place, so any number of them
+qualifies; every captured decimator call must consume a multiple of the rate change (acdsp_cic_run / acdsp_ddc_run refuse other
+lengths while capturing); shorter calls flip a double buffer and have to come in pairs (engine.hip: hist_next_index).  Replays
 continue the stream: the state lives in device memory and is carried from replay to replay exactly as from call to call
 (ac_fir_load_coeffs.h:180-188, ac_cic_full_core.h:71-74)."""
 import numpy as np
@@ -100,3 +101,29 @@ def test_short_fir_calls_flip_the_history_and_replay_in_pairs():
 
     x = torch.from_numpy(rng.integers(-32768, 32768, size=(nk, nch, cs), dtype=np.int16)).cuda()
     _capture_and_check(make, x, (nch, cs), torch.int16, n_replays=4)
+
+
+def test_calls_whose_phase_would_be_baked_in_are_refused_under_capture():
+    """A replay re-runs the host-side phase of capture time: a decimator call that does not consume a multiple of R, and the first
+    call of an interpolator (start-up outputs dropped), cannot be replayed and must fail loudly while the stream is capturing."""
+    nch = 8
+    fin, fout = A.Fmt(32, 16), A.Fmt(47, 31)
+    dec = A.Cic(False, 8, 1, 5, fin, fout, n_channels=nch)
+    x = torch.zeros((nch, 8192 + 3), dtype=torch.int32, device="cuda")
+    dec.run(x[:, :8192])
+    it = A.Cic(True, 8, 1, 5, fin, fin, n_channels=1).int_type
+    intr = A.Cic(True, 8, 1, 5, fin, A.Fmt(it.W, it.I), n_channels=nch)
+    yi = torch.zeros((nch, 8192 * 8 + 64), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    errs = []
+    with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+        dec.run(x[:, :8192])                      # fine: a multiple of R
+        for call in (lambda: dec.run(x[:, :8195]), lambda: intr.run(x[:, :4096], yi)):
+            try:
+                call()
+                errs.append(None)
+            except RuntimeError as e:
+                errs.append(str(e))
+    assert errs[0] and "graph capture" in errs[0], errs
+    assert errs[1] and "graph capture" in errs[1], errs
