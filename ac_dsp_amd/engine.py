@@ -13,11 +13,39 @@ def device_count():
 
 
 def torch_dtype_for(fmt):
-    return {2: torch.int16, 4: torch.int32, 8: torch.int64}[lib.acdsp_elem_bytes(fmt.W)]
+    """Container dtype of a format; formats wider than 64 bits use 16-byte containers = int64 pairs (low quadword first)."""
+    return {2: torch.int16, 4: torch.int32, 8: torch.int64, 16: torch.int64}[lib.acdsp_elem_bytes(fmt.W)]
 
 
 def _np_dtype_for(fmt):
-    return {2: np.int16, 4: np.int32, 8: np.int64}[lib.acdsp_elem_bytes(fmt.W)]
+    return {2: np.int16, 4: np.int32, 8: np.int64, 16: np.int64}[lib.acdsp_elem_bytes(fmt.W)]
+
+
+def is_wide(fmt):
+    return lib.acdsp_elem_bytes(fmt.W) == 16
+
+
+def _alloc_out(fmt, n_ch, n, device):
+    """[n_ch][n] OUT containers; 16-byte containers are a trailing dimension of two int64 (low, high)."""
+    shape = (n_ch, n, 2) if is_wide(fmt) else (n_ch, n)
+    return torch.empty(shape, dtype=torch_dtype_for(fmt), device=device)
+
+
+def _row_stride(t, fmt):
+    """Row stride in containers; checks the inner layout."""
+    if is_wide(fmt):
+        assert t.dim() == 3 and t.shape[2] == 2 and t.stride(2) == 1 and t.stride(1) == 2 and t.stride(0) % 2 == 0
+        return t.stride(0) // 2
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0)
+
+
+def wide_to_int(a):
+    """[..., 2] int64 (low, high) containers -> object array of Python ints (two's complement, 128 bits)."""
+    a = a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    lo = a[..., 0].astype(np.uint64).astype(object)
+    hi = a[..., 1].astype(object)
+    return hi * (1 << 64) + lo
 
 
 def _stream_ptr(t):
@@ -67,10 +95,10 @@ class Fir:
         assert x.dtype == torch_dtype_for(self.fin), (x.dtype, self.fin)
         n = x.shape[1]
         if out is None:
-            out = torch.empty((self.n_channels, n), dtype=torch_dtype_for(self.fout), device=x.device)
-        assert out.dtype == torch_dtype_for(self.fout) and out.stride(1) == 1 and out.shape[1] >= n
+            out = _alloc_out(self.fout, self.n_channels, n, x.device)
+        assert out.dtype == torch_dtype_for(self.fout) and out.shape[1] >= n
         check(lib.acdsp_fir_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), n, C.c_void_p(out.data_ptr()),
-                                out.stride(0), _stream_ptr(x)))
+                                _row_stride(out, self.fout), _stream_ptr(x)))
         return out
 
     def run_host(self, x):
@@ -139,7 +167,7 @@ class Cic:
 
     @property
     def path(self):
-        return {0: "recurrence", 1: "fir_identity", 3: "mfma_gen"}[lib.acdsp_cic_path(self._h)]
+        return {0: "recurrence", 1: "fir_identity", 3: "mfma_gen", 4: "wide"}[lib.acdsp_cic_path(self._h)]
 
     def run(self, x, out=None):
         assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1
@@ -148,12 +176,12 @@ class Cic:
         no = self.out_count(n_in)
         if out is None:
             dt = torch_dtype_for(self.fout)
-            per64 = 64 // torch.empty((), dtype=dt).element_size()       # rows start on 64-byte boundaries (vector stores)
-            out = torch.empty((self.n_channels, (max(no, 1) + per64 - 1) // per64 * per64), dtype=dt, device=x.device)
-        assert out.dtype == torch_dtype_for(self.fout) and out.stride(1) == 1 and out.shape[1] >= no
+            per64 = max(1, 64 // lib.acdsp_elem_bytes(self.fout.W))      # rows start on 64-byte boundaries (vector stores)
+            out = _alloc_out(self.fout, self.n_channels, (max(no, 1) + per64 - 1) // per64 * per64, x.device)
+        assert out.dtype == torch_dtype_for(self.fout) and out.shape[1] >= no
         n_out = C.c_int64()
         check(lib.acdsp_cic_run(self._h, C.c_void_p(x.data_ptr()), x.stride(0), n_in, C.c_void_p(out.data_ptr()),
-                                out.stride(0), C.byref(n_out), _stream_ptr(x)))
+                                _row_stride(out, self.fout), C.byref(n_out), _stream_ptr(x)))
         return out[:, :n_out.value]
 
     def run_host(self, x):

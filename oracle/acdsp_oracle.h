@@ -123,6 +123,23 @@ enum { ORC_WIN_PLAIN = 0, ORC_WIN_MIRROR = 1, ORC_WIN_CLIP = 2 };
 int64_t orc_mv_avg_run(int32_t taps, int32_t win_mode, const orc_fmt_t *in, const orc_fmt_t *coeff, const orc_fmt_t *acc,
                        const orc_fmt_t *out, const int64_t *c, const int64_t *x, int64_t n_sample, int64_t n_frames, int64_t *y);
 
+/* ---- types wider than 64 bits (acdsp_oracle_wide.cpp): the FIR cores and both CIC directions again, on 128-bit raw words ----
+ * IN / COEFF <= 64 bits, ACC / OUT / INT_TYPE <= 128 bits, 256-bit exact intermediates.  Words are little-endian pairs.
+ * These functions also accept formats of <= 64 bits; there they must agree with orc_fir_run / orc_cic_run word for word
+ * (tests/test_wide_cpu.py). */
+typedef struct { uint64_t lo; int64_t hi; } orcw_word_t;
+typedef struct orcw_fir orcw_fir_t;
+typedef struct orcw_cic orcw_cic_t;
+orcw_fir_t *orcw_fir_new(int32_t n_taps, int32_t ftype, const orc_fmt_t *in, const orc_fmt_t *coeff, const orc_fmt_t *acc,
+                         const orc_fmt_t *out);
+void orcw_fir_free(orcw_fir_t *f);
+int32_t orcw_fir_run(orcw_fir_t *f, const int64_t *coeffs, const int64_t *x, int64_t n, orcw_word_t *y);
+orcw_cic_t *orcw_cic_new(int32_t interp, int32_t R, int32_t M, int32_t N, const orc_fmt_t *in, const orc_fmt_t *out);
+void orcw_cic_free(orcw_cic_t *c);
+int64_t orcw_cic_run(orcw_cic_t *c, const int64_t *x, int64_t n_in, orcw_word_t *y, int64_t cap);
+/* exact x * 2^-f_src (x: 256-bit little-endian two's-complement integer) -> raw word of *dst; -1 for an unsupported format */
+int32_t orcw_requant(const uint64_t x[4], int32_t f_src, const orc_fmt_t *dst, orcw_word_t *out);
+
 /* ---- synthetic stimulus shared with the GPU generator ---- */
 uint64_t orc_splitmix64(uint64_t seed, uint64_t index);
 /* raw sample for (channel, t): low `bits` bits of the hash, sign-extended */

@@ -32,8 +32,8 @@ class Fmt(C.Structure):
 
 
 def _build():
-    src = os.path.join(_HERE, "acdsp_oracle.c")
-    if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("acdsp_oracle.c", "acdsp_oracle_wide.cpp", "acdsp_oracle.h")]
+    if (not os.path.exists(_SO)) or any(os.path.exists(f) and os.path.getmtime(_SO) < os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
@@ -84,8 +84,99 @@ lib.orc_splitmix64.restype = C.c_uint64
 lib.orc_splitmix64.argtypes = [C.c_uint64, C.c_uint64]
 
 
+class WWord(C.Structure):
+    """orcw_word_t: a 128-bit raw word, low quadword first."""
+    _fields_ = [("lo", C.c_uint64), ("hi", C.c_int64)]
+
+
+lib.orcw_fir_new.restype = C.c_void_p
+lib.orcw_fir_new.argtypes = [C.c_int32, C.c_int32] + [C.POINTER(Fmt)] * 4
+lib.orcw_fir_free.argtypes = [C.c_void_p]
+lib.orcw_fir_run.restype = C.c_int32
+lib.orcw_fir_run.argtypes = [C.c_void_p, _i64p, _i64p, C.c_int64, C.POINTER(WWord)]
+lib.orcw_cic_new.restype = C.c_void_p
+lib.orcw_cic_new.argtypes = [C.c_int32] * 4 + [C.POINTER(Fmt)] * 2
+lib.orcw_cic_free.argtypes = [C.c_void_p]
+lib.orcw_cic_run.restype = C.c_int64
+lib.orcw_cic_run.argtypes = [C.c_void_p, _i64p, C.c_int64, C.POINTER(WWord), C.c_int64]
+lib.orcw_requant.restype = C.c_int32
+lib.orcw_requant.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.POINTER(Fmt), C.POINTER(WWord)]
+
+
 def _p(a):
     return a.ctypes.data_as(_i64p)
+
+
+def _words_to_int(buf, k):
+    """first k orcw_word_t of a ctypes array -> object array of Python ints"""
+    a = np.frombuffer(buf, dtype=np.dtype([("lo", np.uint64), ("hi", np.int64)]), count=k)
+    return a["hi"].astype(object) * (1 << 64) + a["lo"].astype(object)
+
+
+def requant_wide(x, f_src, fmt):
+    """Exact python-int x * 2^-f_src (|x| < 2^255) -> raw word of fmt (W <= 128), through the wide oracle."""
+    x = int(x) & ((1 << 256) - 1)
+    limbs = (C.c_uint64 * 4)(*[(x >> (64 * i)) & ((1 << 64) - 1) for i in range(4)])
+    w = WWord()
+    if lib.orcw_requant(limbs, f_src, C.byref(fmt), C.byref(w)):
+        raise ValueError("oracle: unsupported format")
+    return w.hi * (1 << 64) + w.lo
+
+
+class OracleFirW:
+    """OracleFir for ACC_TYPE / OUT_TYPE of up to 128 bits (acdsp_oracle_wide.cpp); run() returns an object array of Python ints."""
+
+    def __init__(self, n_taps, ftype, fin, fcoeff, facc, fout, n_ch=1):
+        self.n_taps, self.n_ch = n_taps, n_ch
+        ft = FTYPES[ftype] if isinstance(ftype, str) else ftype
+        self._h = [lib.orcw_fir_new(n_taps, ft, C.byref(fin), C.byref(fcoeff), C.byref(facc), C.byref(fout)) for _ in range(n_ch)]
+        if any(h is None for h in self._h):
+            raise ValueError("oracle: unsupported wide FIR configuration")
+
+    def run(self, coeffs, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int64)
+        n = x.shape[1]
+        out = np.empty((self.n_ch, n), dtype=object)
+        buf = (WWord * max(n, 1))()
+        for ch in range(self.n_ch):
+            c = np.ascontiguousarray(coeffs[ch] if coeffs.ndim == 2 else coeffs)
+            if lib.orcw_fir_run(self._h[ch], _p(c), _p(x[ch]), n, buf):
+                raise ValueError("oracle: ftype not handled by the reference run()")
+            out[ch] = _words_to_int(buf, n)
+        return out
+
+    def __del__(self):
+        for h in getattr(self, "_h", []):
+            if h:
+                lib.orcw_fir_free(h)
+
+
+class OracleCicW:
+    """OracleCic for INT_TYPE / OUT_TYPE of up to 128 bits; run() returns an object array of Python ints."""
+
+    def __init__(self, interp, R, M, N, fin, fout, n_ch=1):
+        self.interp, self.R, self.n_ch = int(interp), R, n_ch
+        self._h = [lib.orcw_cic_new(int(interp), R, M, N, C.byref(fin), C.byref(fout)) for _ in range(n_ch)]
+        if any(h is None for h in self._h):
+            raise ValueError("oracle: unsupported wide CIC configuration")
+
+    def run(self, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64)
+        n = x.shape[1]
+        cap = (n + 2) * (self.R if self.interp else 1) + 8
+        buf = (WWord * cap)()
+        outs = []
+        for ch in range(self.n_ch):
+            k = lib.orcw_cic_run(self._h[ch], _p(x[ch]), n, buf, cap)
+            assert k >= 0
+            outs.append(_words_to_int(buf, k))
+        return np.stack(outs) if outs else np.empty((0, 0), dtype=object)
+
+    def __del__(self):
+        for h in getattr(self, "_h", []):
+            if h:
+                lib.orcw_cic_free(h)
 
 
 def requant(x, f_src, fmt):
