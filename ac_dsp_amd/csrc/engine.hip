@@ -139,6 +139,15 @@ struct Timer {
 struct Staging {
   void *d_in = nullptr, *d_out = nullptr;
   size_t cap_in = 0, cap_out = 0;
+  // Small calls (the drop-in run() of one channel, ac_fir_prog_coeffs: ONE sample per call, reference ac_fir_prog_coeffs.h:281):
+  // a pinned, device-mapped host buffer the kernels read and write directly -- no H2D / D2H copy calls, one synchronisation.
+  static const size_t kPinBytes = 64 * 1024;
+  void *pin_in = nullptr, *pin_out = nullptr;
+  int ensure_pinned() {
+    if (!pin_in) { HIP_TRY(hipHostMalloc(&pin_in, kPinBytes, hipHostMallocMapped)); }
+    if (!pin_out) { HIP_TRY(hipHostMalloc(&pin_out, kPinBytes, hipHostMallocMapped)); }
+    return ACDSP_OK;
+  }
   int ensure(size_t bin, size_t bout) {
     if (bin > cap_in) {
       if (d_in) { (void)hipFree(d_in); }
@@ -155,6 +164,8 @@ struct Staging {
   void destroy() {
     if (d_in) { (void)hipFree(d_in); }
     if (d_out) { (void)hipFree(d_out); }
+    if (pin_in) { (void)hipHostFree(pin_in); }
+    if (pin_out) { (void)hipHostFree(pin_out); }
   }
 };
 
@@ -165,6 +176,7 @@ struct acdsp_fir {
   int in_eb, out_eb, hl;
   bool use_rt, lossless, coeffs_set;
   bool wide = false;   // ACC_TYPE or OUT_TYPE wider than 64 bits: wide.hip (reg_trans words are then 16 bytes)
+  bool small_call = false;   // set by run_host around a call that fits the pinned buffers (launch-bound: see acdsp_fir_run)
   int rt_eb = 8;
   int path;
   void *d_hist[2] = {nullptr, nullptr};
@@ -547,6 +559,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   if (rc) { return rc; }
   hipStream_t s = (hipStream_t)stream;
   FirParams k;
+  k.hist_next = nullptr;
   k.n_taps = d.n_taps; k.ftype = internal_ftype(d.kind, d.ftype); k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
   k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff);
   if (h->wide) { memset(&k.acc, 0, sizeof k.acc); memset(&k.out, 0, sizeof k.out); k.acc.F = d.acc.W - d.acc.I; }
@@ -586,15 +599,24 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
       k.x = h->st.d_in; k.in_stride = si;
     }
   }
-  HIP_TRY(hipEventRecord(h->tm.start(), s));
+  // Small calls (the drop-in run() of one channel; ac_fir_prog_coeffs is ONE sample per call, reference ac_fir_prog_coeffs.h:281)
+  // are launch-bound: no timing events, and the exact-order kernels write the next history themselves -- one launch per call.
+  const bool small = h->small_call;
+  const bool fuse_hist = small && !h->use_rt && (path == ACDSP_PATH_LOSSLESS64 || path == ACDSP_PATH_GENERIC);
+  const int nxt_fused = hist_next_index(h->cur, false);
+  if (fuse_hist) { k.hist_next = h->d_hist[nxt_fused]; }
+  if (!small) { HIP_TRY(hipEventRecord(h->tm.start(), s)); }
   hipError_t e;
   if (path == ACDSP_PATH_MFMA_I8) { e = launch_fir_mfma(k, h->plan, d.coeffs_per_channel, h->d_frag, h->d_corr, s); }
   else if (path == ACDSP_PATH_MFMA_GEN) { e = launch_fir_gen(k, h->gplan, h->d_gfrag, 0, 0, 0, n, s); }
   else if (path == ACDSP_PATH_LOSSLESS64) { e = launch_fir_lossless64(k, s); }
   else { e = launch_fir_generic(k, s); }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR kernel launch failed: %s", hipGetErrorString(e)); }
-  HIP_TRY(hipEventRecord(h->tm.stop(), s));
-  h->tm.commit();
+  if (!small) {
+    HIP_TRY(hipEventRecord(h->tm.stop(), s));
+    h->tm.commit();
+  }
+  if (fuse_hist) { h->cur = nxt_fused; return ACDSP_OK; }
   // state carry.  A call of at least hl samples takes the new history from its input alone: written in place behind the
   // main kernel (same stream), no buffer flip -- the handle's host-side state is then the same after every call, which is what
   // lets any schedule of such calls be captured into a HIP graph.  Shorter calls (and reg_trans, which reads its old value)
@@ -618,6 +640,22 @@ int32_t acdsp_fir_run_host(acdsp_fir_t h, const void *h_in, int64_t n, void *h_o
   if (rc) { return rc; }
   const int64_t stride = (n + 15) / 16 * 16;  // rows 16-byte aligned and readable in whole 16-sample slots
   const size_t bin = (size_t)h->d.n_channels * stride * h->in_eb, bout = (size_t)h->d.n_channels * stride * h->out_eb;
+  static const bool no_pin = getenv("ACDSP_NO_PINNED") != nullptr;   // A/B knob: always go through the device staging buffers
+  if (bin <= Staging::kPinBytes && bout <= Staging::kPinBytes && !no_pin) {
+    if ((rc = h->st.ensure_pinned())) { return rc; }
+    for (int c = 0; c < h->d.n_channels; c++) {
+      memcpy((char *)h->st.pin_in + (size_t)c * stride * h->in_eb, (const char *)h_in + (size_t)c * n * h->in_eb, (size_t)n * h->in_eb);
+    }
+    h->small_call = true;
+    rc = acdsp_fir_run(h, h->st.pin_in, stride, n, h->st.pin_out, stride, nullptr);
+    h->small_call = false;
+    if (rc) { return rc; }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    for (int c = 0; c < h->d.n_channels; c++) {
+      memcpy((char *)h_out + (size_t)c * n * h->out_eb, (const char *)h->st.pin_out + (size_t)c * stride * h->out_eb, (size_t)n * h->out_eb);
+    }
+    return ACDSP_OK;
+  }
   if ((rc = h->st.ensure(bin, bout))) { return rc; }
   HIP_TRY(hipMemcpy2D(h->st.d_in, (size_t)stride * h->in_eb, h_in, (size_t)n * h->in_eb, (size_t)n * h->in_eb,
                       (size_t)h->d.n_channels, hipMemcpyHostToDevice));
@@ -986,6 +1024,20 @@ int32_t acdsp_cic_run_host(acdsp_cic_t h, const void *h_in, int64_t n_in, void *
   int rc = check_device(h->d.device);
   if (rc) { return rc; }
   const int64_t si = (n_in + 15) / 16 * 16, so = (no + 7) / 8 * 8 + 8;
+  static const bool no_pin = getenv("ACDSP_NO_PINNED") != nullptr;
+  if ((size_t)h->d.n_channels * si * h->in_eb <= Staging::kPinBytes && (size_t)h->d.n_channels * so * h->out_eb <= Staging::kPinBytes && !no_pin) {
+    if ((rc = h->st.ensure_pinned())) { return rc; }
+    for (int c = 0; c < h->d.n_channels; c++) {
+      memcpy((char *)h->st.pin_in + (size_t)c * si * h->in_eb, (const char *)h_in + (size_t)c * n_in * h->in_eb, (size_t)n_in * h->in_eb);
+    }
+    int64_t got = 0;
+    if ((rc = acdsp_cic_run(h, h->st.pin_in, si, n_in, h->st.pin_out, so, &got, nullptr))) { return rc; }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    for (int c = 0; c < h->d.n_channels && no > 0; c++) {
+      memcpy((char *)h_out + (size_t)c * no * h->out_eb, (const char *)h->st.pin_out + (size_t)c * so * h->out_eb, (size_t)no * h->out_eb);
+    }
+    return ACDSP_OK;
+  }
   if ((rc = h->st.ensure((size_t)h->d.n_channels * si * h->in_eb, (size_t)h->d.n_channels * so * h->out_eb))) { return rc; }
   HIP_TRY(hipMemcpy2D(h->st.d_in, (size_t)si * h->in_eb, h_in, (size_t)n_in * h->in_eb, (size_t)n_in * h->in_eb,
                       (size_t)h->d.n_channels, hipMemcpyHostToDevice));

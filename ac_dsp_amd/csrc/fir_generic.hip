@@ -58,6 +58,16 @@ __global__ void __launch_bounds__(kTile) fir_direct_kernel(FirParams p) {
   }
   __syncthreads();
 
+  // small calls (hist_next set): block 0 of a channel also writes the next history -- hist_next[j] = sample at local time
+  // n - hl + j, from this call's input or the old history -- so a one-sample run() is ONE launch (cf. fir_hist_update_kernel)
+  if (p.hist_next && blockIdx.x == 0) {
+    for (int j = tid; j < p.hl; j += kTile) {
+      const int64_t g = p.n - p.hl + j;
+      const int64_t v = (g >= 0) ? load_raw(p.x, (int64_t)ch * p.in_stride + g, p.in_eb, p.in.S)
+                                 : load_raw(p.hist, (int64_t)ch * p.hl + p.hl + g, p.in_eb, p.in.S);
+      store_raw(p.hist_next, (int64_t)ch * p.hl + j, p.in_eb, v);
+    }
+  }
   const int64_t t = t0 + tid;
   if (t >= p.n) { return; }
   const int64_t *w = win + tid + (N - 1);  // w[-k] = x[t-k]

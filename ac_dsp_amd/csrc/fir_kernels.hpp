@@ -20,6 +20,7 @@ struct FirParams {
   const void *hist;            // [n_ch][hl] IN containers: the hl samples before t = 0
   const int64_t *coeffs;       // [n_sets][n_taps] raw words
   const int64_t *rt;           // [n_ch][n_taps] ACC raw words (use_rt)
+  void *hist_next;             // small calls: the exact-order kernels write the next history themselves (one launch per call); else null
 };
 
 // Exact per-tap emulation in the reference's loop order (any Q/O, any widths <= 64).

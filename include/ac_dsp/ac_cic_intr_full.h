@@ -65,7 +65,7 @@ public:
 
 private:
   typedef typename find_inter_type_cic_intr <IN_TYPE, R_, M_, N_>::INT_TYPE INT_TYPE;
-  static_assert(INT_TYPE::width <= 64, "ac_dsp_amd engine: CIC intermediate type limited to 64 bits");
+  static_assert(INT_TYPE::width <= 128, "ac_dsp_amd engine: CIC intermediate type limited to 128 bits");
   acdsp::cic_engine<IN_TYPE, OUT_TYPE> engine;
 };
 

@@ -68,7 +68,7 @@ inline int32_t o_code(ac_o_mode o) {
 
 // ac_fixed<W,I,S,Q,O>  ->  acdsp_fmt_t   (cf. reference ac_cic_dec_full.h:119-121 reading T::width etc.)
 template <class T> inline acdsp_fmt_t fmt_of() {
-  static_assert(T::width >= 1 && T::width <= 64, "ac_dsp_amd engine: ac_fixed widths up to 64 bits");
+  static_assert(T::width >= 1 && T::width <= 128, "ac_dsp_amd engine: ac_fixed widths up to 128 bits (IN / COEFF: 64; checked by the engine)");
   acdsp_fmt_t f;
   f.W = T::width; f.I = T::i_width; f.S = T::sign ? 1 : 0;
   f.Q = q_code(T::q_mode); f.O = o_code(T::o_mode);
@@ -83,6 +83,40 @@ template <class T> inline T from_raw(int64_t r) {
   v.set_slc(0, ac_int<T::width, T::sign>((long long)r));
   return v;
 }
+
+// One ac_fixed value <-> its engine container (int16 / int32 / int64 by width; 16 bytes, low quadword first, above 64 bits:
+// ACC_TYPE / OUT_TYPE of the FIR classes and the CIC INT_TYPE may be that wide, reference ac_cic_dec_full.h:116-137).
+template <class T, bool WIDE = (T::width > 64)> struct container_io {
+  static void store(const T &v, unsigned char *p, int eb) {
+    const int64_t r = raw_of(v);
+    if (eb == 2) { int16_t t = (int16_t)r; memcpy(p, &t, 2); }
+    else if (eb == 4) { int32_t t = (int32_t)r; memcpy(p, &t, 4); }
+    else { memcpy(p, &r, 8); }
+  }
+  static T load(const unsigned char *p, int eb) {
+    int64_t r;
+    if (eb == 2) { int16_t t; memcpy(&t, p, 2); r = T::sign ? (int64_t)t : (int64_t)(uint16_t)t; }
+    else if (eb == 4) { int32_t t; memcpy(&t, p, 4); r = T::sign ? (int64_t)t : (int64_t)(uint32_t)t; }
+    else { memcpy(&r, p, 8); }
+    return from_raw<T>(r);
+  }
+};
+template <class T> struct container_io<T, true> {
+  enum { HW = T::width - 64 };
+  static void store(const T &v, unsigned char *p, int) {
+    const uint64_t lo = (uint64_t)v.template slc<64>(0).to_int64();
+    const int64_t hi = (int64_t)v.template slc<HW>(64).to_int64();   // ac_int<HW, S>: sign / zero extended
+    memcpy(p, &lo, 8); memcpy(p + 8, &hi, 8);
+  }
+  static T load(const unsigned char *p, int) {
+    uint64_t lo; int64_t hi;
+    memcpy(&lo, p, 8); memcpy(&hi, p + 8, 8);
+    T v;
+    v.set_slc(0, ac_int<64, false>((unsigned long long)lo));
+    v.set_slc(64, ac_int<HW, T::sign>((long long)hi));
+    return v;
+  }
+};
 
 // pack / unpack raw words into the engine's containers (int16 / int32 / int64 by width)
 inline void pack(const std::vector<int64_t> &src, int eb, std::vector<unsigned char> &dst) {
@@ -160,7 +194,7 @@ public:
     pack(r, in_bytes(), bi);
     run_host(bi.data(), (int64_t)x.size(), bo.data());
     y.resize(x.size());
-    for (size_t i = 0; i < x.size(); i++) { y[i] = from_raw<OUT_TYPE>(unpack_one(&bo[i * out_bytes()], out_bytes(), OUT_TYPE::sign)); }
+    for (size_t i = 0; i < x.size(); i++) { y[i] = container_io<OUT_TYPE>::load(&bo[i * out_bytes()], out_bytes()); }
   }
   void reset() { if (h_) { check(acdsp_fir_reset(h_), "acdsp_fir_reset"); } }
 
@@ -223,7 +257,7 @@ public:
     int64_t n_out = 0;
     check(acdsp_cic_run_host(h_, bi.data(), (int64_t)x.size(), bo.data(), cap, &n_out), "acdsp_cic_run_host");
     y.resize((size_t)n_out);
-    for (int64_t i = 0; i < n_out; i++) { y[(size_t)i] = from_raw<OUT_TYPE>(unpack_one(&bo[(size_t)i * out_bytes()], out_bytes(), OUT_TYPE::sign)); }
+    for (int64_t i = 0; i < n_out; i++) { y[(size_t)i] = container_io<OUT_TYPE>::load(&bo[(size_t)i * out_bytes()], out_bytes()); }
   }
 
 private:

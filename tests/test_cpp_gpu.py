@@ -21,7 +21,7 @@ def run(exe):
     return p.returncode, p.stdout.decode(errors="replace")
 
 
-TBS = ("tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg")
+TBS = ("tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg", "tb_wide")
 # tests/_bin arrived prebuilt (the snapshot of a build container that ran __graft_entry__.build()): then the reference's rtest_*
 # binaries must have arrived with it -- a lost binary is a failure there, not a skip
 PREBUILT = all(os.path.exists(os.path.join(BIN, t)) for t in TBS)
@@ -29,11 +29,11 @@ PREBUILT = all(os.path.exists(os.path.join(BIN, t)) for t in TBS)
 
 @pytest.fixture(scope="module", autouse=True)
 def built():
-    if not all(os.path.exists(os.path.join(BIN, t)) for t in ("tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg")):
+    if not all(os.path.exists(os.path.join(BIN, t)) for t in TBS):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
 
 
-@pytest.mark.parametrize("tb", ["tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg"])
+@pytest.mark.parametrize("tb", list(TBS))
 def test_own_cpp_testbench(tb):
     rc, out = run(os.path.join(BIN, tb))
     assert rc == 0 and "Test PASSED." in out, out
