@@ -119,3 +119,36 @@ def test_wide_cic_oracle_equals_the_python_model(interp, R, Mm, N, fin):
             want, st = M.cic(interp, R, Mm, N, x, fin, fo, st)
             got = o.run(np.array([x], dtype=np.int64))
             assert (list(got[0]) if got.size else []) == want, (interp, R, Mm, N, n)
+
+
+def wide_cases(kind):
+    import golden_cases as G
+    return G.load((kind,))
+
+
+@pytest.mark.parametrize("c", wide_cases("wide_fir"), ids=lambda c: c["name"])
+def test_wide_fir_oracle_matches_the_reference_headers_vectors(c):
+    """tests/golden/ref_hdr/wide.json: the reference's own ac_fir_load_coeffs source compiled over include/ac_types with an 80-bit
+    accumulator (tools/gen_golden/gen_wide.cpp) -- pins loop order, the ACC-typed fold and the per-tap conversions at this width."""
+    f = [Fmt(*c[k][:2], bool(c[k][2]), c[k][3], c[k][4]) for k in ("in", "coeff", "acc", "out")]
+    o = OracleFirW(c["n_taps"], c["ftype"], *f)
+    x = np.array(c["x"], dtype=np.int64)
+    got, pos = [], 0
+    for k in c["calls"]:
+        got += list(o.run(np.array(c["coeffs"], dtype=np.int64), x[None, pos:pos + k])[0])
+        pos += k
+    assert got == c["y"]
+
+
+@pytest.mark.parametrize("c", wide_cases("wide_cic_dec"), ids=lambda c: c["name"])
+def test_wide_cic_oracle_matches_the_reference_headers_vectors(c):
+    fin, fo = (Fmt(*c[k][:2], bool(c[k][2]), c[k][3], c[k][4]) for k in ("in", "out"))
+    o = OracleCicW(0, c["R"], c["M"], c["N"], fin, fo)
+    x = np.array(c["x"], dtype=np.int64)
+    got, pos = [], 0
+    for k, want_n in zip(c["calls"], c["outs_per_call"]):
+        y = o.run(x[None, pos:pos + k])
+        assert y.shape[1] == want_n
+        got += list(y[0])
+        pos += k
+    assert got == c["y"]

@@ -126,3 +126,48 @@ def test_wide_limits_are_refused_loudly():
         A.Fir(8, "SHIFT_REG", A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(130, 50), A.Fmt(100, 50))      # ACC wider than 128 bits
     with pytest.raises(A.AcdspError):
         A.Fir(8, "SHIFT_REG", A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(128, 50, False), A.Fmt(100, 50))   # unsigned 128
+
+
+def _wide_cases(kind):
+    import golden_cases as G
+    return G.load((kind,))
+
+
+def _fmt(a):
+    return A.Fmt(a[0], a[1], bool(a[2]), a[3], a[4])
+
+
+@pytest.mark.parametrize("c", _wide_cases("wide_fir"), ids=lambda c: c["name"])
+def test_wide_fir_matches_the_reference_headers_vectors(c):
+    """The vectors the reference's own ac_fir_load_coeffs source produced with an 80-bit accumulator (tests/golden/ref_hdr/wide.json)."""
+    fin, fc, fa, fo = (_fmt(c[k]) for k in ("in", "coeff", "acc", "out"))
+    nch = 3                                              # the same stream on three channels (addressing: the fuzz / sweep tests)
+    fir = A.Fir(c["n_taps"], c["ftype"], fin, fc, fa, fo, n_channels=nch, kind="load")
+    fir.set_coeffs(np.array(c["coeffs"], dtype=np.int64))
+    x = torch.from_numpy(np.tile(np.array(c["x"], dtype=np.int64).astype(np.int32), (nch, 1))).cuda()
+    got, pos = [], 0
+    for k in c["calls"]:
+        got.append(to_int(fir.run(x[:, pos:pos + k].contiguous()), fo))
+        pos += k
+    got = np.concatenate(got, axis=1)
+    want = np.array(c["y"], dtype=object)
+    for ch in range(nch):
+        assert np.array_equal(got[ch], want), c["name"]
+
+
+@pytest.mark.parametrize("c", _wide_cases("wide_cic_dec"), ids=lambda c: c["name"])
+def test_wide_cic_matches_the_reference_headers_vectors(c):
+    fin, fo = _fmt(c["in"]), _fmt(c["out"])
+    nch = 2
+    cic = A.Cic(False, c["R"], c["M"], c["N"], fin, fo, n_channels=nch)
+    x = torch.from_numpy(np.tile(np.array(c["x"], dtype=np.int64), (nch, 1))).cuda()
+    got, pos = [], 0
+    for k, want_n in zip(c["calls"], c["outs_per_call"]):
+        y = to_int(cic.run(x[:, pos:pos + k].contiguous()), fo)
+        assert y.shape[1] == want_n
+        got.append(y)
+        pos += k
+    got = np.concatenate(got, axis=1)
+    want = np.array(c["y"], dtype=object)
+    for ch in range(nch):
+        assert np.array_equal(got[ch], want), c["name"]
