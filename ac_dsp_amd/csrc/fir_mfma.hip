@@ -435,11 +435,21 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   unsigned char *obuf = lds + (RINGED ? 4 : 2 * 4) * ARR;
   unsigned char *dummy = obuf + (EPI == 3 ? 8192 : 2048);   // 1 KB sink for the surplus lanes of stage()
 
+  // ACDSP_FIR_DIRECT (A/B knob): the int16 classes take the Toeplitz rows in permuted order -- matrix row a + 4 h + 8 q computes output
+  // 16 h + 4 q + a of the block -- so that the 16 accumulator registers of lane (n, h) are the 16 CONSECUTIVE outputs 32 n + 16 h + r:
+  // 32 contiguous bytes per lane, stored straight from registers (no permlane swaps, no LDS tile).  The permutation is a lane
+  // permutation of the fragment load; fragments in memory and every other kernel are untouched.
+#ifdef ACDSP_FIR_DIRECT
+  constexpr bool DIRECT = EPI != 3;
+#else
+  constexpr bool DIRECT = false;
+#endif
+  const int frag_lane = DIRECT ? (16 * ((lane >> 2) & 1) + 4 * ((lane & 31) >> 3) + (lane & 3) + (lane & 32)) : lane;
   v4i Ah[NB], Al[NB];
 #pragma unroll
   for (int b = 0; b < NB; b++) {
-    Ah[b] = frag[((int64_t)set * 2 * NB + 0 * NB + b) * 64 + lane];
-    Al[b] = frag[((int64_t)set * 2 * NB + 1 * NB + b) * 64 + lane];
+    Ah[b] = frag[((int64_t)set * 2 * NB + 0 * NB + b) * 64 + frag_lane];
+    Al[b] = frag[((int64_t)set * 2 * NB + 1 * NB + b) * 64 + frag_lane];
   }
   const int16_t *xrow = (const int16_t *)p.x + (int64_t)ch * p.in_stride;
   const int16_t *hrow = (const int16_t *)p.hist + (int64_t)ch * p.hl + p.hl;
@@ -580,6 +590,26 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     }
     int o[16];
     epi32_t<decltype(wide_c)::value>(hh, mid, ll, rs, o);
+    if constexpr (DIRECT) {
+#pragma unroll
+      for (int pr = 0; pr < 2; pr++) {
+        if (prsel != 2 && prsel != pr) { continue; }
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int a = o[8 * pr + 2 * j], b = o[8 * pr + 2 * j + 1];
+          w[j] = EPI == 2 ? __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(a, b)) : __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x05040100u);
+        }
+        const v4i val = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+        v4i *dst = (v4i *)((char *)(yout + T0) + 64 * n_col + 32 * h + 16 * pr);
+#if ACDSP_FIR_NT & 2
+        __builtin_nontemporal_store(val, dst);
+#else
+        *dst = val;
+#endif
+      }
+      return;
+    }
     // A lane holds rows 8 g + 4 h .. + 3 of column n: 8 bytes per g, and the 16 lanes of a ds_write_b64 group share h, so
     // they can reach only half of the 32 banks (2-way conflict on every store: the 16.6 % SQ_LDS_BANK_CONFLICT of round 1).
     // v_permlane32_swap trades g-odd of the h = 0 lanes for g-even of the h = 1 lanes: every lane then owns 16 contiguous
@@ -607,6 +637,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   };
   // ... and its row-contiguous write-out: two coalesced 16-byte-per-lane stores
   auto flush = [&](int64_t T0) {
+    if constexpr (DIRECT) { return; }   // emit() stored from registers
     if constexpr (EPI == 3) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
