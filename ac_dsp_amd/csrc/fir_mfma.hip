@@ -438,7 +438,10 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   // ACDSP_FIR_DIRECT (A/B knob): the int16 classes take the Toeplitz rows in permuted order -- matrix row a + 4 h + 8 q computes output
   // 16 h + 4 q + a of the block -- so that the 16 accumulator registers of lane (n, h) are the 16 CONSECUTIVE outputs 32 n + 16 h + r:
   // 32 contiguous bytes per lane, stored straight from registers (no permlane swaps, no LDS tile).  The permutation is a lane
-  // permutation of the fragment load; fragments in memory and every other kernel are untouched.
+  // permutation of the fragment load; fragments in memory and every other kernel are untouched.  MEASURED AND REJECTED
+  // (profiles/r3_ab_direct_nt.txt, same box): 0.907 -> 1.23 ms on config 2 -- each store instruction then writes every other 16-byte
+  // piece of a 2 KB run, and the write path wants whole contiguous KB per instruction far more than the kernel wants the four LDS
+  // instructions back.  Off; kept as the record of the experiment.
 #ifdef ACDSP_FIR_DIRECT
   constexpr bool DIRECT = EPI != 3;
 #else
