@@ -586,11 +586,15 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
     return ACDSP_OK;
   }
   if (path == ACDSP_PATH_MFMA_I8 || path == ACDSP_PATH_MFMA_GEN) {
-    // The matrix-core kernels read rows with 16-byte vector loads (fir_gen: in whole 16-sample slots).  Rows that are
-    // not laid out that way are first copied, on the device, into an aligned staging image (one extra read + write of
-    // the input: still ~30x faster than sending the call to the VALU dot-product kernel).
-    const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0) &&
-                         (path == ACDSP_PATH_MFMA_I8 || in_stride >= (n + 15) / 16 * 16);
+    // The matrix-core kernels read rows with 16-byte vector loads (fir_gen: in whole 16-sample slots).  gfx950 serves a vector
+    // access at any ELEMENT-aligned address, so the int8 kernel takes unaligned rows as they are (round 3: a row stride of 2^20 + 3
+    // samples costs +12 %, profiles/r3_unaligned.txt; the staging copy below -- hipMemcpy2DAsync of misaligned rows -- cost 6.4 ms
+    // per 2 GB, 7 x the filter itself) as long as a row is readable up to the next multiple of 8 samples.  fir_gen still wants
+    // whole aligned slots: rows that are not laid out that way are first copied, on the device, into an aligned staging image.
+    static const bool aligned_only = getenv("ACDSP_ALIGNED_ONLY") != nullptr;   // A/B knob: the round-2 behaviour
+    bool aligned = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0) &&
+                   (path == ACDSP_PATH_MFMA_I8 || in_stride >= (n + 15) / 16 * 16);
+    if (!aligned && !aligned_only && path == ACDSP_PATH_MFMA_I8 && in_stride >= (n + 7) / 8 * 8) { aligned = true; }
     if (!aligned) {
       const int64_t si = (n + 15) / 16 * 16;
       if ((rc = h->st.ensure((size_t)d.n_channels * si * h->in_eb, 0))) { return rc; }

@@ -454,9 +454,23 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
       const v4i val = *(const v4i *)(ob + ((lane ^ ((lane >> 4) & 3)) * 16));
       *(v4i *)(yrow + m0 * 4 + 16 * lane) = val;
     } else {
+#if defined(ACDSP_GEN_ST1K) && ACDSP_GEN_ST1K
+      // 2-byte outputs: a step is only 512 bytes.  Steps are paired in the tile (slot = step parity inside the chunk) and leave as ONE
+      // full-wave 1 KB store after the odd step; a chunk with an odd number of steps stores its last 512 bytes alone.
+      const int par = (int)((st - s0) & 1);
+      if (par == 1) {
+        const v4i val = *(const v4i *)(ob + lane * 16);
+        *(v4i *)(yrow + (m0 - 256) * 2 + 16 * lane) = val;
+      } else if (st == s1 - 1) {
+        const int P = lane & 31;
+        const v4i val = *(const v4i *)(ob + P * 16);
+        *(v4i *)(yrow + m0 * 2 + 16 * P) = val;
+      }
+#else
       const int P = lane & 31;                       // both wave halves store the same 512 bytes: no exec-mask branch
       const v4i val = *(const v4i *)(ob + P * 16);
       *(v4i *)(yrow + m0 * 2 + 16 * P) = val;
+#endif
     }
   };
   // One step.  Program order: stage step st (its slots were fetched one step ago), write out step st-1, fetch step
@@ -516,7 +530,11 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
       *(v4i *)(ob + ((L ^ ((n_col >> 2) & 3)) * 16)) = (v4i){(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
     } else {
       typedef short v4s_ __attribute__((ext_vector_type(4)));
+#if defined(ACDSP_GEN_ST1K) && ACDSP_GEN_ST1K
+      *(v4s_ *)(ob + 512 * (int)((st - s0) & 1) + (4 * n_col + kg) * 8) = (v4s_){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+#else
       *(v4s_ *)(ob + (4 * n_col + kg) * 8) = (v4s_){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+#endif
     }
   };
 

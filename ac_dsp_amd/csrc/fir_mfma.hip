@@ -1315,7 +1315,10 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   if (spw_env && atoi(spw_env) > 1) { spw = atoi(spw_env); }
   a.steps_per_wave = spw;
   const int oeb = p.out_eb;
-  a.out_vec_ok = ((uintptr_t)p.y % (4 * oeb) == 0) && ((p.out_stride * oeb) % (4 * oeb) == 0);
+  // vector stores at any element-aligned address (gfx950 takes them: 652 parity tests with unaligned rows forced through the vector
+  // paths, profiles/r3_unaligned.txt); ACDSP_ALIGNED_ONLY=1 restores the round-2 rule (guarded element-wise stores for such rows)
+  static const bool aligned_only = getenv("ACDSP_ALIGNED_ONLY") != nullptr;
+  a.out_vec_ok = !aligned_only || (((uintptr_t)p.y % (4 * oeb) == 0) && ((p.out_stride * oeb) % (4 * oeb) == 0));
   a.frag_per_channel = frag_per_channel;
   a.hi_mask = plan.hi_mask;
   a.lo_mask = plan.lo_mask;
