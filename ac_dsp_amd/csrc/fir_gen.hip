@@ -114,6 +114,7 @@ struct GenArgs {
   int64_t n16;                // n_in rounded up to 16: rows are readable that far
   int32_t obuf_off;           // byte offset of the 256-output tile in LDS (row-contiguous write-out)
   int32_t chunk0;             // first chunk (of steps_per_wave steps) this launch covers: blockIdx.x + chunk0
+  int32_t xcd_map;            // fast kernels: XCD-affine chunk order (xcd_remap below); the host sets it only when grid.x * grid.y % 8 == 0
   // branch-free output conversion of the fast kernel (host-derived from out_mode / the formats):
   //   v = wrapS_{64-ka}(y << ls);  v = ((v + rnd) >> rs) << ls2;  v = clamp(v, lo, hi);  v = wrapS_{64-ko}(v)
   int32_t e_ls, e_ka, e_rs, e_ls2, e_ko;
@@ -125,6 +126,20 @@ struct GenArgs {
   int32_t l_hb_lo, l_hb_hi;   // stage B, AC_SAT: clamp of the high limb in front of the funnel shift
   int32_t l_lo, l_hi, l_w;    // stage B: OUT range (AC_SAT) / OUT width (AC_WRAP: l_lo = l_hi = 0)
 };
+
+// Workgroups are dispatched round-robin over the 8 XCDs (workgroup L runs on XCD L % 8: observed rule, only speed depends on it).
+// With (chunk, channel) = plain launch order every XCD touches every 8th chunk of the stream; remapped, XCD k walks the k-th
+// contiguous eighth of the launch's chunks in memory order -- each L2 then streams its own region (tools/copy_probe2.hip: +3 - 5 %
+// on a copy with 16 KB spans).  Returns (chunk index, channel) for this workgroup.
+__device__ __forceinline__ void xcd_remap(int on, int &bx, int &by) {
+  bx = blockIdx.x; by = blockIdx.y;
+  if (on) {
+    const int64_t T = (int64_t)gridDim.x * gridDim.y, L = (int64_t)by * gridDim.x + bx;
+    const int64_t L2 = (L & 7) * (T >> 3) + (L >> 3);
+    by = (int)(L2 / gridDim.x);
+    bx = (int)(L2 - (int64_t)by * gridDim.x);
+  }
+}
 
 __device__ inline int phys_slot(int s, const GenArgs &a) {
   return a.pad ? s + (int)__umulhi((unsigned)s, a.rcp) : s;   // s + s / R (exact for s < 2^16)
@@ -331,7 +346,8 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [PX][phys slots][16] + output tile
   const int lane = threadIdx.x;
   const int n_col = lane & 15, kg = lane >> 4;
-  const int ch = blockIdx.y;
+  int bx, ch;
+  xcd_remap(a.xcd_map, bx, ch);
   const int NB = a.pl.nb, PC = a.pl.pc, R = a.pl.R;
   const int plane_bytes = a.obuf_off / PX;
 
@@ -345,7 +361,7 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
   }
   const TIN *xrow = (const TIN *)p.x + (int64_t)ch * p.in_stride;
   const TIN *hrow = (const TIN *)p.hist + (int64_t)ch * p.hl + p.hl;
-  const int64_t s0 = ((int64_t)blockIdx.x + a.chunk0) * a.steps_per_wave;
+  const int64_t s0 = ((int64_t)bx + a.chunk0) * a.steps_per_wave;
   const int64_t s1 = s0 + a.steps_per_wave;            // the launch covers complete chunks only
 
   // Loads are coalesced over the window, not over a lane's slot: load k of a lane is 16-byte piece lane + 64 k of the step's
@@ -454,23 +470,9 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
       const v4i val = *(const v4i *)(ob + ((lane ^ ((lane >> 4) & 3)) * 16));
       *(v4i *)(yrow + m0 * 4 + 16 * lane) = val;
     } else {
-#if defined(ACDSP_GEN_ST1K) && ACDSP_GEN_ST1K
-      // 2-byte outputs: a step is only 512 bytes.  Steps are paired in the tile (slot = step parity inside the chunk) and leave as ONE
-      // full-wave 1 KB store after the odd step; a chunk with an odd number of steps stores its last 512 bytes alone.
-      const int par = (int)((st - s0) & 1);
-      if (par == 1) {
-        const v4i val = *(const v4i *)(ob + lane * 16);
-        *(v4i *)(yrow + (m0 - 256) * 2 + 16 * lane) = val;
-      } else if (st == s1 - 1) {
-        const int P = lane & 31;
-        const v4i val = *(const v4i *)(ob + P * 16);
-        *(v4i *)(yrow + m0 * 2 + 16 * P) = val;
-      }
-#else
       const int P = lane & 31;                       // both wave halves store the same 512 bytes: no exec-mask branch
       const v4i val = *(const v4i *)(ob + P * 16);
-      *(v4i *)(yrow + m0 * 2 + 16 * P) = val;
-#endif
+      *(v4i *)(yrow + m0 * 2 + 16 * P) = val;       // (pairing two steps into one 1 KB store: +0.2 %, profiles/r3_ab_store_width.txt -- not kept)
     }
   };
   // One step.  Program order: stage step st (its slots were fetched one step ago), write out step st-1, fetch step
@@ -530,11 +532,7 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
       *(v4i *)(ob + ((L ^ ((n_col >> 2) & 3)) * 16)) = (v4i){(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
     } else {
       typedef short v4s_ __attribute__((ext_vector_type(4)));
-#if defined(ACDSP_GEN_ST1K) && ACDSP_GEN_ST1K
-      *(v4s_ *)(ob + 512 * (int)((st - s0) & 1) + (4 * n_col + kg) * 8) = (v4s_){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
-#else
       *(v4s_ *)(ob + (4 * n_col + kg) * 8) = (v4s_){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
-#endif
     }
   };
 
@@ -657,8 +655,15 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   const int64_t fast_chunks = (nbt && conv_ok && a.out_vec_ok) ? n_out / (spw * 256) : 0;   // chunks made of complete steps only
   const v4i *fr = (const v4i *)d_frag;
   hipError_t e = hipSuccess;
+  a.xcd_map = 0;
   if (fast_chunks > 0) {
     dim3 grid((unsigned)fast_chunks, (unsigned)p.n_ch);
+    // XCD-affine chunk order (xcd_remap): measured per shape, same box, three passes (profiles/r3_xcd_map.txt) -- config 3 (CIC R8 on
+    // int32, 8 KB of input per step) +2.5 % every time, poly_dec -0.6 % twice and +6.6 % once, the fused DDC -3 %: on for the
+    // int32 decimator shape only.  ACDSP_XCD_MAP=0 / 1 forces it off / on for every shape (A/B knob).
+    static const char *xcd_env = getenv("ACDSP_XCD_MAP");
+    const bool xcd_on = xcd_env ? atoi(xcd_env) != 0 : (out_mode == 1 && in_eb == 4);
+    a.xcd_map = (xcd_on && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
     if (in_eb == 4) { e = launch_fast<int32_t, 4, 2, 3, 3, 8>(grid, lds_bytes, s, p, fr, a); }
     else if (in_eb == 8) { e = launch_fast<int64_t, 5, 2, 3, 1, 4>(grid, lds_bytes, s, p, fr, a); }
     else if (oeb == 8) { e = launch_fast<int16_t, 2, 3, 6, 5, 8>(grid, lds_bytes, s, p, fr, a); }
@@ -666,6 +671,7 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     if (e != hipSuccess) { return e; }
   }
   if (fast_chunks >= n_chunks) { return hipSuccess; }
+  a.xcd_map = 0;
   a.chunk0 = (int32_t)fast_chunks;                                    // ragged tail (and every unlisted shape): general kernel
   dim3 grid((unsigned)(n_chunks - fast_chunks), (unsigned)p.n_ch);
   switch (p.in_eb) {
@@ -694,7 +700,8 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [A planes][B ring: PXB x 32 slots][1 KB output tile]
   const int lane = threadIdx.x;
   const int n_col = lane & 15, kg = lane >> 4;
-  const int ch = blockIdx.y;
+  int bx, ch;
+  xcd_remap(a.xcd_map, bx, ch);
   const int R = a.pl.R;
   const int plane_bytes = a.obuf_off / PXA;
   unsigned char *ring = lds + a.obuf_off;
@@ -713,7 +720,7 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   }
   const TIN *xrow = (const TIN *)pa.x + (int64_t)ch * pa.in_stride;
   const TIN *hrow = (const TIN *)pa.hist + (int64_t)ch * pa.hl + pa.hl;
-  const int64_t s0 = ((int64_t)blockIdx.x + a.chunk0) * a.steps_per_wave;
+  const int64_t s0 = ((int64_t)bx + a.chunk0) * a.steps_per_wave;
   const int64_t s1 = GUARD ? ((s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps) : s0 + a.steps_per_wave;
 
   // window loads coalesced over 16-byte pieces (8 samples; a slot is two pieces), as in fir_gen_fast_kernel
@@ -1004,11 +1011,15 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   if (e != hipSuccess) { return e; }                                                                                                 \
   hipLaunchKernelGGL((cascade_kernel<2, 3, 6, 5, 5, 2, 3, GUARD_, LIMB_>), GRID_, dim3(64), lds_bytes, s, pa, pb, fa, fb, a, b);      \
   if ((e = hipGetLastError()) != hipSuccess) { return e; }
+  a.xcd_map = 0;
   if (fast_chunks > 0) {
     const dim3 grid((unsigned)fast_chunks, (unsigned)pa.n_ch);
+    static const char *xcd_env = getenv("ACDSP_XCD_MAP");   // (off by default here: -3 % on config 5, profiles/r3_xcd_map.txt)
+    a.xcd_map = (xcd_env && atoi(xcd_env) != 0 && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
     if (limb) { ACDSP_CASCADE_LAUNCH(false, true, grid) } else { ACDSP_CASCADE_LAUNCH(false, false, grid) }
   }
   if (fast_chunks < n_chunks) {
+    a.xcd_map = 0;
     a.chunk0 = (int32_t)fast_chunks;
     const dim3 grid((unsigned)(n_chunks - fast_chunks), (unsigned)pa.n_ch);
     if (limb) { ACDSP_CASCADE_LAUNCH(true, true, grid) } else { ACDSP_CASCADE_LAUNCH(true, false, grid) }

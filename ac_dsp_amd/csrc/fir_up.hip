@@ -173,25 +173,8 @@ __global__ void __launch_bounds__(64, (PX * NBT >= 4 ? 2 : 3)) fir_up_kernel(UpA
   // write-out of FU finished groups: FU x 8 KB (OEB 8) / FU x 2 KB (OEB 2) contiguous, 8 bytes per lane and instruction.
   // e_unit = output element (before out_off) of column 0, row 0 of the first group.
   auto flush = [&](int64_t e_unit) {
-#if defined(ACDSP_UP_ST16) && ACDSP_UP_ST16   // A/B knob: 16 bytes per lane and store instruction (1 KB per instruction instead of 512 B)
-    typedef int v4i_ __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int k = 0; k < FU * 32 * RUN / 1024; k++) {
-      const int lin = (k * 64 + lane) * 16;
-      const int cc = lin / RUN, w = lin % RUN;
-      v4i_ val;
-      if (RUNP % 16 == 0) { val = *(const v4i_ *)(tile + cc * RUNP + w); }
-      else {                                                    // 8-byte aligned tile rows (OEB 2): two 8-byte reads
-        const long a0 = *(const long *)(tile + cc * RUNP + w), a1 = *(const long *)(tile + cc * RUNP + w + 8);
-        val = (v4i_){(int)a0, (int)(a0 >> 32), (int)a1, (int)(a1 >> 32)};
-      }
-#if defined(ACDSP_UP_NT) && ACDSP_UP_NT
-      __builtin_nontemporal_store(val, (v4i_ *)(yrow + e_unit * OEB + lin));
-#else
-      *(v4i_ *)(yrow + e_unit * OEB + lin) = val;
-#endif
-    }
-#else
+    // (16 bytes per lane and store instruction, i.e. 1 KB instead of 512 B per instruction, was A/B-tested: -0.3 % / +0.3 % on the two
+    // bench rows, profiles/r3_ab_store_width.txt -- not kept)
 #pragma unroll
     for (int k = 0; k < FU * 32 * RUN / 512; k++) {
       const int lin = (k * 64 + lane) * 8;
@@ -206,7 +189,6 @@ __global__ void __launch_bounds__(64, (PX * NBT >= 4 ? 2 : 3)) fir_up_kernel(UpA
       *(long *)(yrow + e_unit * OEB + lin) = val;
 #endif
     }
-#endif
   };
   // One step.  VMEM program order: [wait for this step's samples] -> loads of the step AHEAD later -> the stores of this step.
   // AHEAD = 2 with alternating register sets for the branch-free epilogues: the loads a step waits for were issued two steps
