@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/acdsp.h"
 
@@ -128,6 +129,25 @@ __device__ inline void store_raw(void *p, int64_t idx, int eb, int64_t v) {
   if (eb == 2) { ((int16_t *)p)[idx] = (int16_t)v; }
   else if (eb == 4) { ((int32_t *)p)[idx] = (int32_t)v; }
   else { ((int64_t *)p)[idx] = v; }
+}
+
+// XCD-affine work order.  Workgroups are dispatched round-robin over the 8 XCDs (workgroup L runs on XCD L % 8: observed rule, only
+// speed depends on it).  In plain launch order every XCD touches every 8th piece of a stream; remapped, XCD k walks the k-th
+// contiguous eighth of the launch in memory order (tools/copy_probe2.hip: +3 - 5 % on a copy with 16 KB spans).  `on` is set by the
+// host only when the launch has a multiple of 8 workgroups.  Returns the remapped (x, y) block index.
+__device__ __forceinline__ void xcd_remap(int on, int &bx, int &by) {
+  bx = blockIdx.x; by = blockIdx.y;
+  if (on) {
+    const int64_t T = (int64_t)gridDim.x * gridDim.y, L = (int64_t)by * gridDim.x + bx;
+    const int64_t L2 = (L & 7) * (T >> 3) + (L >> 3);
+    by = (int)(L2 / gridDim.x);
+    bx = (int)(L2 - (int64_t)by * gridDim.x);
+  }
+}
+// default of a kernel family, overridden by ACDSP_XCD_MAP=0 / 1 (A/B knob)
+inline bool xcd_map_wanted(bool family_default) {
+  static const char *e = getenv("ACDSP_XCD_MAP");
+  return e ? atoi(e) != 0 : family_default;
 }
 
 }  // namespace acdsp

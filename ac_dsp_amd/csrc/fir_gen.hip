@@ -127,19 +127,6 @@ struct GenArgs {
   int32_t l_lo, l_hi, l_w;    // stage B: OUT range (AC_SAT) / OUT width (AC_WRAP: l_lo = l_hi = 0)
 };
 
-// Workgroups are dispatched round-robin over the 8 XCDs (workgroup L runs on XCD L % 8: observed rule, only speed depends on it).
-// With (chunk, channel) = plain launch order every XCD touches every 8th chunk of the stream; remapped, XCD k walks the k-th
-// contiguous eighth of the launch's chunks in memory order -- each L2 then streams its own region (tools/copy_probe2.hip: +3 - 5 %
-// on a copy with 16 KB spans).  Returns (chunk index, channel) for this workgroup.
-__device__ __forceinline__ void xcd_remap(int on, int &bx, int &by) {
-  bx = blockIdx.x; by = blockIdx.y;
-  if (on) {
-    const int64_t T = (int64_t)gridDim.x * gridDim.y, L = (int64_t)by * gridDim.x + bx;
-    const int64_t L2 = (L & 7) * (T >> 3) + (L >> 3);
-    by = (int)(L2 / gridDim.x);
-    bx = (int)(L2 - (int64_t)by * gridDim.x);
-  }
-}
 
 __device__ inline int phys_slot(int s, const GenArgs &a) {
   return a.pad ? s + (int)__umulhi((unsigned)s, a.rcp) : s;   // s + s / R (exact for s < 2^16)
@@ -661,9 +648,7 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     // XCD-affine chunk order (xcd_remap): measured per shape, same box, three passes (profiles/r3_xcd_map.txt) -- config 3 (CIC R8 on
     // int32, 8 KB of input per step) +2.5 % every time, poly_dec -0.6 % twice and +6.6 % once, the fused DDC -3 %: on for the
     // int32 decimator shape only.  ACDSP_XCD_MAP=0 / 1 forces it off / on for every shape (A/B knob).
-    static const char *xcd_env = getenv("ACDSP_XCD_MAP");
-    const bool xcd_on = xcd_env ? atoi(xcd_env) != 0 : (out_mode == 1 && in_eb == 4);
-    a.xcd_map = (xcd_on && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
+    a.xcd_map = (xcd_map_wanted(out_mode == 1 && in_eb == 4) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
     if (in_eb == 4) { e = launch_fast<int32_t, 4, 2, 3, 3, 8>(grid, lds_bytes, s, p, fr, a); }
     else if (in_eb == 8) { e = launch_fast<int64_t, 5, 2, 3, 1, 4>(grid, lds_bytes, s, p, fr, a); }
     else if (oeb == 8) { e = launch_fast<int16_t, 2, 3, 6, 5, 8>(grid, lds_bytes, s, p, fr, a); }
@@ -1014,8 +999,7 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   a.xcd_map = 0;
   if (fast_chunks > 0) {
     const dim3 grid((unsigned)fast_chunks, (unsigned)pa.n_ch);
-    static const char *xcd_env = getenv("ACDSP_XCD_MAP");   // (off by default here: -3 % on config 5, profiles/r3_xcd_map.txt)
-    a.xcd_map = (xcd_env && atoi(xcd_env) != 0 && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
+    a.xcd_map = (xcd_map_wanted(false) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;   // off by default here: -3 % on config 5 (profiles/r3_xcd_map.txt)
     if (limb) { ACDSP_CASCADE_LAUNCH(false, true, grid) } else { ACDSP_CASCADE_LAUNCH(false, false, grid) }
   }
   if (fast_chunks < n_chunks) {

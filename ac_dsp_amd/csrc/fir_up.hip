@@ -75,6 +75,7 @@ struct UpArgs {
   // EPI 2 (mode 1, INT_TYPE and OUT_TYPE wider than 32 bits, same fraction, AC_WRAP): bit-field wraps of the high word
   int32_t e_rs, e_rnd, e_lo, e_hi, e_w;
   uint64_t e_mask;
+  int32_t xcd_map;   // XCD-affine chunk order (acdsp_dev.hpp: xcd_remap)
 };
 
 // EPI 0: 64-bit recombination + the generic conversions (any Q / O mode; uniform branches per output).
@@ -105,7 +106,8 @@ __global__ void __launch_bounds__(64, (PX * NBT >= 4 ? 2 : 3)) fir_up_kernel(UpA
   const FirParams &p = a.p;
   const int lane = threadIdx.x;
   const int c = lane & 31, h = lane >> 5;
-  const int ch = blockIdx.y;
+  int bx, ch;
+  xcd_remap(a.xcd_map, bx, ch);
 
   v4i A[NBT][PCT];
 #pragma unroll
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(64, (PX * NBT >= 4 ? 2 : 3)) fir_up_kernel(UpA
 
   const TIN *xrow = (const TIN *)p.x + (int64_t)ch * p.in_stride;
   char *yrow = (char *)p.y + ((int64_t)ch * p.out_stride + a.out_off) * OEB;
-  const int64_t st0 = (int64_t)blockIdx.x * a.steps_per_wave;
+  const int64_t st0 = (int64_t)bx * a.steps_per_wave;
   const int64_t st1 = (st0 + a.steps_per_wave < a.n_steps) ? st0 + a.steps_per_wave : a.n_steps;
 
   const int hl = lane < NHL ? lane : NHL - 1;                 // lanes past the history repeat its last load ...
@@ -470,6 +472,9 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
   if (spw < 1) { spw = 1; }
   a.steps_per_wave = spw;
   dim3 grid((unsigned)((n_steps + spw - 1) / spw), (unsigned)p.n_ch);
+  // XCD-affine chunk order: +2.6 - 2.9 % on the CIC interpolator row (int32 inputs, int64 outputs) in every pass, -2 - 3 % on the
+  // poly_intr row (int16 both ways): on for 4-byte inputs only (profiles/r3_xcd_map.txt)
+  a.xcd_map = (xcd_map_wanted(p.in_eb == 4) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
   if (p.in_eb == 2) {
     if (mode == 0) {
       // poly_intr: the pair taps E_j -+ E_cj can have 17 bits = 3 digit planes; sets whose folded taps stay inside two planes

@@ -342,7 +342,7 @@ __device__ inline void id_reduce_levels(int (&v)[VMAX], int lane) {
 constexpr int id_log2(int x) { return x <= 1 ? 0 : 1 + id_log2(x / 2); }
 
 template <int CHN, int GS, bool SGN>
-__global__ void __launch_bounds__(256) intg_dump_batch_kernel(IntgDumpParams p, IdConv cv, int64_t loads_per_wave, int64_t n_loads) {
+__global__ void __launch_bounds__(256) intg_dump_batch_kernel(IntgDumpParams p, IdConv cv, int64_t loads_per_wave, int64_t n_loads, int xcd_map) {
   constexpr int BATCH = 8, V = BATCH * CHN, LG = id_log2(GS), LV = id_log2(V);
   constexpr int NSC = LG < LV ? LG : LV;         // reduce-scatter levels; the remaining LG - NSC levels are all-reduce steps
   constexpr int NREM = V >> NSC;                 // values a lane ends with
@@ -350,8 +350,9 @@ __global__ void __launch_bounds__(256) intg_dump_batch_kernel(IntgDumpParams p, 
   typedef short v2s __attribute__((ext_vector_type(2)));
   typedef unsigned short v2us __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63;
-  const int obj = blockIdx.y;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int bx, obj;
+  xcd_remap(xcd_map, bx, obj);
+  const int64_t wave = (int64_t)bx * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t q0 = wave * loads_per_wave;
   const int64_t q1 = (q0 + loads_per_wave < n_loads) ? q0 + loads_per_wave : n_loads;
   if (q0 >= q1) { return; }
@@ -404,8 +405,9 @@ __global__ void __launch_bounds__(256) intg_dump_batch_kernel(IntgDumpParams p, 
 
 template <int CHN, int GS>
 static void launch_batch2(const IntgDumpParams &p, const IdConv &cv, int64_t lpw, int64_t n_loads, dim3 grid, hipStream_t s) {
-  if (p.in.S) { hipLaunchKernelGGL((intg_dump_batch_kernel<CHN, GS, true>), grid, dim3(256), 0, s, p, cv, lpw, n_loads); }
-  else { hipLaunchKernelGGL((intg_dump_batch_kernel<CHN, GS, false>), grid, dim3(256), 0, s, p, cv, lpw, n_loads); }
+  const int xm = (xcd_map_wanted(false) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
+  if (p.in.S) { hipLaunchKernelGGL((intg_dump_batch_kernel<CHN, GS, true>), grid, dim3(256), 0, s, p, cv, lpw, n_loads, xm); }
+  else { hipLaunchKernelGGL((intg_dump_batch_kernel<CHN, GS, false>), grid, dim3(256), 0, s, p, cv, lpw, n_loads, xm); }
 }
 template <int CHN>
 static bool launch_batch(const IntgDumpParams &p, const IdConv &cv, int gs, int64_t lpw, int64_t n_loads, dim3 grid, hipStream_t s) {

@@ -106,6 +106,7 @@ struct MvStreamArgs {
   int64_t n_sample, n_frames, opf, in_stride, out_stride, tpf, n_tiles, tiles_per_wave;
   const int16_t *x;
   void *y;
+  int32_t xcd_map;   // XCD-affine block order (acdsp_dev.hpp: xcd_remap)
 };
 
 typedef short v2s_t __attribute__((ext_vector_type(2)));
@@ -124,7 +125,9 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   __shared__ __attribute__((aligned(16))) int16_t sm[4][REGION];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int16_t *img = sm[wave];
-  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * a.tiles_per_wave;
+  int bx, by_;
+  xcd_remap(a.xcd_map, bx, by_);
+  const int64_t t0 = ((int64_t)bx * 4 + wave) * a.tiles_per_wave;
   const int64_t t_end = (t0 + a.tiles_per_wave < a.n_tiles) ? t0 + a.tiles_per_wave : a.n_tiles;
   if (t0 >= t_end) { return; }
   const int n_my = (int)(t_end - t0);
@@ -338,6 +341,7 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   const int64_t blocks = (waves + 3) / 4;
   if (blocks > 0x7FFFFFFF) { return false; }
   dim3 grid((unsigned)blocks);
+  a.xcd_map = (xcd_map_wanted(false) && blocks % 8 == 0) ? 1 : 0;
   const int nr = p.taps <= 9 ? 2 : (p.taps <= 17 ? 3 : (p.taps <= 25 ? 4 : 5));
 #define ACDSP_MV_LAUNCH2(NR_, LIN_, CV_)                                                                                           \
   if (a.mode != 0) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true>), grid, dim3(256), 0, s, a); }                  \
