@@ -31,7 +31,12 @@ def rand_raw(rng, f, shape):
 
 
 def to_int(y, fmt):
-    return A.wide_to_int(y) if A.is_wide(fmt) else y.cpu().numpy().astype(object)
+    if A.is_wide(fmt):
+        return A.wide_to_int(y)
+    v = y.cpu().numpy()
+    if not fmt.S:                                  # unsigned raw words come back in signed containers of the same size
+        v = v.view({2: np.uint16, 4: np.uint32, 8: np.uint64}[v.dtype.itemsize])
+    return v.astype(object)
 
 
 @pytest.mark.parametrize("ftype", FT)
@@ -171,3 +176,57 @@ def test_wide_cic_matches_the_reference_headers_vectors(c):
     want = np.array(c["y"], dtype=object)
     for ch in range(nch):
         assert np.array_equal(got[ch], want), c["name"]
+
+
+FUZZ = int(__import__("os").environ.get("ACDSP_FUZZ_CASES", "40"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_wide_random_types_and_shapes(seed):
+    """Seeded differential cases over widths (65 - 128 bit ACC / OUT, any Q / O), tap counts, ftypes, channel counts and call splits."""
+    rng = np.random.default_rng(7000 + seed)
+    qs, os_ = list(A.Q_MODES), list(A.O_MODES)
+
+    def fmt(wlo, whi, signed=None):
+        W = int(rng.integers(wlo, whi + 1))
+        S = bool(rng.integers(0, 2)) if signed is None else signed
+        if W in (64, 128):
+            S = True
+        return A.Fmt(W, int(rng.integers(1, W)), S, qs[rng.integers(0, 8)], os_[rng.integers(0, 4)])
+
+    if seed % 3 != 2:
+        fin, fc = fmt(4, 40), fmt(4, 32)
+        fa, fo = fmt(65, 128), fmt(8, 128)
+        ftype = FT[int(rng.integers(0, 6))]
+        n_taps, n_ch, n = int(rng.integers(1, 70)), int(rng.integers(1, 5)), int(rng.integers(1, 700))
+        c, x = rand_raw(rng, fc, (n_taps,)), rand_raw(rng, fin, (n_ch, n))
+        try:
+            fir = A.Fir(n_taps, ftype, fin, fc, fa, fo, n_channels=n_ch, kind="prog" if ftype == "TRANSPOSED" else "load")
+        except A.AcdspError as e:      # intermediates beyond 256 bits: refused loudly, nothing to compare
+            assert "intermediates" in str(e)
+            return
+        fir.set_coeffs(c)
+        assert fir.path == "wide"
+        xd = torch.from_numpy(x.astype({2: np.int16, 4: np.int32, 8: np.int64}[A.elem_bytes(fin.W)])).cuda()
+        k = int(rng.integers(0, n + 1))
+        parts = [to_int(fir.run(xd[:, a:b].contiguous()), fo) for a, b in ((0, k), (k, n)) if b > a]
+        want = OracleFirW(n_taps, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch).run(c, x)
+        assert np.array_equal(np.concatenate(parts, axis=1), want), (seed, ftype)
+    else:
+        interp = int(rng.integers(0, 2))
+        R, M, N = int(rng.integers(2, 17)), int(rng.integers(1, 4)), int(rng.integers(1, 6))
+        if (R * M) ** N >= 2 ** 31:
+            N = 2
+        fin = A.Fmt(int(rng.integers(34, 65)), int(rng.integers(1, 30)), True)
+        it = cic_int_type(interp, R, M, N, ofmt(fin))
+        fo = fmt(8, 128) if rng.integers(0, 2) else A.Fmt(it.W, it.I)
+        if it.W <= 64 and fo.W <= 64:
+            fo = A.Fmt(80, 40, True, "RND", "SAT")
+        n_ch = int(rng.integers(1, 4))
+        cic = A.Cic(bool(interp), R, M, N, fin, fo, n_channels=n_ch)
+        orc = OracleCicW(interp, R, M, N, ofmt(fin), ofmt(fo), n_ch=n_ch)
+        for n in (int(rng.integers(1, 300)), int(rng.integers(1, 60))):
+            x = rand_raw(rng, fin, (n_ch, n))
+            got = to_int(cic.run(torch.from_numpy(x).cuda()), fo)
+            want = orc.run(x)
+            assert got.shape == want.shape and np.array_equal(got, want), (seed, interp, R, M, N)
