@@ -903,7 +903,20 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   typedef std::integral_constant<bool, true> T;
   typedef std::integral_constant<bool, false> F;
   if (interior) {
-    fetch(s0 - 1, T());
+    // The warm-up step exists for stage B's ring: B's first real step reads A's outputs m0 - 128 ... m0 - 1 only (plb.off = 128), i.e.
+    // columns 8 .. 15 of the warm-up step, whose windows start at slot 8 R.  The 1 KB pieces entirely below that slot are not
+    // loaded (zeros are staged instead): with six steps per chunk the warm-up re-read was +15.6 % of HBM fetches (PMC, round 3).
+    {
+      const int64_t W0 = a.first + (s0 - 1) * 256 * R - a.pl.off;
+      const char *base = (const char *)(xrow + W0);
+      const int kskip = (8 * R * 32) / 1024;
+#pragma unroll
+      for (int k = 0; k < NPCA; k++) {
+        const unsigned off = k < NPCA - 2 ? lane16 + 1024u * k : 2u * (unsigned)pc_off[k];
+        if (k < NPCA - 2 && k < kskip) { pre[k] = (v4i){0, 0, 0, 0}; }
+        else { pre[k] = ACDSP_GEN_LD((const v4i *)(base + off)); }
+      }
+    }
     body(s0 - 1, T(), F(), T());
     body(s0, F(), F(), T());
     for (int64_t st = s0 + 1; st < s1; st++) { body(st, F(), T(), T()); }
@@ -944,7 +957,7 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   b.corr = gen_rebias_corr(b.px, plb.sum_h);
   a.first = first; a.n_out = n_out; b.first = 0; b.n_out = n_out;
   a.n_steps = (n_out + 255) / 256;
-  int64_t spw = 6;                           // short spans (see launch_fir_gen) against one warm-up step per chunk: 4: 0.600, 6: 0.637, 8: 0.629, 12: 0.608 of the roofline
+  int64_t spw = 8;                           // short spans (see launch_fir_gen) against one (half-loaded) warm-up step per chunk: 4: 0.605, 6: 0.642 - 0.667, 8: 0.653 - 0.669 of the roofline (profiles/r3_span_sweep.txt, last block)
   static const char *cspw_env = getenv("ACDSP_CASC_SPW");   // tuning knob: steps per wave of the fused cascade
   if (cspw_env && atoi(cspw_env) > 0) { spw = atoi(cspw_env); }
   a.steps_per_wave = spw;
