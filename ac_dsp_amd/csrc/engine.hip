@@ -374,6 +374,10 @@ int fir_validate(const acdsp_fir_desc_t &d) {
   if (wp + (f - fp) > limit || d.acc.W + (f - fa) > limit || (wide && d.acc.W + (fo > fa ? fo - fa : 0) > limit)) {
     return fail(ACDSP_EUNSUPPORTED, "type combination needs more than %d-bit intermediates", wide ? 256 : 128);
   }
+  // FOLD_ODD: the ACC_TYPE `fold` of the pre-add (ac_fir_const_coeffs.h:262-269) is formed from an (in.W + 1)-bit sum shifted to ACC's fraction
+  if (wide && is_fold_odd(internal_ftype(d.kind, d.ftype)) && d.in.W + 1 + (fa > fi ? fa - fi : 0) > limit) {
+    return fail(ACDSP_EUNSUPPORTED, "type combination needs more than 256-bit intermediates");
+  }
   if (wide && d.kind == ACDSP_FIR_REG_SHARE) { return fail(ACDSP_EUNSUPPORTED, "ac_fir_reg_share: ACC / OUT wider than 64 bits not supported"); }
   return ACDSP_OK;
 }
