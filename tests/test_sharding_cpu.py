@@ -76,3 +76,29 @@ def test_channel_slices_cover_and_match_unsharded():
                                                                          stimulus(0xACD5, n_total, 256, 16))
     got = np.concatenate([g[2] for g in sorted(gathered, key=lambda g: g[0])], axis=0)
     assert np.array_equal(got, full)
+
+
+def test_bench_self_launch_gives_every_rank_the_launcher_environment(monkeypatch):
+    """`python bench.py --gpus N` with no launcher spawns N ranks itself: every child must see the environment a
+    `torch.distributed.run --nproc-per-node N` launch would give it (one rank per GPU, loopback rendezvous)."""
+    sys.path.insert(0, ROOT)
+    import subprocess
+
+    import bench
+    seen = []
+
+    class FakeProc:
+        def __init__(self, cmd, env):
+            seen.append((cmd, env))
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(subprocess, "Popen", lambda cmd, env=None: FakeProc(cmd, env))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    assert bench.self_launch(4) == 0
+    assert len(seen) == 4
+    ports = {e["MASTER_PORT"] for _, e in seen}
+    assert len(ports) == 1 and all(e["MASTER_ADDR"] == "127.0.0.1" and e["WORLD_SIZE"] == "4" for _, e in seen)
+    assert [e["RANK"] for _, e in seen] == ["0", "1", "2", "3"] and [e["LOCAL_RANK"] for _, e in seen] == ["0", "1", "2", "3"]
+    assert all(cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "7"] for cmd, _ in seen)
