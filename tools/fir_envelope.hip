@@ -6,7 +6,7 @@
 // byte planes of the uniform int16 stimulus are).  No byte-plane split, no LDS, no epilogue arithmetic: everything the product
 // kernel does beyond this costs extra.  Not part of the product.
 //
-//   fir_envelope [reps=10]
+//   fir_envelope [reps=10] [stream | mfma | both: one row only, for power sampling]
 //
 // Each row: wall ms per launch of 1024 ch x 2^20 samples (4.29 GB algorithmic), the rate, MFMA rate, and what fraction of
 // 8 TB/s that is.  The 70 % target is 0.767 ms.
@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -174,6 +175,13 @@ int main(int argc, char **argv) {
     for (long off = 0; off < c.n_vec * 16; off += (long)r.size() * 4) { CK(hipMemcpy((char *)c.x + off, r.data(), r.size() * 4, hipMemcpyHostToDevice)); }
   }
   printf("# fir_envelope: 1024 ch x 2^20 samples, 2 B in + 2 B out per sample = %.3f GB per launch; target 0.767 ms (70 %% of 8 TB/s)\n", 2.0 * c.n_vec * 16 / 1e9);
+  if (argc > 2) {   // one row only, `reps` launches back to back: a steady load for tools/power_sample_cmd.sh
+    const std::string row = argv[2];
+    if (row == "stream") { run<0, 0, 8, 2, true>(c, 32, "stream only"); }
+    else if (row == "mfma") { run_mfma<13, 4, 2>(c, 0); }
+    else { run<13, 4, 8, 2, true>(c, 32, "stream + MFMA (config 2)"); }
+    return 0;
+  }
   printf("# --- the stream alone, best geometry ---\n");
   run<0, 0, 8, 2, true>(c, 32, "stream only");
   run<0, 0, 8, 4, true>(c, 32, "stream only");
