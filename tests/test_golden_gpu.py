@@ -144,3 +144,53 @@ def test_mv_avg_engine_matches_reference_header(c, force_generic):
     assert y.shape[1] == len(want)
     if len(want):
         assert np.array_equal(host(y), want)
+
+
+NOREL = [c for c in FIR if c.get("reload_at", -1) < 0]
+
+
+@pytest.mark.parametrize("c", NOREL, ids=G.ids(NOREL))
+def test_fir_engine_matches_reference_headers_on_distinct_channels(c):
+    """The same vectors with a DIFFERENT stream in every channel: channel k carries the fixture delayed by d_k samples (zeros in
+    front).  The reference objects start from zeroed registers (ac_fir_const_coeffs.h:145), so channel k must produce the
+    fixture's output delayed by d_k -- which checks per-row addressing, history and call splitting against reference-made
+    numbers, not only against the oracle (the identical-channel test above cannot see a row mix-up)."""
+    fin, fo = F(c["in"]), F(c["out"])
+    x, want = G.arr(c, "x"), G.arr(c, "y")
+    n = len(x)
+    delays = [0, 1 + (n // 7), 3 + (n // 3)]
+    rows = np.zeros((len(delays), n), dtype=np.int64)
+    for k, d in enumerate(delays):
+        rows[k, d:] = x[:n - d]
+    fir = A.Fir(c["n_taps"], c["ftype"], fin, F(c["coeff"]), F(c["acc"]), fo, n_channels=len(delays), kind=c["class"])
+    fir.set_coeffs(G.arr(c, "coeffs"))
+    xd = torch.from_numpy(rows).to(A.torch_dtype_for(fin)).cuda()
+    ys = [fir.run(xd[:, a:b].contiguous()).cpu().numpy().astype(np.int64) for _, a, b in G.segments(c)]
+    y = np.concatenate(ys, axis=1)
+    for k, d in enumerate(delays):
+        assert np.array_equal(y[k, d:], want[:n - d]) and not y[k, :d].any(), "channel %d (delay %d), path %s" % (k, d, fir.path)
+
+
+DEC = [c for c in CIC if c["class"] == "cic_dec"]
+
+
+@pytest.mark.parametrize("c", DEC, ids=G.ids(DEC))
+def test_cic_decimator_matches_reference_headers_on_distinct_channels(c):
+    """As above for ac_cic_dec_full: delays are multiples of R, so the decimation phase of every channel is the fixture's."""
+    fin, fo = F(c["in"]), F(c["out"])
+    x, want = G.arr(c, "x"), G.arr(c, "y")
+    n, R = len(x), c["R"]
+    delays = [0, R * (1 + n // (9 * R)), R * (2 + n // (4 * R))]
+    rows = np.zeros((len(delays), n), dtype=np.int64)
+    for k, d in enumerate(delays):
+        rows[k, d:] = x[:n - d]
+    cic = A.Cic(False, R, c["M"], c["N"], fin, fo, n_channels=len(delays))
+    xd = torch.from_numpy(rows).to(A.torch_dtype_for(fin)).cuda()
+    pos, ys = 0, []
+    for k in c["calls"]:
+        ys.append(cic.run(xd[:, pos:pos + k].contiguous()).cpu().numpy().astype(np.int64))
+        pos += k
+    y = np.concatenate(ys, axis=1)
+    for k, d in enumerate(delays):
+        m = d // R
+        assert np.array_equal(y[k, m:], want[:y.shape[1] - m]) and not y[k, :m].any(), "channel %d (delay %d)" % (k, d)
