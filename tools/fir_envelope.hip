@@ -88,7 +88,127 @@ __global__ void __launch_bounds__(256, OCC) mfma_only(const v4i *__restrict__ fr
   y[wave * 64 + lane] = (v4i){acc[0][0], acc[1][1], acc[2][2], acc[3][3]};
 }
 
+// the same int8 MAC count per load on the other int8 shape (v_mfma_i32_16x16x64_i8: half the MACs of a 32x32x32, so 2 MK per load):
+// is one shape cheaper per MAC than the other?
+template <int MK, int U, int OCC, bool STREAM>
+__global__ void __launch_bounds__(256, OCC) env16(const v4i *__restrict__ frag, const v4i *__restrict__ x, v4i *__restrict__ y, long n_vec,
+                                                 long span_vec) {
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  v4i A[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { A[i] = frag[i * 64 + lane]; }
+  v4i acc[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+  const long s = wave * span_vec, e = s + span_vec < n_vec ? s + span_vec : n_vec;
+  v4i v[U];
+  if (!STREAM) {
+#pragma unroll
+    for (int u = 0; u < U; u++) { v[u] = x[wave * 64 * U + 64 * u + lane]; }
+  }
+  for (long i = s + lane; i < e; i += 64 * U) {
+    if (STREAM) {
+#pragma unroll
+      for (int u = 0; u < U; u++) { v[u] = __builtin_nontemporal_load(x + i + 64 * u); }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      v4i o = (v4i){acc[0][u & 3], acc[1][(u + 1) & 3], acc[2][(u + 2) & 3], acc[3][(u + 3) & 3]};
+      asm volatile("" : "+v"(o));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 2 * MK; m++) { acc[m & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[m & 3], v[u], acc[m & 7], 0, 0, 0); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (STREAM) { __builtin_nontemporal_store(o, y + i + 64 * u); }
+    }
+  }
+  if (!STREAM) { y[wave * 64 + lane] = (v4i){acc[0][0], acc[1][1], acc[2][2], acc[3][3]}; }
+}
+
+// Both shapes WITH the data operand going through LDS, as any Toeplitz kernel must fetch it (the K-blocks of a step are shifted
+// copies of each other; LDS addressing is the shifter): every load is staged once (ds_write_b128) and RPL conflict-free ds_read_b128
+// per load feed the MFMAs.  The 32x32x32 formulation of config 2 reads 18 fragments per 26 MFMAs per 1024 samples (RPL 9 of MK 13);
+// the 16x16x64 formulation (16 outputs x 16 blocks, K = 64: 5 K-blocks, 2 of them in the high-byte band) issues 56 instructions
+// = 28 equivalents and reads 40 fragments per 1024 samples (RPL 20 of 28 instructions per load).
+template <bool S16, int NI, int RPL, int U, int OCC>
+__global__ void __launch_bounds__(256, OCC) env_lds(const v4i *__restrict__ frag, const v4i *__restrict__ x, v4i *__restrict__ y, long n_vec,
+                                                   long span_vec) {
+  __shared__ __attribute__((aligned(16))) v4i sm[4][2][64 + 32];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + wv;
+  v4i A[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { A[i] = frag[i * 64 + lane]; }
+  v16i acc[S16 ? 1 : 4];
+  v4i acc16[S16 ? 8 : 1];
+#pragma unroll
+  for (int i = 0; i < (S16 ? 1 : 4); i++) { acc[i] = (v16i){0}; }
+#pragma unroll
+  for (int i = 0; i < (S16 ? 8 : 1); i++) { acc16[i] = (v4i){0, 0, 0, 0}; }
+  const long s = wave * span_vec, e = s + span_vec < n_vec ? s + span_vec : n_vec;
+  for (long i = s + lane; i < e; i += 64 * U) {
+    v4i v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { v[u] = __builtin_nontemporal_load(x + i + 64 * u); }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      v4i o = S16 ? (v4i){acc16[0][u & 3], acc16[1][(u + 1) & 3], acc16[2][(u + 2) & 3], acc16[3][(u + 3) & 3]}
+                  : (v4i){acc[0][u & 15], acc[1][(u + 1) & 15], acc[2][(u + 2) & 15], acc[3][(u + 3) & 15]};
+      asm volatile("" : "+v"(o));
+      sm[wv][u & 1][lane] = v[u];                     // stage the load (1 KB)
+      v4i B[RPL];
+#pragma unroll
+      for (int r = 0; r < RPL; r++) { B[r] = sm[wv][u & 1][lane + (r & 31)]; }   // shifted windows of the staged data (garbage tail: timing only)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < NI; m++) {
+        if (S16) { acc16[m & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[m % 6], B[m % RPL], acc16[m & 7], 0, 0, 0); }
+        else { acc[m & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[m % 6], B[m % RPL], acc[m & 3], 0, 0, 0); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_nontemporal_store(o, y + i + 64 * u);
+    }
+  }
+}
+
 struct Ctx { v4i *frag, *x, *y; long n_vec; int reps; };
+
+template <bool S16, int NI, int RPL, int U, int OCC>
+static void run_lds(const Ctx &c, long span_kb) {
+  const long span_vec = span_kb * 64, waves = (c.n_vec + span_vec - 1) / span_vec, nb = (waves + 3) / 4;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 20; w++) { hipLaunchKernelGGL((env_lds<S16, NI, RPL, U, OCC>), dim3((unsigned)nb), dim3(256), 0, 0, c.frag, c.x, c.y, c.n_vec, span_vec); }
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < c.reps; r++) { hipLaunchKernelGGL((env_lds<S16, NI, RPL, U, OCC>), dim3((unsigned)nb), dim3(256), 0, 0, c.frag, c.x, c.y, c.n_vec, span_vec); }
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= c.reps;
+  printf("stream + MFMA + LDS reads  %s: %2d instructions (%4.1f equivalents of 32x32x32) and %2d fragment reads per 1024 samples  %7.3f ms  frac of 8 TB/s %.3f\n",
+         S16 ? "16x16x64" : "32x32x32", 2 * NI, S16 ? (double)NI : 2.0 * NI, 2 * RPL, ms, 2.0 * c.n_vec * 16 / ms / 1e9 / 8000.0);
+  fflush(stdout);
+}
+
+template <int MK, int U, int OCC, bool STREAM>
+static void run16(const Ctx &c, long span_kb) {
+  const long span_vec = span_kb * 64, waves = (c.n_vec + span_vec - 1) / span_vec, nb = (waves + 3) / 4;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 20; w++) { hipLaunchKernelGGL((env16<MK, U, OCC, STREAM>), dim3((unsigned)nb), dim3(256), 0, 0, c.frag, c.x, c.y, c.n_vec, span_vec); }
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < c.reps; r++) { hipLaunchKernelGGL((env16<MK, U, OCC, STREAM>), dim3((unsigned)nb), dim3(256), 0, 0, c.frag, c.x, c.y, c.n_vec, span_vec); }
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= c.reps;
+  printf("%-26s 16x16x64 shape, %2d MFMA-equivalents of 32x32x32 per 1024 samples (%d instructions), %s  %7.3f ms\n", STREAM ? "stream + MFMA" : "MFMA only", 2 * MK, 4 * MK,
+         STREAM ? "stream" : "no memory traffic", ms);
+  fflush(stdout);
+}
 
 template <int MK, int HI, int OCC>
 static void run_mfma(const Ctx &c, int zero) {
@@ -205,6 +325,14 @@ int main(int argc, char **argv) {
   run<13, 4, 8, 2, true>(c, 16, "stream + MFMA (config 2)");
   run<13, 4, 8, 2, true>(c, 128, "stream + MFMA (config 2)");
   run<13, 4, 8, 2, false>(c, 32, "stream + MFMA (config 2)");
+  printf("# --- the other int8 shape (v_mfma_i32_16x16x64_i8), same MAC count: is it cheaper per MAC? ---\n");
+  run16<13, 8, 2, false>(c, 32); run16<13, 8, 2, true>(c, 32);
+  printf("# --- both shapes with the data operand fetched through LDS (what a Toeplitz kernel has to do) ---\n");
+  run_lds<false, 13, 9, 8, 2>(c, 32);    // config 2 on 32x32x32: 26 MFMAs, 18 fragment reads per 1024 samples
+  run_lds<true, 28, 20, 8, 2>(c, 32);    // config 2 on 16x16x64: 56 instructions (28 equivalents), 40 fragment reads
+  run_lds<true, 26, 18, 8, 2>(c, 32);    // 16x16x64 at the 32x32x32 formulation's counts (what the shape alone buys)
+  run_lds<false, 13, 9, 8, 3>(c, 32);
+  run_lds<true, 28, 20, 8, 3>(c, 32);
   printf("# --- drift check ---\n");
   run<13, 4, 8, 2, true>(c, 32, "stream + MFMA (config 2)");
   run<0, 0, 8, 2, true>(c, 32, "stream only");
