@@ -160,17 +160,17 @@ def test_wide_fir_matches_the_reference_headers_vectors(c):
         assert np.array_equal(got[ch], want), c["name"]
 
 
-@pytest.mark.parametrize("c", _wide_cases("wide_cic_dec"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("c", _wide_cases("wide_cic_dec") + _wide_cases("wide_cic_intr"), ids=lambda c: c["name"])
 def test_wide_cic_matches_the_reference_headers_vectors(c):
     fin, fo = _fmt(c["in"]), _fmt(c["out"])
     nch = 2
-    cic = A.Cic(False, c["R"], c["M"], c["N"], fin, fo, n_channels=nch)
+    cic = A.Cic(c["class"] == "wide_cic_intr", c["R"], c["M"], c["N"], fin, fo, n_channels=nch)
     x = torch.from_numpy(np.tile(np.array(c["x"], dtype=np.int64), (nch, 1))).cuda()
     got, pos = [], 0
     for k, want_n in zip(c["calls"], c["outs_per_call"]):
         y = to_int(cic.run(x[:, pos:pos + k].contiguous()), fo)
         assert y.shape[1] == want_n
-        got.append(y)
+        got.append(y.reshape(nch, want_n))
         pos += k
     got = np.concatenate(got, axis=1)
     want = np.array(c["y"], dtype=object)

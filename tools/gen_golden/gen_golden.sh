@@ -18,7 +18,8 @@ $CXX "$R/tools/gen_golden/gen_poly_dec.cpp" -o "$B/gen_poly_dec"
 $CXX "$R/tools/gen_golden/gen_poly_intr.cpp" -o "$B/gen_poly_intr"
 $CXX "$R/tools/gen_golden/gen_mv_avg.cpp" -o "$B/gen_mv_avg"
 $CXX "$R/tools/gen_golden/gen_wide.cpp" -o "$B/gen_wide"
-for g in gen_fir gen_cic_dec gen_cic_intr gen_reg_share gen_poly_dec gen_poly_intr gen_wide; do "$B/$g" "$OUT"; done
+$CXX -DGEN_INTR "$R/tools/gen_golden/gen_wide.cpp" -o "$B/gen_wide_intr"
+for g in gen_fir gen_cic_dec gen_cic_intr gen_reg_share gen_poly_dec gen_poly_intr gen_wide gen_wide_intr; do "$B/$g" "$OUT"; done
 # ac_mv_avg runs over this repo's own ac_window_1d_flag restatement (the class is part of the absent ac_types): its vectors pin the
 # reference's MAC loop only and live in their own directory
 mkdir -p "$R/tests/golden/ref_hdr_window_unpinned"
