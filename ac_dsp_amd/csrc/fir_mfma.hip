@@ -813,6 +813,18 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
     if (interior) { fir_mfma_body<NB, EPI, HS, WAVES, true>(p, frag, a, lds); }
     else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
   }
+  if constexpr (WAVES == 1) {
+    // small host-side calls (FirParams::hist_next set): the first chunk's wave also writes the channel's next history, so that a
+    // one-sample run() of the drop-in classes is ONE launch (cf. fir_hist_update_kernel)
+    if (p.hist_next && blockIdx.x == 0 && (int)blockIdx.y < p.n_ch) {
+      const int64_t row = (int64_t)blockIdx.y;
+      for (int j = threadIdx.x; j < p.hl; j += 64) {
+        const int64_t g = p.n - p.hl + j;
+        const int64_t v = (g >= 0) ? load_raw(p.x, row * p.in_stride + g, p.in_eb, p.in.S) : load_raw(p.hist, row * p.hl + p.hl + g, p.in_eb, p.in.S);
+        store_raw(p.hist_next, row * p.hl + j, p.in_eb, v);
+      }
+    }
+  }
   if (a.dbg && (threadIdx.x & 63) == 0) {
     const int64_t w = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6);
     a.dbg[2 * w] = (int64_t)(__builtin_readcyclecounter() - c0);
