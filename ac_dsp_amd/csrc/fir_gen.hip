@@ -101,9 +101,8 @@ bool fir_gen_plan(const int64_t *h, int n_taps, int R, int first_mod16, FirGenPl
 struct GenArgs {
   FirGenPlan pl;
   int32_t px;                 // input byte planes
-  int32_t pad;                // slot -> LDS slot map (gen_slot_map): 0 identity, 1 slot + slot / R, 2 bits 1 - 3 XOR (slot >> xsh) & xmask
+  int32_t pad;                // slot -> LDS slot map (gen_slot_map): 1 = two empty slots after every R (R % 4 == 0), 0 = identity
   uint32_t rcp;               // ceil(2^32 / R) for the slot / R division
-  int32_t xsh, xmask;
   int32_t n_slots;            // slots staged per step
   int32_t out_mode;           // 0: FIR class A (shift, ACC wrap, requant)   1: CIC (wrap to w_int, requant from F_in)
   int32_t out_simple;         // CIC: 2 = OUT holds INT_TYPE (one wrap), 1 = same fraction + AC_WRAP (two wraps), 0 = general
@@ -130,33 +129,26 @@ struct GenArgs {
 
 
 __device__ inline int phys_slot(int s, const GenArgs &a) {
-  if (a.pad == 2) { return s ^ (((s >> a.xsh) & a.xmask) << 1); }
-  return a.pad ? s + (int)__umulhi((unsigned)s, a.rcp) : s;   // s + s / R (exact for s < 2^16)
+  return a.pad ? s + 2 * (int)__umulhi((unsigned)s, a.rcp) : s;   // s + 2 (s / R) (exact for s < 2^16)
 }
 
 // LDS slot map of a plane.  The MFMA operand read of lane (n_col, kg) is slot R n_col + 4 b + kg, a ds_read_b128, which the LDS
 // serves in four NON-contiguous 16-lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, +32: MI355X_MICROARCH.md, LDS) over 64
-// dword banks = 16 slots: a group holds eight columns at kg and the other eight at kg + 1.  The staging writes are consecutive
-// slots, 8 of them (32 banks) per bank pass.  Even R = 2^k m: XOR bits 1 - 3 of the slot with (slot >> max(4, k)) & {0, 1, 3, 7, 7 ..}[k]
-// -- bit 0 keeps the kg parity that separates the two halves of a group, the XOR makes bits 1 - 3 count the column within each
-// half, and inside an aligned 8-slot run it is a permutation, so the writes stay conflict-free.  tools/lds_slot_map_check.py
-// replays the groups: 0 extra cycles for every even R < 256 (the former s + s / R padding: 4 per K block -- the 24 - 33 %
-// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of configs 3, 5 and poly_dec in profiles/r2_*).  Odd R keeps the identity (one extra
-// cycle per group).  Returns the slots a plane must allocate for n slots.
+// dword banks = 16 slots: a group holds eight columns at kg and the other eight at kg + 1.  With R a multiple of 4, TWO empty slots
+// after every R make column n start at (R + 2) n: the eight columns of one half land on eight distinct even offsets mod 16 and the
+// other half, one slot on, on the odd ones -- no conflict for any K block.  (Round 2 padded ONE slot per R, right for contiguous
+// 16-lane groups and 4 extra cycles per K-block read on the real ones: the 24 - 33 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of
+// configs 3, 5 and poly_dec in profiles/r2_*.)  R = 2 mod 4 is conflict-free as it stands; odd R keeps the identity (one or two
+// extra cycles per group).  The staging writes are consecutive slots, 8 of them (32 banks) per bank pass: holes at multiples of 8
+// slots leave them conflict-free (R = 4 mod 8: 2-way on some passes).  An XOR map (bits 1 - 3 of the slot ^ the column index) does
+// the same without the holes and was measured first; it is not an add, so the cascade kernel could no longer address its ten
+// staging pieces as one base register + immediates, and the register allocation of that kernel (255 VGPRs) fell over: +3 .. +35 %
+// on the fused DDC depending on the form.  tools/lds_slot_map_check.py replays the lane groups for any R and map.
+// Returns the slots a plane must allocate for n slots.
 static int gen_slot_map(GenArgs &a, int R, int n) {
   a.rcp = (uint32_t)((0x100000000ull + R - 1) / R);
-  a.xsh = 0; a.xmask = 0; a.pad = 0;
-  static const char *force_pad = getenv("ACDSP_GEN_SLOT_PAD");   // A/B knob: the former padded map
-  if (force_pad && atoi(force_pad)) {
-    a.pad = (R % 2 == 0 && R > 1) ? 1 : 0;
-    return a.pad ? n + n / R : n;
-  }
-  if (R > 1 && R % 2 == 0) {
-    const int tz = __builtin_ctz((unsigned)R);
-    a.pad = 2; a.xsh = tz > 4 ? tz : 4; a.xmask = tz == 1 ? 0 : (tz == 2 ? 1 : (tz == 3 ? 3 : 7));
-    return (n + 15) / 16 * 16;
-  }
-  return n;
+  a.pad = (R % 4 == 0) ? 1 : 0;
+  return a.pad ? n + 2 * (n / R) : n;
 }
 
 // gather byte `p` (0..3 of a dword) of four dwords into one dword
@@ -797,7 +789,9 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
     constexpr bool WARM = decltype(warm_c)::value, FLUSH = decltype(flush_c)::value;
 #pragma unroll
     for (int k = 0; k < NPCA; k++) {
-      if constexpr (LIMB) {   // LDS offsets recomputed per piece (3 - 5 VALU) instead of ten resident registers: the loop must not spill
+      if constexpr (LIMB) {
+        // LDS offsets re-derived per piece rather than ten resident registers (the loop must not spill); the slot map is an add, so
+        // the compiler folds the regular pieces into one base register + immediate offsets.
         int slot = (lane >> 1) + 32 * k;
         if (k >= NPCA - 2 && slot >= a.n_slots) { slot = a.n_slots - 1; }
         stage_piece(pre[k], phys_slot(slot, a) * 16 + 8 * (lane & 1));
@@ -989,7 +983,7 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   a.steps_per_wave = spw;
   a.n16 = (pa.n + 15) / 16 * 16;
   a.out_vec_ok = 1; a.chunk0 = 0;
-  b.pad = 0; b.rcp = 0; b.xsh = 0; b.xmask = 0; b.n_slots = 0; b.out_mode = 0; b.w_int = 0; b.out_simple = 0; b.n_steps = a.n_steps; b.steps_per_wave = spw;
+  b.pad = 0; b.rcp = 0; b.n_slots = 0; b.out_mode = 0; b.w_int = 0; b.out_simple = 0; b.n_steps = a.n_steps; b.steps_per_wave = spw;
   b.n16 = 0; b.obuf_off = 0; b.chunk0 = 0; b.out_vec_ok = 1;
   const int slots_alloc = 15 * pla.R + 4 * 6;
   const int phys = gen_slot_map(a, pla.R, slots_alloc);

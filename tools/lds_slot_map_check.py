@@ -24,11 +24,11 @@ def extra(addrs_by_lane, groups, width, banks):
 
 
 def maps(R):
-    out = {"identity": lambda s: s, "pad s + s/R (round 2)": lambda s: s + s // R}
+    out = {"identity": lambda s: s, "pad 1 per R (round 2)": lambda s: s + s // R, "pad 2 per R": lambda s: s + 2 * (s // R)}
     if R > 1 and R % 2 == 0:
         tz = (R & -R).bit_length() - 1
         sh, m = max(4, tz), {1: 0, 2: 1, 3: 3}.get(tz, 7)
-        out["xor bits 1-3 (gen_slot_map)"] = lambda s: s ^ (((s >> sh) & m) << 1)
+        out["xor bits 1-3 ^ column"] = lambda s: s ^ (((s >> sh) & m) << 1)
     return out
 
 
@@ -51,7 +51,8 @@ def main():
                 addrs = [16 * f(min((l + 64 * k) // 2, n_slots - 1)) + 8 * (l % 2) for l in range(64)]
                 w64 += extra(addrs, [range(16 * g, 16 * g + 16) for g in range(4)], 8, 32)
                 k += 1
-            print(f"R={R:2d} {name:30s} read extra cycles per K block b=0..5: {rd}   staging writes: b32 {w32}, b64 {w64}")
+            mark = "  <- gen_slot_map" if name == ("pad 2 per R" if R % 4 == 0 else "identity") else ""
+            print(f"R={R:2d} {name:24s} read extra cycles per K block b=0..5: {rd}   staging writes: b32 {w32}, b64 {w64}{mark}")
 
 
 if __name__ == "__main__":
