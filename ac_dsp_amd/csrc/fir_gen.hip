@@ -39,6 +39,15 @@
 #define ACDSP_GEN_LD(ptr) (*(ptr))
 #endif
 
+// Output tiles of the fast kernels leave with the non-temporal policy (-DACDSP_GEN_ST_PLAIN: plain stores, the A/B reference).  The
+// speed of these rows depends on where the driver placed the input / output pair (profiles/r3_placement_modes.txt); the policy
+// changes nothing on a fast pair and takes 2 - 4 % off a slow one (poly_dec, eight placements, two processes each).
+#ifdef ACDSP_GEN_ST_PLAIN
+#define ACDSP_GEN_ST(val, ptr) (*(ptr) = (val))
+#else
+#define ACDSP_GEN_ST(val, ptr) __builtin_nontemporal_store(val, ptr)
+#endif
+
 namespace acdsp {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -470,17 +479,17 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
       for (int k = 0; k < 2; k++) {
         const int P = 64 * k + lane;
         const v4i val = *(const v4i *)(ob + ((P ^ ((P >> 3) & 7)) * 16));
-        *(v4i *)(yrow + m0 * 8 + 16 * P) = val;
+        ACDSP_GEN_ST(val, (v4i *)(yrow + m0 * 8 + 16 * P));
       }
     } else if (OEB == 4) {
       const v4i val = *(const v4i *)(ob + ((lane ^ ((lane >> 3) & 3)) * 16));
-      *(v4i *)(yrow + m0 * 4 + 16 * lane) = val;
+      ACDSP_GEN_ST(val, (v4i *)(yrow + m0 * 4 + 16 * lane));
     } else {
       const int P = lane & 31;                       // both wave halves store the same 512 bytes: no exec-mask branch
       const int x = (P >> 3) & 3;                    // 8-byte units are XORed with x (below): the pair of a 16-byte piece moves by x >> 1, swaps by x & 1
       v4i val = *(const v4i *)(ob + (P ^ (x >> 1)) * 16);
       if (x & 1) { val = (v4i){val.z, val.w, val.x, val.y}; }
-      *(v4i *)(yrow + m0 * 2 + 16 * P) = val;       // (pairing two steps into one 1 KB store: +0.2 %, profiles/r3_ab_store_width.txt -- not kept)
+      ACDSP_GEN_ST(val, (v4i *)(yrow + m0 * 2 + 16 * P));     // (pairing two steps into one 1 KB store: +0.2 %, profiles/r3_ab_store_width.txt -- not kept)
     }
   };
   // One step.  Program order: stage step st (its slots were fetched one step ago), write out step st-1, fetch step
@@ -782,7 +791,7 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
 
   auto flush = [&](int64_t st) {   // 256 int32 outputs of a finished step: one 1 KB store
     const v4i val = *(const v4i *)(ob + ((lane ^ ((lane >> 3) & 3)) * 16));
-    *(v4i *)(yrow + st * 1024 + 16 * lane) = val;
+    ACDSP_GEN_ST(val, (v4i *)(yrow + st * 1024 + 16 * lane));
   };
   // One step.  WARM: stage A only (fills the ring for the chunk's first stage-B step).  FLUSH: step st-1 waits in the tile.
   auto body = [&](int64_t st, auto warm_c, auto flush_c, auto fast_c) {
