@@ -118,6 +118,13 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 #define ACDSP_MV_LD(ptr) (*(ptr))
 #endif
 
+// 2-byte outputs (the bench row: one 16-byte store per lane) leave with the non-temporal policy; -DACDSP_MV_ST_PLAIN: plain (A/B)
+#ifdef ACDSP_MV_ST_PLAIN
+#define ACDSP_MV_ST(v, ptr) (*(ptr) = (v))
+#else
+#define ACDSP_MV_ST(v, ptr) __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(&(v)), reinterpret_cast<v4u_t *>(ptr))
+#endif
+
 template <int NR, bool LINEAR, bool CV32, bool EDGE>
 __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   constexpr int REGION = 512 + 8 * NR;          // samples of one wave's LDS image
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
             uint4 v;
             v.x = __builtin_amdgcn_perm((uint32_t)o[1], (uint32_t)o[0], 0x05040100u); v.y = __builtin_amdgcn_perm((uint32_t)o[3], (uint32_t)o[2], 0x05040100u);
             v.z = __builtin_amdgcn_perm((uint32_t)o[5], (uint32_t)o[4], 0x05040100u); v.w = __builtin_amdgcn_perm((uint32_t)o[7], (uint32_t)o[6], 0x05040100u);
-            *reinterpret_cast<uint4 *>((int16_t *)a.y + yb) = v;
+            ACDSP_MV_ST(v, reinterpret_cast<uint4 *>((int16_t *)a.y + yb));
           } else if (a.out_eb == 4) {
             uint4 *d = reinterpret_cast<uint4 *>((int32_t *)a.y + yb);
             d[0] = make_uint4(o[0], o[1], o[2], o[3]); d[1] = make_uint4(o[4], o[5], o[6], o[7]);
