@@ -185,11 +185,11 @@ __global__ void __launch_bounds__(64, (PX * NBT >= 4 ? 2 : 3)) fir_up_kernel(UpA
 #ifdef UP_ABLATE_STORES
       if (a.n_steps < 0)
 #endif
-#if defined(ACDSP_UP_NT) && ACDSP_UP_NT   // A/B knob: the interpolated stream is written once and not read back by this kernel
-      __builtin_nontemporal_store(val, (long *)(yrow + e_unit * OEB + lin));
-#else
-      *(long *)(yrow + e_unit * OEB + lin) = val;
-#endif
+      // Store policy by output container, measured per shape on one box (alternating processes, 4 pairs each): 2-byte outputs
+      // (ac_poly_intr row) non-temporal 0.950 against plain 0.975 ms; 8-byte outputs (ac_cic_intr_full row) non-temporal 4.26
+      // against plain 3.63 ms -- round 2 saw the same signs under the long-span geometry.
+      if constexpr (OEB == 2) { __builtin_nontemporal_store(val, (long *)(yrow + e_unit * OEB + lin)); }
+      else { *(long *)(yrow + e_unit * OEB + lin) = val; }
     }
   };
   // One step.  VMEM program order: [wait for this step's samples] -> loads of the step AHEAD later -> the stores of this step.
