@@ -1323,6 +1323,10 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   // >= 16384 waves when the problem allows it; a chunk re-reads NB-1 halo blocks per step anyway
   int64_t spw = (a.n_steps * p.n_ch + 16383) / 16384;
   if (spw < 8) { spw = 8; }
+  // Short filters (<= 4 K-blocks, up to 97 taps) are bound by the memory system, not by the MFMAs or the power cap: 32 KB spans per wave,
+  // the best span of a bare copy (tools/copy_probe2.hip), run them 13 % faster than 128 KB spans (15 - 95 taps: 0.733 against 0.84 ms per
+  // 1024 ch x 2^20 samples, same box; 12 and 24 steps: 0.76 / 0.78).  From 127 taps on 16 .. 64 steps measure alike (profiles/r3_taps_sweep.txt).
+  if (plan.nb <= 4 && spw > 16) { spw = 16; }
   static const char *spw_env = getenv("ACDSP_FIR_SPW");   // tuning knob: 1024-sample steps per wave
   if (spw_env && atoi(spw_env) > 1) { spw = atoi(spw_env); }
   a.steps_per_wave = spw;

@@ -16,7 +16,8 @@ fin, fc, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(16, 2, True, "RND", "SAT")
 x = torch.empty((NCH, N), dtype=torch.int16, device=dev)
 A.fill_stimulus(x, 0xACD5, 16, ch0=0)
 y = torch.empty((NCH, N), dtype=torch.int16, device=dev)
-for taps in (31, 63, 127, 191, 255, 287, 289, 319, 383, 447, 511, 639, 767, 895, 991, 993, 1023):
+TAPS = [int(t) for t in os.environ["TAPS"].split(",")] if os.environ.get("TAPS") else (31, 63, 127, 191, 255, 287, 289, 319, 383, 447, 511, 639, 767, 895, 991, 993, 1023)
+for taps in TAPS:
     fa = A.Fmt(42, 14)
     eng = A.Fir(taps, "SHIFT_REG", fin, fc, fa, fo, n_channels=NCH, kind="load", device=0)
     if dense:
