@@ -398,6 +398,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   h->wide = desc->acc.W > 64 || desc->out.W > 64;
   h->rt_eb = h->wide ? 16 : 8;
   h->hl = round_up(desc->n_taps + 15, 32);  // >= n_taps-1 for every kernel, >= n_taps+14 for the 16-aligned windows of fir_gen
+  if (h->hl < 32 * fir_mfma_plan_blocks(desc->n_taps)) { h->hl = 32 * fir_mfma_plan_blocks(desc->n_taps); }   // a padded plan reaches one K-block further back
   // reg_trans[] carries partial sums computed with the coefficients of their own time; only
   // the const-coefficient class may trade it for an input history.
   h->use_rt = desc->ftype == ACDSP_TRANSPOSED && desc->kind != ACDSP_FIR_CONST;
@@ -430,7 +431,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_coeffs, n_sets * desc->n_taps * sizeof(int64_t)); }
   {
-    const int nbk = (desc->n_taps - 1 + 31) / 32 + 1;
+    const int nbk = fir_mfma_plan_blocks(desc->n_taps);
     if (e == hipSuccess) { e = hipMalloc((void **)&h->d_frag, n_sets * sizeof(uint32_t) * 2 * (size_t)(nbk > 0 ? nbk : 1) * 64 * 4); }
   }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_corr, n_sets * sizeof(int64_t)); }
@@ -482,8 +483,8 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   const bool i16_in = d.in.S ? d.in.W <= 16 : d.in.W <= 15;
   const bool i16_cf = d.coeff.S ? d.coeff.W <= 16 : d.coeff.W <= 15;
   if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && i16_in && i16_cf && d.in.S && h->in_eb == 2 &&
-      (d.n_taps - 1 + 31) / 32 + 1 <= (d.coeffs_per_channel ? fir_mfma_max_reg_blocks() : fir_mfma_max_blocks())) {
-    const int nb = (d.n_taps - 1 + 31) / 32 + 1;
+      fir_mfma_plan_blocks(d.n_taps) <= (d.coeffs_per_channel ? fir_mfma_max_reg_blocks() : fir_mfma_max_blocks())) {
+    const int nb = fir_mfma_plan_blocks(d.n_taps);
     const size_t per_set = (size_t)2 * nb * 64 * 4;
     std::vector<uint32_t> frag(n_sets * per_set, 0u);
     std::vector<int64_t> corr(n_sets, 0);

@@ -58,7 +58,9 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 constexpr int kMaxRegNB = 9;  // register-resident Toeplitz fragments: up to 32*8+1 = 257 taps
 constexpr int kMaxNB = 33;    // Toeplitz fragments in LDS (shared coefficient set): up to 1025 taps
 
+#ifndef ACDSP_FIR_TU_MID   // fir_mfma_mid.hip re-includes this file for the kernels and launch_nb_hs only
 static bool use_reg33(int nb, uint64_t hi_mask, int epi);
+static bool use_mid(int nb, uint64_t hi_mask, int epi);
 int fir_mfma_max_blocks() { return kMaxNB; }
 int fir_mfma_max_reg_blocks() { return kMaxRegNB; }
 
@@ -66,8 +68,17 @@ int fir_mfma_max_reg_blocks() { return kMaxRegNB; }
 // Lane l holds row i = l & 31 and the 16 K-positions k = 16*(l>>5) + j, j = 0..15 (the same
 // (lane-group, byte) -> k map is used for the data operand, so any K permutation inside the
 // instruction cancels).
+// K-blocks of the plan for n_taps: the Toeplitz band of 32 outputs spans n_taps + 31 inputs; 10 .. 16 blocks are padded to the next odd
+// count (the register-resident shapes of fir_mfma_mid.hip exist for odd counts; the extra leading block holds zeros).
+int fir_mfma_plan_blocks(int n_taps) {
+  int nb = (n_taps - 1 + 31) / 32 + 1;
+  static const bool no_mid = getenv("ACDSP_NO_MID") != nullptr;
+  if (!no_mid && nb >= 10 && nb <= 16 && (nb & 1) == 0) { nb++; }
+  return nb;
+}
+
 bool fir_mfma_build_fragments(const int64_t *c, int n_taps, FirMfmaPlan *plan, uint32_t *frag) {
-  const int nb = (n_taps - 1 + 31) / 32 + 1;
+  const int nb = fir_mfma_plan_blocks(n_taps);
   if (nb > kMaxNB) { return false; }
   std::vector<int8_t> chi(n_taps), clo(n_taps);
   int64_t sum = 0, sa = 0, sah = 0, sal = 0;
@@ -108,6 +119,8 @@ bool fir_mfma_build_fragments(const int64_t *c, int n_taps, FirMfmaPlan *plan, u
   }
   return true;
 }
+
+#endif  // !ACDSP_FIR_TU_MID
 
 // Bytes of one staged [plane][half] array of nc 16-byte chunks.  The two halves of a plane are written by one
 // ds_write_b64 (lanes alternate between them) and LDS stores see 32 banks: pad so that the arrays sit 16 banks apart
@@ -844,6 +857,7 @@ static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const
   return hipGetLastError();
 }
 
+#ifndef ACDSP_FIR_TU_MID
 // Waves per workgroup of the register-resident kernel.  8 = ping-pong (MFMA run of waves 0-3 against the
 // epilogue / staging of waves 4-7, s_barrier between): measured 4 % SLOWER than independent single-wave
 // workgroups on MI355X (1.215 vs 1.163 ms on config 2), because MFMA and VALU issue serialise per SIMD
@@ -898,6 +912,8 @@ static hipError_t launch_nb33(const FirParams &p, const uint32_t *d_frag, const 
   if (reg33_band_code(a.hi_mask, epi) == 14 + 16 * 14) { return launch_nb_hs<33, 14 + 16 * 14, 1>(p, d_frag, a, epi, grid, s); }
   return launch_nb_hs<33, 12 + 16 * 12, 1>(p, d_frag, a, epi, grid, s);
 }
+
+#endif  // !ACDSP_FIR_TU_MID
 
 // =============================================================================================
 // Large tap counts (NB = 10 .. 33, e.g. the 1023-tap configuration): the 2*NB Toeplitz fragments no
@@ -1212,6 +1228,20 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   }
 }
 
+#ifdef ACDSP_FIR_TU_MID
+// ---- second translation unit (fir_mfma_mid.hip): the register-resident shapes for 10 .. 17 K-blocks ----
+hipError_t launch_fir_mfma_mid(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  switch (nb) {
+    case 11: return launch_nb_hs<11, 3 + 16 * 3, 1>(p, d_frag, a, epi, grid, s);
+    case 13: return launch_nb_hs<13, 4 + 16 * 4, 1>(p, d_frag, a, epi, grid, s);
+    case 15: return launch_nb_hs<15, 5 + 16 * 5, 1>(p, d_frag, a, epi, grid, s);
+    case 17: return launch_nb_hs<17, 6 + 16 * 6, 1>(p, d_frag, a, epi, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#else
+hipError_t launch_fir_mfma_mid(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s);
+
 static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArgs a, int epi, dim3 grid, hipStream_t s) {
   const int nb = a.nb;
   // contiguous range of non-zero high-byte blocks
@@ -1309,6 +1339,7 @@ int fir_mfma_issued_per_step(const FirParams &p, const FirMfmaPlan &plan) {
       band = b1 - b0 + 1;
     }
     if (use_reg33(nb, plan.hi_mask, epi)) { const int code = reg33_band_code(plan.hi_mask, epi); band = nb - (code & 15) - (code >> 4); }
+    if (use_mid(nb, plan.hi_mask, epi)) { band = 5; }
   }
   return 2 * nb + 2 * band;
 }
@@ -1340,7 +1371,7 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   a.lo_mask = plan.lo_mask;
   a.nb = plan.nb; a.hb0 = 0; a.hb1 = plan.nb - 1; a.step0 = 0;
   a.corr = d_corr;
-  const int wpb = (plan.nb > kMaxRegNB && !use_reg33(plan.nb, plan.hi_mask, epi)) ? 8 : kSmallWaves;   // channels (waves) per workgroup
+  const int wpb = (plan.nb > kMaxRegNB && !use_reg33(plan.nb, plan.hi_mask, epi) && !use_mid(plan.nb, plan.hi_mask, epi)) ? 8 : kSmallWaves;   // channels (waves) per workgroup
   dim3 grid((unsigned)((a.n_steps + spw - 1) / spw), (unsigned)((p.n_ch + wpb - 1) / wpb));
   a.dbg = nullptr;
   static const bool dbg_clock = getenv("ACDSP_DEBUG_CLOCK") != nullptr;
@@ -1375,8 +1406,29 @@ static bool use_reg33(int nb, uint64_t hi_mask, int epi) {
   return nb == 33 && !off && reg33_band_code(hi_mask, epi) != 0;
 }
 
+// NB = 10 .. 17 (258 - 513 taps): the register-resident kernel at one wave per SIMD, like NB = 33, for sets whose high-byte band fits the
+// five central K-blocks of the instantiated shape.  Shapes exist for odd NB (11, 13, 15, 17: fir_mfma_mid.hip, its own translation
+// unit for the compile time); fir_mfma_plan_blocks pads an even plan by one leading zero block (2 MFMAs per step).  Same-box A/B at 319
+// taps: 1.27 -> 1.12 ms (profiles/r3_taps_sweep.txt); dense sets and wider bands stay on the LDS-resident kernels.
+static int mid_band_code(int nb, uint64_t hi_mask, int epi) {
+  if ((epi != 1 && epi != 2) || nb < 11 || nb > 17 || (nb & 1) == 0) { return 0; }
+  const int sk = (nb - 5) / 2;
+  int lo = 0, hi = 0;
+  if (hi_mask == 0) { lo = hi = nb; }
+  else {
+    while (lo < nb && !((hi_mask >> lo) & 1)) { lo++; }
+    while (hi < nb && !((hi_mask >> (nb - 1 - hi)) & 1)) { hi++; }
+  }
+  return (lo >= sk && hi >= sk) ? sk + 16 * sk : 0;
+}
+static bool use_mid(int nb, uint64_t hi_mask, int epi) {
+  static const bool off = getenv("ACDSP_NO_MID") != nullptr;   // A/B knob: LDS-resident fragments (fir_mfma_big2_kernel)
+  return !off && mid_band_code(nb, hi_mask, epi) != 0;
+}
+
 static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   if (use_reg33(nb, a.hi_mask, epi)) { return launch_nb33(p, d_frag, a, epi, grid, s); }
+  if (use_mid(nb, a.hi_mask, epi)) { return launch_fir_mfma_mid(p, nb, d_frag, a, epi, grid, s); }
   if (nb > kMaxRegNB) { return launch_big(p, d_frag, a, epi, grid, s); }
   switch (nb) {
 #ifndef ACDSP_FIR_DEV_NB9   // development builds: only the 255-tap shape (compile time 3 min -> 35 s)
@@ -1393,5 +1445,7 @@ static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_fr
     default: return hipErrorInvalidValue;
   }
 }
+
+#endif  // !ACDSP_FIR_TU_MID
 
 }  // namespace acdsp

@@ -387,6 +387,25 @@ def test_mfma_large_tap_counts_double_wide_chunks(n_taps, fo):
                seed=n_taps)
 
 
+@pytest.mark.parametrize("n_taps", [258, 289, 290, 321, 352, 383, 416, 449, 480, 511, 513])
+@pytest.mark.parametrize("fo", [A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(16, 2, True, "TRN", "WRAP")])
+def test_mfma_mid_tap_counts_register_resident_shapes(n_taps, fo):
+    """258 - 513 taps (10 .. 17 K-blocks): unit-gain low-pass sets run on the register-resident shapes of fir_mfma_mid.hip (an even
+    plan is padded by one zero block: the history reaches one block further back), every other set on the LDS-resident kernels."""
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16)
+    c = windowed_sinc(n_taps, 0.08, fc)
+    fir = check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=5, n=3 * 8192 + 700 + n_taps, coeffs=c, expect_path="mfma_i8",
+                     splits=[1, 8192 + 24, 9000], seed=n_taps)
+    nb = (n_taps - 1 + 31) // 32 + 1
+    nb += (nb % 2 == 0)
+    assert fir.mfma_issued() == 2 * nb + 2 * 5, (fir.mfma_issued(), nb)      # five high-byte blocks: the mid shapes took the set
+    # a set with large coefficients at both ends has no central band: LDS-resident kernel, same answers
+    c2 = c.copy()
+    c2[0] = c2[-1] = 9000
+    fir2 = check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=3, n=8192 + 300, coeffs=c2, expect_path="mfma_i8", splits=[4100], seed=n_taps + 1)
+    assert fir2.mfma_issued() > 2 * nb + 2 * 5
+
+
 def test_config4_shape_1023_taps_prog_coeffs():
     """BASELINE config 4 shape (ac_fir_prog_coeffs, 1023 taps, <16,2>, ACC <42,14>) at a reduced size."""
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
