@@ -352,11 +352,13 @@ __global__ void __launch_bounds__(64, SMALL ? 3 : 2) fir_gen_kernel(FirParams p,
 // (counted s_waitcnt vmcnt(k)) while this step multiplies, converts and writes out.  The general kernel above had
 // ~1500 basic blocks and an s_waitcnt vmcnt(0) in front of every MFMA group -- the prefetch never overlapped anything.
 //   PCT / NBT: coefficient digits / K blocks compiled in (fragments beyond the plan's pc / nb are zero)
-//   SPL: slots per lane (exact)        OEB: output container bytes
+//   NLD: loads per lane and step -- 16-byte pieces for 2- and 4-byte samples (ceil(n_slots * sizeof(TIN) / 64): the former
+//        whole-slot count made config 3 issue 12 loads and 48 staging writes per step where 9 and 36 cover its window), slots for
+//        8-byte samples        OEB: output container bytes
 #ifndef ACDSP_GEN_FAST_WAVES
 #define ACDSP_GEN_FAST_WAVES 2
 #endif
-template <typename TIN, int PX, int PCT, int NBT, int SPL, int OEB>
+template <typename TIN, int PX, int PCT, int NBT, int NLD, int OEB>
 __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [PX][phys slots][16] + output tile
   const int lane = threadIdx.x;
@@ -385,8 +387,9 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
   // 4 : 1 read / write stream reaches 5.8, tools/copy_probe).  The byte planes of a piece are 16 / S bytes each.
   constexpr int S = (int)sizeof(TIN);
   constexpr bool COAL = S <= 4;
-  constexpr int NPC = SPL * S;                                // pieces (COAL) per lane and step
-  v4i pre[SPL][sizeof(TIN)];
+  constexpr int NPC = COAL ? NLD : 1;                         // pieces (COAL) per lane and step
+  constexpr int SPL = COAL ? 1 : NLD;                         // slots per lane (8-byte samples)
+  v4i pre[COAL ? NPC : SPL][COAL ? 1 : sizeof(TIN)];
   int sl_of[SPL], ps_of[SPL];
   int pc_off[COAL ? NPC : 1], pc_ps[COAL ? NPC : 1];         // COAL: sample offset of the piece in the window, LDS byte offset of its planes
 #pragma unroll
@@ -411,7 +414,7 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
       for (int k = 0; k < NPC; k++) {
         const int64_t t = W0 + pc_off[k];
         const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
-        pre[k / S][k % S] = ACDSP_GEN_LD((const v4i *)src);
+        pre[k][0] = ACDSP_GEN_LD((const v4i *)src);
       }
     } else {
 #pragma unroll
@@ -499,7 +502,7 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
   auto body = [&](int64_t st, auto first_c) {
     if constexpr (COAL) {
 #pragma unroll
-      for (int k = 0; k < NPC; k++) { stage_piece(pre[k / S][k % S], pc_ps[k]); }
+      for (int k = 0; k < NPC; k++) { stage_piece(pre[k][0], pc_ps[k]); }
     } else {
 #pragma unroll
       for (int j = 0; j < SPL; j++) { stage_slot(pre[j], ps_of[j]); }
@@ -560,12 +563,12 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
   flush(s1 - 1);
 }
 
-template <typename TIN, int PX, int PCT, int NBT, int SPL, int OEB>
+template <typename TIN, int PX, int PCT, int NBT, int NLD, int OEB>
 static hipError_t launch_fast(dim3 grid, size_t lds_bytes, hipStream_t s, const FirParams &p, const v4i *frag, const GenArgs &a) {
-  hipError_t e = hipFuncSetAttribute((const void *)fir_gen_fast_kernel<TIN, PX, PCT, NBT, SPL, OEB>,
+  hipError_t e = hipFuncSetAttribute((const void *)fir_gen_fast_kernel<TIN, PX, PCT, NBT, NLD, OEB>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) { return e; }
-  hipLaunchKernelGGL((fir_gen_fast_kernel<TIN, PX, PCT, NBT, SPL, OEB>), grid, dim3(64), lds_bytes, s, p, frag, a);
+  hipLaunchKernelGGL((fir_gen_fast_kernel<TIN, PX, PCT, NBT, NLD, OEB>), grid, dim3(64), lds_bytes, s, p, frag, a);
   return hipGetLastError();
 }
 
@@ -654,10 +657,11 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   // Fast kernel: table of compiled shapes (BASELINE configs 3, 5a, 5b and the poly_dec row); nbt = K blocks compiled in.
   int nbt = 0;
   const int in_eb = p.in_eb, oeb = p.out_eb, px = a.px, pc = pl.pc, nb = pl.nb;
-  if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 3 && spl == 3 && oeb == 8) { nbt = 3; }        // CIC R8 N5 on int32 -> int64
-  else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 6 && spl == 5 && oeb == 8) { nbt = 6; }   // CIC R16 N5 on int16 -> int64
+  const int npc = (a.n_slots * in_eb + 63) / 64;   // 16-byte pieces per lane
+  if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 3 && spl == 3 && npc <= 9 && oeb == 8) { nbt = 3; }        // CIC R8 N5 on int32 -> int64
+  else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 6 && spl == 5 && npc <= 9 && oeb == 8) { nbt = 6; }   // CIC R16 N5 on int16 -> int64
   else if (in_eb == 8 && px == 5 && pc <= 2 && nb <= 3 && spl == 1 && oeb == 4) { nbt = 3; }   // 127-tap FIR on 36-bit words -> int32
-  else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && spl == 3 && oeb == 2) { nbt = 4; }   // 128-tap decimate-by-8 on int16 -> int16
+  else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && spl == 3 && npc <= 5 && oeb == 2) { nbt = 4; }   // 128-tap decimate-by-8 on int16 -> int16
   // ... and a conversion the branch-free form covers: signed wrapping accumulator, signed OUT, TRN/RND, WRAP/SAT
   const bool conv_ok = gen_conv_params(p, out_mode, w_int, &a);
 
@@ -678,10 +682,10 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     // int32, 8 KB of input per step) +2.5 % every time, poly_dec -0.6 % twice and +6.6 % once, the fused DDC -3 %: on for the
     // int32 decimator shape only.  ACDSP_XCD_MAP=0 / 1 forces it off / on for every shape (A/B knob).
     a.xcd_map = (xcd_map_wanted(out_mode == 1 && in_eb == 4) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
-    if (in_eb == 4) { e = launch_fast<int32_t, 4, 2, 3, 3, 8>(grid, lds_bytes, s, p, fr, a); }
+    if (in_eb == 4) { e = launch_fast<int32_t, 4, 2, 3, 9, 8>(grid, lds_bytes, s, p, fr, a); }
     else if (in_eb == 8) { e = launch_fast<int64_t, 5, 2, 3, 1, 4>(grid, lds_bytes, s, p, fr, a); }
-    else if (oeb == 8) { e = launch_fast<int16_t, 2, 3, 6, 5, 8>(grid, lds_bytes, s, p, fr, a); }
-    else { e = launch_fast<int16_t, 2, 2, 4, 3, 2>(grid, lds_bytes, s, p, fr, a); }
+    else if (oeb == 8) { e = launch_fast<int16_t, 2, 3, 6, 9, 8>(grid, lds_bytes, s, p, fr, a); }
+    else { e = launch_fast<int16_t, 2, 2, 4, 5, 2>(grid, lds_bytes, s, p, fr, a); }
     if (e != hipSuccess) { return e; }
   }
   if (fast_chunks >= n_chunks) { return hipSuccess; }
@@ -738,7 +742,7 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   const int64_t s1 = GUARD ? ((s0 + a.steps_per_wave < a.n_steps) ? s0 + a.steps_per_wave : a.n_steps) : s0 + a.steps_per_wave;
 
   // window loads coalesced over 16-byte pieces (8 samples; a slot is two pieces), as in fir_gen_fast_kernel
-  constexpr int NPCA = SPLA * 2;
+  constexpr int NPCA = SPLA;   // 16-byte pieces per lane and step (ceil(n_slots * 2 / 64): 9 for R = 16, six K blocks)
   v4i pre[NPCA];
   int pc_off[NPCA], pc_ps[NPCA];
 #pragma unroll
@@ -973,7 +977,7 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   b.px = (w_int + 7) / 8;
   a.n_slots = 15 * pla.R + 4 * pla.nb;
   const int spl = (a.n_slots + 63) / 64;
-  const bool shape_ok = pa.in_eb == 2 && a.px == 2 && pla.pc <= 3 && pla.nb <= 6 && spl == 5 && pla.R >= 2 &&
+  const bool shape_ok = pa.in_eb == 2 && a.px == 2 && pla.pc <= 3 && pla.nb <= 6 && spl == 5 && (a.n_slots * 2 + 63) / 64 <= 9 && pla.R >= 2 &&
                         b.px == 5 && plb.pc <= 2 && plb.nb <= 3 && plb.R == 1 && plb.off == 128 && pb.out_eb == 4;
   a.out_mode = 1; a.w_int = w_int; a.out_simple = 2;
   FirParams pint = pa;                       // stage A's "OUT_TYPE" is the INT_TYPE itself: wrap only
@@ -1033,10 +1037,10 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   }
   hipError_t e;
 #define ACDSP_CASCADE_LAUNCH(GUARD_, LIMB_, GRID_)                                                                                   \
-  e = hipFuncSetAttribute((const void *)cascade_kernel<2, 3, 6, 5, 5, 2, 3, GUARD_, LIMB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+  e = hipFuncSetAttribute((const void *)cascade_kernel<2, 3, 6, 9, 5, 2, 3, GUARD_, LIMB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                           (int)lds_bytes);                                                                                           \
   if (e != hipSuccess) { return e; }                                                                                                 \
-  hipLaunchKernelGGL((cascade_kernel<2, 3, 6, 5, 5, 2, 3, GUARD_, LIMB_>), GRID_, dim3(64), lds_bytes, s, pa, pb, fa, fb, a, b);      \
+  hipLaunchKernelGGL((cascade_kernel<2, 3, 6, 9, 5, 2, 3, GUARD_, LIMB_>), GRID_, dim3(64), lds_bytes, s, pa, pb, fa, fb, a, b);      \
   if ((e = hipGetLastError()) != hipSuccess) { return e; }
   a.xcd_map = 0;
   if (fast_chunks > 0) {

@@ -60,6 +60,29 @@ __global__ void __launch_bounds__(256) elem_reduce_kernel(const v4i *src, v4i *d
   if (NT) { __builtin_nontemporal_store(acc, dst + (size_t)blockIdx.x * 256 + threadIdx.x); } else { dst[(size_t)blockIdx.x * 256 + threadIdx.x] = acc; }
 }
 
+// span geometry of the product kernels: one wave per workgroup reads `pieces` KB contiguous (U loads in flight), writes pieces / R KB;
+// workgroups in memory order; LNT / SNT: non-temporal loads / stores; XCD: workgroup L works on span (L % 8) * (n / 8) + L / 8
+template <int R, int U, bool LNT, bool SNT, bool XCD>
+__global__ void __launch_bounds__(64) span_reduce_kernel(const v4i *src, v4i *dst, int pieces) {
+  const int lane = threadIdx.x;
+  size_t blk = blockIdx.x;
+  if (XCD) { const size_t T = gridDim.x; blk = (blk & 7) * (T >> 3) + (blk >> 3); }
+  const v4i *s0 = src + blk * pieces * 64 + lane;
+  v4i *d0 = dst + blk * (pieces / R) * 64 + lane;
+  for (int p = 0; p < pieces; p += U) {
+    v4i v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { v[u] = LNT ? __builtin_nontemporal_load(s0 + (p + u) * 64) : s0[(p + u) * 64]; }
+#pragma unroll
+    for (int o = 0; o < U / R; o++) {
+      v4i acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < R; r++) { acc += v[o * R + r]; }
+      if (SNT) { __builtin_nontemporal_store(acc, d0 + (p / R + o) * 64); } else { d0[(p / R + o) * 64] = acc; }
+    }
+  }
+}
+
 template <typename F>
 static float time_ms(F f, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -109,5 +132,16 @@ int main(int argc, char **argv) {
            (out_bytes + out_bytes / R_) / ms / 1e9);                                                                          \
   }
   REDUCE(2, false) REDUCE(4, false) REDUCE(4, true) REDUCE(8, false) REDUCE(8, true) REDUCE(16, false) REDUCE(16, true) REDUCE(32, false)
+#define SPANR(R_, U_, LNT_, SNT_, XCD_, PIECES_)                                                                              \
+  {                                                                                                                           \
+    const size_t in_kb = out_bytes / 1024;                                                                                    \
+    ms = time_ms([&] { hipLaunchKernelGGL((span_reduce_kernel<R_, U_, LNT_, SNT_, XCD_>), dim3((unsigned)(in_kb / PIECES_)), dim3(64), 0, 0, src, dst, PIECES_); }, reps); \
+    printf("span-reduce %2d:1 U=%2d lnt=%d snt=%d xcd=%d  %2d KB per wave  %.3f ms  %.2f TB/s (read + written)\n", R_, U_, LNT_, SNT_, XCD_, PIECES_, ms, \
+           (out_bytes + out_bytes / R_) / ms / 1e9);                                                                          \
+  }
+  SPANR(8, 8, false, false, false, 16) SPANR(8, 8, false, true, false, 16) SPANR(8, 8, true, true, false, 16) SPANR(8, 16, false, true, false, 16)
+  SPANR(8, 16, true, true, false, 16) SPANR(8, 16, false, true, false, 32) SPANR(8, 16, true, true, false, 32) SPANR(8, 16, false, true, true, 16)
+  SPANR(8, 16, true, true, true, 16) SPANR(8, 16, true, true, true, 32) SPANR(8, 8, false, true, false, 8)
+  SPANR(4, 16, false, true, false, 16) SPANR(4, 16, true, true, false, 16) SPANR(4, 16, true, true, true, 16)
   return 0;
 }
