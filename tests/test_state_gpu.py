@@ -22,7 +22,8 @@ def dev(x, fmt):
 
 
 @pytest.mark.parametrize("ftype,kind,n_taps", [("SHIFT_REG", "load", 255), ("FOLD_ODD", "const", 63), ("TRANSPOSED", "load", 40),
-                                               ("C_BUFF", "prog", 17), ("TRANSPOSED", "const", 33)])
+                                               ("C_BUFF", "prog", 17), ("TRANSPOSED", "const", 33),
+                                               ("SHIFT_REG", "load", 258), ("SHIFT_REG", "prog", 352)])   # padded plans: longer history
 def test_fir_state_round_trip(ftype, kind, n_taps):
     fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
     rng = np.random.default_rng(3)
