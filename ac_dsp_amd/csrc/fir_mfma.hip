@@ -68,12 +68,12 @@ int fir_mfma_max_reg_blocks() { return kMaxRegNB; }
 // Lane l holds row i = l & 31 and the 16 K-positions k = 16*(l>>5) + j, j = 0..15 (the same
 // (lane-group, byte) -> k map is used for the data operand, so any K permutation inside the
 // instruction cancels).
-// K-blocks of the plan for n_taps: the Toeplitz band of 32 outputs spans n_taps + 31 inputs; 10 .. 16 blocks are padded to the next odd
+// K-blocks of the plan for n_taps: the Toeplitz band of 32 outputs spans n_taps + 31 inputs; 10 .. 32 blocks are padded to the next odd
 // count (the register-resident shapes of fir_mfma_mid.hip exist for odd counts; the extra leading block holds zeros).
 int fir_mfma_plan_blocks(int n_taps) {
   int nb = (n_taps - 1 + 31) / 32 + 1;
   static const bool no_mid = getenv("ACDSP_NO_MID") != nullptr;
-  if (!no_mid && nb >= 10 && nb <= 16 && (nb & 1) == 0) { nb++; }
+  if (!no_mid && nb >= 10 && nb <= 32 && (nb & 1) == 0) { nb++; }
   return nb;
 }
 
@@ -1229,7 +1229,8 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
 }
 
 #ifdef ACDSP_FIR_TU_MID
-// ---- second translation unit (fir_mfma_mid.hip): the register-resident shapes for 10 .. 17 K-blocks ----
+// ---- further translation units (fir_mfma_mid*.hip): the register-resident shapes for 11 .. 31 K-blocks, split three ways for compile time ----
+#if ACDSP_FIR_TU_MID == 1
 hipError_t launch_fir_mfma_mid(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   switch (nb) {
     case 11: return launch_nb_hs<11, 3 + 16 * 3, 1>(p, d_frag, a, epi, grid, s);
@@ -1239,8 +1240,30 @@ hipError_t launch_fir_mfma_mid(const FirParams &p, int nb, const uint32_t *d_fra
     default: return hipErrorInvalidValue;
   }
 }
+#elif ACDSP_FIR_TU_MID == 2
+hipError_t launch_fir_mfma_mid2(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  switch (nb) {
+    case 19: return launch_nb_hs<19, 7 + 16 * 7, 1>(p, d_frag, a, epi, grid, s);
+    case 21: return launch_nb_hs<21, 8 + 16 * 8, 1>(p, d_frag, a, epi, grid, s);
+    case 23: return launch_nb_hs<23, 9 + 16 * 9, 1>(p, d_frag, a, epi, grid, s);
+    case 25: return launch_nb_hs<25, 10 + 16 * 10, 1>(p, d_frag, a, epi, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#else
+hipError_t launch_fir_mfma_mid3(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  switch (nb) {
+    case 27: return launch_nb_hs<27, 11 + 16 * 11, 1>(p, d_frag, a, epi, grid, s);
+    case 29: return launch_nb_hs<29, 12 + 16 * 12, 1>(p, d_frag, a, epi, grid, s);
+    case 31: return launch_nb_hs<31, 13 + 16 * 13, 1>(p, d_frag, a, epi, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#endif
 #else
 hipError_t launch_fir_mfma_mid(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s);
+hipError_t launch_fir_mfma_mid2(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s);
+hipError_t launch_fir_mfma_mid3(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s);
 
 static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArgs a, int epi, dim3 grid, hipStream_t s) {
   const int nb = a.nb;
@@ -1406,12 +1429,12 @@ static bool use_reg33(int nb, uint64_t hi_mask, int epi) {
   return nb == 33 && !off && reg33_band_code(hi_mask, epi) != 0;
 }
 
-// NB = 10 .. 17 (258 - 513 taps): the register-resident kernel at one wave per SIMD, like NB = 33, for sets whose high-byte band fits the
-// five central K-blocks of the instantiated shape.  Shapes exist for odd NB (11, 13, 15, 17: fir_mfma_mid.hip, its own translation
-// unit for the compile time); fir_mfma_plan_blocks pads an even plan by one leading zero block (2 MFMAs per step).  Same-box A/B at 319
+// NB = 10 .. 31 (258 - 961 taps): the register-resident kernel at one wave per SIMD, like NB = 33, for sets whose high-byte band fits the
+// five central K-blocks of the instantiated shape.  Shapes exist for odd NB (11 .. 31: fir_mfma_mid.hip, _mid2, _mid3, translation
+// units of their own for the compile time); fir_mfma_plan_blocks pads an even plan by one leading zero block (2 MFMAs per step).  Same-box A/B at 319
 // taps: 1.27 -> 1.12 ms (profiles/r3_taps_sweep.txt); dense sets and wider bands stay on the LDS-resident kernels.
 static int mid_band_code(int nb, uint64_t hi_mask, int epi) {
-  if ((epi != 1 && epi != 2) || nb < 11 || nb > 17 || (nb & 1) == 0) { return 0; }
+  if ((epi != 1 && epi != 2) || nb < 11 || nb > 31 || (nb & 1) == 0) { return 0; }
   const int sk = (nb - 5) / 2;
   int lo = 0, hi = 0;
   if (hi_mask == 0) { lo = hi = nb; }
@@ -1428,7 +1451,10 @@ static bool use_mid(int nb, uint64_t hi_mask, int epi) {
 
 static hipError_t launch_switch(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   if (use_reg33(nb, a.hi_mask, epi)) { return launch_nb33(p, d_frag, a, epi, grid, s); }
-  if (use_mid(nb, a.hi_mask, epi)) { return launch_fir_mfma_mid(p, nb, d_frag, a, epi, grid, s); }
+  if (use_mid(nb, a.hi_mask, epi)) {
+    return nb <= 17 ? launch_fir_mfma_mid(p, nb, d_frag, a, epi, grid, s)
+                    : (nb <= 25 ? launch_fir_mfma_mid2(p, nb, d_frag, a, epi, grid, s) : launch_fir_mfma_mid3(p, nb, d_frag, a, epi, grid, s));
+  }
   if (nb > kMaxRegNB) { return launch_big(p, d_frag, a, epi, grid, s); }
   switch (nb) {
 #ifndef ACDSP_FIR_DEV_NB9   // development builds: only the 255-tap shape (compile time 3 min -> 35 s)

@@ -387,10 +387,10 @@ def test_mfma_large_tap_counts_double_wide_chunks(n_taps, fo):
                seed=n_taps)
 
 
-@pytest.mark.parametrize("n_taps", [258, 289, 290, 321, 352, 383, 416, 449, 480, 511, 513])
+@pytest.mark.parametrize("n_taps", [258, 289, 290, 321, 352, 383, 416, 449, 480, 511, 513, 514, 546, 577, 640, 705, 769, 830, 897, 930, 961, 975, 992])
 @pytest.mark.parametrize("fo", [A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(16, 2, True, "TRN", "WRAP")])
 def test_mfma_mid_tap_counts_register_resident_shapes(n_taps, fo):
-    """258 - 513 taps (10 .. 17 K-blocks): unit-gain low-pass sets run on the register-resident shapes of fir_mfma_mid.hip (an even
+    """258 - 961 taps (10 .. 31 K-blocks): unit-gain low-pass sets run on the register-resident shapes of fir_mfma_mid*.hip (an even
     plan is padded by one zero block: the history reaches one block further back), every other set on the LDS-resident kernels."""
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16)
     c = windowed_sinc(n_taps, 0.08, fc)
