@@ -483,7 +483,7 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   const bool i16_in = d.in.S ? d.in.W <= 16 : d.in.W <= 15;
   const bool i16_cf = d.coeff.S ? d.coeff.W <= 16 : d.coeff.W <= 15;
   if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && i16_in && i16_cf && d.in.S && h->in_eb == 2 &&
-      fir_mfma_plan_blocks(d.n_taps) <= (d.coeffs_per_channel ? fir_mfma_max_reg_blocks() : fir_mfma_max_blocks())) {
+      fir_mfma_plan_blocks(d.n_taps) <= fir_mfma_max_blocks()) {
     const int nb = fir_mfma_plan_blocks(d.n_taps);
     const size_t per_set = (size_t)2 * nb * 64 * 4;
     std::vector<uint32_t> frag(n_sets * per_set, 0u);
@@ -504,6 +504,14 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
       if (pl.sum_abs_lo > worst.sum_abs_lo) { worst.sum_abs_lo = pl.sum_abs_lo; }
       const int64_t ca = pl.corr < 0 ? -pl.corr : pl.corr, wa = worst.corr < 0 ? -worst.corr : worst.corr;
       if (st == 0 || ca > wa) { worst.corr = pl.corr; }
+    }
+    if (ok && d.coeffs_per_channel && worst.nb > fir_mfma_max_reg_blocks()) {
+      // a set per channel needs the register-resident kernels: beyond 9 K-blocks only band-limited sets with the fast int16 epilogue
+      FirParams k;
+      memset(&k, 0, sizeof k);
+      k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+      k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
+      ok = fir_mfma_register_resident(k, worst);
     }
     if (ok) {
       HIP_TRY(hipMemcpy(h->d_frag, frag.data(), frag.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -1367,6 +1367,14 @@ int fir_mfma_issued_per_step(const FirParams &p, const FirMfmaPlan &plan) {
   return 2 * nb + 2 * band;
 }
 
+// true if the plan runs on a kernel that keeps the Toeplitz fragments in registers (the only ones that can take a coefficient set per
+// channel): up to 9 K-blocks always, more when the set's high-byte band fits a compiled shape and the fast int16 epilogue applies
+bool fir_mfma_register_resident(const FirParams &p, const FirMfmaPlan &plan) {
+  if (plan.nb <= kMaxRegNB) { return true; }
+  const int epi = fir_mfma_epilogue_class(p, plan);
+  return use_mid(plan.nb, plan.hi_mask, epi) || use_reg33(plan.nb, plan.hi_mask, epi);
+}
+
 hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag_per_channel, const uint32_t *d_frag,
                            const int64_t *d_corr, hipStream_t s) {
   if (p.n <= 0) { return hipSuccess; }

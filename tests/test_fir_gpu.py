@@ -406,6 +406,21 @@ def test_mfma_mid_tap_counts_register_resident_shapes(n_taps, fo):
     assert fir2.mfma_issued() > 2 * nb + 2 * 5
 
 
+@pytest.mark.parametrize("n_taps", [300, 640, 1023])
+def test_per_channel_coefficients_beyond_257_taps(n_taps):
+    """A coefficient set per channel needs the register-resident kernels; beyond 9 K-blocks those exist for band-limited sets
+    (every object of a bank of ac_fir_prog_coeffs filters with its own low-pass): matrix-core path.  Dense sets: exact-order path."""
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16), A.Fmt(16, 2, True, "RND", "SAT")
+    n_ch = 7
+    c = np.stack([windowed_sinc(n_taps, 0.03 + 0.01 * ch, fc, gain=0.5 + 0.07 * ch) for ch in range(n_ch)])
+    fir = check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=n_ch, n=2 * 8192 + 333, per_channel=True, coeffs=c, expect_path="mfma_i8",
+                     splits=[8192 + 16, 9001], seed=n_taps)
+    assert fir.mfma_issued() > 0
+    dense = np.minimum(rand_raw(np.random.default_rng(n_taps), fc, (n_ch, n_taps)), 32639) // 64
+    fir2 = check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=n_ch, n=1500, per_channel=True, coeffs=dense, seed=n_taps + 1)
+    assert fir2.path != "mfma_i8", fir2.path
+
+
 def test_config4_shape_1023_taps_prog_coeffs():
     """BASELINE config 4 shape (ac_fir_prog_coeffs, 1023 taps, <16,2>, ACC <42,14>) at a reduced size."""
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
