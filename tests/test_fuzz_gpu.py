@@ -81,6 +81,45 @@ def test_fir_random_shapes(seed):
         seed, len(bad), bad[0], fir.path, kind, ftype, n_taps, n_ch, n_total, cuts, per_ch)
 
 
+@pytest.mark.parametrize("seed", range(max(CASES // 2, 1)))   # the oracle needs ~1 s per case at these lengths
+def test_fir_long_band_limited_sets(seed):
+    """258 .. 1025 taps, low-pass sets of random cutoff and gain (the register-resident shapes for 11 .. 33 K-blocks when the high-byte
+    band is narrow, the LDS-resident kernels when it is not), one set or a set per channel, ragged calls on unaligned views."""
+    from helpers import windowed_sinc
+    rng = np.random.default_rng(7000 + seed)
+    fin, fc, fa = FIR_TYPES[rng.integers(2)]
+    fo = FIR_OUTS[rng.integers(4)]
+    kind = ["const", "load", "prog"][rng.integers(3)]
+    ftype = ["SHIFT_REG", "C_BUFF", "FOLD_ODD", "ROTATE_SHIFT"][rng.integers(4)]
+    n_taps = int(rng.integers(258, 1026))
+    if ftype == "FOLD_ODD":
+        n_taps |= 1
+    n_ch = int(rng.choice([1, 3, 8, 9]))
+    per_ch = bool(rng.integers(2))
+    n_total = int(rng.choice([700, 2048, 5000, 8192 + 40, 20000]))
+    def one():
+        return windowed_sinc(n_taps, float(rng.uniform(0.01, 0.2)), fc, gain=float(rng.choice([0.3, 0.9, 1.0, 3.0])))
+    c = np.stack([one() for _ in range(n_ch)]) if per_ch else one()
+    x = rand_raw(rng, fin, (n_ch, n_total))
+    fir = A.Fir(n_taps, ftype, fin, fc, fa, fo, n_channels=n_ch, kind=kind, coeffs_per_channel=per_ch)
+    fir.set_coeffs(c)
+    yo = OracleFir(n_taps, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch).run(c, x)
+    cuts = sorted(set(int(v) for v in rng.integers(0, n_total + 1, size=rng.integers(0, 3))))
+    bounds = [0] + cuts + [n_total]
+    dt_in, dt_out = A.torch_dtype_for(fin), A.torch_dtype_for(fo)
+    outs = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b == a:
+            continue
+        xv = padded_view(x[:, a:b], dt_in, int(rng.integers(0, 9)), int(rng.integers(0, 9)))
+        out = torch.zeros((n_ch, b - a + int(rng.integers(0, 9))), dtype=dt_out, device="cuda")
+        outs.append(fir.run(xv, out)[:, :b - a].cpu().numpy().astype(np.int64))
+    y = np.concatenate(outs, axis=1)
+    bad = np.argwhere(y != yo)
+    assert bad.size == 0, "seed %d: %d mismatches, first %s (path %s issued %d, %s %s taps %d ch %d n %d cuts %s per_ch %s)" % (
+        seed, len(bad), bad[0], fir.path, fir.mfma_issued(), kind, ftype, n_taps, n_ch, n_total, cuts, per_ch)
+
+
 @pytest.mark.parametrize("seed", range(CASES))
 def test_cic_random_shapes(seed):
     rng = np.random.default_rng(2000 + seed)
