@@ -1389,6 +1389,9 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   // the best span of a bare copy (tools/copy_probe2.hip), run them 13 % faster than 128 KB spans (15 - 95 taps: 0.733 against 0.84 ms per
   // 1024 ch x 2^20 samples, same box; 12 and 24 steps: 0.76 / 0.78).  From 127 taps on 16 .. 64 steps measure alike (profiles/r3_taps_sweep.txt).
   if (plan.nb <= 4 && spw > 16) { spw = 16; }
+  // 8-byte outputs (OUT = ACC rows: 2 KB read and 8 KB written per step): 8 steps per wave, 1.96 against 2.07 ms at 64 on the config-2
+  // wide row (2 / 4 / 6 / 12 / 16 steps: 2.02 / 1.98 / 1.98 / 2.02 / 2.02; same box, two passes)
+  if (epi == 3 && spw > 8) { spw = 8; }
   static const char *spw_env = getenv("ACDSP_FIR_SPW");   // tuning knob: 1024-sample steps per wave
   if (spw_env && atoi(spw_env) > 1) { spw = atoi(spw_env); }
   a.steps_per_wave = spw;
