@@ -390,7 +390,17 @@ def main():
         # Channels are independent filter objects: the data path has no exchange step, so no RCCL communicator is built.
         # The timing contract (barrier, MAX of the times, SUM of the samples) runs over gloo on host scalars.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        # gloo announces its connections on the C-level stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one process per GPU; without a launcher bench.py spawns the ranks itself)" % (args.gpus, world))
     if not os.environ.get("ACDSP_BENCH_ONE_GPU") and torch.cuda.device_count() < world:
