@@ -172,6 +172,9 @@ __device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16
 #ifndef ACDSP_FIR_NT
 #define ACDSP_FIR_NT 15
 #endif
+#ifndef ACDSP_FIR_PRIO
+#define ACDSP_FIR_PRIO 0
+#endif
 constexpr int kGroupSize = ACDSP_GS, kOccupancy = ACDSP_OCC;
 
 // EPI 0: any OUT_TYPE / ACC width through requant64.
@@ -730,6 +733,9 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
 #ifndef ACDSP_ABL_FLUSH
       if (PREV && g == gE2) { flush(T0 - 1024); }
 #endif
+#if ACDSP_FIR_PRIO   // A/B knob: raise the wave's issue priority over its MFMA runs (round-2 review item 1c)
+      __builtin_amdgcn_s_setprio(ACDSP_FIR_PRIO);
+#endif
 #pragma unroll
       for (int i = 0; i < GS; i++) {
         const int b = g * GS + i;
@@ -742,6 +748,9 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
           mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[cb][i], mid, 0, 0, 0);
         }
       }
+#if ACDSP_FIR_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
   };
