@@ -620,7 +620,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   // are launch-bound: no timing events, and the exact-order kernels write the next history themselves -- one launch per call.
   const bool small = h->small_call;
   const bool fuse_hist = small && !h->use_rt && (path == ACDSP_PATH_LOSSLESS64 || path == ACDSP_PATH_GENERIC ||
-                                                (path == ACDSP_PATH_MFMA_I8 && h->plan.nb <= fir_mfma_max_reg_blocks()));   // single-wave workgroups
+                                                (path == ACDSP_PATH_MFMA_I8 && fir_mfma_register_resident(k, h->plan)));   // single-wave workgroups
   const int nxt_fused = hist_next_index(h->cur, false);
   if (fuse_hist) { k.hist_next = h->d_hist[nxt_fused]; }
   if (!small) { HIP_TRY(hipEventRecord(h->tm.start(), s)); }

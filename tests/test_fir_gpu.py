@@ -255,6 +255,23 @@ def test_reference_fir_testbench_vectors():
         assert np.array_equal(y, OracleFir(taps, "FOLD_ODD", ofmt(fi), ofmt(fc), ofmt(fa), ofmt(fa)).run(c, x)[0])
 
 
+@pytest.mark.parametrize("n_taps", [63, 255, 300, 1023])
+def test_one_sample_host_calls_carry_the_history(n_taps):
+    """ac_fir_prog_coeffs::run is one sample per call (reference ac_fir_prog_coeffs.h:281): small host-side calls go through the pinned
+    buffers and the register-resident MFMA kernels write the next history themselves (one launch per call, every shape)."""
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16), A.Fmt(16, 2, True, "RND", "SAT")
+    c = windowed_sinc(n_taps, 0.05, fc)
+    rng = np.random.default_rng(n_taps)
+    x = rng.integers(-32768, 32768, size=(1, 3 * n_taps + 70), dtype=np.int64)
+    fir = A.Fir(n_taps, "SHIFT_REG", fin, fc, fa, fo, kind="prog")
+    fir.set_coeffs(c)
+    assert fir.path == "mfma_i8"
+    cuts = [0, 1, 2, 3, 20, 21, n_taps, n_taps + 1, 2 * n_taps + 5, x.shape[1]]
+    y = np.concatenate([fir.run_host(x[:, a:b]).astype(np.int64) for a, b in zip(cuts[:-1], cuts[1:])] , axis=1)
+    want = OracleFir(n_taps, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo)).run(c, x)
+    assert np.array_equal(y, want)
+
+
 def test_ragged_and_empty_inputs():
     fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
     fir = check_case(40, "SHIFT_REG", fin, fc, fa, fo, n_ch=1, n=1)            # single sample
