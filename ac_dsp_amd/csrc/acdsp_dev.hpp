@@ -144,9 +144,19 @@ __device__ __forceinline__ void xcd_remap(int on, int &bx, int &by) {
     bx = (int)(L2 - (int64_t)by * gridDim.x);
   }
 }
+// Tuning knobs are environment variables read ONCE per process; with ACDSP_TUNE_LIVE set they are re-read at every launch, so that one
+// process (tools/knob_sweep.py) can compare variants on the same allocations -- the streaming rows move 3 - 8 % with the placement of
+// their buffers from process to process (profiles/r3_placement_modes.txt), more than most knobs.
+inline bool tune_live() {
+  static const bool l = getenv("ACDSP_TUNE_LIVE") != nullptr;
+  return l;
+}
+#define ACDSP_TUNE_ENV(var, name)                    \
+  static const char *var##_once = getenv(name);      \
+  const char *var = ::acdsp::tune_live() ? getenv(name) : var##_once
 // default of a kernel family, overridden by ACDSP_XCD_MAP=0 / 1 (A/B knob)
 inline bool xcd_map_wanted(bool family_default) {
-  static const char *e = getenv("ACDSP_XCD_MAP");
+  ACDSP_TUNE_ENV(e, "ACDSP_XCD_MAP");
   return e ? atoi(e) != 0 : family_default;
 }
 

@@ -124,6 +124,7 @@ struct GenArgs {
   int32_t obuf_off;           // byte offset of the 256-output tile in LDS (row-contiguous write-out)
   int32_t chunk0;             // first chunk (of steps_per_wave steps) this launch covers: blockIdx.x + chunk0
   int32_t xcd_map;            // fast kernels: XCD-affine chunk order (xcd_remap below); the host sets it only when grid.x * grid.y % 8 == 0
+  int32_t ring_delta;         // ring kernel: slots between the first window's start and its 128-byte line (< 8 / sizeof(TIN))
   // branch-free output conversion of the fast kernel (host-derived from out_mode / the formats):
   //   v = wrapS_{64-ka}(y << ls);  v = ((v + rnd) >> rs) << ls2;  v = clamp(v, lo, hi);  v = wrapS_{64-ko}(v)
   int32_t e_ls, e_ka, e_rs, e_ls2, e_ko;
@@ -170,8 +171,10 @@ __device__ inline unsigned gather4(unsigned d0, unsigned d1, unsigned d2, unsign
 
 // SMALL: at most 3 K blocks x 2 coefficient digits (24 VGPRs of A fragments instead of 96): the common CIC /
 // DDC shapes then fit three or four waves per SIMD, which is what hides the HBM latency of this streaming kernel.
+// (Three waves per SIMD only while the byte planes leave room: six and more planes of 8-byte samples hold 24 - 32 VGPRs of X fragments
+// and 36 - 40 of accumulators beside the A fragments, and spilled at 168 registers.)
 template <typename TIN, int PX, bool SMALL>
-__global__ void __launch_bounds__(64, SMALL ? 3 : 2) fir_gen_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
+__global__ void __launch_bounds__(64, (SMALL && PX <= 5) ? 3 : 2) fir_gen_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
   constexpr int kMaxNB = SMALL ? 3 : kGenMaxNB, kMaxPC = SMALL ? 2 : kGenMaxPC;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [PX][phys slots][16]
   const int lane = threadIdx.x;
@@ -196,9 +199,12 @@ __global__ void __launch_bounds__(64, SMALL ? 3 : 2) fir_gen_kernel(FirParams p,
 
   // Slots of the next step are fetched into registers while the current step multiplies (when the
   // per-lane slot count fits the register budget), so the HBM latency overlaps MFMA + epilogue.
-  constexpr int SPLMAX = 16 / (int)sizeof(TIN);            // 64 VGPRs of prefetch
+  // (not for six and more planes of 8-byte samples: 96 VGPRs of A fragments + 40 of accumulators + 32 of X fragments leave no room
+  // for 64 of prefetch -- those instantiations spilled 2 - 27 registers; they load each slot right before staging it)
+  constexpr bool CAN_PF = !(sizeof(TIN) == 8 && PX >= 6);
+  constexpr int SPLMAX = CAN_PF ? 16 / (int)sizeof(TIN) : 1;            // 64 VGPRs of prefetch
   const int spl = (a.n_slots + 63) / 64;
-  const bool prefetch = spl <= SPLMAX;
+  const bool prefetch = CAN_PF && spl <= SPLMAX;
   v4i pre[SPLMAX][sizeof(TIN)];
   auto slot_src = [&](int64_t W0, int sl) -> const TIN * {
     const int64_t t = W0 + 16 * (int64_t)sl;
@@ -572,6 +578,216 @@ static hipError_t launch_fast(dim3 grid, size_t lds_bytes, hipStream_t s, const 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ring variant of the fast kernel (round 4): the decimating shapes of the BASELINE rows (R = 8 / 16 on int16 / int32 rows).
+//
+// The fast kernel above re-stages the whole window of every step: n_slots = 15 R + 4 NBT slots where the step advances 16 R, so the
+// tail of a window is fetched twice (L2), the surplus lanes of the last load repeat a piece, and the loads start on 16-sample, not
+// 128-byte, boundaries.  Here the byte planes live in an LDS RING of two steps: every step loads exactly its own 16 R new slots -- R S / 4
+// full 1 KB wave-loads on 128-byte lines -- and a chunk reads every input byte ONCE (plus a halo of H <= 12 slots at its start).  With
+// that the window loads can take the non-temporal policy (they bypass the vector L1, which the old form's re-reads needed).
+//
+//   ring position q (slots, relative to the chunk's line-aligned origin C0)  ->  q mod 2 ADV, linear range [0, 2 ADV + H):
+//     prime   [0, H)                      loaded once at the chunk start
+//     step k  [H + k ADV, H + (k+1) ADV)  -> even k: [H, H + ADV); odd k: [H + ADV, H + 2 ADV), whose last H slots are the MIRROR of
+//                                            [0, H) and are written to both places (the wrap of the ring without modular addressing)
+//     window of step k = [delta + (k & 1) ADV, ... + 15 R + 4 NBT), delta = misalignment of the window start against its line (< 8 / S)
+//   The chunk is fully unrolled (SPW steps), so every ring offset is an immediate beside one base register per access class.
+//   The slot -> LDS map is gen_slot_map's (two empty slots after every R), which commutes with the ring because ADV and the slots
+//   of one 1 KB load are multiples of R.
+//   PF = steps the loads run ahead (1 or 2); NT = non-temporal window loads.
+//   FB = the output tiles of the whole chunk wait in LDS and leave in one burst at its end (SPW tiles instead of one).
+template <typename TIN, int PX, int PCT, int NBT, int R, int OEB, int SPW, int PF, bool NT, bool FB>
+__global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
+  constexpr int S = (int)sizeof(TIN);
+  constexpr int LS = 8 / S;                                   // slots per 128-byte line
+  constexpr int ADV = 16 * R, NSL = 15 * R + 4 * NBT;
+  constexpr int H = (LS - 1 + NSL - ADV + LS - 1) / LS * LS;  // halo slots (line multiple): covers any delta
+  constexpr int NLD = R * S / 4;                              // 1 KB loads per step
+  constexpr int PPB = 16 / S;                                 // samples of a 16-byte piece = bytes of one of its planes
+  constexpr int SPK = 64 / S;                                 // slots per 1 KB load
+  static_assert(S == 2 || S == 4, "ring kernel: 2- and 4-byte samples");
+  static_assert(R % 4 == 0 && SPK % R == 0 && H <= ADV && S * H <= 64 && NLD * SPK == ADV, "ring geometry");
+  constexpr int KSTEP = (SPK + 2 * (SPK / R)) * 16;           // LDS bytes from a piece of load k to the same lane's piece of load k + 1
+  constexpr int PADV = (ADV + 2 * (ADV / R)) * 16;            // LDS bytes a step advances
+  constexpr int RING = (SPW < 2 ? SPW : 2) * ADV + H;         // chunks of one or two steps never wrap
+  constexpr int PLANE = (RING + 2 * (RING / R) + 2) * 16;     // + one dump slot (mirror writes of the lanes that have none)
+  constexpr int DUMP = PLANE - 16;
+  constexpr int TILE = 256 * OEB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PX * PLANE + (FB ? SPW : 1) * TILE];
+  const int lane = threadIdx.x;
+  const int n_col = lane & 15, kg = lane >> 4;
+  int bx, ch;
+  xcd_remap(a.xcd_map, bx, ch);
+  const int NB = a.pl.nb, PC = a.pl.pc;
+  auto phys = [](int s) { return s + 2 * (s / R); };
+
+  v4i A[NBT][PCT];
+#pragma unroll
+  for (int b = 0; b < NBT; b++) {
+#pragma unroll
+    for (int q = 0; q < PCT; q++) { A[b][q] = (b < NB && q < PC) ? frag[((size_t)q * NB + b) * 64 + lane] : (v4i){0, 0, 0, 0}; }
+  }
+  const TIN *xrow = (const TIN *)p.x + (int64_t)ch * p.in_stride;
+  const TIN *hrow = (const TIN *)p.hist + (int64_t)ch * p.hl + p.hl;
+  const int64_t s0 = ((int64_t)bx + a.chunk0) * SPW;
+  // C0: sample index of the chunk's ring origin = the first window's start, moved down onto its 128-byte line
+  const int64_t c0 = a.first - a.pl.off - 16 * (int64_t)a.ring_delta + s0 * (256 * R);
+  const bool interior = c0 >= 0 && c0 + 16 * (int64_t)(H + SPW * ADV) <= a.n16;   // every load of the chunk lies inside the call's samples
+
+  const int pl_lane = lane < S * H ? lane : S * H - 1;          // prime: S H pieces; the other lanes repeat the last one
+  const int pr_off = phys(pl_lane / S) * 16 + (pl_lane % S) * PPB;
+  const int st_base = phys(H + lane / S) * 16 + (lane % S) * PPB;
+  const int mir_off = lane >= 64 - S * H ? st_base - KSTEP : DUMP;
+  int xs[NBT];
+#pragma unroll
+  for (int b = 0; b < NBT; b++) { xs[b] = phys(a.ring_delta + R * n_col + 4 * b + kg) * 16; }
+
+  auto ld = [&](const v4i *ptr) -> v4i {
+    if constexpr (NT) { return __builtin_nontemporal_load(ptr); } else { return *ptr; }
+  };
+  // piece `pc` (16 bytes) of the chunk: sample offset tp from C0
+  auto piece = [&](int64_t tp, auto fast_c) -> v4i {
+    if constexpr (decltype(fast_c)::value) {
+      return ld((const v4i *)(xrow + c0 + tp));
+    } else {
+      const int64_t t = c0 + tp;
+      const int64_t th = t < -(int64_t)p.hl ? -(int64_t)p.hl : t;     // before the history: slots below the first window, never read
+      const TIN *src = (t < 0) ? hrow + th : xrow + ((t < a.n16) ? t : 0);
+      return ld((const v4i *)src);
+    }
+  };
+  auto stage_piece = [&](const v4i &v, int off) {
+#pragma unroll
+    for (int pp = 0; pp < PX; pp++) {
+      if constexpr (S == 2) {
+        const unsigned sel = pp == 0 ? 0x06040200u : 0x07050301u;
+        unsigned lo = __builtin_amdgcn_perm((unsigned)v.y, (unsigned)v.x, sel), hi = __builtin_amdgcn_perm((unsigned)v.w, (unsigned)v.z, sel);
+        if (pp < PX - 1) { lo ^= 0x80808080u; hi ^= 0x80808080u; }
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        *(v2u *)(lds + pp * PLANE + off) = (v2u){lo, hi};
+      } else {
+        unsigned w = gather4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w, pp);
+        if (pp < PX - 1) { w ^= 0x80808080u; }
+        *(unsigned *)(lds + pp * PLANE + off) = w;
+      }
+    }
+  };
+  unsigned char *ob0 = lds + PX * PLANE;
+  char *yrow = (char *)p.y + (int64_t)ch * p.out_stride * OEB;
+  auto flush = [&](int64_t st, int k) {   // as in fir_gen_fast_kernel; k = the step's tile (FB)
+    const int64_t m0 = st * 256;
+    unsigned char *ob = ob0 + (FB ? k * TILE : 0);
+    if (OEB == 8) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int P = 64 * j + lane;
+        const v4i val = *(const v4i *)(ob + ((P ^ ((P >> 3) & 7)) * 16));
+        ACDSP_GEN_ST(val, (v4i *)(yrow + m0 * 8 + 16 * P));
+      }
+    } else if (OEB == 4) {
+      const v4i val = *(const v4i *)(ob + ((lane ^ ((lane >> 3) & 3)) * 16));
+      ACDSP_GEN_ST(val, (v4i *)(yrow + m0 * 4 + 16 * lane));
+    } else {
+      // 512 bytes per step: alone, both wave halves store the same bytes (no exec-mask branch); in the chunk-end burst (FB) the
+      // halves take steps k and k + 1 -- one 1 KB store (called for even k only)
+      const int P = lane & 31;
+      const int x = (P >> 3) & 3;
+      const int half = FB ? (lane >> 5) : 0;
+      v4i val = *(const v4i *)(ob + half * TILE + (P ^ (x >> 1)) * 16);
+      if (x & 1) { val = (v4i){val.z, val.w, val.x, val.y}; }
+      ACDSP_GEN_ST(val, (v4i *)(yrow + m0 * 2 + half * TILE + 16 * P));
+    }
+  };
+
+  auto chunk = [&](auto fast_c) {
+    v4i pre[PF][NLD];
+    auto fetch = [&](int j) {      // the 16 R new slots of step j
+#pragma unroll
+      for (int k = 0; k < NLD; k++) { pre[j % PF][k] = piece(16 * (int64_t)(H + j * ADV) + (int64_t)(lane + 64 * k) * PPB, fast_c); }
+    };
+    const v4i prm = piece((int64_t)pl_lane * PPB, fast_c);
+#pragma unroll
+    for (int j = 0; j < PF && j < SPW; j++) { fetch(j); }
+    stage_piece(prm, pr_off);
+#pragma unroll
+    for (int k = 0; k < SPW; k++) {
+      const int par = (k & 1) * PADV;
+#pragma unroll
+      for (int q = 0; q < NLD; q++) { stage_piece(pre[k % PF][q], st_base + q * KSTEP + par); }
+      if ((k & 1) && k + 1 < SPW) { stage_piece(pre[k % PF][NLD - 1], mir_off); }   // the mirror is read by step k + 1
+      if (!FB && k > 0) { flush(s0 + k - 1, 0); }
+      if (k + PF < SPW) { fetch(k + PF); }
+      asm volatile("" ::: "memory");   // keep the loads in front of the step's arithmetic (see cascade_kernel)
+
+      v4i acc[PX + PCT - 1];
+#pragma unroll
+      for (int w = 0; w < PX + PCT - 1; w++) { acc[w] = (v4i){0, 0, 0, 0}; }
+#pragma unroll
+      for (int b = 0; b < NBT; b++) {
+        v4i X[PX];
+#pragma unroll
+        for (int pp = 0; pp < PX; pp++) { X[pp] = *(const v4i *)(lds + pp * PLANE + xs[b] + par); }
+#pragma unroll
+        for (int q = 0; q < PCT; q++) {
+#pragma unroll
+          for (int pp = 0; pp < PX; pp++) { acc[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b][q], X[pp], acc[pp + q], 0, 0, 0); }
+        }
+      }
+      int64_t o[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        uint64_t y = (uint64_t)a.corr;
+#pragma unroll
+        for (int w = 0; w < PX + PCT - 1; w++) {
+          if (w < 8) { y += (uint64_t)(int64_t)acc[w][r] << (8 * w); }
+        }
+        int64_t v = (int64_t)(y << a.e_ls);
+        v = (int64_t)((uint64_t)v << a.e_ka) >> a.e_ka;
+        v = (int64_t)((uint64_t)((v + a.e_rnd) >> a.e_rs) << a.e_ls2);
+        v = v < a.e_lo ? a.e_lo : (v > a.e_hi ? a.e_hi : v);
+        o[r] = (int64_t)((uint64_t)v << a.e_ko) >> a.e_ko;
+      }
+      typedef long v2l __attribute__((ext_vector_type(2)));
+      unsigned char *ob = ob0 + (FB ? k * TILE : 0);
+      if (OEB == 8) {
+        const int L = 8 * n_col + 2 * kg, sw = n_col & 7;
+        *(v2l *)(ob + ((L ^ sw) * 16)) = (v2l){o[0], o[1]};
+        *(v2l *)(ob + (((L + 1) ^ sw) * 16)) = (v2l){o[2], o[3]};
+      } else if (OEB == 4) {
+        const int L = 4 * n_col + kg;
+        *(v4i *)(ob + ((L ^ ((n_col >> 1) & 3)) * 16)) = (v4i){(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+      } else {
+        typedef short v4s_ __attribute__((ext_vector_type(4)));
+        *(v4s_ *)(ob + ((4 * n_col + kg) ^ ((n_col >> 2) & 3)) * 8) = (v4s_){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+      }
+    }
+    if constexpr (FB) {
+#pragma unroll
+      for (int k = 0; k < SPW; k += (OEB == 2 ? 2 : 1)) { flush(s0 + k, k); }
+    } else {
+      flush(s0 + SPW - 1, 0);
+    }
+  };
+  if (interior) { chunk(std::integral_constant<bool, true>()); } else { chunk(std::integral_constant<bool, false>()); }
+}
+
+template <typename TIN, int PX, int PCT, int NBT, int R, int OEB, int SPW, int PF, bool NT, bool FB>
+static hipError_t launch_ring1(dim3 grid, hipStream_t s, const FirParams &p, const v4i *frag, const GenArgs &a) {
+  hipLaunchKernelGGL((fir_gen_ring_kernel<TIN, PX, PCT, NBT, R, OEB, SPW, PF, NT, FB>), grid, dim3(64), 0, s, p, frag, a);
+  return hipGetLastError();
+}
+// variant = spw (steps per chunk), pf (steps the loads run ahead), nt (non-temporal loads), fb (chunk-end store burst)
+template <typename TIN, int PX, int PCT, int NBT, int R, int OEB>
+static hipError_t launch_ring(int spw, int pf, int nt, int fb, dim3 grid, hipStream_t s, const FirParams &p, const v4i *frag, const GenArgs &a) {
+#define ACDSP_RING_CASE(SPWV, PFV, NTV, FBV) \
+  if (spw == SPWV && pf == PFV && nt == NTV && fb == FBV) { return launch_ring1<TIN, PX, PCT, NBT, R, OEB, SPWV, PFV, (NTV != 0), (FBV != 0)>(grid, s, p, frag, a); }
+  ACDSP_RING_CASE(2, 2, 1, 0) ACDSP_RING_CASE(2, 2, 1, 1)                                 // the defaults (launch_fir_gen)
+  ACDSP_RING_CASE(1, 1, 1, 0) ACDSP_RING_CASE(4, 1, 1, 0) ACDSP_RING_CASE(4, 2, 1, 1) ACDSP_RING_CASE(4, 4, 1, 1)   // A/B set
+#undef ACDSP_RING_CASE
+  return hipErrorInvalidValue;
+}
+
 template <typename TIN>
 static hipError_t launch_px(int px, dim3 grid, size_t lds_bytes, hipStream_t s, const FirParams &p, const v4i *frag, const GenArgs &a) {
   const bool small = a.pl.nb <= 3 && a.pl.pc <= 2;
@@ -588,10 +804,18 @@ static hipError_t launch_px(int px, dim3 grid, size_t lds_bytes, hipStream_t s, 
     }                                                                                                               \
     return hipGetLastError();                                                                                       \
   }
-  switch (px) {
-    ACDSP_GEN_CASE(1) ACDSP_GEN_CASE(2) ACDSP_GEN_CASE(3) ACDSP_GEN_CASE(4)
-    ACDSP_GEN_CASE(5) ACDSP_GEN_CASE(6) ACDSP_GEN_CASE(7) ACDSP_GEN_CASE(8)
-    default: return hipErrorInvalidValue;
+  // byte planes never exceed the container (launch_fir_gen checks px <= in_eb): only those instantiations exist
+  if (px > (int)sizeof(TIN)) { return hipErrorInvalidValue; }
+  if constexpr (sizeof(TIN) == 2) {
+    switch (px) { ACDSP_GEN_CASE(1) ACDSP_GEN_CASE(2) default: return hipErrorInvalidValue; }
+  } else if constexpr (sizeof(TIN) == 4) {
+    switch (px) { ACDSP_GEN_CASE(1) ACDSP_GEN_CASE(2) ACDSP_GEN_CASE(3) ACDSP_GEN_CASE(4) default: return hipErrorInvalidValue; }
+  } else {
+    switch (px) {
+      ACDSP_GEN_CASE(1) ACDSP_GEN_CASE(2) ACDSP_GEN_CASE(3) ACDSP_GEN_CASE(4)
+      ACDSP_GEN_CASE(5) ACDSP_GEN_CASE(6) ACDSP_GEN_CASE(7) ACDSP_GEN_CASE(8)
+      default: return hipErrorInvalidValue;
+    }
   }
 #undef ACDSP_GEN_CASE
 }
@@ -632,6 +856,7 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   if (n_out <= 0) { return hipSuccess; }
   GenArgs a;
   a.pl = pl;
+  a.ring_delta = 0;
   const int in_bits = p.in.W + (p.in.S ? 0 : 1);
   a.px = (in_bits + 7) / 8;
   if (a.px > p.in_eb) { return hipErrorInvalidValue; }
@@ -665,6 +890,31 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   // ... and a conversion the branch-free form covers: signed wrapping accumulator, signed OUT, TRN/RND, WRAP/SAT
   const bool conv_ok = gen_conv_params(p, out_mode, w_int, &a);
 
+  // Ring variant (fir_gen_ring_kernel) for the decimating BASELINE shapes.  ACDSP_GEN_RING=0: the window-per-step kernel (A/B
+  // reference); ACDSP_GEN_RING=spw,pf,nt,fb picks another compiled variant (steps per chunk, load distance, non-temporal loads,
+  // chunk-end store burst).  Defaults from same-process sweeps on three boxes (profiles/r4_ring_sweep.txt): TWO-step chunks with
+  // every load of the chunk issued up front (16 KB bursts on config 3, 8 KB on poly_dec) beat longer chunks by 3 - 5 % and the
+  // window-per-step kernel by 7 - 11 %; the store burst pays for 2-byte outputs (one 1 KB store per chunk instead of two half-wave
+  // ones) and costs occupancy for 8-byte outputs.
+  ACDSP_TUNE_ENV(ring_env, "ACDSP_GEN_RING");
+  int r_spw = 2, r_pf = 2, r_nt = 1, r_fb = (oeb == 2) ? 1 : 0, ring_shape = 0;
+  bool ring_on = true;
+  if (ring_env) {
+    int v[4];
+    if (sscanf(ring_env, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) { r_spw = v[0]; r_pf = v[1]; r_nt = v[2]; r_fb = v[3]; }
+    else { ring_on = atoi(ring_env) != 0; }
+  }
+  if (ring_on && conv_ok && a.out_vec_ok) {
+    if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 3 && oeb == 8 && pl.R == 8) { ring_shape = 1; }          // CIC R8 N5 on int32 -> int64
+    else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 2; }   // CIC R16 N5 on int16 -> int64
+    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && oeb == 2 && pl.R == 8) { ring_shape = 3; }    // 128-tap decimate-by-8 on int16 -> int16
+  }
+  if (ring_shape) {
+    spw = r_spw; a.steps_per_wave = spw;
+    const int ls = 8 / in_eb;
+    const int64_t w0slot = (first - pl.off) / 16;                      // exact: the plan aligns the window start to a slot
+    a.ring_delta = (int32_t)(((w0slot % ls) + ls) % ls);
+  }
   const int phys_nb = nbt > pl.nb ? nbt : pl.nb;                     // zero-fragment blocks still read their (stale) slots
   const int slots_alloc = 15 * pl.R + 4 * phys_nb;
   const int phys = gen_slot_map(a, pl.R, slots_alloc);
@@ -672,7 +922,7 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   static const char *lds_pad_env = getenv("ACDSP_GEN_LDS_PAD");   // diagnostic: extra LDS bytes per wave (lowers the occupancy)
   const size_t lds_bytes = (size_t)a.obuf_off + 2048 + (lds_pad_env ? (size_t)atoi(lds_pad_env) : 0);
   const int64_t n_chunks = (a.n_steps + spw - 1) / spw;
-  const int64_t fast_chunks = (nbt && conv_ok && a.out_vec_ok) ? n_out / (spw * 256) : 0;   // chunks made of complete steps only
+  const int64_t fast_chunks = ((nbt || ring_shape) && conv_ok && a.out_vec_ok) ? n_out / (spw * 256) : 0;   // chunks made of complete steps only
   const v4i *fr = (const v4i *)d_frag;
   hipError_t e = hipSuccess;
   a.xcd_map = 0;
@@ -682,7 +932,10 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     // int32, 8 KB of input per step) +2.5 % every time, poly_dec -0.6 % twice and +6.6 % once, the fused DDC -3 %: on for the
     // int32 decimator shape only.  ACDSP_XCD_MAP=0 / 1 forces it off / on for every shape (A/B knob).
     a.xcd_map = (xcd_map_wanted(out_mode == 1 && in_eb == 4) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
-    if (in_eb == 4) { e = launch_fast<int32_t, 4, 2, 3, 9, 8>(grid, lds_bytes, s, p, fr, a); }
+    if (ring_shape == 1) { e = launch_ring<int32_t, 4, 2, 3, 8, 8>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
+    else if (ring_shape == 2) { e = launch_ring<int16_t, 2, 3, 6, 16, 8>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
+    else if (ring_shape == 3) { e = launch_ring<int16_t, 2, 2, 4, 8, 2>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
+    else if (in_eb == 4) { e = launch_fast<int32_t, 4, 2, 3, 9, 8>(grid, lds_bytes, s, p, fr, a); }
     else if (in_eb == 8) { e = launch_fast<int64_t, 5, 2, 3, 1, 4>(grid, lds_bytes, s, p, fr, a); }
     else if (oeb == 8) { e = launch_fast<int16_t, 2, 3, 6, 9, 8>(grid, lds_bytes, s, p, fr, a); }
     else { e = launch_fast<int16_t, 2, 2, 4, 5, 2>(grid, lds_bytes, s, p, fr, a); }
@@ -991,7 +1244,7 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   a.first = first; a.n_out = n_out; b.first = 0; b.n_out = n_out;
   a.n_steps = (n_out + 255) / 256;
   int64_t spw = 8;                           // short spans (see launch_fir_gen) against one (half-loaded) warm-up step per chunk: 4: 0.605, 6: 0.642 - 0.667, 8: 0.653 - 0.669 of the roofline (profiles/r3_span_sweep.txt, last block)
-  static const char *cspw_env = getenv("ACDSP_CASC_SPW");   // tuning knob: steps per wave of the fused cascade
+  ACDSP_TUNE_ENV(cspw_env, "ACDSP_CASC_SPW");   // tuning knob: steps per wave of the fused cascade
   if (cspw_env && atoi(cspw_env) > 0) { spw = atoi(cspw_env); }
   a.steps_per_wave = spw;
   a.n16 = (pa.n + 15) / 16 * 16;

@@ -31,6 +31,12 @@ def _alloc_out(fmt, n_ch, n, device):
     return torch.empty(shape, dtype=torch_dtype_for(fmt), device=device)
 
 
+def _alloc_out_host(fmt, n_ch, n):
+    """Host twin of _alloc_out: the C side writes n containers of acdsp_elem_bytes(W) bytes per row, 16 for formats wider than 64 bits."""
+    shape = (n_ch, n, 2) if is_wide(fmt) else (n_ch, n)
+    return np.empty(shape, dtype=_np_dtype_for(fmt))
+
+
 def _row_stride(t, fmt):
     """Row stride in containers; checks the inner layout."""
     if is_wide(fmt):
@@ -104,7 +110,7 @@ class Fir:
     def run_host(self, x):
         x = np.ascontiguousarray(np.atleast_2d(x), dtype=_np_dtype_for(self.fin))
         assert x.shape[0] == self.n_channels
-        y = np.empty(x.shape, dtype=_np_dtype_for(self.fout))
+        y = _alloc_out_host(self.fout, self.n_channels, x.shape[1])
         check(lib.acdsp_fir_run_host(self._h, x.ctypes.data_as(C.c_void_p), x.shape[1], y.ctypes.data_as(C.c_void_p)))
         return y
 
@@ -187,7 +193,7 @@ class Cic:
     def run_host(self, x):
         x = np.ascontiguousarray(np.atleast_2d(x), dtype=_np_dtype_for(self.fin))
         no = self.out_count(x.shape[1])
-        y = np.empty((self.n_channels, max(no, 1)), dtype=_np_dtype_for(self.fout))
+        y = _alloc_out_host(self.fout, self.n_channels, max(no, 1))
         n_out = C.c_int64()
         check(lib.acdsp_cic_run_host(self._h, x.ctypes.data_as(C.c_void_p), x.shape[1], y.ctypes.data_as(C.c_void_p),
                                      y.shape[1], C.byref(n_out)))
