@@ -93,6 +93,8 @@ SYMBOLS = {
     "acdsp_copy_d2h": (_i32, [_i32, _vp, _vp, C.c_uint64]),
     "acdsp_sync": (_i32, [_i32, _vp]),
     "acdsp_fill_stimulus": (_i32, [_i32, _vp, _i32, _i64, _i64, _i64, C.c_uint64, _i32, C.c_uint64, C.c_uint64, _vp]),
+    "acdsp_diag_copy_ms": (_i32, [_i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
+    "acdsp_diag_fir_envelope_ms": (_i32, [_i32, C.POINTER(_i64), _i32, _i32, _i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_fir_create": (_i32, [C.POINTER(FirDesc), C.POINTER(_vp)]),
     "acdsp_fir_destroy": (_i32, [_vp]),
     "acdsp_fir_clone": (_i32, [_vp, C.POINTER(_vp)]),

@@ -1,0 +1,95 @@
+// diag.hip -- measurement kernels behind acdsp_diag_* (include/acdsp.h): what bench.py prints beside the roofline of the FIR rows.
+// They are NOT part of the filter path and compute nothing a caller could use; they exist so that the two reference speeds of
+// SURVEY 8(d) / DESIGN 5.2 are timed in the SAME process, on the same buffers and at the same settled clocks as the product kernel:
+//
+//   * copy      -- the plainest device copy there is: one 16-byte element per thread, 256-thread workgroups dispatched in memory
+//                  order ("measured device-copy bandwidth", the guide's float4 copy: ~6.3 TB/s).
+//   * envelope  -- the power / issue envelope of the exact int8-split formulation of a FIR row: stream 2 B in + 2 B out per sample in
+//                  the best streaming geometry (4-wave workgroups, 32 KB spans in memory order, bursts of 8 non-temporal loads then
+//                  8 non-temporal stores) and issue NM v_mfma_i32_32x32x32_i8 per 1024 samples, NH of them on high-byte-plane
+//                  fragments -- with NOTHING else in the loop: no byte-plane split, no LDS, no epilogue.  A operands: Toeplitz
+//                  fragments of the caller's coefficient set (low plane dense, high plane small); B operands: the loaded bytes.
+//                  Whatever the product kernel does beyond this costs extra, so envelope_ms <= kernel_ms is the expectation and
+//                  envelope_ms / kernel_ms says how much of the kernel's time the formulation itself accounts for
+//                  (round 3 ran this as a separate tool on a builder-chosen box: tools/fir_envelope.hip, profiles/r3_fir255_envelope.txt).
+#include "fir_kernels.hpp"
+
+namespace acdsp {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) diag_copy_kernel(const v4i *__restrict__ src, v4i *__restrict__ dst, int64_t n_vec) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_vec) { dst[i] = src[i]; }
+}
+
+hipError_t launch_diag_copy(const void *src, void *dst, int64_t bytes, hipStream_t s) {
+  const int64_t n_vec = bytes / 16;
+  if (n_vec <= 0) { return hipSuccess; }
+  hipLaunchKernelGGL(diag_copy_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, s, (const v4i *)src, (v4i *)dst, n_vec);
+  return hipGetLastError();
+}
+
+// MK = MFMAs per 1 KB wave-load (a 1024-sample step of int16 is two loads), HI of them on a high-plane fragment; U loads per burst.
+// The stored words come from the accumulators as the PREVIOUS load left them (one load of pipelining, as the product's epilogue runs
+// one step behind its MFMAs), so a store never waits for this load's MFMAs.
+template <int MK, int HI, int U>
+__global__ void __launch_bounds__(256, 2) diag_envelope_kernel(const v4i *__restrict__ frag, const v4i *__restrict__ x, v4i *__restrict__ y,
+                                                             int64_t n_vec, int64_t span_vec) {
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  v4i Al[4], Ah[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { Al[i] = frag[i * 64 + lane]; }
+#pragma unroll
+  for (int i = 0; i < 2; i++) { Ah[i] = frag[(4 + i) * 64 + lane]; }
+  v16i acc[4] = {{0}, {0}, {0}, {0}};
+  const int64_t s = wave * span_vec, e = s + span_vec < n_vec ? s + span_vec : n_vec;
+  for (int64_t i = s + lane; i + 64 * (U - 1) < e; i += 64 * U) {
+    v4i v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { v[u] = __builtin_nontemporal_load(x + i + 64 * u); }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      v4i o = v[u];
+      if (MK > 0) { o = (v4i){acc[0][u & 15], acc[1][(u + 1) & 15], acc[2][(u + 2) & 15], acc[3][(u + 3) & 15]}; }
+      asm volatile("" : "+v"(o));                 // the four words are read HERE (else the scheduler keeps whole copies of the accumulators)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MK; m++) {
+        const v4i a = m < HI ? Ah[m & 1] : Al[m & 3];
+        acc[m & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, v[u], acc[m & 3], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_nontemporal_store(o, y + i + 64 * u);
+    }
+  }
+}
+
+bool diag_envelope_compiled(int mfma, int mfma_hi) {
+  return (mfma == 0 && mfma_hi == 0) || (mfma == 26 && mfma_hi == 8) || (mfma == 36 && mfma_hi == 18) || (mfma == 76 && mfma_hi == 10) ||
+         (mfma == 132 && mfma_hi == 66);
+}
+
+// d_frag: six fragments [4 low-plane blocks][2 high-plane blocks] x 64 lanes x 16 bytes.  mfma / mfma_hi: per 1024 samples (even).
+hipError_t launch_diag_envelope(const uint32_t *d_frag, const void *x, void *y, int64_t bytes, int mfma, int mfma_hi, hipStream_t s) {
+  const int64_t n_vec = bytes / 16, span_vec = 32 * 64;            // 32 KB spans
+  const int64_t waves = (n_vec + span_vec - 1) / span_vec, nb = (waves + 3) / 4;
+  if (n_vec <= 0) { return hipSuccess; }
+  const v4i *f = (const v4i *)d_frag;
+#define ACDSP_ENV_CASE(NM, NH)                                                                                                   \
+  if (mfma == NM && mfma_hi == NH) {                                                                                             \
+    hipLaunchKernelGGL((diag_envelope_kernel<NM / 2, NH / 2, 8>), dim3((unsigned)nb), dim3(256), 0, s, f, (const v4i *)x, (v4i *)y, n_vec, span_vec); \
+    return hipGetLastError();                                                                                                    \
+  }
+  ACDSP_ENV_CASE(0, 0)      // the stream alone
+  ACDSP_ENV_CASE(26, 8)     // config 2: 255 taps, windowed-sinc set (18 low-plane + 8 high-plane products)
+  ACDSP_ENV_CASE(36, 18)    // config 2, dense set
+  ACDSP_ENV_CASE(76, 10)    // config 4: 1023 taps, five-block high band (66 + 10)
+  ACDSP_ENV_CASE(132, 66)   // config 4, dense set
+#undef ACDSP_ENV_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace acdsp

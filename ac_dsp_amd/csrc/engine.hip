@@ -310,6 +310,87 @@ extern "C" int32_t acdsp_fill_stimulus(int32_t device, void *d_ptr, int32_t eb, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// diagnostics (bench.py: roofline.copy_GBps, roofline.envelope_ms)
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <typename F>
+int time_launches(F launch, int warmup, int reps, hipStream_t s, float *ms_avg) {
+  if (!ms_avg || reps < 1 || warmup < 0) { return fail(ACDSP_EINVAL, "diag: bad repetition counts"); }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < warmup && e == hipSuccess; i++) { e = launch(); }
+  if (e == hipSuccess) { e = hipEventRecord(e0, s); }
+  for (int i = 0; i < reps && e == hipSuccess; i++) { e = launch(); }
+  if (e == hipSuccess) { e = hipEventRecord(e1, s); }
+  if (e == hipSuccess) { e = hipEventSynchronize(e1); }
+  float ms = 0;
+  if (e == hipSuccess) { e = hipEventElapsedTime(&ms, e0, e1); }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "diag launch failed: %s", hipGetErrorString(e)); }
+  *ms_avg = ms / reps;
+  return ACDSP_OK;
+}
+}  // namespace
+
+extern "C" int32_t acdsp_diag_copy_ms(int32_t device, const void *d_src, void *d_dst, uint64_t bytes, int32_t warmup, int32_t reps,
+                                      void *stream, float *ms_avg) {
+  if (!d_src || !d_dst || bytes < 16 || bytes % 16 || ((uintptr_t)d_src | (uintptr_t)d_dst) % 16) { return fail(ACDSP_EINVAL, "diag_copy: 16-byte aligned buffers of a multiple of 16 bytes"); }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  return time_launches([&] { return launch_diag_copy(d_src, d_dst, (int64_t)bytes, s); }, warmup, reps, s, ms_avg);
+}
+
+extern "C" int32_t acdsp_diag_fir_envelope_ms(int32_t device, const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, int32_t mfma_hi_per_step,
+                                              const void *d_x, void *d_y, uint64_t bytes, int32_t warmup, int32_t reps, void *stream, float *ms_avg) {
+  if (!d_x || !d_y || bytes < 16 || bytes % 16 || ((uintptr_t)d_x | (uintptr_t)d_y) % 16) { return fail(ACDSP_EINVAL, "diag_fir_envelope: 16-byte aligned buffers of a multiple of 16 bytes"); }
+  if (mfma_per_step < 0 || mfma_hi_per_step < 0 || mfma_hi_per_step > mfma_per_step || (mfma_per_step > 0 && (!coeffs || n_taps < 1 || n_taps > 1025))) {
+    return fail(ACDSP_EINVAL, "diag_fir_envelope: bad coefficient set or MFMA counts");
+  }
+  if (!diag_envelope_compiled(mfma_per_step, mfma_hi_per_step)) {
+    return fail(ACDSP_EUNSUPPORTED, "diag_fir_envelope: (%d, %d) MFMAs per step is not a compiled count", mfma_per_step, mfma_hi_per_step);
+  }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  // A operands with the statistics of the product's: Toeplitz fragments of the caller's set (fir_mfma_build_fragments: [2 planes][nb][64][4]
+  // dwords), four blocks of the low-byte plane spread over the taps and two non-zero blocks of the high-byte plane (the centre of the band)
+  std::vector<uint32_t> six((size_t)6 * 64 * 4, 0u);
+  if (mfma_per_step > 0) {
+    for (int i = 0; i < n_taps; i++) {
+      if (coeffs[i] < -32768 || coeffs[i] > 32767) { return fail(ACDSP_EINVAL, "diag_fir_envelope: coefficient %d is not a 16-bit word", i); }
+    }
+    FirMfmaPlan plan;
+    const int nb = fir_mfma_plan_blocks(n_taps);
+    std::vector<uint32_t> frag((size_t)2 * nb * 64 * 4);
+    if (!fir_mfma_build_fragments(coeffs, n_taps, &plan, frag.data()) || plan.nb != nb) { return fail(ACDSP_EUNSUPPORTED, "diag_fir_envelope: set not splittable into two signed bytes"); }
+    auto take = [&](int slot, int plane, int b) { memcpy(&six[(size_t)slot * 256], &frag[((size_t)plane * nb + b) * 256], 256 * sizeof(uint32_t)); };
+    const int lo_pick[4] = {nb / 8 + (nb > 8 ? 1 : 0), (3 * nb) / 8, nb / 2, (3 * nb) / 4};
+    for (int i = 0; i < 4; i++) { take(i, 1, lo_pick[i] < nb ? lo_pick[i] : nb - 1); }
+    int h0 = -1, h1 = -1;    // the two non-zero high-plane blocks nearest the centre
+    for (int d = 0; d < nb && h1 < 0; d++) {
+      const int cand[2] = {nb / 2 - d, nb / 2 + d + 1};
+      for (int k = 0; k < 2 && h1 < 0; k++) {
+        const int b = cand[k];
+        if (b >= 0 && b < nb && ((plan.hi_mask >> b) & 1)) { if (h0 < 0) { h0 = b; } else if (b != h0) { h1 = b; } }
+      }
+    }
+    if (h0 < 0) { h0 = nb / 2; }
+    if (h1 < 0) { h1 = h0; }
+    take(4, 0, h0); take(5, 0, h1);
+  }
+  uint32_t *d_frag = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_frag, six.size() * sizeof(uint32_t)));
+  hipError_t ce = hipMemcpy(d_frag, six.data(), six.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (ce != hipSuccess) { (void)hipFree(d_frag); return fail(ACDSP_EHIP, "diag_fir_envelope: upload failed: %s", hipGetErrorString(ce)); }
+  int out = time_launches([&] { return launch_diag_envelope(d_frag, d_x, d_y, (int64_t)bytes, mfma_per_step, mfma_hi_per_step, s); }, warmup, reps, s, ms_avg);
+  (void)hipFree(d_frag);
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------
 // FIR
 // ---------------------------------------------------------------------------------------------
 namespace {

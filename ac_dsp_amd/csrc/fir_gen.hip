@@ -124,6 +124,7 @@ struct GenArgs {
   int32_t obuf_off;           // byte offset of the 256-output tile in LDS (row-contiguous write-out)
   int32_t chunk0;             // first chunk (of steps_per_wave steps) this launch covers: blockIdx.x + chunk0
   int32_t xcd_map;            // fast kernels: XCD-affine chunk order (xcd_remap below); the host sets it only when grid.x * grid.y % 8 == 0
+  int32_t edge_chunk;         // cascade kernel, PART 2: the row's last complete chunk (block x = 1; block x = 0 is chunk 0)
   int32_t ring_delta;         // ring kernel: slots between the first window's start and its 128-byte line (< 8 / sizeof(TIN))
   // branch-free output conversion of the fast kernel (host-derived from out_mode / the formats):
   //   v = wrapS_{64-ka}(y << ls);  v = ((v + rnd) >> rs) << ls2;  v = clamp(v, lo, hi);  v = wrapS_{64-ko}(v)
@@ -871,7 +872,7 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   // spans at 5.2).  The former rule (>= 16384 waves, i.e. 0.5 - 4 MB spans on the BASELINE shapes) ran cic_dec 6 %, polydec 11 %
   // slower; 3 - 4 steps measured best on both, 1 - 2 and 8+ lose 2 - 4 % (profiles/r3_span_sweep.txt).
   int64_t spw = 4;
-  static const char *spw_env = getenv("ACDSP_GEN_SPW");   // tuning knob: steps (of 256 outputs) per wave
+  ACDSP_TUNE_ENV(spw_env, "ACDSP_GEN_SPW");   // tuning knob: steps (of 256 outputs) per wave
   if (spw_env && atoi(spw_env) > 0) { spw = atoi(spw_env); }
   a.steps_per_wave = spw;
   a.n16 = (p.n + 15) / 16 * 16;
@@ -919,7 +920,7 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   const int slots_alloc = 15 * pl.R + 4 * phys_nb;
   const int phys = gen_slot_map(a, pl.R, slots_alloc);
   a.obuf_off = a.px * (phys + 1) * 16;
-  static const char *lds_pad_env = getenv("ACDSP_GEN_LDS_PAD");   // diagnostic: extra LDS bytes per wave (lowers the occupancy)
+  ACDSP_TUNE_ENV(lds_pad_env, "ACDSP_GEN_LDS_PAD");   // diagnostic: extra LDS bytes per wave (lowers the occupancy)
   const size_t lds_bytes = (size_t)a.obuf_off + 2048 + (lds_pad_env ? (size_t)atoi(lds_pad_env) : 0);
   const int64_t n_chunks = (a.n_steps + spw - 1) / spw;
   const int64_t fast_chunks = ((nbt || ring_shape) && conv_ok && a.out_vec_ok) ? n_out / (spw * 256) : 0;   // chunks made of complete steps only
@@ -964,7 +965,11 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
 #ifndef ACDSP_CASC_BARRIER
 #define ACDSP_CASC_BARRIER 1
 #endif
-template <int PXA, int PCA, int NBA, int SPLA, int PXB, int PCB, int NBB, bool GUARD, bool LIMB>
+//   PART:  0 = every chunk of the grid; 1 = interior chunks only (every window inside the call's samples: uniform base + immediate
+//          addressing), 2 = the edge chunks only (a row's first chunk, which reaches into the history, and its last complete one when
+//          that window passes the end of the row) on a (2, n_ch) grid.  One kernel holding both forms kept the edge form's per-piece
+//          offsets alive across the interior loop: 2 VGPRs of scratch at 256 registers.
+template <int PXA, int PCA, int NBA, int SPLA, int PXB, int PCB, int NBB, bool GUARD, bool LIMB, int PART>
 __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams pb, const v4i *__restrict__ fragA,
                                                        const v4i *__restrict__ fragB, GenArgs a, GenArgs b) {
   typedef int16_t TIN;
@@ -973,6 +978,7 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   const int n_col = lane & 15, kg = lane >> 4;
   int bx, ch;
   xcd_remap(a.xcd_map, bx, ch);
+  if constexpr (PART == 2) { bx = blockIdx.x == 0 ? 0 : a.edge_chunk; ch = blockIdx.y; }
   const int R = a.pl.R;
   const int plane_bytes = a.obuf_off / PXA;
   unsigned char *ring = lds + a.obuf_off;
@@ -1012,6 +1018,8 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   // was measured: no gain over the general form -- the split loop body schedules worse.)
   const int64_t W_first = a.first + (s0 - 1) * 256 * R - a.pl.off, W_last = a.first + (s1 - 1) * 256 * R - a.pl.off;
   const bool interior = !GUARD && W_first >= 0 && W_last + 16 * a.n_slots <= a.n16;
+  if constexpr (PART == 1) { if (!interior) { return; } }
+  if constexpr (PART == 2) { if (interior) { return; } }
   const unsigned lane16 = 16u * (unsigned)lane;
   auto fetch = [&](int64_t st, auto fast_c) {
     const int64_t W0 = a.first + st * 256 * R - a.pl.off;
@@ -1190,7 +1198,7 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   };
   typedef std::integral_constant<bool, true> T;
   typedef std::integral_constant<bool, false> F;
-  if (interior) {
+  if (PART != 2 && (PART == 1 || interior)) {
     // The warm-up step exists for stage B's ring: B's first real step reads A's outputs m0 - 128 ... m0 - 1 only (plb.off = 128), i.e.
     // columns 8 .. 15 of the warm-up step, whose windows start at slot 8 R.  The 1 KB pieces entirely below that slot are not
     // loaded (zeros are staged instead): with six steps per chunk the warm-up re-read was +15.6 % of HBM fetches (PMC, round 3).
@@ -1246,6 +1254,7 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   int64_t spw = 8;                           // short spans (see launch_fir_gen) against one (half-loaded) warm-up step per chunk: 4: 0.605, 6: 0.642 - 0.667, 8: 0.653 - 0.669 of the roofline (profiles/r3_span_sweep.txt, last block)
   ACDSP_TUNE_ENV(cspw_env, "ACDSP_CASC_SPW");   // tuning knob: steps per wave of the fused cascade
   if (cspw_env && atoi(cspw_env) > 0) { spw = atoi(cspw_env); }
+  if (spw < 2) { spw = 2; }                  // (with one-step chunks chunk 1's warm-up window would still start in the history: the edge launch covers chunk 0 only)
   a.steps_per_wave = spw;
   a.n16 = (pa.n + 15) / 16 * 16;
   a.out_vec_ok = 1; a.chunk0 = 0;
@@ -1289,23 +1298,31 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
     }
   }
   hipError_t e;
-#define ACDSP_CASCADE_LAUNCH(GUARD_, LIMB_, GRID_)                                                                                   \
-  e = hipFuncSetAttribute((const void *)cascade_kernel<2, 3, 6, 9, 5, 2, 3, GUARD_, LIMB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+#define ACDSP_CASCADE_LAUNCH(GUARD_, LIMB_, PART_, GRID_)                                                                            \
+  e = hipFuncSetAttribute((const void *)cascade_kernel<2, 3, 6, 9, 5, 2, 3, GUARD_, LIMB_, PART_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                           (int)lds_bytes);                                                                                           \
   if (e != hipSuccess) { return e; }                                                                                                 \
-  hipLaunchKernelGGL((cascade_kernel<2, 3, 6, 9, 5, 2, 3, GUARD_, LIMB_>), GRID_, dim3(64), lds_bytes, s, pa, pb, fa, fb, a, b);      \
+  hipLaunchKernelGGL((cascade_kernel<2, 3, 6, 9, 5, 2, 3, GUARD_, LIMB_, PART_>), GRID_, dim3(64), lds_bytes, s, pa, pb, fa, fb, a, b); \
   if ((e = hipGetLastError()) != hipSuccess) { return e; }
-  a.xcd_map = 0;
+  a.xcd_map = 0; a.edge_chunk = 0;
   if (fast_chunks > 0) {
     const dim3 grid((unsigned)fast_chunks, (unsigned)pa.n_ch);
     a.xcd_map = (xcd_map_wanted(false) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;   // off by default here: -3 % on config 5 (profiles/r3_xcd_map.txt)
-    if (limb) { ACDSP_CASCADE_LAUNCH(false, true, grid) } else { ACDSP_CASCADE_LAUNCH(false, false, grid) }
+    {
+      if (limb) { ACDSP_CASCADE_LAUNCH(false, true, 1, grid) } else { ACDSP_CASCADE_LAUNCH(false, false, 1, grid) }
+      // the complete chunks whose windows leave the call's samples: chunk 0 (history) and possibly the last one (its window ends
+      // 16 n_slots - 256 R - off < 16 R samples behind the last output's input: every earlier chunk ends a whole chunk before that)
+      a.xcd_map = 0;
+      a.edge_chunk = (int32_t)(fast_chunks - 1);
+      const dim3 egrid(fast_chunks > 1 ? 2u : 1u, (unsigned)pa.n_ch);
+      if (limb) { ACDSP_CASCADE_LAUNCH(false, true, 2, egrid) } else { ACDSP_CASCADE_LAUNCH(false, false, 2, egrid) }
+    }
   }
   if (fast_chunks < n_chunks) {
     a.xcd_map = 0;
     a.chunk0 = (int32_t)fast_chunks;
     const dim3 grid((unsigned)(n_chunks - fast_chunks), (unsigned)pa.n_ch);
-    if (limb) { ACDSP_CASCADE_LAUNCH(true, true, grid) } else { ACDSP_CASCADE_LAUNCH(true, false, grid) }
+    if (limb) { ACDSP_CASCADE_LAUNCH(true, true, 0, grid) } else { ACDSP_CASCADE_LAUNCH(true, false, 0, grid) }
   }
 #undef ACDSP_CASCADE_LAUNCH
   return hipSuccess;

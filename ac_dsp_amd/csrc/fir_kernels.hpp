@@ -138,6 +138,12 @@ struct MvAvgParams {
 };
 hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s, int *path);   // *path: 0 exact order, 1 int64 sums, 2 streaming kernel
 
+// Measurement kernels of acdsp_diag_* (diag.hip): a plain 16-byte-per-thread copy, and the stream + issued-MFMA envelope of a FIR row.
+hipError_t launch_diag_copy(const void *src, void *dst, int64_t bytes, hipStream_t s);
+// d_frag: six Toeplitz fragments [4 low-plane blocks][2 high-plane blocks] x 64 lanes x 16 bytes; hipErrorInvalidValue: count not compiled
+bool diag_envelope_compiled(int mfma, int mfma_hi);
+hipError_t launch_diag_envelope(const uint32_t *d_frag, const void *x, void *y, int64_t bytes, int mfma, int mfma_hi, hipStream_t s);
+
 // Polyphase decimator, exact per-MAC order (polydec.hip); p.coeffs = STR_COEFF_TYPE array [ntaps*df], p.n = inputs used
 hipError_t launch_polydec_generic(const FirParams &p, int ntaps, int df, int64_t n_out, hipStream_t s);
 

@@ -441,7 +441,8 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   constexpr bool RINGED = EPI != 3;
   constexpr int RING = 128 + HB, ARR = RINGED ? staged_array_bytes(RING) : staged_array_bytes(NC);
   // two accumulator sets + all Toeplitz fragments leave room for GS = 2 only when some high-byte blocks are skipped
-  constexpr int GS = (HS == 0 && NB >= 8) ? 1 : 2, NG = (NB + GS - 1) / GS;
+  // (round 4: also NB = 7 dense and the wide-output class with at most two blocks skipped per side -- those spilled 1 - 9 VGPRs at GS = 2)
+  constexpr int GS = ((HS == 0 && NB >= 7) || (EPI == 3 && NB >= 9 && (HS == 0 || HS == 2 + 16 * 2))) ? 1 : 2, NG = (NB + GS - 1) / GS;
   const int lane = threadIdx.x & 63;
   const int n_col = lane & 31, h = lane >> 5;
   int ch = blockIdx.y;
@@ -759,13 +760,13 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   typedef integral_constant<int, 2> P2; typedef integral_constant<int, 3> P3;
   typedef integral_constant<bool, true> WithPrev; typedef integral_constant<bool, false> NoPrev;
 
-  // prologue: step s0 staged, step s0+1 in flight, first B group read
-  issue_loads_first(s0 * 1024);
-  stage(lds);
-  issue_loads_new((s0 + 1) * 1024);
-  read_group(0, 0, Bh[0], Bl[0]);
-
   auto go = [&](auto wide_c) {   // the loop exists once per epilogue shift class: no branch inside it
+    // prologue: step s0 staged, step s0+1 in flight, first B group read.  Inside the arm: hoisted above the branch on the shift class,
+    // the first B fragments were live across the OTHER arm's loop and spilled around it (4 VGPRs of scratch in eight instantiations).
+    issue_loads_first(s0 * 1024);
+    stage(lds);
+    issue_loads_new((s0 + 1) * 1024);
+    read_group(0, 0, Bh[0], Bl[0]);
     v16i hA, mA, lA, hB, mB, lB;
     run_step(wide_c, P0(), NoPrev(), 0, hA, mA, lA, hA, mA, lA);
     int s = 1;
@@ -1401,7 +1402,7 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   // 8-byte outputs (OUT = ACC rows: 2 KB read and 8 KB written per step): 8 steps per wave, 1.96 against 2.07 ms at 64 on the config-2
   // wide row (2 / 4 / 6 / 12 / 16 steps: 2.02 / 1.98 / 1.98 / 2.02 / 2.02; same box, two passes)
   if (epi == 3 && spw > 8) { spw = 8; }
-  static const char *spw_env = getenv("ACDSP_FIR_SPW");   // tuning knob: 1024-sample steps per wave
+  ACDSP_TUNE_ENV(spw_env, "ACDSP_FIR_SPW");   // tuning knob: 1024-sample steps per wave
   if (spw_env && atoi(spw_env) > 1) { spw = atoi(spw_env); }
   a.steps_per_wave = spw;
   const int oeb = p.out_eb;

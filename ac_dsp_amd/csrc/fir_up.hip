@@ -38,6 +38,14 @@
 
 #include "fir_kernels.hpp"
 
+// The 512 new samples of a step are read exactly once: non-temporal loads (-DACDSP_UP_LD_PLAIN: plain loads, the A/B reference).  The
+// 32 NB history samples in front of them were the previous step's tail and keep the plain policy.
+#ifdef ACDSP_UP_LD_PLAIN
+#define ACDSP_UP_LD(ptr) (*(ptr))
+#else
+#define ACDSP_UP_LD(ptr) __builtin_nontemporal_load(ptr)
+#endif
+
 namespace acdsp {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -85,7 +93,8 @@ struct UpArgs {
 template <typename TIN, int PX, int PCT, int NBT, int L, int OEB, int EPI>
 // (two waves per SIMD where the fragments + two prefetch sets + accumulators need more than 168 registers: spills inside the
 // step loop are VMEM operations that every store-counting wait would have to drain)
-__global__ void __launch_bounds__(64, (PX * NBT >= 4 ? 2 : 3)) fir_up_kernel(UpArgs a, const v4i *__restrict__ frag) {
+// (round 4: also three digit planes into 8-byte outputs at L = 16 with the CIC epilogue -- 7 VGPRs spilled at 168)
+__global__ void __launch_bounds__(64, ((PX * NBT >= 4 || (PCT == 3 && L == 16 && OEB == 8 && EPI == 2)) ? 2 : 3)) fir_up_kernel(UpArgs a, const v4i *__restrict__ frag) {
   constexpr int SPC = 32 / L;                                 // input samples per MFMA column
   constexpr int G = L / 2;                                    // MFMA groups (1024 outputs each) per step of 512 samples
   constexpr int HP = 32 * NBT;                                // history samples staged in front of a step
@@ -144,7 +153,7 @@ __global__ void __launch_bounds__(64, (PX * NBT >= 4 ? 2 : 3)) fir_up_kernel(UpA
     if (st > st1 - 1) { st = st1 - 1; }                       // past the chunk: the last step again (never consumed or idempotent)
     const TIN *src = xrow + 16 * (a.slot0 + 32 * st);
 #pragma unroll
-    for (int q = 0; q < (int)sizeof(TIN) / 2; q++) { pre[S][q] = ((const v4i *)src)[64 * q + lane]; }
+    for (int q = 0; q < (int)sizeof(TIN) / 2; q++) { pre[S][q] = ACDSP_UP_LD((const v4i *)src + 64 * q + lane); }
     preh[S] = ((const v4i *)(src - HP))[hl];
   };
   // byte plane pp of the SPL samples in one 16-byte register set -> SPL bytes at `dst`
@@ -466,7 +475,7 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
       if (!so) { a.e_mask = (uint64_t)(~uint32_t(0) >> (64 - wo)); }
     }
   }
-  static const char *spw_env = getenv("ACDSP_UP_SPW");   // tuning knob: 512-sample steps per wave
+  ACDSP_TUNE_ENV(spw_env, "ACDSP_UP_SPW");   // tuning knob: 512-sample steps per wave
   int64_t spw = 4;                            // short spans, dispatched in memory order (see launch_fir_gen); 1 step: the prologue dominates
   if (spw_env && atoi(spw_env) > 0) { spw = atoi(spw_env); }
   if (spw < 1) { spw = 1; }

@@ -473,7 +473,7 @@ static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
     // 8 KB per wave (one 8-load batch; 8: 0.361 ms, 16: 0.373, 32: 0.375 on the bench row, profiles/r3_span_sweep.txt)
     int64_t lpw = 8;
     while (lpw > 8 && (n_reds / lpw) * p.n_obj < 16384) { lpw /= 2; }
-    static const char *lpw_env = getenv("ACDSP_INTG_RPW");
+    ACDSP_TUNE_ENV(lpw_env, "ACDSP_INTG_RPW");
     if (lpw_env && atoi(lpw_env) > 0) { lpw = (atoi(lpw_env) + 7) / 8 * 8; }
     const int64_t waves_b = (n_reds + lpw - 1) / lpw;
     dim3 grid_b((unsigned)((waves_b + 3) / 4), (unsigned)p.n_obj);
@@ -486,7 +486,7 @@ static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
   // ~32 KB per wave (8 .. 32 KB measured alike, 64 KB 4 % slower), >= ~16 K waves when the problem allows it
   int64_t rpw = (32 + lpr - 1) / lpr;
   while (rpw > 1 && (n_reds / rpw) * p.n_obj < 16384) { rpw /= 2; }
-  static const char *rpw_env = getenv("ACDSP_INTG_RPW");   // tuning knob: reduces per wave
+  ACDSP_TUNE_ENV(rpw_env, "ACDSP_INTG_RPW");   // tuning knob: reduces per wave
   if (rpw_env && atoi(rpw_env) > 0) { rpw = atoi(rpw_env); }
   const int64_t waves = (n_reds + rpw - 1) / rpw;
   dim3 grid((unsigned)((waves + 3) / 4), (unsigned)p.n_obj);

@@ -341,7 +341,7 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   a.n_tiles = (int64_t)p.n_obj * p.n_frames * a.tpf;
   a.tiles_per_wave = 16;   // 16 KB spans (8 / 16 tiles alike, 32: -5 %, 64: -9 %: profiles/r3_span_sweep.txt)
   while (a.tiles_per_wave > 1 && a.n_tiles / a.tiles_per_wave < 16384) { a.tiles_per_wave /= 2; }
-  static const char *tpw_env = getenv("ACDSP_MVAVG_TPW");   // tuning knob: tiles per wave
+  ACDSP_TUNE_ENV(tpw_env, "ACDSP_MVAVG_TPW");   // tuning knob: tiles per wave
   if (tpw_env && atoi(tpw_env) > 0) { a.tiles_per_wave = atoi(tpw_env); }
   a.x = (const int16_t *)p.x; a.y = p.y;
   const int64_t waves = (a.n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;

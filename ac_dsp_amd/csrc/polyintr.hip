@@ -24,7 +24,7 @@ __device__ inline int64_t pi_mac(int64_t acc, i128 prod, int f_prod, const DFmt 
 }
 
 // sub-filter sum of phase j at local sample m (taps[i] = x[m - i])
-__device__ int64_t polyintr_acc(const PolyIntrParams &p, int ch, int64_t m, int j) {
+__device__ __forceinline__ int64_t polyintr_acc(const PolyIntrParams &p, int ch, int64_t m, int j) {
   const int N = p.n_taps;
   auto xs = [&](int64_t t) -> int64_t {
     if (t >= 0) { return load_raw(p.x, (int64_t)ch * p.in_stride + t, p.in_eb, p.in.S); }
@@ -63,7 +63,7 @@ __device__ int64_t polyintr_acc(const PolyIntrParams &p, int ch, int64_t m, int 
 // Lossless class (host-checked: signed IN, signed wrapping ACC with F_acc >= F_in + F_coeff and room for the fold): every
 // `acc +=` is exact, so the sub-filter sum is an integer dot product mod 2^64 wrapped once to ACC_TYPE.  The only
 // non-linear step left is the IN_TYPE negation of the most negative word, reproduced by a select.
-__device__ int64_t polyintr_acc_fast(const PolyIntrParams &p, int ch, int64_t m, int j) {
+__device__ __forceinline__ int64_t polyintr_acc_fast(const PolyIntrParams &p, int ch, int64_t m, int j) {
   const int N = p.n_taps;
   auto xs = [&](int64_t t) -> int64_t {
     if (t >= 0) { return load_raw(p.x, (int64_t)ch * p.in_stride + t, p.in_eb, 1); }

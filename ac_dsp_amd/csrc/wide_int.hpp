@@ -25,7 +25,14 @@ struct i256 {
 
   __host__ __device__ bool neg() const { return (w[3] >> 63) != 0; }
   __host__ __device__ bool zero() const { return (w[0] | w[1] | w[2] | w[3]) == 0; }
-  __host__ __device__ int bit(int k) const { return (k < 0 || k > 255) ? (k > 255 ? (int)neg() : 0) : (int)((w[k >> 6] >> (k & 63)) & 1); }
+  // (limb picked by selects, not by a run-time index: an indexed private array lives in scratch memory on the device)
+  __host__ __device__ int bit(int k) const {
+    if (k < 0) { return 0; }
+    if (k > 255) { return (int)neg(); }
+    const int q = k >> 6;
+    const uint64_t v = q == 0 ? w[0] : (q == 1 ? w[1] : (q == 2 ? w[2] : w[3]));
+    return (int)((v >> (k & 63)) & 1);
+  }
   // OR of bits [0, k)
   __host__ __device__ bool any_below(int k) const {
     if (k <= 0) { return false; }
@@ -50,6 +57,7 @@ struct i256 {
 __host__ __device__ inline i256 operator+(const i256 &a, const i256 &b) {
   i256 r;
   unsigned __int128 c = 0;
+#pragma unroll
   for (int i = 0; i < 4; i++) {
     c += (unsigned __int128)a.w[i] + b.w[i];
     r.w[i] = (uint64_t)c;
@@ -67,9 +75,11 @@ __host__ __device__ inline i256 operator-(const i256 &a, const i256 &b) { return
 // product modulo 2^256 (two's complement: the low 256 bits of the signed product)
 __host__ __device__ inline i256 operator*(const i256 &a, const i256 &b) {
   i256 r;
+#pragma unroll
   for (int i = 0; i < 4; i++) {
     unsigned __int128 c = 0;
-    for (int j = 0; i + j < 4; j++) {
+#pragma unroll
+    for (int j = 0; j < 4 - i; j++) {
       c += (unsigned __int128)a.w[i] * b.w[j] + r.w[i + j];
       r.w[i + j] = (uint64_t)c;
       c >>= 64;
@@ -77,15 +87,19 @@ __host__ __device__ inline i256 operator*(const i256 &a, const i256 &b) {
   }
   return r;
 }
+// limb a.w[k] for a run-time k by selects (k outside 0..3: `ext`); see bit()
+__host__ __device__ inline uint64_t limb_or(const i256 &a, int k, uint64_t ext) {
+  return k == 0 ? a.w[0] : (k == 1 ? a.w[1] : (k == 2 ? a.w[2] : (k == 3 ? a.w[3] : ext)));
+}
 __host__ __device__ inline i256 shl(const i256 &a, int s) {
   i256 r;
   if (s <= 0) { return s == 0 ? a : r; }
   if (s >= 256) { return r; }
   const int q = s >> 6, b = s & 63;
+#pragma unroll
   for (int i = 3; i >= 0; i--) {
-    uint64_t v = 0;
-    if (i - q >= 0) { v = a.w[i - q] << b; }
-    if (b && i - q - 1 >= 0) { v |= a.w[i - q - 1] >> (64 - b); }
+    uint64_t v = limb_or(a, i - q, 0) << b;
+    if (b) { v |= limb_or(a, i - q - 1, 0) >> (64 - b); }
     r.w[i] = v;
   }
   return r;
@@ -97,8 +111,9 @@ __host__ __device__ inline i256 sar(const i256 &a, int s) {
   i256 r;
   if (s >= 256) { for (int i = 0; i < 4; i++) { r.w[i] = ext; } return r; }
   const int q = s >> 6, b = s & 63;
+#pragma unroll
   for (int i = 0; i < 4; i++) {
-    const uint64_t lo = (i + q < 4) ? a.w[i + q] : ext, hi = (i + q + 1 < 4) ? a.w[i + q + 1] : ext;
+    const uint64_t lo = limb_or(a, i + q, ext), hi = limb_or(a, i + q + 1, ext);
     r.w[i] = b ? ((lo >> b) | (hi << (64 - b))) : lo;
   }
   return r;

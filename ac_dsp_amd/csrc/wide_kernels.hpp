@@ -15,8 +15,8 @@ inline WFmt make_wfmt(const acdsp_fmt_t &f) {
   WFmt d;
   d.W = f.W; d.F = f.W - f.I; d.S = f.S; d.Q = f.Q; d.O = f.O;
   if (f.S) {
-    d.lo = -(i128)((u128)1 << (f.W - 1));
     d.hi = (i128)(((u128)1 << (f.W - 1)) - 1);
+    d.lo = -d.hi - 1;                      // (not -(1 << (W-1)): negating the 128-bit minimum is signed overflow)
   } else {
     d.lo = 0;
     d.hi = (i128)(((u128)1 << f.W) - 1);   // unsigned W = 128 is rejected at create

@@ -71,6 +71,27 @@ def fill_stimulus(out, seed, bits, ch0=0, t0=0):
     return out
 
 
+def diag_copy_ms(src, dst, warmup=3, reps=10):
+    """Average ms of the plain 16-byte-per-thread device copy src -> dst (acdsp_diag_copy_ms): bench.py's roofline.copy_GBps."""
+    assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()
+    nbytes = min(src.numel() * src.element_size(), dst.numel() * dst.element_size()) // 16 * 16
+    ms = C.c_float()
+    check(lib.acdsp_diag_copy_ms(_dev_index(src.device), C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), nbytes, warmup, reps,
+                                 _stream_ptr(src), C.byref(ms)))
+    return ms.value, nbytes
+
+
+def diag_fir_envelope_ms(coeffs, mfma_per_step, mfma_hi_per_step, x, y, warmup=3, reps=10):
+    """Average ms of the stream + issued-MFMA envelope of a FIR row over x -> y (acdsp_diag_fir_envelope_ms): roofline.envelope_ms."""
+    assert x.is_cuda and y.is_cuda and x.is_contiguous() and y.is_contiguous()
+    nbytes = min(x.numel() * x.element_size(), y.numel() * y.element_size()) // 16 * 16
+    c = np.ascontiguousarray(coeffs if coeffs is not None else [0], dtype=np.int64)
+    ms = C.c_float()
+    check(lib.acdsp_diag_fir_envelope_ms(_dev_index(x.device), c.ctypes.data_as(C.POINTER(C.c_int64)), len(c), mfma_per_step, mfma_hi_per_step,
+                                         C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), nbytes, warmup, reps, _stream_ptr(x), C.byref(ms)))
+    return ms.value, nbytes
+
+
 class Fir:
     """n_channels independent reference FIR objects (ac_fir_{const,load,prog}_coeffs) behind one handle."""
 

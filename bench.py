@@ -345,6 +345,48 @@ def roofline_of(w, k_avg, k_min, ev_ms):
                           "frac": xb * w["samples_per_step"] / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
+def diag_of(w, k_avg, roof):
+    """Driver-timed reference speeds beside a FIR row's roofline, measured HERE -- same process, same input buffer, clocks settled by
+    the workload that just ran (acdsp_diag_* in include/acdsp.h, kernels in ac_dsp_amd/csrc/diag.hip):
+      copy_GBps         plain 16-byte-per-thread device copy of the workload's input block ("also report vs a measured
+                        device-copy bandwidth")
+      envelope_ms       2 B in + 2 B out per sample streamed in the best geometry the part offers while issuing the SAME number of
+                        int8 MFMAs per 1024 samples as the product kernel (same split between low- and high-byte-plane fragments of
+                        the same coefficient set) and nothing else: no byte-plane split, no LDS, no epilogue
+      frac_of_envelope  envelope_ms / kernel_ms_avg: 1.0 = the kernel runs at the envelope of its own exact formulation."""
+    import ac_dsp_amd as A
+    x = w["x"]
+    if not x.is_contiguous():
+        return
+    scratch = torch.empty_like(x)
+    cms, cbytes = A.diag_copy_ms(x, scratch, warmup=10, reps=20)
+    roof["copy_GBps"] = 2.0 * cbytes / (cms * 1e-3) / 1e9
+    roof["frac_of_copy"] = roof["achieved"] / roof["copy_GBps"]
+    if w["issued_macs_per_sample"] and w["coeffs"] is not None and w["x"].element_size() == 2:
+        issued = int(round(w["issued_macs_per_sample"] / 32.0))
+        hi = issued - 2 * eng_nb_plan(w["n_taps"])
+        try:
+            ems, ebytes = A.diag_fir_envelope_ms(w["coeffs"], issued, hi, x, scratch, warmup=20, reps=20)
+            sms, _ = A.diag_fir_envelope_ms(None, 0, 0, x, scratch, warmup=10, reps=20)
+            # the envelope moves 2 B + 2 B per sample whatever the product's output width: scale nothing, compare times per launch
+            roof["envelope_ms"] = ems
+            roof["envelope_stream_only_ms"] = sms
+            roof["envelope_mfma_per_1024_samples"] = {"issued": issued, "high_plane": hi}
+            roof["frac_of_envelope"] = ems / k_avg
+            roof["envelope_note"] = ("stream (2 B in + 2 B out per sample, 32 KB spans, 8-load / 8-store non-temporal bursts) + the product's MFMA count on "
+                                     "Toeplitz fragments of the same coefficient set, nothing else in the loop; timed in this process after the workload "
+                                     "(ac_dsp_amd/csrc/diag.hip)")
+        except A.AcdspError as e:
+            roof["envelope_error"] = str(e)
+    del scratch
+
+
+def eng_nb_plan(n_taps):
+    """K-blocks of the MFMA plan (fir_mfma_plan_blocks): even counts of 10 .. 32 blocks are padded to the next odd one."""
+    nb = (n_taps - 1 + 31) // 32 + 1
+    return nb + 1 if 10 <= nb <= 32 and nb % 2 == 0 else nb
+
+
 def mfma_roofline_of(w, k_avg):
     """Matrix-pipe utilisation from the MFMAs the kernel ISSUES (acdsp_fir_mfma_issued: all-zero high-byte Toeplitz blocks are
     skipped); the figure of the dense 4-plane formulation is kept beside it, labelled."""
@@ -447,6 +489,8 @@ def main():
                              "note": "untimed pre-conditioning in front of the W warm-up steps (same step, same data): the shader clock needs "
                                      "20-40 ms of load to settle from idle; --settle 0 measures the cold-start transient instead"},
         }
+        if world == 1:
+            diag_of(w, k_avg, out["roofline"])
         if cold is not None:
             out["cold_start"] = cold
         if w["macs_per_sample"]:
@@ -471,6 +515,11 @@ def main():
                     m2 = mfma_roofline_of(w2, ka2)
                     sec[name]["mfma_frac"] = m2["frac"]
                     sec[name]["mfma_per_1024_samples"] = m2["mfma_per_1024_samples"]
+                    if name in ("fir255_dense", "fir1023"):      # int16 in / int16 out rows: the envelope moves the same bytes
+                        diag_of(w2, ka2, r2)
+                        for k in ("copy_GBps", "envelope_ms", "envelope_stream_only_ms", "frac_of_envelope", "envelope_mfma_per_1024_samples", "envelope_error"):
+                            if k in r2:
+                                sec[name][k] = r2[k]
                 del w2
                 torch.cuda.empty_cache()
             out["secondary"] = sec
@@ -482,6 +531,8 @@ def main():
                     out["cpu_baseline_ref_headers"] = ref
         elif world == 1 and not args.no_cpu_baseline and args.workload == "cic_dec":
             out["cpu_baseline"] = cpu_baseline_cic(fin, fo, cpu_args[6])
+        if world == 1 and not args.no_cpu_baseline and args.workload == "fir255":
+            out["cfg1_cpu"] = cpu_cfg1()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -533,6 +584,46 @@ def cpu_baseline_ref_headers():
         return {"error": repr(e), "kind": "reference-headers-over-own-ac_types"}
 
 
+def cpu_cfg1():
+    """BASELINE configs[0] (the one CPU-only configuration) exactly as SURVEY 8(d) fixes it: ac_fir_const_coeffs, 63 taps <16,2,true>,
+    ACC = OUT <38,10>, ONE channel, 1024 samples of the reference testbench's two-tone stimulus.  Inputs, coefficients and expected
+    outputs come from tests/golden/ref_hdr/fir_cfg1_63.json (dumped from the reference's own header, tools/gen_golden/gen_cfg1.cpp);
+    the oracle port is checked bit for bit against them while it is timed (one core: one channel), and the prebuilt reference-header
+    binary runs the same configuration (`cref_bench 1 N cfg1`)."""
+    import subprocess
+    from oracle import OracleFir, Fmt as OFmt
+    out = {"config": "ac_fir_const_coeffs 63-tap ac_fixed<16,2,true>, ACC = OUT <38,10>, FOLD_ODD, 1 channel x 1024 samples, two-tone stimulus (BASELINE configs[0])"}
+    path = os.path.join(ROOT, "tests", "golden", "ref_hdr", "fir_cfg1_63.json")
+    try:
+        case = [c for c in json.load(open(path))["cases"] if c["ftype"] == "FOLD_ODD"][0]
+        f = [OFmt(a[0], a[1], bool(a[2]), a[3], a[4]) for a in (case["in"], case["coeff"], case["acc"], case["out"])]
+        x = np.array(case["x"], dtype=np.int64)[None, :]
+        c = np.array(case["coeffs"], dtype=np.int64)
+        want = np.array(case["y"], dtype=np.int64)
+        xt = np.tile(x, 64)                                     # the record 64 times over per call (ctypes call overhead out of the way)
+        reps, t0, ok = 0, time.perf_counter(), True
+        while time.perf_counter() - t0 < 2.0:
+            y = OracleFir(case["n_taps"], "FOLD_ODD", *f).run(c, xt)[0]
+            ok = ok and np.array_equal(y[:want.size], want)     # a fresh object's first 1024 outputs are the fixture's
+            reps += 1
+        dt = time.perf_counter() - t0
+        out["oracle_port"] = {"value": reps * xt.shape[1] / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                              "bit_exact_vs_reference_header_vectors": bool(ok),
+                              "sample": "%d calls of 64 x the 1024-sample record (fresh filter object each), %.1f s wall" % (reps, dt)}
+    except (OSError, KeyError, IndexError, ValueError) as e:
+        out["oracle_port"] = {"error": repr(e)}
+    exe = os.path.join(ROOT, "tests", "_bin", "cref_bench")
+    if os.path.isfile(exe):
+        try:
+            txt = subprocess.run([exe, "1", str(1 << 21), "cfg1"], capture_output=True, text=True, timeout=120).stdout
+            fl = [l for l in txt.splitlines() if l.startswith("CREF cfg1")][0].split()
+            out["ref_headers"] = {"value": float(fl[2]), "unit": "Msamples/s", "cores": 1, "kind": "reference-headers-over-own-ac_types",
+                                  "sample": "%s samples in run() calls of 1024, %s s inside run(); g++ -O2 -std=c++11" % (fl[4], fl[5])}
+        except (OSError, IndexError, ValueError, subprocess.SubprocessError) as e:
+            out["ref_headers"] = {"error": repr(e)}
+    return out
+
+
 def host_cores():
     """Cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
     try:
@@ -560,7 +651,7 @@ def pmc_traffic(tag):
     (profiles/r<round>_<tag>_rocprof.txt, newest round first): FETCH_SIZE (KB, x2 on gfx950 for 16-byte streaming reads, see
     MI355X_MICROARCH.md) + WRITE_SIZE (KB).  A static value from the profile of the same binary, NOT measured in this run
     (the PMC passes are separate rocprofv3 invocations); (None, None) when no summary has been committed."""
-    for rnd in ("r3", "r2", "r1"):
+    for rnd in ("r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", "%s_%s_rocprof.txt" % (rnd, tag))
         try:
             vals = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}

@@ -170,6 +170,19 @@ int32_t acdsp_sync(int32_t device, void *stream);
 int32_t acdsp_fill_stimulus(int32_t device, void *d_ptr, int32_t elem_bytes, int64_t n_ch, int64_t n, int64_t stride,
                             uint64_t seed, int32_t bits, uint64_t ch0, uint64_t t0, void *stream);
 
+/* ---- diagnostics: the two reference speeds bench.py prints beside a FIR row's roofline ("also report vs a measured
+ * device-copy bandwidth"; DESIGN 5.2: the envelope of the int8-split formulation).  Measurement kernels only -- nothing a filter
+ * caller needs; they run on the caller's buffers and stream, `warmup` untimed launches then `reps` launches between two events.
+ *   copy:      dst[i] = src[i], one 16-byte element per thread, 256-thread workgroups in memory order.  GB/s = 2 * bytes / ms.
+ *   envelope:  streams `bytes` from d_x to d_y (d_y receives meaningless words) in 32 KB spans with 8-load / 8-store non-temporal
+ *              bursts while issuing `mfma_per_step` v_mfma_i32_32x32x32_i8 per 1024 int16 samples, `mfma_hi_per_step` of them on
+ *              high-byte-plane Toeplitz fragments of `coeffs` (n_taps raw 16-bit words) -- no byte-plane split, no LDS, no
+ *              epilogue.  Compiled (per_step, hi): (0,0) (26,8) (36,18) (76,10) (132,66); anything else is ACDSP_EUNSUPPORTED. */
+int32_t acdsp_diag_copy_ms(int32_t device, const void *d_src, void *d_dst, uint64_t bytes, int32_t warmup, int32_t reps, void *stream,
+                           float *ms_avg);
+int32_t acdsp_diag_fir_envelope_ms(int32_t device, const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, int32_t mfma_hi_per_step,
+                                   const void *d_x, void *d_y, uint64_t bytes, int32_t warmup, int32_t reps, void *stream, float *ms_avg);
+
 /* ---- FIR ---- */
 int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out);
 int32_t acdsp_fir_destroy(acdsp_fir_t h);

@@ -91,3 +91,40 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle|#include\s*[<\"].*oracle|libacdsp_oracle", txt, flags=re.M):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+# Kernels allowed to carry a private segment, with the reason.  Everything else in libacdsp.so must have none: a spill inside a
+# streaming loop is a VMEM operation every counted wait has to drain, and round 3 shipped 39 kernels with scratch.
+SCRATCH_ALLOWED = {
+    # exact per-MAC poly_intr kernels (128-bit arithmetic, correctness path): 20 bytes RESERVED for the VGPR that holds spilled
+    # SGPRs -- the ISA of both kernels contains no scratch instruction (`.uses_flat_scratch, 0`; hipcc -S shows none)
+    "polyintr_kernel": 20,
+    "polyintr_save_kernel": 20,
+    # 255 taps, DENSE 16-bit set, OUT = ACC in int64 containers: 72 VGPRs of Toeplitz fragments + two 48-register accumulator sets +
+    # the 64-bit epilogue leave 9 registers too few at two waves per SIMD; the band-limited instantiations <9,3,34|35|50|51,1>
+    # (the bench's fir255_wide row among them) are clean
+    "fir_mfma_kernel<9, 3, 0, 1>": 40,
+}
+
+
+def test_no_kernel_uses_scratch():
+    """Parses the code-object notes of the shipped library (tools/codeobj_notes.py: pure Python, msgpack metadata of every
+    gfx950 code object) and fails on any kernel with a private segment or spilled VGPRs outside SCRATCH_ALLOWED."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import codeobj_notes as N
+    import ac_dsp_amd._lib as L
+    ks = N.kernels(L.LIB_PATH)
+    assert len(ks) >= 300, "expected the engine's kernels in %s, found %d" % (L.LIB_PATH, len(ks))
+    names = N.demangle([k["name"] for k in ks])
+    bad = []
+    for k, dn in zip(ks, names):
+        short = dn.replace("acdsp::", "")
+        if k["scratch"] > 0 or k["vgpr_spill"] > 0:
+            if SCRATCH_ALLOWED.get(short, -1) >= k["scratch"]:
+                continue
+            bad.append("%s: scratch %d B, %d VGPRs spilled" % (short, k["scratch"], k["vgpr_spill"]))
+    assert not bad, "kernels with scratch memory:\n  " + "\n  ".join(bad)
+    # the allow-list must not outlive its entries
+    present = {dn.replace("acdsp::", "") for k, dn in zip(ks, names) if k["scratch"] > 0}
+    assert set(SCRATCH_ALLOWED) <= present, "stale SCRATCH_ALLOWED entries: %s" % (set(SCRATCH_ALLOWED) - present)

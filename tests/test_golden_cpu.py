@@ -25,6 +25,9 @@ def test_fixture_inventory():
     for ft in ("SHIFT_REG", "ROTATE_SHIFT", "C_BUFF", "FOLD_EVEN", "FOLD_ODD", "TRANSPOSED"):
         for cls in ("const", "load", "prog"):
             assert any(n.startswith("%s_base_%s_255" % (cls, ft)) for n in names), (cls, ft)
+    # BASELINE configs[0] as SURVEY 8(d) fixes it: 63 taps <16,2,true>, ACC = OUT <38,10>, the testbench's two-tone stimulus, 1024 samples
+    cfg1 = [c for c in FIR if c["name"].startswith("const_cfg1_63_")]
+    assert len(cfg1) == 6 and all(c["n_taps"] == 63 and c["acc"][:3] == [38, 10, 1] and c["out"][:3] == [38, 10, 1] and len(c["x"]) == 1024 for c in cfg1)
     assert len(FIR) >= 100 and len(RS) >= 10 and len(CIC) >= 12 and len(PDEC) >= 5 and len(PINT) >= 8 and len(IDMP) >= 4
 
 

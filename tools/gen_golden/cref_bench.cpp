@@ -1,12 +1,17 @@
 // cref_bench.cpp -- "C-ref" CPU baseline: the REFERENCE's own header-only path
 // (/root/reference/include/ac_dsp, compiled where it lies) over this repo's ac_types subset, one filter object per
 // channel, channels split over the host threads.  Build container only; the numbers go into BASELINE.md.
-//   cref_bench [threads=nproc] [samples per channel=65536] [what: both | fir | cic]
+//   cref_bench [threads=nproc] [samples per channel=65536] [what: both | fir | cic | cfg1]
+// cfg1 = BASELINE configs[0] as SURVEY 8(d) fixes it: ac_fir_const_coeffs, 63 taps <16,2,true>, ACC = OUT <38,10>, FOLD_ODD (the ftype of
+// the reference's own testbench), ONE channel, the testbench's two-tone stimulus, `samples` samples in calls of 1024 ("CREF cfg1 ...")
 // Prebuilt by __graft_entry__.build() into tests/_bin/ (binary only: no reference source travels); bench.py runs `cref_bench T N fir`
 // on the GPU node's host cores and reports the "CREF fir <Msamples/s> <threads> <samples> <seconds>" line as
 // cpu_baseline_ref_headers (kind "reference-headers-over-own-ac_types").
+#include <ac_dsp/ac_fir_const_coeffs.h>
 #include <ac_dsp/ac_fir_load_coeffs.h>
 #include <ac_dsp/ac_cic_dec_full.h>
+
+#include <cmath>
 
 #include <chrono>
 #include <cstdio>
@@ -36,10 +41,54 @@ typedef ac_cic_dec_full<IN32, INT47, 8, 1, 5> Cic;
 struct FirJob { Fir fir; ac_channel<IN16> in, cch; ac_channel<OUT16> out; ac_channel<bool> ld; };
 struct CicJob { Cic cic; ac_channel<IN32> in; ac_channel<INT47> out; };
 
+typedef ac_fixed<38, 10, true> ACC38;
+typedef ac_fir_const_coeffs<IN16, ACC38, IN16, ACC38, 63, FOLD_ODD> FirCfg1;
+
+static int run_cfg1(int n) {
+  const double pi = 3.14159265358979323846, fc = 75.0 / 500.0, m = 31.0;
+  static IN16 c[63];
+  double h[63], sum = 0;
+  for (int i = 0; i < 63; i++) {
+    const double k = i - m, sinc = k == 0 ? 2 * fc : std::sin(2 * pi * fc * k) / (pi * k);
+    h[i] = sinc * (0.54 - 0.46 * std::cos(2 * pi * i / 62.0));
+    sum += h[i];
+  }
+  for (int i = 0; i < 63; i++) { c[i] = IN16::from_raw128((__int128)std::llround(h[i] / sum * 16384.0)); }
+  for (int i = 0; i < 31; i++) { c[62 - i] = c[i]; }
+  std::vector<IN16> x(1024);
+  {
+    IN16 probe;
+    const double tmax = probe.template set_val<AC_VAL_MAX>().to_double();
+    std::vector<double> tone(1024);
+    double amax = 0;
+    for (int i = 0; i < 1024; i++) { tone[i] = std::sin(2 * pi * 25 * i / 500.0) + std::sin(2 * pi * 150 * i / 500.0); amax = std::fabs(tone[i]) > amax ? std::fabs(tone[i]) : amax; }
+    for (int i = 0; i < 1024; i++) { x[i] = (tone[i] / amax) * tmax; }
+  }
+  FirCfg1 fir(c);
+  ac_channel<IN16> in;
+  ac_channel<ACC38> out;
+  long long sink = 0;
+  const int calls = (n + 1023) / 1024;
+  double dt = 0;
+  for (int k = 0; k < calls; k++) {
+    for (int i = 0; i < 1024; i++) { in.write(x[i]); }          // stimulus queued outside the timed region
+    const auto t0 = std::chrono::steady_clock::now();
+    fir.run(in, out);
+    dt += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    while (out.available(1)) { sink += gg::raw(out.read()); }
+  }
+  printf("C-ref ac_fir_const_coeffs 63 taps <16,2,true>, ACC = OUT <38,10>, FOLD_ODD, 1 channel, two-tone stimulus: %d calls x 1024 samples in %.3f s = %.3f Msamples/s\n",
+         calls, dt, (double)calls * 1024 / dt / 1e6);
+  printf("CREF cfg1 %.6f 1 %d %.3f\n", (double)calls * 1024 / dt / 1e6, calls * 1024, dt);
+  printf("(checksum %lld)\n", sink);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const int threads = argc > 1 ? atoi(argv[1]) : (int)std::thread::hardware_concurrency();
   const int n = argc > 2 ? atoi(argv[2]) : 65536;
   const std::string what = argc > 3 ? argv[3] : "both";
+  if (what == "cfg1") { return run_cfg1(n); }
   std::vector<long long> sink((size_t)threads, 0);
   if (what != "cic") {   // BASELINE configs[1]: ac_fir_load_coeffs, 255 taps, SHIFT_REG; stimulus generation is outside the timed region
     std::vector<FirJob> jobs((size_t)threads);
