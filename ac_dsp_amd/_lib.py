@@ -93,6 +93,22 @@ SYMBOLS = {
     "acdsp_copy_d2h": (_i32, [_i32, _vp, _vp, C.c_uint64]),
     "acdsp_sync": (_i32, [_i32, _vp]),
     "acdsp_fill_stimulus": (_i32, [_i32, _vp, _i32, _i64, _i64, _i64, C.c_uint64, _i32, C.c_uint64, C.c_uint64, _vp]),
+    "acdsp_node_shard": (_i32, [_i64, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "acdsp_node_n_shards": (_i32, [_vp]),
+    "acdsp_node_shard_info": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp)]),
+    "acdsp_node_last_ms": (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "acdsp_node_destroy": (_i32, [_vp]),
+    "acdsp_node_fir_create": (_i32, [C.POINTER(FirDesc), _i32, C.POINTER(_i32), C.POINTER(_vp)]),
+    "acdsp_node_fir_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
+    "acdsp_node_fir_run": (_i32, [_vp, C.POINTER(_vp), _i64, _i64, C.POINTER(_vp), _i64]),
+    "acdsp_node_fir_run_host": (_i32, [_vp, _vp, _i64, _vp]),
+    "acdsp_node_cic_create": (_i32, [C.POINTER(CicDesc), _i32, C.POINTER(_i32), C.POINTER(_vp)]),
+    "acdsp_node_cic_out_count": (_i64, [_vp, _i64]),
+    "acdsp_node_cic_run": (_i32, [_vp, C.POINTER(_vp), _i64, _i64, C.POINTER(_vp), _i64, C.POINTER(_i64)]),
+    "acdsp_node_ddc_create": (_i32, [C.POINTER(CicDesc), C.POINTER(FirDesc), _i32, C.POINTER(_i32), C.POINTER(_vp)]),
+    "acdsp_node_ddc_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
+    "acdsp_node_ddc_out_count": (_i64, [_vp, _i64]),
+    "acdsp_node_ddc_run": (_i32, [_vp, C.POINTER(_vp), _i64, _i64, C.POINTER(_vp), _i64, C.POINTER(_i64)]),
     "acdsp_diag_copy_ms": (_i32, [_i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_diag_fir_envelope_ms": (_i32, [_i32, C.POINTER(_i64), _i32, _i32, _i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_fir_create": (_i32, [C.POINTER(FirDesc), C.POINTER(_vp)]),

@@ -309,6 +309,10 @@ extern "C" int32_t acdsp_fill_stimulus(int32_t device, void *d_ptr, int32_t eb, 
   return ACDSP_OK;
 }
 
+namespace acdsp {
+int set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
+}  // namespace acdsp
+
 // ---------------------------------------------------------------------------------------------
 // diagnostics (bench.py: roofline.copy_GBps, roofline.envelope_ms)
 // ---------------------------------------------------------------------------------------------

@@ -138,6 +138,9 @@ struct MvAvgParams {
 };
 hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s, int *path);   // *path: 0 exact order, 1 int64 sums, 2 streaming kernel
 
+// Sets the calling thread's acdsp_last_error() message and returns `code` (engine.hip); for the layers above the engine (node.hip).
+int set_error(int code, const char *msg);
+
 // Measurement kernels of acdsp_diag_* (diag.hip): a plain 16-byte-per-thread copy, and the stream + issued-MFMA envelope of a FIR row.
 hipError_t launch_diag_copy(const void *src, void *dst, int64_t bytes, hipStream_t s);
 // d_frag: six Toeplitz fragments [4 low-plane blocks][2 high-plane blocks] x 64 lanes x 16 bytes; hipErrorInvalidValue: count not compiled

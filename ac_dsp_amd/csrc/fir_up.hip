@@ -38,12 +38,14 @@
 
 #include "fir_kernels.hpp"
 
-// The 512 new samples of a step are read exactly once: non-temporal loads (-DACDSP_UP_LD_PLAIN: plain loads, the A/B reference).  The
-// 32 NB history samples in front of them were the previous step's tail and keep the plain policy.
-#ifdef ACDSP_UP_LD_PLAIN
-#define ACDSP_UP_LD(ptr) (*(ptr))
-#else
+// Load policy of the 512 new samples of a step (read exactly once).  Round 4 A/B, same box, alternating processes, 4 pairs each
+// (profiles/r4_ab_up_nt.txt): non-temporal loads 3.55 against plain 3.47 ms on the ac_cic_intr_full row (+2.3 %), 0.947 against 0.948 ms
+// on the ac_poly_intr row -- the bare 1:16 stream's gain from that policy (tools/fill_probe.hip: 5.4 -> 6.1 TB/s) does not carry over
+// to a kernel whose time is its stores.  Plain loads; -DACDSP_UP_LD_NT builds the other form.
+#ifdef ACDSP_UP_LD_NT
 #define ACDSP_UP_LD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define ACDSP_UP_LD(ptr) (*(ptr))
 #endif
 
 namespace acdsp {

@@ -497,6 +497,167 @@ class MvAvg:
         self.close()
 
 
+def node_shard(n_total, n_shards, shard):
+    """Channel slice [lo, hi) of shard `shard` (acdsp_node_shard: contiguous, the first n_total % n_shards slices one longer)."""
+    lo, hi = C.c_int64(), C.c_int64()
+    check(lib.acdsp_node_shard(n_total, n_shards, shard, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+class _Node:
+    """Common part of the node-level handles (acdsp_node_*): one filter bank cut into contiguous channel slices, one per entry of
+    `devices` (a device may repeat: its shards are then concurrent streams of one GPU), one engine handle + stream + host thread each."""
+
+    def _finish_create(self, devices):
+        self.devices = list(devices)
+        self.n_shards = lib.acdsp_node_n_shards(self._h)
+        self.slices = []
+        for s in range(self.n_shards):
+            dev, lo, hi = C.c_int32(), C.c_int64(), C.c_int64()
+            check(lib.acdsp_node_shard_info(self._h, s, C.byref(dev), C.byref(lo), C.byref(hi), None, None))
+            assert dev.value == self.devices[s]
+            self.slices.append((lo.value, hi.value))
+
+    @staticmethod
+    def _dev_array(devices):
+        return (C.c_int32 * len(devices))(*devices)
+
+    def _ptrs(self, tensors, fmt):
+        assert len(tensors) == self.n_shards
+        for t, (lo, hi), d in zip(tensors, self.slices, self.devices):
+            assert t.is_cuda and _dev_index(t.device) == d and t.shape[0] == hi - lo and t.dtype == torch_dtype_for(fmt), (t.shape, t.device, lo, hi, d)
+        strides = {_row_stride(t, fmt) for t in tensors}
+        assert len(strides) == 1, "every shard's block must have the same row stride"
+        return (C.c_void_p * self.n_shards)(*[t.data_ptr() for t in tensors]), strides.pop()
+
+    def alloc(self, fmt, n, fill=None):
+        """One [slice channels][n] device block per shard, on that shard's device."""
+        out = []
+        for (lo, hi), d in zip(self.slices, self.devices):
+            t = _alloc_out(fmt, hi - lo, n, torch.device("cuda", d))
+            if fill is not None:
+                fill(t, lo)
+            out.append(t)
+        return out
+
+    def last_ms(self):
+        """(per-shard kernel ms of the last run(), their maximum): aggregate rate = channels x samples / max."""
+        per = (C.c_float * self.n_shards)()
+        mx = C.c_float()
+        check(lib.acdsp_node_last_ms(self._h, per, C.byref(mx)))
+        return list(per), mx.value
+
+    def shard_handle(self, s):
+        h = C.c_void_p()
+        check(lib.acdsp_node_shard_info(self._h, s, None, None, None, C.byref(h), None))
+        return h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.acdsp_node_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class NodeFir(_Node):
+    """A Fir bank sharded over `devices` (acdsp_node_fir_*): no collective, coefficients replicated (or sliced when per channel)."""
+
+    def __init__(self, n_taps, ftype, fin, fcoeff, facc, fout, n_channels, devices, kind="load", coeffs_per_channel=False):
+        self.fin, self.fout, self.n_taps, self.n_channels = fin, fout, n_taps, n_channels
+        self.coeffs_per_channel = bool(coeffs_per_channel)
+        d = FirDesc(KINDS[kind], FTYPES[ftype] if isinstance(ftype, str) else ftype, n_taps, n_channels, int(self.coeffs_per_channel),
+                    fin, fcoeff, facc, fout, 0, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_node_fir_create(C.byref(d), len(devices), self._dev_array(devices), C.byref(self._h)))
+        self._finish_create(devices)
+
+    def set_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert c.shape == ((self.n_channels, self.n_taps) if self.coeffs_per_channel else (self.n_taps,))
+        check(lib.acdsp_node_fir_set_coeffs(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def run(self, xs, outs=None):
+        """xs: one [slice channels][n] device tensor per shard (on that shard's device) -> list of output tensors."""
+        n = xs[0].shape[1]
+        assert all(x.shape[1] == n for x in xs)
+        if outs is None:
+            outs = self.alloc(self.fout, n)
+        pin, sin = self._ptrs(xs, self.fin)
+        pout, sout = self._ptrs(outs, self.fout)
+        check(lib.acdsp_node_fir_run(self._h, pin, sin, n, pout, sout))
+        return outs
+
+    def run_host(self, x):
+        x = np.ascontiguousarray(x, dtype=_np_dtype_for(self.fin))
+        assert x.shape[0] == self.n_channels
+        y = _alloc_out_host(self.fout, self.n_channels, x.shape[1])
+        check(lib.acdsp_node_fir_run_host(self._h, x.ctypes.data_as(C.c_void_p), x.shape[1], y.ctypes.data_as(C.c_void_p)))
+        return y
+
+
+class NodeCic(_Node):
+    """A Cic bank sharded over `devices` (acdsp_node_cic_*)."""
+
+    def __init__(self, interp, R, M, N, fin, fout, n_channels, devices):
+        self.fin, self.fout, self.n_channels = fin, fout, n_channels
+        d = CicDesc(int(bool(interp)), R, M, N, n_channels, fin, fout, 0, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_node_cic_create(C.byref(d), len(devices), self._dev_array(devices), C.byref(self._h)))
+        self._finish_create(devices)
+
+    def out_count(self, n_in):
+        return lib.acdsp_node_cic_out_count(self._h, n_in)
+
+    def run(self, xs, outs=None):
+        n_in = xs[0].shape[1]
+        no = self.out_count(n_in)
+        if outs is None:
+            per64 = max(1, 64 // lib.acdsp_elem_bytes(self.fout.W))
+            outs = self.alloc(self.fout, (max(no, 1) + per64 - 1) // per64 * per64)
+        pin, sin = self._ptrs(xs, self.fin)
+        pout, sout = self._ptrs(outs, self.fout)
+        n_out = C.c_int64()
+        check(lib.acdsp_node_cic_run(self._h, pin, sin, n_in, pout, sout, C.byref(n_out)))
+        return [o[:, :n_out.value] for o in outs]
+
+
+class NodeDdc(_Node):
+    """A Ddc bank sharded over `devices` (acdsp_node_ddc_*)."""
+
+    def __init__(self, R, M, N, fin, n_taps, ftype, fcoeff, facc, fout, n_channels, devices, kind="const"):
+        self.fin, self.fout, self.n_channels, self.n_taps = fin, fout, n_channels, n_taps
+        probe = CicDesc(0, R, M, N, n_channels, fin, fin, 0, 0)
+        it = Fmt()
+        check(lib.acdsp_cic_int_type(C.byref(probe), C.byref(it)))
+        self.int_type = Fmt(it.W, it.I, True)
+        cd = CicDesc(0, R, M, N, n_channels, fin, self.int_type, 0, 0)
+        fd = FirDesc(KINDS[kind], FTYPES[ftype] if isinstance(ftype, str) else ftype, n_taps, n_channels, 0, self.int_type, fcoeff, facc, fout, 0, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_node_ddc_create(C.byref(cd), C.byref(fd), len(devices), self._dev_array(devices), C.byref(self._h)))
+        self._finish_create(devices)
+
+    def set_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert c.shape == (self.n_taps,)
+        check(lib.acdsp_node_ddc_set_coeffs(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def out_count(self, n_in):
+        return lib.acdsp_node_ddc_out_count(self._h, n_in)
+
+    def run(self, xs, outs=None):
+        n_in = xs[0].shape[1]
+        no = self.out_count(n_in)
+        if outs is None:
+            outs = self.alloc(self.fout, (max(no, 1) + 7) // 8 * 8)
+        pin, sin = self._ptrs(xs, self.fin)
+        pout, sout = self._ptrs(outs, self.fout)
+        n_out = C.c_int64()
+        check(lib.acdsp_node_ddc_run(self._h, pin, sin, n_in, pout, sout, C.byref(n_out)))
+        return [o[:, :n_out.value] for o in outs]
+
+
 def save_stream(path, x, fmt):
     """[n_channels][n] raw words (numpy, any integer dtype) -> ACDSPRAW file (include/acdsp.h: acdsp_stream_hdr_t)."""
     a = np.ascontiguousarray(np.atleast_2d(x), dtype=_np_dtype_for(fmt))

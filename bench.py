@@ -278,6 +278,81 @@ def build_workload(workload, args, world, rank, local_rank):
             "ch_per_gpu": ch_per_gpu, "n_taps": n_taps, "fmts": (fin, fc, fa, fo), "seed": seed}
 
 
+def build_node_workload(workload, args, n_shards, one_gpu):
+    """--inproc: the same per-GPU workload as build_workload, but ONE process and ONE node-level handle (acdsp_node_*: a contiguous
+    channel slice, an engine handle, a stream and a host thread per device; no collective).  Weak scaling: channels per GPU fixed."""
+    import ac_dsp_amd as A
+    devices = [0] * n_shards if one_gpu else list(range(n_shards))
+    seed = 0xACD5
+
+    def fill(bits):
+        return lambda t, lo: A.fill_stimulus(t, seed, bits, ch0=lo)
+    if workload in ("fir255", "fir1023"):
+        n_taps = 1023 if workload == "fir1023" else 255
+        ch, n = args.channels or 1024, args.samples or (1 << 20)
+        fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14) if workload == "fir1023" else A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+        node = A.NodeFir(n_taps, "SHIFT_REG", fin, fc, fa, fo, ch * n_shards, devices, kind="prog" if workload == "fir1023" else "load")
+        node.set_coeffs(windowed_sinc_raw(n_taps, 0.05 if workload == "fir1023" else 0.1, fc.F))
+        xs, ys = node.alloc(fin, n, fill(16)), node.alloc(fo, n)
+        bps, name = 4.0, "ac_fir_%s_coeffs %d-tap ac_fixed<16,2> -> <16,2,RND,SAT>, %d ch x %d samples per GPU" % ("prog" if workload == "fir1023" else "load", n_taps, ch, n)
+    elif workload == "cic_dec":
+        ch, n = args.channels or 4096, args.samples or (1 << 22)
+        fin, fo = A.Fmt(32, 16), A.Fmt(47, 31)
+        node = A.NodeCic(False, 8, 1, 5, fin, fo, ch * n_shards, devices)
+        xs, ys = node.alloc(fin, n, fill(32)), node.alloc(fo, n // 8 + 8)
+        bps, name = 5.0, "ac_cic_dec_full N=5 R=8 M=1 ac_fixed<32,16> -> <47,31>, %d ch x %d samples per GPU" % (ch, n)
+    elif workload == "ddc":
+        ch, n = args.channels or 4096, args.samples or (1 << 20)
+        cin, fc, fa, fo = A.Fmt(16, 1), A.Fmt(16, 1), A.Fmt(60, 30), A.Fmt(24, 9, True, "RND", "SAT")
+        node = A.NodeDdc(16, 1, 5, cin, 127, "SHIFT_REG", fc, fa, fo, ch * n_shards, devices)
+        node.set_coeffs(windowed_sinc_raw(127, 0.2, fc.F))
+        xs, ys = node.alloc(cin, n, fill(16)), node.alloc(fo, n // 16 + 8)
+        bps, name = 2.25, "DDC: ac_cic_dec_full R=16 N=5 <16,1> -> 127-tap ac_fir_const_coeffs, %d real streams x %d samples per GPU" % (ch, n)
+    else:
+        raise SystemExit("bench.py --inproc: workloads fir255, fir1023, cic_dec, ddc")
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    return {"node": node, "step": lambda: node.run(xs, ys), "name": name, "samples_per_step": ch * n_shards * n, "samples_per_gpu": ch * n,
+            "bytes_per_sample": bps, "ch_per_gpu": ch, "n": n, "devices": devices}
+
+
+def run_inproc(args):
+    """`python bench.py --gpus N --inproc`: N shards of one node-level handle in this process.  A step = node.run() = every shard's
+    thread launches its slice and waits for it; K steps are timed on the host clock around the blocking calls (the barrier of the
+    process-per-GPU contract is the join inside run())."""
+    one_gpu = bool(os.environ.get("ACDSP_BENCH_ONE_GPU"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the HIP engine)")
+    if not one_gpu and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, torch.cuda.device_count()))
+    w = build_node_workload(args.workload, args, args.gpus, one_gpu)
+    step, node = w["step"], w["node"]
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < args.settle:
+        step()
+    for _ in range(args.warmup):
+        step()
+    per = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        per.append(node.last_ms())
+    dt = time.perf_counter() - t0
+    kmax = sum(m for _, m in per) / len(per)                      # mean over the steps of the slowest shard's kernel time
+    nbytes = w["bytes_per_sample"] * w["samples_per_gpu"]
+    out = {"metric": "Msamples/s", "value": w["samples_per_step"] * args.steps / dt / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "int16 / int32 / int64 (exact)", "data": "synthetic (on-device splitmix64 counter hash, seed 0xACD5)",
+           "config": {"workload": w["name"], "channels_per_gpu": w["ch_per_gpu"], "samples_per_step": w["n"], "devices": w["devices"],
+                      "parallelism": "channel-slice x%d, no collectives; ONE process, one acdsp_node_* handle (engine handle + stream + host thread per device)" % args.gpus},
+           "roofline": {"bound": "hbm", "achieved": nbytes / (kmax * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": nbytes / (kmax * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "basis": "per GPU: algorithmic bytes of one shard / the slowest shard's kernel time (engine handles' HIP events), mean over the steps",
+                        "kernel_ms_per_shard_last_step": per[-1][0]},
+           "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+
+
 def settle_clocks(step, seconds):
     """Untimed pre-conditioning, reported in the JSON line as `clock_settle`: the same step in a loop for `seconds` of wall
     time BEFORE the W warm-up steps.  The part idles at ~100 MHz and its power management needs 20 - 40 ms of this load to
@@ -416,8 +491,12 @@ def main():
     ap.add_argument("--stim-bits", type=int, default=0, help="diagnostic: amplitude of the FIR stimulus in bits (default: full 16)")
     ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed pre-conditioning steps in front of the warm-up "
                     "(shader-clock ramp from idle; 0 = cold start, the K timed steps then include the DVFS transient)")
+    ap.add_argument("--inproc", action="store_true", help="one process, one node-level handle (acdsp_node_*) with --gpus shards, instead "
+                    "of one process per GPU")
     args = ap.parse_args()
 
+    if args.inproc:
+        return run_inproc(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -312,6 +312,55 @@ private:
   int n_taps_;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Node level: one FIR bank sharded over the GPUs of a node (acdsp_node_fir_*).  Contiguous channel slices, one engine
+// handle + stream + host thread per device, coefficients replicated, no collective.  BASELINE config 4's 8192 channels on 8 GPUs:
+//     acdsp::node_fir_engine<IN, OUT, COEFF, ACC> bank(ACDSP_FIR_PROG, ACDSP_SHIFT_REG, 1023, 8192, 8);
+//     bank.set_coeffs(c);  bank.run_device(d_in, stride, n, d_out, stride);   // d_in[s] / d_out[s]: shard s's block on device s
+// ---------------------------------------------------------------------------------------------
+template <class IN_TYPE, class OUT_TYPE, class COEFF_TYPE, class ACC_TYPE>
+class node_fir_engine {
+public:
+  // devices == 0: devices 0 .. n_devices-1; an entry may repeat (concurrent streams of one GPU)
+  node_fir_engine(int kind, int ftype, int n_taps, int n_channels, int n_devices, const int32_t *devices = 0, bool coeffs_per_channel = false)
+      : h_(0), n_taps_(n_taps), n_ch_(n_channels), per_ch_(coeffs_per_channel) {
+    acdsp_fir_desc_t d;
+    d.kind = kind; d.ftype = ftype; d.n_taps = n_taps; d.n_channels = n_channels; d.coeffs_per_channel = per_ch_ ? 1 : 0;
+    d.in = fmt_of<IN_TYPE>(); d.coeff = fmt_of<COEFF_TYPE>(); d.acc = fmt_of<ACC_TYPE>(); d.out = fmt_of<OUT_TYPE>();
+    d.device = 0; d.flags = 0;
+    check(acdsp_node_fir_create(&d, n_devices, devices, &h_), "acdsp_node_fir_create");
+  }
+  ~node_fir_engine() { if (h_) { acdsp_node_destroy(h_); } }
+  int n_shards() const { return acdsp_node_n_shards(h_); }
+  // channel slice [lo, hi) and device of shard s; `engine` = its ordinary acdsp_fir_t (state get / set, reset, kernel_stats ...)
+  void shard(int s, int32_t *device, int64_t *lo, int64_t *hi, acdsp_fir_t *engine = 0) {
+    void *e = 0;
+    check(acdsp_node_shard_info(h_, s, device, lo, hi, &e, 0), "acdsp_node_shard_info");
+    if (engine) { *engine = (acdsp_fir_t)e; }
+  }
+  void set_coeffs(const COEFF_TYPE *c) {
+    std::vector<int64_t> r((size_t)n_taps_ * (per_ch_ ? n_ch_ : 1));
+    for (size_t i = 0; i < r.size(); i++) { r[i] = raw_of(c[i]); }
+    check(acdsp_node_fir_set_coeffs(h_, r.data()), "acdsp_node_fir_set_coeffs");
+  }
+  // d_in[s] / d_out[s]: device pointers on shard s's device to its [hi - lo][stride] block; returns when every shard has finished
+  void run_device(const void *const *d_in, int64_t in_stride, int64_t n, void *const *d_out, int64_t out_stride) {
+    check(acdsp_node_fir_run(h_, d_in, in_stride, n, d_out, out_stride), "acdsp_node_fir_run");
+  }
+  // dense host block [n_channels][n]
+  void run_host(const void *h_in, int64_t n, void *h_out) { check(acdsp_node_fir_run_host(h_, h_in, n, h_out), "acdsp_node_fir_run_host"); }
+  // kernel time of the slowest shard in the last run (aggregate rate = n_channels * n / that)
+  float last_ms_max() { float m = 0; check(acdsp_node_last_ms(h_, 0, &m), "acdsp_node_last_ms"); return m; }
+  acdsp_node_t handle() { return h_; }
+
+private:
+  node_fir_engine(const node_fir_engine &);
+  node_fir_engine &operator=(const node_fir_engine &);
+  acdsp_node_t h_;
+  int n_taps_, n_ch_;
+  bool per_ch_;
+};
+
 }  // namespace acdsp
 
 #endif

@@ -322,6 +322,39 @@ int64_t acdsp_ddc_state_size(acdsp_ddc_t h);
 int32_t acdsp_ddc_state_get(acdsp_ddc_t h, void *h_buf, uint64_t cap_bytes);
 int32_t acdsp_ddc_state_set(acdsp_ddc_t h, const void *h_buf, uint64_t bytes);
 
+/* ---- node level: one filter bank sharded over the GPUs of a node ----
+ * Channels are independent filter objects (reference ac_fir_const_coeffs.h:124-127, ac_cic_full_core.h:71-74,219), so a bank of
+ * desc->n_channels filters is cut into n_devices CONTIGUOUS channel slices (acdsp_node_shard: the first n_channels % n_devices
+ * slices hold one channel more), one per entry of `devices` (NULL: devices 0 .. n_devices-1; a device may be listed more than once:
+ * its shards are then concurrent streams of that GPU).  Per shard the node handle owns an ordinary engine handle (`desc` with that
+ * slice's channel count and device), a non-blocking stream and a host thread bound to the device.  Coefficients are replicated
+ * (or, with coeffs_per_channel, sliced); there is NO collective and no cross-device traffic.
+ * run():      d_in[s] / d_out[s] = device pointers ON shard s's device to its [ch_hi - ch_lo][stride] block; every shard's thread
+ *             launches its slice on its stream and waits for it; the call returns when all have.  Aggregate rate of a call =
+ *             n_channels * n / acdsp_node_last_ms's maximum (per-shard times: the engine handles' own HIP events).
+ * run_host(): dense host block [n_channels][n]: every thread moves and filters its rows (acdsp_fir_run_host of the slice).
+ * The shard handles (acdsp_node_shard_info) take every per-handle call of this header: state get / set, reset, path, kernel_stats. */
+typedef struct acdsp_node *acdsp_node_t;
+int32_t acdsp_node_shard(int64_t n_total, int32_t n_shards, int32_t shard, int64_t *lo, int64_t *hi);
+int32_t acdsp_node_n_shards(acdsp_node_t h);   /* -1 on a null handle */
+int32_t acdsp_node_shard_info(acdsp_node_t h, int32_t shard, int32_t *device, int64_t *ch_lo, int64_t *ch_hi, void **handle, void **stream);
+int32_t acdsp_node_last_ms(acdsp_node_t h, float *per_shard_ms /* [n_shards] or NULL */, float *max_ms);
+int32_t acdsp_node_destroy(acdsp_node_t h);
+int32_t acdsp_node_fir_create(const acdsp_fir_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out);
+int32_t acdsp_node_fir_set_coeffs(acdsp_node_t h, const int64_t *coeffs);   /* [n_taps], or [n_channels][n_taps] with coeffs_per_channel */
+int32_t acdsp_node_fir_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_samples, void *const *d_out, int64_t out_stride);
+int32_t acdsp_node_fir_run_host(acdsp_node_t h, const void *h_in, int64_t n_samples, void *h_out);
+int32_t acdsp_node_cic_create(const acdsp_cic_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out);
+int64_t acdsp_node_cic_out_count(acdsp_node_t h, int64_t n_in);
+int32_t acdsp_node_cic_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_in, void *const *d_out, int64_t out_stride,
+                           int64_t *n_out);
+int32_t acdsp_node_ddc_create(const acdsp_cic_desc_t *cic, const acdsp_fir_desc_t *fir, int32_t n_devices, const int32_t *devices,
+                              acdsp_node_t *out);
+int32_t acdsp_node_ddc_set_coeffs(acdsp_node_t h, const int64_t *coeffs);
+int64_t acdsp_node_ddc_out_count(acdsp_node_t h, int64_t n_in);
+int32_t acdsp_node_ddc_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_in, void *const *d_out, int64_t out_stride,
+                           int64_t *n_out);
+
 /* ---- raw-integer stream files (host side; no device needed) ---- */
 int32_t acdsp_stream_write(const char *path, const acdsp_stream_hdr_t *hdr, const void *data);
 int32_t acdsp_stream_read_header(const char *path, acdsp_stream_hdr_t *hdr);

@@ -81,6 +81,26 @@ def test_argument_validation_happens_before_device_use():
     assert e.value.code == 2
 
 
+def test_node_shard_rule_and_no_device_errors():
+    """acdsp_node_shard needs no device: contiguous slices that cover the bank, sizes within one of each other, the same rule
+    bench.py's process-per-GPU mode uses; creating a node handle without a GPU fails loudly (no CPU path behind it either)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import ac_dsp_amd as A
+    import bench
+    for n_total, n in ((8192, 8), (1030, 8), (7, 2), (3, 3), (16384, 5)):
+        cuts = [A.node_shard(n_total, n, s) for s in range(n)]
+        assert cuts == [bench.shard(n_total, n, s) for s in range(n)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n_total and all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
+    with pytest.raises(A.AcdspError):
+        A.node_shard(10, 0, 0)
+    import torch
+    if not torch.cuda.is_available():
+        f = A.Fmt(16, 2)
+        with pytest.raises(A.AcdspError):
+            A.NodeFir(31, "SHIFT_REG", f, f, A.Fmt(40, 12), f, 64, [0, 0])
+
+
 def test_product_never_imports_the_oracle():
     bad = []
     for base in ("ac_dsp_amd", "include"):
