@@ -32,13 +32,8 @@
 
 #include "fir_kernels.hpp"
 
-// A/B knob (tools/ab_build.sh ... -DACDSP_GEN_NT): non-temporal policy on the streaming window loads
-#ifdef ACDSP_GEN_NT
-#define ACDSP_GEN_LD(ptr) __builtin_nontemporal_load(ptr)
-#else
-#define ACDSP_GEN_LD(ptr) (*(ptr))
-#endif
-
+// (The window-per-step kernels keep plain loads: their windows overlap and non-temporal loads bypass the L1 the re-reads need -- 13 - 25 %
+// slower, profiles/r3_fill_probe.txt.  The ring kernel reads every byte once and takes that policy: fir_gen_ring_kernel.)
 // Output tiles of the fast kernels leave with the non-temporal policy (-DACDSP_GEN_ST_PLAIN: plain stores, the A/B reference).  The
 // speed of these rows depends on where the driver placed the input / output pair (profiles/r3_placement_modes.txt); the policy
 // changes nothing on a fast pair and takes 2 - 4 % off a slow one (poly_dec, eight placements, two processes each).
@@ -421,7 +416,7 @@ __global__ void __launch_bounds__(64, ACDSP_GEN_FAST_WAVES) fir_gen_fast_kernel(
       for (int k = 0; k < NPC; k++) {
         const int64_t t = W0 + pc_off[k];
         const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
-        pre[k][0] = ACDSP_GEN_LD((const v4i *)src);
+        pre[k][0] = *(const v4i *)src;
       }
     } else {
 #pragma unroll
@@ -1028,14 +1023,14 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
 #pragma unroll
       for (int k = 0; k < NPCA; k++) {
         const unsigned off = k < NPCA - 2 ? lane16 + 1024u * k : 2u * (unsigned)pc_off[k];
-        pre[k] = ACDSP_GEN_LD((const v4i *)(base + off));
+        pre[k] = *(const v4i *)(base + off);
       }
     } else {
 #pragma unroll
       for (int k = 0; k < NPCA; k++) {
         const int64_t t = W0 + pc_off[k];
         const TIN *src = (t < 0) ? hrow + t : xrow + ((t < a.n16) ? t : 0);
-        pre[k] = ACDSP_GEN_LD((const v4i *)src);
+        pre[k] = *(const v4i *)src;
       }
     }
   };
@@ -1210,7 +1205,7 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
       for (int k = 0; k < NPCA; k++) {
         const unsigned off = k < NPCA - 2 ? lane16 + 1024u * k : 2u * (unsigned)pc_off[k];
         if (k < NPCA - 2 && k < kskip) { pre[k] = (v4i){0, 0, 0, 0}; }
-        else { pre[k] = ACDSP_GEN_LD((const v4i *)(base + off)); }
+        else { pre[k] = *(const v4i *)(base + off); }
       }
     }
     body(s0 - 1, T(), F(), T());

@@ -159,6 +159,34 @@ __device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16
   else { epi32_t<true>(hh, mid, ll, rs, o); }
 }
 
+// EPI 4 (round 4; the LDS-resident kernels only): int16 OUT containers when the 32-bit epilogue's bounds fail -- dense or
+// high-gain sets of 258+ taps, where 2^8 mid + ll leaves int32 or the sum may wrap the accumulator.  V = 2^16 hh + 2^8 mid + ll + C
+// in 64 bits, then the reference's two conversions branch-free: acc = wrap_ACC(V << lossless_shift); q = (acc + rnd) >> rs2 with
+// rs2 = F_acc - F_out >= 1; AC_SAT clamps, AC_WRAP keeps the low W_out bits (host-derived constants in Epi64).  ~35 VALU per output
+// instead of 3, still in the shadow of the 132 MFMAs of such a step; results leave through the same LDS tile and 16-byte stores as
+// EPI 1 / 2 (the generic class, EPI 0, converts with uniform branches and stores element by element: 4.6 - 6.1 ms on the dense rows
+// of profiles/r3_taps_sweep.txt).
+struct Epi64 { int64_t corr, rnd, lo, hi; int ls, ka, rs, ko; };
+__device__ __forceinline__ Epi64 make_epi64(const FirParams &p, int64_t corr) {
+  Epi64 e;
+  e.corr = corr; e.ls = p.lossless_shift; e.ka = 64 - p.acc.W; e.rs = p.acc.F - p.out.F;
+  e.rnd = (p.out.Q == ACDSP_RND && e.rs >= 1 && e.rs <= 62) ? (int64_t(1) << (e.rs - 1)) : 0;   // (EPI 4 guarantees the range; the other classes never read it)
+  if (p.out.O == ACDSP_SAT) { e.lo = p.out.lo; e.hi = p.out.hi; e.ko = 0; }
+  else { e.lo = INT64_MIN; e.hi = INT64_MAX; e.ko = 64 - p.out.W; }
+  return e;
+}
+__device__ __forceinline__ void epi64(const v16i &hh, const v16i &mid, const v16i &ll, const Epi64 &e, int (&o)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int64_t v = ((int64_t)hh[r] << 16) + ((int64_t)mid[r] << 8) + (int64_t)ll[r] + e.corr;
+    int64_t acc = (int64_t)((uint64_t)v << e.ls);
+    acc = (int64_t)((uint64_t)acc << e.ka) >> e.ka;                   // wrap to ACC_TYPE (signed)
+    int64_t q = (acc + e.rnd) >> e.rs;                                // W_acc <= 62: the rounding add cannot leave int64
+    q = q < e.lo ? e.lo : (q > e.hi ? e.hi : q);
+    o[r] = (int)((int64_t)((uint64_t)q << e.ko) >> e.ko);
+  }
+}
+
 // B-fragment read-ahead group size and target waves per SIMD of the register-resident kernel (tuning knobs:
 // (3, 2) measured 1.117 ms on config 2, (1, 3) 1.068 ms but spills on dense coefficient sets -> 2.2 ms).
 #ifndef ACDSP_GS
@@ -452,24 +480,14 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   unsigned char *obuf = lds + (RINGED ? 4 : 2 * 4) * ARR;
   unsigned char *dummy = obuf + (EPI == 3 ? 8192 : 2048);   // 1 KB sink for the surplus lanes of stage()
 
-  // ACDSP_FIR_DIRECT (A/B knob): the int16 classes take the Toeplitz rows in permuted order -- matrix row a + 4 h + 8 q computes output
-  // 16 h + 4 q + a of the block -- so that the 16 accumulator registers of lane (n, h) are the 16 CONSECUTIVE outputs 32 n + 16 h + r:
-  // 32 contiguous bytes per lane, stored straight from registers (no permlane swaps, no LDS tile).  The permutation is a lane
-  // permutation of the fragment load; fragments in memory and every other kernel are untouched.  MEASURED AND REJECTED
-  // (profiles/r3_ab_direct_nt.txt, same box): 0.907 -> 1.23 ms on config 2 -- each store instruction then writes every other 16-byte
-  // piece of a 2 KB run, and the write path wants whole contiguous KB per instruction far more than the kernel wants the four LDS
-  // instructions back.  Off; kept as the record of the experiment.
-#ifdef ACDSP_FIR_DIRECT
-  constexpr bool DIRECT = EPI != 3;
-#else
-  constexpr bool DIRECT = false;
-#endif
-  const int frag_lane = DIRECT ? (16 * ((lane >> 2) & 1) + 4 * ((lane & 31) >> 3) + (lane & 3) + (lane & 32)) : lane;
+  // (Round 3 also built a form whose Toeplitz rows were permuted so that a lane held 16 CONSECUTIVE outputs and stored 32 contiguous
+  // bytes straight from registers, no LDS tile: 0.907 -> 1.23 ms on config 2, profiles/r3_ab_direct_nt.txt -- each store instruction then
+  // writes every other 16-byte piece of a 2 KB run.  Rejected; the code was removed in round 4.)
   v4i Ah[NB], Al[NB];
 #pragma unroll
   for (int b = 0; b < NB; b++) {
-    Ah[b] = frag[((int64_t)set * 2 * NB + 0 * NB + b) * 64 + frag_lane];
-    Al[b] = frag[((int64_t)set * 2 * NB + 1 * NB + b) * 64 + frag_lane];
+    Ah[b] = frag[((int64_t)set * 2 * NB + 0 * NB + b) * 64 + lane];
+    Al[b] = frag[((int64_t)set * 2 * NB + 1 * NB + b) * 64 + lane];
   }
   const int16_t *xrow = (const int16_t *)p.x + (int64_t)ch * p.in_stride;
   const int16_t *hrow = (const int16_t *)p.hist + (int64_t)ch * p.hl + p.hl;
@@ -610,26 +628,6 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     }
     int o[16];
     epi32_t<decltype(wide_c)::value>(hh, mid, ll, rs, o);
-    if constexpr (DIRECT) {
-#pragma unroll
-      for (int pr = 0; pr < 2; pr++) {
-        if (prsel != 2 && prsel != pr) { continue; }
-        unsigned w[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int a = o[8 * pr + 2 * j], b = o[8 * pr + 2 * j + 1];
-          w[j] = EPI == 2 ? __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(a, b)) : __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x05040100u);
-        }
-        const v4i val = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-        v4i *dst = (v4i *)((char *)(yout + T0) + 64 * n_col + 32 * h + 16 * pr);
-#if ACDSP_FIR_NT & 2
-        __builtin_nontemporal_store(val, dst);
-#else
-        *dst = val;
-#endif
-      }
-      return;
-    }
     // A lane holds rows 8 g + 4 h .. + 3 of column n: 8 bytes per g, and the 16 lanes of a ds_write_b64 group share h, so
     // they can reach only half of the 32 banks (2-way conflict on every store: the 16.6 % SQ_LDS_BANK_CONFLICT of round 1).
     // v_permlane32_swap trades g-odd of the h = 0 lanes for g-even of the h = 1 lanes: every lane then owns 16 contiguous
@@ -657,7 +655,6 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   };
   // ... and its row-contiguous write-out: two coalesced 16-byte-per-lane stores
   auto flush = [&](int64_t T0) {
-    if constexpr (DIRECT) { return; }   // emit() stored from registers
     if constexpr (EPI == 3) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
@@ -985,7 +982,8 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
   const int rs = p.in.F + p.cf.F - p.out.F;
   const int64_t corr = a.corr[0];
   const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
-  const int c_ll = (EPI != 0) ? (int)corr_t : 0;
+  const int c_ll = (EPI == 1 || EPI == 2) ? (int)corr_t : 0;   // EPI 4 adds C in 64 bits: 128 sum(c) need not fit int32
+  const Epi64 e64 = make_epi64(p, corr);
   const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
   int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 32 * n_col + 4 * h;
 
@@ -1022,7 +1020,8 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
 
     // ---------------- phase O ----------------
     int o16[16];
-    if (EPI != 0) { epi32(hh, mid, ll, rs, o16); }
+    if (EPI == 4) { epi64(hh, mid, ll, e64, o16); }
+    else if (EPI != 0) { epi32(hh, mid, ll, rs, o16); }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const int64_t t0 = T0 + 32 * n_col + 8 * g + 4 * h;
@@ -1145,7 +1144,8 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   };
 
   const int rs = p.in.F + p.cf.F - p.out.F;
-  const int c_ll = (int)(a.corr[0] + ((p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0));
+  const int c_ll = EPI == 4 ? 0 : (int)(a.corr[0] + ((p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0));
+  const Epi64 e64 = make_epi64(p, a.corr[0]);
   const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
   int16_t *yout = (int16_t *)p.y + (int64_t)ch * p.out_stride;
   const unsigned char *fh = lds + (0 * 2 + h) * ARR + n_col * 16;
@@ -1203,7 +1203,8 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
 #pragma unroll
     for (int set = 0; set < 2; set++) {
       int o[16];
-      if (set == 0) { epi32(h0, m0, l0, rs, o); } else { epi32(h1, m1, l1, rs, o); }
+      if (EPI == 4) { if (set == 0) { epi64(h0, m0, l0, e64, o); } else { epi64(h1, m1, l1, e64, o); } }
+      else if (set == 0) { epi32(h0, m0, l0, rs, o); } else { epi32(h1, m1, l1, rs, o); }
 #pragma unroll
       // (the permlane32-swap / ds_write_b128 tile of fir_mfma_pipe_body was tried here: conflicts 2.5e7 -> 0 but +0.8 % time,
       // the phase is not in the shadow of MFMAs)
@@ -1290,7 +1291,7 @@ static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArg
   a.step0 = 0;
   // complete chunks of double steps on the double-wide kernel ...
   const int64_t spw2 = a.steps_per_wave >= 8 ? a.steps_per_wave / 2 : 4;
-  const int64_t fast_chunks = (epi == 1 || epi == 2) && a.out_vec_ok ? (p.n / 2048) / spw2 : 0;
+  const int64_t fast_chunks = (epi == 1 || epi == 2 || epi == 4) && a.out_vec_ok ? (p.n / 2048) / spw2 : 0;
   if (fast_chunks > 0) {
     MfmaArgs a2 = a;
     a2.steps_per_wave = spw2;
@@ -1299,6 +1300,9 @@ static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArg
     if (epi == 1) {
       e = hipFuncSetAttribute((const void *)fir_mfma_big2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big2_kernel<1>), g2, dim3(512), lds2, s, p, (const v4i *)d_frag, a2); }
+    } else if (epi == 4) {
+      e = hipFuncSetAttribute((const void *)fir_mfma_big2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big2_kernel<4>), g2, dim3(512), lds2, s, p, (const v4i *)d_frag, a2); }
     } else {
       e = hipFuncSetAttribute((const void *)fir_mfma_big2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big2_kernel<2>), g2, dim3(512), lds2, s, p, (const v4i *)d_frag, a2); }
@@ -1316,6 +1320,9 @@ static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArg
   } else if (epi == 2) {
     e = hipFuncSetAttribute((const void *)fir_mfma_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big_kernel<2>), grid, dim3(512), lds_bytes, s, p, (const v4i *)d_frag, a); }
+  } else if (epi == 4) {
+    e = hipFuncSetAttribute((const void *)fir_mfma_big_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big_kernel<4>), grid, dim3(512), lds_bytes, s, p, (const v4i *)d_frag, a); }
   } else {
     e = hipFuncSetAttribute((const void *)fir_mfma_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess) { hipLaunchKernelGGL((fir_mfma_big_kernel<0>), grid, dim3(512), lds_bytes, s, p, (const v4i *)d_frag, a); }
@@ -1343,6 +1350,14 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
       rs >= 1 && rs <= 31 && acc_wide && small && p.out.W == 16) {
     return p.out.O == ACDSP_SAT ? 2 : 1;
+  }
+  // EPI 4: int16 containers past the 32-bit bounds, on the LDS-resident kernels (more than kMaxRegNB K-blocks): exact 64-bit recombination,
+  // ACC_TYPE wrap included, branch-free (epi64).  ACDSP_NO_EPI4: the generic class instead (A/B knob).
+  static const bool no_epi4 = getenv("ACDSP_NO_EPI4") != nullptr;
+  if (!no_epi4 && plan.nb > kMaxRegNB && p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) &&
+      (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && p.acc.W >= 2 && p.acc.W <= 62 && p.lossless_shift >= 0 && p.lossless_shift <= 32 &&
+      p.acc.F - p.out.F >= 1 && p.acc.F - p.out.F <= 62 && p.out.W >= 2 && p.out.W <= 16) {
+    return 4;
   }
   // wide rows: 64-bit shift-and-wrap epilogue of the pipelined body (the low plane still carries C in 32 bits)
   if (p.out_eb == 8 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && p.out.O == ACDSP_WRAP && acc_wide &&

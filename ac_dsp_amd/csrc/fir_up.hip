@@ -186,21 +186,28 @@ __global__ void __launch_bounds__(64, ((PX * NBT >= 4 || (PCT == 3 && L == 16 &&
   // write-out of FU finished groups: FU x 8 KB (OEB 8) / FU x 2 KB (OEB 2) contiguous, 8 bytes per lane and instruction.
   // e_unit = output element (before out_off) of column 0, row 0 of the first group.
   auto flush = [&](int64_t e_unit) {
-    // (16 bytes per lane and store instruction, i.e. 1 KB instead of 512 B per instruction, was A/B-tested: -0.3 % / +0.3 % on the two
-    // bench rows, profiles/r3_ab_store_width.txt -- not kept)
+    // Store shape and policy by output container, same-box A/B (alternating processes; profiles/r4_ab_up_store.txt, r3_ab_store_width.txt):
+    //   2-byte outputs (ac_poly_intr row): 16 bytes per lane (1 KB per instruction), non-temporal -- 0.959 -> 0.911 ms against the
+    //   8-byte-per-lane form of round 3 (which had measured the same as 16 bytes under the round-3 plain-store policy);
+    //   8-byte outputs (ac_cic_intr_full row): 8 bytes per lane, plain -- 16 bytes per lane 3.64 against 3.63 ms, and the non-temporal
+    //   policy costs 13 % at either width (4.10 ms).
+    if constexpr (OEB == 2) {
 #pragma unroll
-    for (int k = 0; k < FU * 32 * RUN / 512; k++) {
-      const int lin = (k * 64 + lane) * 8;
-      const int cc = lin / RUN, w = lin % RUN;
-      const long val = *(const long *)(tile + cc * RUNP + w);
-#ifdef UP_ABLATE_STORES
-      if (a.n_steps < 0)
-#endif
-      // Store policy by output container, measured per shape on one box (alternating processes, 4 pairs each): 2-byte outputs
-      // (ac_poly_intr row) non-temporal 0.950 against plain 0.975 ms; 8-byte outputs (ac_cic_intr_full row) non-temporal 4.26
-      // against plain 3.63 ms -- round 2 saw the same signs under the long-span geometry.
-      if constexpr (OEB == 2) { __builtin_nontemporal_store(val, (long *)(yrow + e_unit * OEB + lin)); }
-      else { *(long *)(yrow + e_unit * OEB + lin) = val; }
+      for (int k = 0; k < FU * 32 * RUN / 1024; k++) {
+        const int lin = (k * 64 + lane) * 16;
+        const int cc = lin / RUN, w = lin % RUN;
+        v4i val;
+        __builtin_memcpy(&val, (const unsigned char *)__builtin_assume_aligned(tile + cc * RUNP + w, 8), 16);   // column pitch 72: 8-byte aligned
+        __builtin_nontemporal_store(val, (v4i *)(yrow + e_unit * OEB + lin));
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < FU * 32 * RUN / 512; k++) {
+        const int lin = (k * 64 + lane) * 8;
+        const int cc = lin / RUN, w = lin % RUN;
+        const long val = *(const long *)(tile + cc * RUNP + w);
+        *(long *)(yrow + e_unit * OEB + lin) = val;
+      }
     }
   };
   // One step.  VMEM program order: [wait for this step's samples] -> loads of the step AHEAD later -> the stores of this step.
@@ -211,9 +218,7 @@ __global__ void __launch_bounds__(64, ((PX * NBT >= 4 || (PCT == 3 && L == 16 &&
   auto body = [&](int64_t st, auto set_c, auto ahead_c) __attribute__((always_inline)) {
     // (single-wave workgroup: the LDS operations of a wave execute in order, no barrier needed)
     stage(set_c);
-#ifndef UP_TEST_NOFETCH
     fetch(st + decltype(ahead_c)::value, set_c);
-#endif
     const int64_t e_step = 16 * (a.slot0 + 32 * st) * (int64_t)L;   // output element (before out_off) of the step's first sample, phase 0
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -437,9 +442,11 @@ static hipError_t launch_up_oeb(const UpArgs &a, const uint32_t *d_frag, int out
 template <typename TIN, int PX, int PCT, int NBT>
 static hipError_t launch_up_l(const UpArgs &a, const uint32_t *d_frag, int L, int out_eb, int epi, dim3 grid, hipStream_t s) {
   switch (L) {
+#ifndef ACDSP_UP_ONLY_L8   // A/B builds compile the bench shapes only (the full set takes five minutes)
     case 4: return launch_up_oeb<TIN, PX, PCT, NBT, 4>(a, d_frag, out_eb, epi, grid, s);
-    case 8: return launch_up_oeb<TIN, PX, PCT, NBT, 8>(a, d_frag, out_eb, epi, grid, s);
     case 16: return launch_up_oeb<TIN, PX, PCT, NBT, 16>(a, d_frag, out_eb, epi, grid, s);
+#endif
+    case 8: return launch_up_oeb<TIN, PX, PCT, NBT, 8>(a, d_frag, out_eb, epi, grid, s);
     default: return hipErrorNotSupported;
   }
 }
@@ -452,9 +459,6 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
   UpArgs a;
   a.p = p; a.slot0 = slot0; a.n_steps = n_steps; a.out_off = out_off; a.mode = mode; a.w_int = w_int; a.out_simple = out_simple;
   a.sh_mask = sh_mask; a.corr = d_corr;
-#ifdef UP_TEST_ALIGNED
-  a.out_off = 0;   // timing experiment only (wrong placement)
-#endif
   a.e_rs = a.e_rnd = a.e_w = 0; a.e_lo = INT32_MIN; a.e_hi = INT32_MAX; a.e_mask = ~uint64_t(0);
   int epi = 0;
   const int rs = p.acc.F - p.out.F;

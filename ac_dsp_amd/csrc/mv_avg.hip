@@ -111,13 +111,7 @@ struct MvStreamArgs {
 
 typedef short v2s_t __attribute__((ext_vector_type(2)));
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-// A/B knob (-DACDSP_MV_NT): non-temporal policy on the tile loads
-#ifdef ACDSP_MV_NT
-#define ACDSP_MV_LD(ptr) __builtin_nontemporal_load(ptr)
-#else
-#define ACDSP_MV_LD(ptr) (*(ptr))
-#endif
-
+// (tile loads keep the plain policy: non-temporal +3 % in time, profiles/r2_copy_probe_ldsdma.txt / DESIGN 5.1)
 // 2-byte outputs (the bench row: one 16-byte store per lane) leave with the non-temporal policy; -DACDSP_MV_ST_PLAIN: plain (A/B)
 #ifdef ACDSP_MV_ST_PLAIN
 #define ACDSP_MV_ST(v, ptr) (*(ptr) = (v))
@@ -125,6 +119,9 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 #define ACDSP_MV_ST(v, ptr) __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(&(v)), reinterpret_cast<v4u_t *>(ptr))
 #endif
 
+#ifndef ACDSP_MV_AHEAD
+#define ACDSP_MV_AHEAD 2   // 4: -3 %, 8: -15 %, 16: -80 % on the bench row (profiles/r4_ab_up_store.txt, last block): more tiles in flight cost occupancy
+#endif
 template <int NR, bool LINEAR, bool CV32, bool EDGE>
 __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   constexpr int REGION = 512 + 8 * NR;          // samples of one wave's LDS image
@@ -154,7 +151,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     // every load is unconditional (addresses clamped into the frame; what the clamped lanes fetch is never used), so
     // the loop body has no load under a branch and the waits stay counted
     const int64_t gc = g < 0 ? 0 : (g < n ? g : n - 8);
-    { const v4u_t t_ = ACDSP_MV_LD(reinterpret_cast<const v4u_t *>(row + gc)); T.mv = make_uint4(t_.x, t_.y, t_.z, t_.w); }
+    { const v4u_t t_ = *reinterpret_cast<const v4u_t *>(row + gc); T.mv = make_uint4(t_.x, t_.y, t_.z, t_.w); }
     const int64_t g2 = f_ti * 512 - a.hb + 512 + 8 * (lane < a.nxg ? lane : 0);
     T.ev = *reinterpret_cast<const uint4 *>(row + (g2 < n ? g2 : n - 8));
     if constexpr (EDGE) {   // frame-edge patches of AC_CLIP / AC_MIRROR: the source samples of positions -1 - lane and n + lane
@@ -272,14 +269,20 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
       }
     }
   };
-  Tile A, B;
-  A.mv = A.ev = B.mv = B.ev = make_uint4(0, 0, 0, 0);
-  A.fxl = A.fxr = B.fxl = B.fxr = 0;
-  fetch(A);
-  fetch(B);
-  for (int it = 0; it < n_my; it += 2) {
-    process(A);
-    if (it + 1 < n_my) { process(B); }
+  // ACDSP_MV_AHEAD register sets: tiles in flight per wave (A/B knob; 2 = rounds 2 - 3)
+  Tile T[ACDSP_MV_AHEAD];
+#pragma unroll
+  for (int j = 0; j < ACDSP_MV_AHEAD; j++) {
+    T[j].mv = T[j].ev = make_uint4(0, 0, 0, 0);
+    T[j].fxl = T[j].fxr = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < ACDSP_MV_AHEAD; j++) { fetch(T[j]); }
+  for (int it = 0; it < n_my; it += ACDSP_MV_AHEAD) {
+#pragma unroll
+    for (int j = 0; j < ACDSP_MV_AHEAD; j++) {
+      if (j == 0 || it + j < n_my) { process(T[j]); }
+    }
   }
 }
 

@@ -423,6 +423,24 @@ def test_mfma_mid_tap_counts_register_resident_shapes(n_taps, fo):
     assert fir2.mfma_issued() > 2 * nb + 2 * 5
 
 
+@pytest.mark.parametrize("n_taps", [511, 767, 1023])
+@pytest.mark.parametrize("fo", [A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(16, 2, True, "TRN", "WRAP"), A.Fmt(12, 0, True, "RND", "WRAP")])
+@pytest.mark.parametrize("fa", [A.Fmt(44, 16), A.Fmt(38, 10)])
+def test_dense_sets_past_the_32_bit_epilogue_bounds(n_taps, fo, fa):
+    """DENSE random 16-bit sets of 511+ taps: 2^8 mid + ll no longer fits int32, and with ACC <38,10> the gain of 2^9 wraps the
+    accumulator (ac_fir_prog_coeffs.h:147-155: every `acc +=` wraps into ACC_TYPE; for the lossless class = one wrap of the exact
+    sum).  Round 3 sent these to the generic epilogue (4.6 - 6.1 ms on the bench shape); the 64-bit branch-free class (EPI 4) keeps
+    them on the matrix cores with the packed tile stores.  SAT / WRAP outputs, narrow OUT in a 16-bit container, split calls."""
+    fin, fc = A.Fmt(16, 2), A.Fmt(16, 2)
+    rng = np.random.default_rng(n_taps)
+    c = np.minimum(rand_raw(rng, fc, (n_taps,)), 32639)
+    fir = check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=9, n=2 * 8192 + 1500, coeffs=c, expect_path="mfma_i8", splits=[8192 + 8],
+                     seed=n_taps + 7)
+    nb = (n_taps - 1 + 31) // 32 + 1
+    nb += (nb % 2 == 0 and 10 <= nb <= 32)
+    assert fir.mfma_issued() == 4 * nb, (fir.mfma_issued(), nb)       # every block of both planes
+
+
 @pytest.mark.parametrize("n_taps", [300, 640, 1023])
 def test_per_channel_coefficients_beyond_257_taps(n_taps):
     """A coefficient set per channel needs the register-resident kernels; beyond 9 K-blocks those exist for band-limited sets
