@@ -20,14 +20,16 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(256) diag_copy_kernel(const v4i *__restrict__ src, v4i *__restrict__ dst, int64_t n_vec) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
   if (i < n_vec) { dst[i] = src[i]; }
 }
 
 hipError_t launch_diag_copy(const void *src, void *dst, int64_t bytes, hipStream_t s) {
   const int64_t n_vec = bytes / 16;
   if (n_vec <= 0) { return hipSuccess; }
-  hipLaunchKernelGGL(diag_copy_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, s, (const v4i *)src, (v4i *)dst, n_vec);
+  // a launch holds fewer than 2^32 threads per dimension (config 3's 68.7 GB block is 2^32 of them): rows of 2^20 workgroups
+  const int64_t blocks = (n_vec + 255) / 256, gx = blocks < (1 << 20) ? blocks : (1 << 20), gy = (blocks + gx - 1) / gx;
+  hipLaunchKernelGGL(diag_copy_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, (const v4i *)src, (v4i *)dst, n_vec);
   return hipGetLastError();
 }
 

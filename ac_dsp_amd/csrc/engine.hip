@@ -37,8 +37,14 @@ int fail(int code, const char *fmt, ...) {
 // their arguments (decimation / interpolation phase, "first call of the stream" special cases), so calls whose bookkeeping would
 // not return to the captured value are refused while capturing instead of replaying the wrong phase silently.
 static bool stream_is_capturing(hipStream_t s) {
+  // The legacy NULL stream cannot be captured, and asking about it while ANOTHER stream is in a global-mode capture returns an
+  // error that may invalidate that capture and stays behind as the thread's last error (the next launch's hipGetLastError would
+  // report it as a kernel failure): the host-buffer paths, which run on the NULL stream, never ask.
+  if (s == nullptr) { return false; }
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+  const hipError_t e = hipStreamIsCapturing(s, &st);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
 }
 
 #define HIP_TRY(expr)                                                                                  \
@@ -483,7 +489,10 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   h->wide = desc->acc.W > 64 || desc->out.W > 64;
   h->rt_eb = h->wide ? 16 : 8;
   h->hl = round_up(desc->n_taps + 15, 32);  // >= n_taps-1 for every kernel, >= n_taps+14 for the 16-aligned windows of fir_gen
-  if (h->hl < 32 * fir_mfma_plan_blocks(desc->n_taps)) { h->hl = 32 * fir_mfma_plan_blocks(desc->n_taps); }   // a padded plan reaches one K-block further back
+  // a plan of NB K-blocks reaches 32 (NB - 1) samples back; a padded plan (fir_mfma_plan_blocks: even counts of 10 .. 32 blocks) one block
+  // further than the tap count asks for.  Sized from the padded count whatever the ACDSP_NO_MID knob says, and from NB - 1, not NB:
+  // round 3 grew the history of UNpadded plans too (240 taps: 288 instead of 256) and let the knob change the state geometry.
+  if (h->hl < 32 * (fir_mfma_plan_blocks_padded(desc->n_taps) - 1)) { h->hl = 32 * (fir_mfma_plan_blocks_padded(desc->n_taps) - 1); }
   // reg_trans[] carries partial sums computed with the coefficients of their own time; only
   // the const-coefficient class may trade it for an input history.
   h->use_rt = desc->ftype == ACDSP_TRANSPOSED && desc->kind != ACDSP_FIR_CONST;
@@ -2248,12 +2257,27 @@ int32_t acdsp_fir_state_set(acdsp_fir_t h, const void *buf, uint64_t bytes) {
   StateHdr s;
   if (bytes < sizeof s) { return fail(ACDSP_EINVAL, "fir_state_set: blob shorter than its header"); }
   memcpy(&s, buf, sizeof s);
-  if (!state_compatible(s, mine) || bytes != sizeof s + state_payload(mine)) {
+  // An input-history blob (kind 1) of another history LENGTH is still this filter's state as long as it covers the taps: the handle's
+  // length is n_taps - 1 rounded up for the kernels' windows (and changed between builds: a padded MFMA plan reaches a block further
+  // back), the samples beyond n_taps - 1 only ever meet zero coefficients.  The newest min(blob, mine) samples are kept, older ones zero.
+  StateHdr same_len = s;
+  same_len.per_channel = mine.per_channel;
+  const bool relen = s.kind == 1 && mine.kind == 1 && s.per_channel != mine.per_channel && s.per_channel + 1 >= (uint64_t)h->d.n_taps &&
+                     s.per_channel <= (uint64_t(1) << 20) && state_compatible(same_len, mine) && bytes == sizeof s + state_payload(s);
+  if (!relen && (!state_compatible(s, mine) || bytes != sizeof s + state_payload(mine))) {
     return fail(ACDSP_EINVAL, "fir_state_set: blob does not belong to a filter of this class / tap count / channel count");
   }
   int rc = check_device(h->d.device);
   if (rc) { return rc; }
   HIP_TRY(hipDeviceSynchronize());
+  if (relen) {
+    const size_t eb = mine.elem_bytes, pm = (size_t)mine.per_channel, pb = (size_t)s.per_channel, keep = pm < pb ? pm : pb;
+    std::vector<unsigned char> img((size_t)mine.n_channels * pm * eb, 0);
+    const unsigned char *src = (const unsigned char *)buf + sizeof s;
+    for (size_t c = 0; c < mine.n_channels; c++) { memcpy(&img[(c * pm + (pm - keep)) * eb], src + (c * pb + (pb - keep)) * eb, keep * eb); }
+    HIP_TRY(hipMemcpy(h->d_hist[h->cur], img.data(), img.size(), hipMemcpyHostToDevice));
+    return ACDSP_OK;
+  }
   HIP_TRY(hipMemcpy(h->use_rt ? (void *)h->d_rt[h->cur] : h->d_hist[h->cur], (const char *)buf + sizeof s, state_payload(mine), hipMemcpyHostToDevice));
   return ACDSP_OK;
 }

@@ -607,7 +607,12 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   constexpr int KSTEP = (SPK + 2 * (SPK / R)) * 16;           // LDS bytes from a piece of load k to the same lane's piece of load k + 1
   constexpr int PADV = (ADV + 2 * (ADV / R)) * 16;            // LDS bytes a step advances
   constexpr int RING = (SPW < 2 ? SPW : 2) * ADV + H;         // chunks of one or two steps never wrap
-  constexpr int PLANE = (RING + 2 * (RING / R) + 2) * 16;     // + one dump slot (mirror writes of the lanes that have none)
+  // The two empty slots per R sit right in FRONT of ring slots H, H + R, ...: a staging store pass covers eight consecutive slots from
+  // H + 8 j on, and must not straddle a hole (with the holes at multiples of R, as in gen_slot_map, every pass of this layout did: 2-way
+  // conflicts on two of its eight slots, SQ_LDS_BANK_CONFLICT 31 % of SQ_LDS_IDX_ACTIVE in the first profile of this kernel).  The reads
+  // only need one hole per R slots, wherever it sits (tools/lds_slot_map_check.py, and the replay in profiles/r4_ring_sweep.txt).
+  constexpr int PH = (R - H % R) % R;
+  constexpr int PLANE = (RING + 2 * ((RING + PH) / R) + 2) * 16;   // + one dump slot (mirror writes of the lanes that have none)
   constexpr int DUMP = PLANE - 16;
   constexpr int TILE = 256 * OEB;
   __shared__ __attribute__((aligned(16))) unsigned char lds[PX * PLANE + (FB ? SPW : 1) * TILE];
@@ -616,7 +621,7 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   int bx, ch;
   xcd_remap(a.xcd_map, bx, ch);
   const int NB = a.pl.nb, PC = a.pl.pc;
-  auto phys = [](int s) { return s + 2 * (s / R); };
+  auto phys = [](int s) { return s + 2 * ((s + PH) / R); };
 
   v4i A[NBT][PCT];
 #pragma unroll
@@ -964,6 +969,8 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
 //          addressing), 2 = the edge chunks only (a row's first chunk, which reaches into the history, and its last complete one when
 //          that window passes the end of the row) on a (2, n_ch) grid.  One kernel holding both forms kept the edge form's per-piece
 //          offsets alive across the interior loop: 2 VGPRs of scratch at 256 registers.
+//   (Store bursts -- the tiles of 2 / 4 / 8 steps leaving as one contiguous burst -- were built and measured in round 4: no gain,
+//   profiles/r4_cascade_ablation.txt; removed.)
 template <int PXA, int PCA, int NBA, int SPLA, int PXB, int PCB, int NBB, bool GUARD, bool LIMB, int PART>
 __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams pb, const v4i *__restrict__ fragA,
                                                        const v4i *__restrict__ fragB, GenArgs a, GenArgs b) {
@@ -1023,6 +1030,9 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
 #pragma unroll
       for (int k = 0; k < NPCA; k++) {
         const unsigned off = k < NPCA - 2 ? lane16 + 1024u * k : 2u * (unsigned)pc_off[k];
+#ifdef ACDSP_CASC_ABL_LOAD   // timing-only ablation: one load per step instead of nine
+        if (k > 0) { pre[k] = pre[0]; continue; }
+#endif
         pre[k] = *(const v4i *)(base + off);
       }
     } else {
@@ -1051,6 +1061,9 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
 
   auto flush = [&](int64_t st) {   // 256 int32 outputs of a finished step: one 1 KB store
     const v4i val = *(const v4i *)(ob + ((lane ^ ((lane >> 3) & 3)) * 16));
+#ifdef ACDSP_CASC_ABL_STORE  // timing-only ablation: no output stores (except a never-true one that keeps the values alive)
+    if (a.n_out >= 0) { return; }
+#endif
     ACDSP_GEN_ST(val, (v4i *)(yrow + st * 1024 + 16 * lane));
   };
   // One step.  WARM: stage A only (fills the ring for the chunk's first stage-B step).  FLUSH: step st-1 waits in the tile.
@@ -1068,8 +1081,17 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
         stage_piece(pre[k], pc_ps[k]);
       }
     }
+#ifdef ACDSP_CASC_FLUSH_FIRST   // A/B: the round-2/3 order (store, then the next step's loads)
     if (FLUSH && !GUARD) { flush(st - 1); }
     fetch(st + 1 < s1 ? st + 1 : st, fast_c);
+#else
+    // The next step's loads first, THEN the store of the previous step's tile: VMEM operations of a wave retire in order (one vmcnt
+    // for loads and stores on gfx9), so the wait for these loads at the top of the next step no longer includes the store's write
+    // acknowledge -- with the stores compiled out the kernel runs 1.87 -> 1.60 ms although they are 1/9 of its traffic
+    // (profiles/r4_cascade_ablation.txt); the store now has two steps to retire.
+    fetch(st + 1 < s1 ? st + 1 : st, fast_c);
+    if (FLUSH && !GUARD) { flush(st - 1); }
+#endif
     // The next step's loads must leave before this step's arithmetic: left alone, the scheduler sinks them to the end of the
     // step and the wave eats the whole HBM latency at the top of the next one.  A compiler-level memory barrier pins them
     // between the staging writes above and the fragment reads below; ALU work stays free to move.
@@ -1087,7 +1109,12 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
 #pragma unroll
       for (int q = 0; q < PCA; q++) {
 #pragma unroll
-        for (int pp = 0; pp < PXA; pp++) { accA[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(AA[bb][q], X[pp], accA[pp + q], 0, 0, 0); }
+        for (int pp = 0; pp < PXA; pp++) {
+#ifdef ACDSP_CASC_ABL_A      // timing-only ablation: one K-block of stage A instead of six
+          if (bb > 0) { continue; }
+#endif
+          accA[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(AA[bb][q], X[pp], accA[pp + q], 0, 0, 0);
+        }
       }
     }
     // byte planes of the four words of this lane -> ring slot (st * 16 + n_col) & 31, bytes 4 kg .. 4 kg + 3
@@ -1145,7 +1172,12 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
 #pragma unroll
       for (int q = 0; q < PCB; q++) {
 #pragma unroll
-        for (int pp = 0; pp < PXB; pp++) { accB[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(AB[bb][q], X[pp], accB[pp + q], 0, 0, 0); }
+        for (int pp = 0; pp < PXB; pp++) {
+#ifdef ACDSP_CASC_ABL_B      // timing-only ablation: one K-block of stage B instead of three
+          if (bb > 0) { continue; }
+#endif
+          accB[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(AB[bb][q], X[pp], accB[pp + q], 0, 0, 0);
+        }
       }
     }
     int o[4];
@@ -1220,6 +1252,12 @@ __global__ void __launch_bounds__(64, 2) cascade_kernel(FirParams pa, FirParams 
   if (!GUARD) { flush(s1 - 1); }
 }
 
+// (Round 4 built and measured two other forms of this kernel for the interior chunks of the config-5 class, both REMOVED again -- the
+// record is profiles/r4_cascade_ablation.txt: (1) a workgroup of four waves sharing stage A's outputs through LDS, two steps per wave
+// with every load issued up front and one warm-up per workgroup: +4 % in time; (2) this kernel's step with the ring kernel's data
+// movement -- eight aligned non-temporal 1 KB loads per step, every byte once, the halo kept in registers -- and loads TWO steps ahead
+// (stage B's fragments in LDS to make room): +2 %.  Neither the access pattern nor the bytes in flight bound this kernel.)
+
 // pa: stage A (decimator) -- in / x / hist / hl / in_stride / n / n_ch as for launch_fir_gen with out_mode 1;
 // pb: stage B formats (in = the INT_TYPE, acc, out, lossless_shift) and the output buffer (y, out_stride, int32 containers).
 // Returns hipErrorNotSupported when the shapes are not the compiled ones (the caller then runs the two kernels).
@@ -1249,7 +1287,7 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   int64_t spw = 8;                           // short spans (see launch_fir_gen) against one (half-loaded) warm-up step per chunk: 4: 0.605, 6: 0.642 - 0.667, 8: 0.653 - 0.669 of the roofline (profiles/r3_span_sweep.txt, last block)
   ACDSP_TUNE_ENV(cspw_env, "ACDSP_CASC_SPW");   // tuning knob: steps per wave of the fused cascade
   if (cspw_env && atoi(cspw_env) > 0) { spw = atoi(cspw_env); }
-  if (spw < 2) { spw = 2; }                  // (with one-step chunks chunk 1's warm-up window would still start in the history: the edge launch covers chunk 0 only)
+  if (spw < 2) { spw = 2; }
   a.steps_per_wave = spw;
   a.n16 = (pa.n + 15) / 16 * 16;
   a.out_vec_ok = 1; a.chunk0 = 0;
@@ -1258,7 +1296,8 @@ hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint
   const int slots_alloc = 15 * pla.R + 4 * 6;
   const int phys = gen_slot_map(a, pla.R, slots_alloc);
   a.obuf_off = a.px * (phys + 1) * 16;
-  const size_t lds_bytes = (size_t)a.obuf_off + 5 * 512 + 1024;
+  ACDSP_TUNE_ENV(clp_env, "ACDSP_CASC_LDS_PAD");   // diagnostic: extra LDS bytes per wave (lowers the occupancy)
+  const size_t lds_bytes = (size_t)a.obuf_off + 5 * 512 + 1024 + (clp_env ? (size_t)atoi(clp_env) : 0);
   const int64_t n_chunks = (a.n_steps + spw - 1) / spw, fast_chunks = n_out / (spw * 256);
   const v4i *fa = (const v4i *)d_fragA, *fb = (const v4i *)d_fragB;
 

@@ -43,6 +43,7 @@ struct FirMfmaPlan {
 // Builds the per-lane A fragments (host side) into frag[2][nb][64][4] dwords; returns false if the
 // coefficient set cannot be split into two signed bytes per tap.
 bool fir_mfma_build_fragments(const int64_t *coeffs, int n_taps, FirMfmaPlan *plan, uint32_t *frag /* host */);
+int fir_mfma_plan_blocks_padded(int n_taps);   // the same with the padding applied regardless of the ACDSP_NO_MID knob (state geometry)
 int fir_mfma_plan_blocks(int n_taps);   // K-blocks of the plan (258 - 513 taps: padded to an odd count, fir_mfma.hip)
 int fir_mfma_max_blocks();       // K-blocks the MFMA path can take at all (A fragments in LDS): 33 -> 1025 taps
 int fir_mfma_max_reg_blocks();   // ... with the A fragments register-resident (needed for per-channel coefficient sets): 9

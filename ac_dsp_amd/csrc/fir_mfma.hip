@@ -70,6 +70,12 @@ int fir_mfma_max_reg_blocks() { return kMaxRegNB; }
 // instruction cancels).
 // K-blocks of the plan for n_taps: the Toeplitz band of 32 outputs spans n_taps + 31 inputs; 10 .. 32 blocks are padded to the next odd
 // count (the register-resident shapes of fir_mfma_mid.hip exist for odd counts; the extra leading block holds zeros).
+// ... and the count with the padding applied whatever the ACDSP_NO_MID knob says: the handle's state geometry (history length) must not
+// depend on an A/B environment variable
+int fir_mfma_plan_blocks_padded(int n_taps) {
+  const int nb = (n_taps - 1 + 31) / 32 + 1;
+  return (nb >= 10 && nb <= 32 && (nb & 1) == 0) ? nb + 1 : nb;
+}
 int fir_mfma_plan_blocks(int n_taps) {
   int nb = (n_taps - 1 + 31) / 32 + 1;
   static const bool no_mid = getenv("ACDSP_NO_MID") != nullptr;
@@ -870,6 +876,9 @@ static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const
 // workgroups on MI355X (1.215 vs 1.163 ms on config 2), because MFMA and VALU issue serialise per SIMD
 // whatever the pairing; kept selectable for the record.
 constexpr int kSmallWaves = 1;
+// engine.hip's small-call path (FirParams::hist_next) relies on the single-wave kernel writing the next history itself
+// (`if constexpr (WAVES == 1)` in fir_mfma_kernel): with the 8-wave form selected it would silently drop the state.
+static_assert(kSmallWaves == 1, "the fused history update of small host-side calls exists in the single-wave kernel only");
 
 // Band skip code (HS = lo + 16 hi) for the non-zero high-byte blocks: each side skips 2 or 3 blocks when the set allows it
 // (instantiated: both sides >= 2), else nothing is skipped.

@@ -203,8 +203,11 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
 int32_t acdsp_fir_run_host(acdsp_fir_t h, const void *h_in, int64_t n_samples, void *h_out);
 int32_t acdsp_fir_reset(acdsp_fir_t h);        /* back to the freshly constructed state (coefficients kept) */
 int32_t acdsp_fir_path(acdsp_fir_t h);         /* ACDSP_PATH_* chosen for the current coefficients */
-/* Duration of the main kernel of the most recent run(), from HIP events
- * recorded on the launch stream (blocks until that kernel has finished). */
+/* Duration of the main kernel of the most recent TIMED run(), from HIP events
+ * recorded on the launch stream (blocks until that kernel has finished).  Small host-side
+ * calls (run_host of at most 64 KB: the drop-in classes' one-channel path) are launch-bound
+ * and record no events: after such a call these two report the last timed run (ACDSP_ESTATE
+ * when there has been none). */
 int32_t acdsp_fir_last_kernel_ms(acdsp_fir_t h, float *ms);
 /* Average / minimum main-kernel duration over the last `last_k` (<= 64) run() calls. */
 int32_t acdsp_fir_kernel_stats(acdsp_fir_t h, int32_t last_k, float *avg_ms, float *min_ms);

@@ -47,6 +47,39 @@ def test_fir_state_round_trip(ftype, kind, n_taps):
     assert b.state() == a.state()
 
 
+@pytest.mark.parametrize("n_taps,delta", [(240, 32), (240, -16), (353, 32), (63, 96)])
+def test_fir_state_blob_of_another_history_length_restores(n_taps, delta):
+    """The history length is n_taps - 1 rounded up for the kernels' windows and has changed between builds (round 3 kept 288 samples
+    for 240 taps, round 4 keeps 256).  A blob with a longer or shorter history that still covers the taps is this filter's state:
+    the newest samples are kept (the older ones only ever meet zero coefficients)."""
+    import struct
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+    rng = np.random.default_rng(11)
+    n_ch, n1, n2 = 4, 2100, 900
+    x = rand_raw(rng, fin, (n_ch, n1 + n2))
+    c = rand_raw(rng, fc, (n_taps,)) // 4
+    want = OracleFir(n_taps, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch).run(c, x)
+    a = A.Fir(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_channels=n_ch, kind="load")
+    a.set_coeffs(c)
+    a.run(dev(x[:, :n1], fin))
+    blob = a.state()
+    hl = struct.unpack_from("<Q", blob, 24)[0]                    # StateHdr.per_channel
+    assert len(blob) == 64 + n_ch * hl * 2 and hl + 1 >= n_taps
+    new_hl = hl + delta
+    assert new_hl + 1 >= n_taps
+    rows = np.frombuffer(blob[64:], dtype=np.int16).reshape(n_ch, hl)
+    hist = x[:, n1 - new_hl:n1].astype(np.int16) if delta > 0 else rows[:, -new_hl:]   # what a handle with that length would hold
+    other = blob[:24] + struct.pack("<Q", new_hl) + blob[32:64] + np.ascontiguousarray(hist).tobytes()
+    b = A.Fir(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_channels=n_ch, kind="load")
+    b.set_coeffs(c)
+    b.set_state(other)
+    y2 = b.run(dev(x[:, n1:], fin)).cpu().numpy().astype(np.int64)
+    assert np.array_equal(y2, want[:, n1:])
+    too_short = blob[:24] + struct.pack("<Q", n_taps - 2) + blob[32:64] + b"\0" * (n_ch * (n_taps - 2) * 2)
+    with pytest.raises(A.AcdspError):
+        b.set_state(too_short)
+
+
 def test_fir_state_blob_is_checked():
     fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2)
     a = A.Fir(31, "SHIFT_REG", fin, fc, fa, fo, n_channels=2)
