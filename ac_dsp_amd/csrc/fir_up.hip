@@ -482,7 +482,10 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
     }
   }
   ACDSP_TUNE_ENV(spw_env, "ACDSP_UP_SPW");   // tuning knob: 512-sample steps per wave
-  int64_t spw = 4;                            // short spans, dispatched in memory order (see launch_fir_gen); 1 step: the prologue dominates
+  // short spans, dispatched in memory order (see launch_fir_gen); a chunk is at least one step PAIR (the loop body).  Round 4, same-process
+  // sweep (profiles/r4_knob_sweeps.txt): the ac_cic_intr_full row (4-byte inputs, 32 KB of outputs per step) 3.38 ms at two steps per wave
+  // against 3.49 at four and 3.63 at eight (XCD-affine order on); the ac_poly_intr row is flat from two to eight.
+  int64_t spw = p.in_eb == 4 ? 2 : 4;
   if (spw_env && atoi(spw_env) > 0) { spw = atoi(spw_env); }
   if (spw < 1) { spw = 1; }
   a.steps_per_wave = spw;

@@ -339,7 +339,9 @@ def run_inproc(args):
         per.append(node.last_ms())
     dt = time.perf_counter() - t0
     kmax = sum(m for _, m in per) / len(per)                      # mean over the steps of the slowest shard's kernel time
-    nbytes = w["bytes_per_sample"] * w["samples_per_gpu"]
+    # per physical device: a device listed k times (the one-GPU test mode) runs k shards side by side, so its bytes are k shards'
+    shards_on_dev = max(w["devices"].count(d) for d in set(w["devices"]))
+    nbytes = w["bytes_per_sample"] * w["samples_per_gpu"] * shards_on_dev
     out = {"metric": "Msamples/s", "value": w["samples_per_step"] * args.steps / dt / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "int16 / int32 / int64 (exact)", "data": "synthetic (on-device splitmix64 counter hash, seed 0xACD5)",
@@ -347,7 +349,8 @@ def run_inproc(args):
                       "parallelism": "channel-slice x%d, no collectives; ONE process, one acdsp_node_* handle (engine handle + stream + host thread per device)" % args.gpus},
            "roofline": {"bound": "hbm", "achieved": nbytes / (kmax * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": nbytes / (kmax * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "basis": "per GPU: algorithmic bytes of one shard / the slowest shard's kernel time (engine handles' HIP events), mean over the steps",
+                        "basis": "per GPU: algorithmic bytes of the shards on one device / the slowest shard's kernel time (engine handles' HIP events), mean over the steps",
+                        "shards_per_device": shards_on_dev,
                         "kernel_ms_per_shard_last_step": per[-1][0]},
            "cpu_baseline": None}
     print(json.dumps(out), flush=True)
@@ -437,7 +440,7 @@ def diag_of(w, k_avg, roof):
     cms, cbytes = A.diag_copy_ms(x, scratch, warmup=10, reps=20)
     roof["copy_GBps"] = 2.0 * cbytes / (cms * 1e-3) / 1e9
     roof["frac_of_copy"] = roof["achieved"] / roof["copy_GBps"]
-    if w["issued_macs_per_sample"] and w["coeffs"] is not None and w["x"].element_size() == 2:
+    if w["issued_macs_per_sample"] and w["coeffs"] is not None and w["x"].element_size() == 2 and w["bytes_per_sample"] == 4:
         issued = int(round(w["issued_macs_per_sample"] / 32.0))
         hi = issued - 2 * eng_nb_plan(w["n_taps"])
         try:
