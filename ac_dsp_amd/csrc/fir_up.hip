@@ -23,14 +23,16 @@
 // runs once per output.  The re-bias correction depends on the phase: 128 * sum_k E_j[k] * sum_{p < PX-1} 256^p, a small
 // per-lane table (the rows of a lane repeat with period L <= 32).
 //
-// Data movement.  One wave = one channel x a chunk of steps; a step is 512 input samples = L / 2 MFMA groups.  The samples
-// of step st + 1 (+ 32 NB of history in front) are loaded while step st is computed, split into byte planes (v_perm_b32)
-// and staged in LDS as plain byte arrays; X_c is a 16-byte read at byte offset SPC (32 g + c + 1) + 32 b + 16 h of the plane
+// Data movement.  One wave = one channel x a short chunk of 1 .. 4 steps (about 32 KB of outputs); a step is 512 input samples =
+// L / 2 MFMA groups.  The samples of every step of the chunk (+ 32 NB of history in front of each) are loaded up front, one
+// register set per step; a step splits its set into byte planes (v_perm_b32) and stages them in LDS as plain byte arrays; X_c is a 16-byte read at byte offset SPC (32 g + c + 1) + 32 b + 16 h of the plane
 // (unaligned for SPC < 16: the LDS takes it).  Every group is converted into a padded LDS tile (conflict-free 8..32-byte
 // writes per lane) and leaves as full-wave contiguous 8-byte-per-lane stores: 8 KB runs per group for 8-byte outputs
 // (the first version of this kernel wrote 256-byte runs from 32 places per wave and reached 2.6 TB/s on the CIC row; the
-// one-thread-per-output VALU kernel, 512-byte runs, 4.0 TB/s).  The step loop is one basic block with the first step
-// peeled, so the wait for the prefetched samples is a counted vmcnt that leaves the stores of the step in flight.
+// one-thread-per-output VALU kernel, 512-byte runs, 4.0 TB/s).  Rounds 2 - 4 ran chunks of 2 - 8 steps with the loads of a
+// step two steps ahead of their use; the one-shot chunks measure 4 - 7 % faster on both bench rows and 13 % at L = 4
+// (profiles/r4_up_oneshot.txt) -- as with the decimating kernels (fir_gen_ring_kernel), what the memory system rewards is many short
+// waves in memory order whose loads are all in flight before their first store.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -38,10 +40,10 @@
 
 #include "fir_kernels.hpp"
 
-// Load policy of the 512 new samples of a step (read exactly once).  Round 4 A/B, same box, alternating processes, 4 pairs each
-// (profiles/r4_ab_up_nt.txt): non-temporal loads 3.55 against plain 3.47 ms on the ac_cic_intr_full row (+2.3 %), 0.947 against 0.948 ms
-// on the ac_poly_intr row -- the bare 1:16 stream's gain from that policy (tools/fill_probe.hip: 5.4 -> 6.1 TB/s) does not carry over
-// to a kernel whose time is its stores.  Plain loads; -DACDSP_UP_LD_NT builds the other form.
+// Load policy of the 512 new samples of a step (read exactly once).  Round 4 A/B (profiles/r4_ab_up_nt.txt, pipelined form: non-temporal
+// loads +2.3 % on the ac_cic_intr_full row, +-0 on the ac_poly_intr row; profiles/r4_up_oneshot.txt, one-shot form: +2 - 3 %) -- the
+// bare 1:16 stream's gain from that policy (tools/fill_probe.hip: 5.4 -> 6.1 TB/s) does not carry over to a kernel whose time is its
+// stores.  Plain loads; -DACDSP_UP_LD_NT builds the other form.
 #ifdef ACDSP_UP_LD_NT
 #define ACDSP_UP_LD(ptr) __builtin_nontemporal_load(ptr)
 #else
@@ -92,17 +94,23 @@ struct UpArgs {
 // EPI 1: poly_intr with every intermediate inside int32 and a shift / clamp / wrap conversion (host-checked).
 // EPI 2: CIC with a bit-field wrap conversion.  1 and 2 are branch-free: the step loop stays one basic block.
 // PCT: coefficient digit planes compiled in (2 or 3; the fragment array always has 3 per K block).
-template <typename TIN, int PX, int PCT, int NBT, int L, int OEB, int EPI>
-// (two waves per SIMD where the fragments + two prefetch sets + accumulators need more than 168 registers: spills inside the
-// step loop are VMEM operations that every store-counting wait would have to drain)
-// (round 4: also three digit planes into 8-byte outputs at L = 16 with the CIC epilogue -- 7 VGPRs spilled at 168)
-__global__ void __launch_bounds__(64, ((PX * NBT >= 4 || (PCT == 3 && L == 16 && OEB == 8 && EPI == 2)) ? 2 : 3)) fir_up_kernel(UpArgs a, const v4i *__restrict__ frag) {
+// NST: steps per wave (1 .. 4).  A wave is a short one-shot chunk: the samples of all its NST steps are loaded up front into NST register
+// sets, then the steps run back to back with nothing but their stores on the memory pipeline; no prefetch state is carried.  The host
+// picks NST so that a wave writes about 32 KB, dispatched in memory order (round 4; the software-pipelined form it replaces -- chunks
+// of 2 - 8 steps, loads two steps ahead of their use -- measured 4 - 7 % slower on both interpolator rows: profiles/r4_up_oneshot.txt).
+template <typename TIN, int PX, int PCT, int NBT, int L, int OEB, int EPI, int NST>
+// (two waves per SIMD where the fragments + the register sets + accumulators need more than 168 registers: spills inside a step are
+// VMEM operations that every store-counting wait would have to drain)
+__global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_kernel(UpArgs a, const v4i *__restrict__ frag) {
   constexpr int SPC = 32 / L;                                 // input samples per MFMA column
-  constexpr int G = L / 2;                                    // MFMA groups (1024 outputs each) per step of 512 samples
+  constexpr int SS = 512;                                     // samples per step
+  constexpr int G = L / 2;                                    // MFMA groups (1024 outputs each) per step
+  constexpr int NLD = (int)sizeof(TIN) / 2;                   // 1 KB loads per step
+  static_assert(NST >= 1 && NST <= 4, "up to four steps loaded up front");
   constexpr int HP = 32 * NBT;                                // history samples staged in front of a step
   constexpr int SPL = 16 / (int)sizeof(TIN);                  // samples per 16-byte load
   constexpr int NHL = HP / SPL;                               // lanes that load history
-  constexpr int PLB = HP + 512 + 16;                          // bytes of one plane array
+  constexpr int PLB = HP + SS + 16;                           // bytes of one plane array
   constexpr int FU = OEB == 8 ? 1 : ((OEB == 4 ? 2 : 4) < G ? (OEB == 4 ? 2 : 4) : G);   // groups per write-out
   constexpr int RUN = 32 * OEB;                               // output bytes of one column
   constexpr int RUNP = RUN + (OEB == 2 ? 8 : 16);             // padded column pitch of the tile (conflict-free writes)
@@ -148,14 +156,16 @@ __global__ void __launch_bounds__(64, ((PX * NBT >= 4 || (PCT == 3 && L == 16 &&
   const int64_t st1 = (st0 + a.steps_per_wave < a.n_steps) ? st0 + a.steps_per_wave : a.n_steps;
 
   const int hl = lane < NHL ? lane : NHL - 1;                 // lanes past the history repeat its last load ...
-  // two register sets: the branch-free epilogues prefetch two steps ahead (set = step parity within the wave's chunk)
-  v4i pre[2][sizeof(TIN) / 2], preh[2];
+  // one register set per step of the chunk
+  v4i pre[NST][NLD], preh[NST];
   auto fetch = [&](int64_t st, auto set_c) {
     constexpr int S = decltype(set_c)::value;
-    if (st > st1 - 1) { st = st1 - 1; }                       // past the chunk: the last step again (never consumed or idempotent)
-    const TIN *src = xrow + 16 * (a.slot0 + 32 * st);
+    if (st > st1 - 1) { st = st1 - 1; }                       // past the chunk: the last step again (never consumed)
+    const TIN *src = xrow + 16 * a.slot0 + SS * st;
 #pragma unroll
-    for (int q = 0; q < (int)sizeof(TIN) / 2; q++) { pre[S][q] = ACDSP_UP_LD((const v4i *)src + 64 * q + lane); }
+    for (int q = 0; q < NLD; q++) {
+      pre[S][q] = ACDSP_UP_LD((const v4i *)src + 64 * q + lane);
+    }
     preh[S] = ((const v4i *)(src - HP))[hl];
   };
   // byte plane pp of the SPL samples in one 16-byte register set -> SPL bytes at `dst`
@@ -178,7 +188,7 @@ __global__ void __launch_bounds__(64, ((PX * NBT >= 4 || (PCT == 3 && L == 16 &&
     for (int pp = 0; pp < PX; pp++) {
       unsigned char *pl = lds + pp * PLB;
 #pragma unroll
-      for (int q = 0; q < (int)sizeof(TIN) / 2; q++) { put(pre[S][q], pp, pl + HP + (64 * q + lane) * SPL); }
+      for (int q = 0; q < NLD; q++) { put(pre[S][q], pp, pl + HP + (64 * q + lane) * SPL); }
       put(preh[S], pp, lane < NHL ? pl + lane * SPL : sink + lane * 16);   // ... and dump it into a private sink (branch-free)
     }
   };
@@ -210,16 +220,11 @@ __global__ void __launch_bounds__(64, ((PX * NBT >= 4 || (PCT == 3 && L == 16 &&
       }
     }
   };
-  // One step.  VMEM program order: [wait for this step's samples] -> loads of the step AHEAD later -> the stores of this step.
-  // AHEAD = 2 with alternating register sets for the branch-free epilogues: the loads a step waits for were issued two steps
-  // earlier, in front of two steps' worth of stores, so the wait is a counted vmcnt that leaves those stores in flight and the
-  // load has had two steps to come back through a memory pipeline that is full of stores (one step ahead: 13 - 18 % slower).
-  // The first pair of steps is peeled so that both predecessors of the loop header carry the same vmcnt state.
-  auto body = [&](int64_t st, auto set_c, auto ahead_c) __attribute__((always_inline)) {
+  // One step: stage its register set, then per group read the fragments, run the MFMAs, convert into the tile, write the tile out.
+  auto body = [&](int64_t st, auto set_c) __attribute__((always_inline)) {
     // (single-wave workgroup: the LDS operations of a wave execute in order, no barrier needed)
     stage(set_c);
-    fetch(st + decltype(ahead_c)::value, set_c);
-    const int64_t e_step = 16 * (a.slot0 + 32 * st) * (int64_t)L;   // output element (before out_off) of the step's first sample, phase 0
+    const int64_t e_step = (16 * a.slot0 + SS * st) * (int64_t)L;   // output element (before out_off) of the step's first sample, phase 0
 #pragma unroll
     for (int g = 0; g < G; g++) {
       v4i X[NBT][PX];
@@ -338,18 +343,15 @@ __global__ void __launch_bounds__(64, ((PX * NBT >= 4 || (PCT == 3 && L == 16 &&
   typedef std::integral_constant<int, 0> C0;
   typedef std::integral_constant<int, 1> C1;
   typedef std::integral_constant<int, 2> C2;
+  typedef std::integral_constant<int, 3> C3;
   fetch(st0, C0());
-  if constexpr (EPI == 0) {   // branchy conversions: every wait is vmcnt(0) anyway; one call site keeps the body small
-    for (int64_t st = st0; st < st1; st++) { body(st, C0(), C1()); }
-  } else {
-    fetch(st0 + 1, C1());
-    auto pair = [&](int64_t st) __attribute__((always_inline)) {
-      body(st, C0(), C2());
-      body(st + 1 < st1 ? st + 1 : st1 - 1, C1(), C2());      // odd chunk: the last step twice (same outputs)
-    };
-    pair(st0);
-    for (int64_t st = st0 + 2; st < st1; st += 2) { pair(st); }
-  }
+  if constexpr (NST >= 2) { fetch(st0 + 1, C1()); }
+  if constexpr (NST >= 3) { fetch(st0 + 2, C2()); }
+  if constexpr (NST >= 4) { fetch(st0 + 3, C3()); }
+  body(st0, C0());
+  if constexpr (NST >= 2) { if (st0 + 1 < st1) { body(st0 + 1, C1()); } }
+  if constexpr (NST >= 3) { if (st0 + 2 < st1) { body(st0 + 2, C2()); } }
+  if constexpr (NST >= 4) { if (st0 + 3 < st1) { body(st0 + 3, C3()); } }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -417,21 +419,26 @@ bool fir_up_shape_ok(int in_eb, int px, int nb, int L, int out_eb) {
 // compiled shapes: poly_intr = int16 samples, 3 digit planes (the pair taps E_j - E_cj have 17 bits) or 2 when the set allows it, 2- or 8-byte outputs;
 // CIC = int16 / int32 samples, 2 digit planes (boxcar^N taps of the BASELINE shapes fit 16 bits), 8-byte outputs (2-byte ones
 // for int16 samples)
+// steps per wave: about 32 KB of outputs (a step writes 512 L OEB bytes)
+constexpr int up_nst(int L, int oeb) { return 32768 / (512 * L * oeb) < 1 ? 1 : (32768 / (512 * L * oeb) > 4 ? 4 : 32768 / (512 * L * oeb)); }
+
 template <typename TIN, int PX, int PCT, int NBT, int L>
 static hipError_t launch_up_oeb(const UpArgs &a, const uint32_t *d_frag, int out_eb, int epi, dim3 grid, hipStream_t s) {
   const v4i *f = (const v4i *)d_frag;
   if (out_eb == 8) {
-    if (epi == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 2>), grid, dim3(64), 0, s, a, f); }
-    else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 0>), grid, dim3(64), 0, s, a, f); }
+    constexpr int NST = up_nst(L, 8);
+    if (epi == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 2, NST>), grid, dim3(64), 0, s, a, f); }
+    else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 0, NST>), grid, dim3(64), 0, s, a, f); }
   } else if (out_eb == 2) {
+    constexpr int NST = up_nst(L, 2);
     if constexpr (sizeof(TIN) == 2) {
       if (epi == 1) {
-        if constexpr (PCT == 3 || NBT == 1) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 1>), grid, dim3(64), 0, s, a, f); }
+        if constexpr (PCT == 3 || NBT == 1) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 1, NST>), grid, dim3(64), 0, s, a, f); }
         else { return hipErrorNotSupported; }
       } else if (epi == 2) {
-        if constexpr (PCT == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 2>), grid, dim3(64), 0, s, a, f); }
+        if constexpr (PCT == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 2, NST>), grid, dim3(64), 0, s, a, f); }
         else { return hipErrorNotSupported; }
-      } else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 0>), grid, dim3(64), 0, s, a, f); }
+      } else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 0, NST>), grid, dim3(64), 0, s, a, f); }
     } else { return hipErrorNotSupported; }
   } else {
     return hipErrorNotSupported;
@@ -481,18 +488,12 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
       if (!so) { a.e_mask = (uint64_t)(~uint32_t(0) >> (64 - wo)); }
     }
   }
-  ACDSP_TUNE_ENV(spw_env, "ACDSP_UP_SPW");   // tuning knob: 512-sample steps per wave
-  // short spans, dispatched in memory order (see launch_fir_gen); a chunk is at least one step PAIR (the loop body).  Round 4, same-process
-  // sweep (profiles/r4_knob_sweeps.txt): the ac_cic_intr_full row (4-byte inputs, 32 KB of outputs per step) 3.38 ms at two steps per wave
-  // against 3.49 at four and 3.63 at eight (XCD-affine order on); the ac_poly_intr row is flat from two to eight.
-  int64_t spw = p.in_eb == 4 ? 2 : 4;
-  if (spw_env && atoi(spw_env) > 0) { spw = atoi(spw_env); }
-  if (spw < 1) { spw = 1; }
+  // one-shot waves of about 32 KB of outputs, dispatched in memory order (fir_up_kernel's NST)
+  const int64_t spw = up_nst(pl.L, p.out_eb);
   a.steps_per_wave = spw;
   dim3 grid((unsigned)((n_steps + spw - 1) / spw), (unsigned)p.n_ch);
-  // XCD-affine chunk order: +2.6 - 2.9 % on the CIC interpolator row (int32 inputs, int64 outputs) in every pass, -2 - 3 % on the
-  // poly_intr row (int16 both ways): on for 4-byte inputs only (profiles/r3_xcd_map.txt)
-  a.xcd_map = (xcd_map_wanted(p.in_eb == 4) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
+  // XCD-affine chunk order: loses 2 - 5 % on both interpolator rows in the one-shot form (profiles/r4_up_oneshot.txt); ACDSP_XCD_MAP=1 forces it
+  a.xcd_map = (xcd_map_wanted(false) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
   if (p.in_eb == 2) {
     if (mode == 0) {
       // poly_intr: the pair taps E_j -+ E_cj can have 17 bits = 3 digit planes; sets whose folded taps stay inside two planes
