@@ -914,7 +914,7 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
         std::vector<uint32_t> frag;
         std::vector<int64_t> ucorr;
         FirUpPlan pl;
-        if (fir_up_plan(E.data(), R, kmax, h->in_eb, &pl, &frag, &ucorr) && pl.pc <= 2 && pl.nb == 1 && fir_up_shape_ok(h->in_eb, h->in_eb, pl.nb, R, h->out_eb)) {
+        if (fir_up_plan(E.data(), R, kmax, h->in_eb, &pl, &frag, &ucorr) && pl.pc <= 3 && pl.nb == 1 && fir_up_shape_ok(h->in_eb, h->in_eb, pl.nb, R, h->out_eb)) {
           e = hipMalloc((void **)&h->d_upfrag, frag.size() * sizeof(uint32_t));
           if (e == hipSuccess) { e = hipMalloc((void **)&h->d_upcorr, ucorr.size() * sizeof(int64_t)); }
           if (e == hipSuccess) { e = hipMemcpy(h->d_upfrag, frag.data(), frag.size() * sizeof(uint32_t), hipMemcpyHostToDevice); }
@@ -1089,7 +1089,10 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
     if (h->up_ok && p.vec_ok && !no_up) {
       const int64_t slot_a = h->up_plan.hs, n_steps = ((n_in - 1) / 16 - slot_a) / 32;
       const int64_t out_off = (int64_t)d.R * p.t_prev - lo;
-      const bool out_ok = ((uintptr_t)d_out % 8 == 0) && ((out_stride * h->out_eb) % 8 == 0) && ((out_off * h->out_eb) % 8 == 0);
+      // 8-byte stores: 4-byte containers may start on odd elements (a continuing call starts R - 1 outputs into a phase group, a first
+      // call N - 1): gfx950 serves dword-aligned multi-dword stores
+      const int64_t oal = h->out_eb == 4 ? 4 : 8;
+      const bool out_ok = ((uintptr_t)d_out % oal == 0) && ((out_stride * h->out_eb) % oal == 0) && ((out_off * h->out_eb) % oal == 0);
       if (n_steps > 0 && out_ok && (int64_t)d.R * (p.t_prev + 16 * slot_a) >= lo) {
         FirParams k;
         memset(&k, 0, sizeof k);

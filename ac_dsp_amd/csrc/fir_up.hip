@@ -92,7 +92,8 @@ struct UpArgs {
 
 // EPI 0: 64-bit recombination + the generic conversions (any Q / O mode; uniform branches per output).
 // EPI 1: poly_intr with every intermediate inside int32 and a shift / clamp / wrap conversion (host-checked).
-// EPI 2: CIC with a bit-field wrap conversion.  1 and 2 are branch-free: the step loop stays one basic block.
+// EPI 2: CIC with a bit-field wrap conversion.  1, 2 and 3 are branch-free.
+// EPI 3: CIC whose INT_TYPE (and OUT_TYPE container) fit 32 bits: EPI 1's recombination mod 2^32, one sign-extending wrap, a mask.
 // PCT: coefficient digit planes compiled in (2 or 3; the fragment array always has 3 per K block).
 // NST: steps per wave (1 .. 4).  A wave is a short one-shot chunk: the samples of all its NST steps are loaded up front into NST register
 // sets, then the steps run back to back with nothing but their stores on the memory pipeline; no prefetch state is carried.  The host
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc[0][r] = (int)0x80000000u; acc[2][r] = (int)0x80000000u; }
       }
-      if constexpr (EPI == 1) {   // the correction + rounding constant rides in as the initial value of the lowest accumulator
+      if constexpr (EPI == 1 || EPI == 3) {   // the correction + rounding constant rides in as the initial value of the lowest accumulator
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc[0][r] = corr32_t[up_tab_idx<L>(r)]; }
       }
@@ -273,7 +274,14 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
           for (int m = 0; m < (NACC + 1) / 2; m++) {
             pr[m] = (2 * m + 1 < NACC) ? (int)(((unsigned)acc[2 * m + 1][r] << 8) + (unsigned)acc[2 * m][r]) : acc[2 * m][r];
           }
-          if constexpr (EPI == 1) {
+          if constexpr (EPI == 3) {
+            // everything mod 2^32: planes of weight 2^32 and above drop out; wrap to min(W_int, W_out) bits (sign-extending), mask for
+            // unsigned OUT_TYPEs
+            unsigned y32 = 0;
+#pragma unroll
+            for (int w = (NACC < 4 ? NACC : 4) - 1; w >= 0; w--) { y32 = (y32 << 8) + (unsigned)acc[w][r]; }
+            o32[rr] = ((int)(y32 << a.e_rs) >> a.e_rs) & (int)a.e_mask;
+          } else if constexpr (EPI == 1) {
             static_assert(EPI != 1 || NACC <= 4, "32-bit epilogue: four accumulators");
             // V + corr = sum_w acc[w] << 8 w by Horner's rule mod 2^32 (|V + corr| < 2^31, host-checked), one shift, one clamp
             // (v_med3_i32; the bounds are the int32 range when OUT_TYPE wraps at its container width)
@@ -316,7 +324,7 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
           }
         }
         unsigned char *dst = tile + ((g % FU) * 32 + c) * RUNP + (8 * g4 + 4 * h) * OEB;
-        if (EPI == 1) {
+        if (EPI == 1 || EPI == 3) {
           if (OEB == 4) { *(v4i *)dst = (v4i){o32[0], o32[1], o32[2], o32[3]}; }
           else {
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -354,6 +362,7 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
   if constexpr (NST >= 4) { if (st0 + 3 < st1) { body(st0 + 3, C3()); } }
 }
 
+#ifndef ACDSP_UP_TU
 // ---------------------------------------------------------------------------------------------
 // host: digit planes, Toeplitz fragments, correction table
 // ---------------------------------------------------------------------------------------------
@@ -411,7 +420,7 @@ bool fir_up_plan(const int64_t *E, int L, int nt, int px, FirUpPlan *pl, std::ve
 
 bool fir_up_shape_ok(int in_eb, int px, int nb, int L, int out_eb) {
   if (nb < 1 || nb > 2 || (L != 4 && L != 8 && L != 16)) { return false; }
-  if (in_eb == 2 && px == 2) { return out_eb == 2 || out_eb == 8; }
+  if (in_eb == 2 && px == 2) { return out_eb == 2 || (out_eb == 4 && nb == 1) || out_eb == 8; }
   if (in_eb == 4 && px == 4) { return nb == 1 && out_eb == 8; }
   return false;
 }
@@ -419,26 +428,35 @@ bool fir_up_shape_ok(int in_eb, int px, int nb, int L, int out_eb) {
 // compiled shapes: poly_intr = int16 samples, 3 digit planes (the pair taps E_j - E_cj have 17 bits) or 2 when the set allows it, 2- or 8-byte outputs;
 // CIC = int16 / int32 samples, 2 digit planes (boxcar^N taps of the BASELINE shapes fit 16 bits), 8-byte outputs (2-byte ones
 // for int16 samples)
-// steps per wave: about 32 KB of outputs (a step writes 512 L OEB bytes)
-constexpr int up_nst(int L, int oeb) { return 32768 / (512 * L * oeb) < 1 ? 1 : (32768 / (512 * L * oeb) > 4 ? 4 : 32768 / (512 * L * oeb)); }
+#endif   // ACDSP_UP_TU
+
+// steps per wave: about 32 KB of outputs (a step writes 512 L OEB bytes); at most two for the branchy generic epilogue (code size, registers)
+constexpr int up_nst(int L, int oeb, int epi) {
+  const int n = 32768 / (512 * L * oeb), cap = epi == 0 ? 2 : 4;
+  return n < 1 ? 1 : (n > cap ? cap : n);
+}
 
 template <typename TIN, int PX, int PCT, int NBT, int L>
 static hipError_t launch_up_oeb(const UpArgs &a, const uint32_t *d_frag, int out_eb, int epi, dim3 grid, hipStream_t s) {
   const v4i *f = (const v4i *)d_frag;
   if (out_eb == 8) {
-    constexpr int NST = up_nst(L, 8);
-    if (epi == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 2, NST>), grid, dim3(64), 0, s, a, f); }
-    else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 0, NST>), grid, dim3(64), 0, s, a, f); }
+    if (epi == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 2, up_nst(L, 8, 2)>), grid, dim3(64), 0, s, a, f); }
+    else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 0, up_nst(L, 8, 0)>), grid, dim3(64), 0, s, a, f); }
+  } else if (out_eb == 4) {
+    if constexpr (sizeof(TIN) == 2 && NBT == 1) {   // CIC on 16-bit inputs: INT_TYPE of up to 32 bits
+      if (epi == 3) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 4, 3, up_nst(L, 4, 3)>), grid, dim3(64), 0, s, a, f); }
+      else if (epi == 0) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 4, 0, up_nst(L, 4, 0)>), grid, dim3(64), 0, s, a, f); }
+      else { return hipErrorNotSupported; }
+    } else { return hipErrorNotSupported; }
   } else if (out_eb == 2) {
-    constexpr int NST = up_nst(L, 2);
     if constexpr (sizeof(TIN) == 2) {
       if (epi == 1) {
-        if constexpr (PCT == 3 || NBT == 1) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 1, NST>), grid, dim3(64), 0, s, a, f); }
+        if constexpr (PCT == 3 || NBT == 1) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 1, up_nst(L, 2, 1)>), grid, dim3(64), 0, s, a, f); }
         else { return hipErrorNotSupported; }
       } else if (epi == 2) {
-        if constexpr (PCT == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 2, NST>), grid, dim3(64), 0, s, a, f); }
+        if constexpr (PCT == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 2, up_nst(L, 2, 2)>), grid, dim3(64), 0, s, a, f); }
         else { return hipErrorNotSupported; }
-      } else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 0, NST>), grid, dim3(64), 0, s, a, f); }
+      } else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 2, 0, up_nst(L, 2, 0)>), grid, dim3(64), 0, s, a, f); }
     } else { return hipErrorNotSupported; }
   } else {
     return hipErrorNotSupported;
@@ -457,6 +475,28 @@ static hipError_t launch_up_l(const UpArgs &a, const uint32_t *d_frag, int L, in
     default: return hipErrorNotSupported;
   }
 }
+
+// ---- translation units: the shapes are split three ways for compile time (fir_up_b.hip, fir_up_c.hip re-include this file) ----
+#define ACDSP_UP_SHAPE(NAME, TIN, PX, PCT, NBT)                                                                                   \
+  hipError_t NAME(const UpArgs &a, const uint32_t *d_frag, int L, int out_eb, int epi, dim3 grid, hipStream_t s) {               \
+    return launch_up_l<TIN, PX, PCT, NBT>(a, d_frag, L, out_eb, epi, grid, s);                                                   \
+  }
+#if !defined(ACDSP_UP_TU)
+ACDSP_UP_SHAPE(launch_up_s221, int16_t, 2, 2, 1)
+#elif ACDSP_UP_TU == 1
+ACDSP_UP_SHAPE(launch_up_s231, int16_t, 2, 3, 1)
+ACDSP_UP_SHAPE(launch_up_s232, int16_t, 2, 3, 2)
+#else
+ACDSP_UP_SHAPE(launch_up_i421, int32_t, 4, 2, 1)
+ACDSP_UP_SHAPE(launch_up_i431, int32_t, 4, 3, 1)
+#endif
+#undef ACDSP_UP_SHAPE
+
+#ifndef ACDSP_UP_TU
+hipError_t launch_up_s231(const UpArgs &a, const uint32_t *d_frag, int L, int out_eb, int epi, dim3 grid, hipStream_t s);
+hipError_t launch_up_s232(const UpArgs &a, const uint32_t *d_frag, int L, int out_eb, int epi, dim3 grid, hipStream_t s);
+hipError_t launch_up_i421(const UpArgs &a, const uint32_t *d_frag, int L, int out_eb, int epi, dim3 grid, hipStream_t s);
+hipError_t launch_up_i431(const UpArgs &a, const uint32_t *d_frag, int L, int out_eb, int epi, dim3 grid, hipStream_t s);
 
 // Input slots [slot0, slot0 + 32 n_steps) of every channel; the caller covers everything else with the VALU kernels.
 hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const uint32_t *d_frag, const int64_t *d_corr, int mode, int w_int,
@@ -486,10 +526,14 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
       epi = 2;
       a.e_w = wmin - 32;
       if (!so) { a.e_mask = (uint64_t)(~uint32_t(0) >> (64 - wo)); }
+    } else if (w_int <= 32 && p.out_eb == 4 && wmin >= 1 && (so || wo <= w_int)) {
+      epi = 3;
+      a.e_rs = 32 - wmin;   // (y << rs) >> rs: sign-extending wrap to wmin bits
+      if (!so) { a.e_mask = (uint64_t)(~uint32_t(0) >> (32 - wo)); }
     }
   }
   // one-shot waves of about 32 KB of outputs, dispatched in memory order (fir_up_kernel's NST)
-  const int64_t spw = up_nst(pl.L, p.out_eb);
+  const int64_t spw = up_nst(pl.L, p.out_eb, epi);
   a.steps_per_wave = spw;
   dim3 grid((unsigned)((n_steps + spw - 1) / spw), (unsigned)p.n_ch);
   // XCD-affine chunk order: loses 2 - 5 % on both interpolator rows in the one-shot form (profiles/r4_up_oneshot.txt); ACDSP_XCD_MAP=1 forces it
@@ -498,15 +542,18 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
     if (mode == 0) {
       // poly_intr: the pair taps E_j -+ E_cj can have 17 bits = 3 digit planes; sets whose folded taps stay inside two planes
       // (|tap| < 2^15: e.g. any low-pass with sum |c| < 2) skip the third plane's MFMAs and its accumulator
-      if (pl.nb == 1 && pl.pc <= 2) { return launch_up_l<int16_t, 2, 2, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s); }
-      return pl.nb == 1 ? launch_up_l<int16_t, 2, 3, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s)
-                        : launch_up_l<int16_t, 2, 3, 2>(a, d_frag, pl.L, p.out_eb, epi, grid, s);
+      if (pl.nb == 1 && pl.pc <= 2) { return launch_up_s221(a, d_frag, pl.L, p.out_eb, epi, grid, s); }
+      return pl.nb == 1 ? launch_up_s231(a, d_frag, pl.L, p.out_eb, epi, grid, s)
+                        : launch_up_s232(a, d_frag, pl.L, p.out_eb, epi, grid, s);
     }
-    if (pl.pc > 2 || pl.nb != 1) { return hipErrorNotSupported; }
-    return launch_up_l<int16_t, 2, 2, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s);
+    // CIC: boxcar^N taps in two digit planes (the BASELINE shapes) or three (R^(N-1) past 2^15: R = 16 at N = 5)
+    if (pl.nb != 1) { return hipErrorNotSupported; }
+    return pl.pc <= 2 ? launch_up_s221(a, d_frag, pl.L, p.out_eb, epi, grid, s) : launch_up_s231(a, d_frag, pl.L, p.out_eb, epi, grid, s);
   }
-  if (pl.pc > 2 || pl.nb != 1) { return hipErrorNotSupported; }
-  return launch_up_l<int32_t, 4, 2, 1>(a, d_frag, pl.L, p.out_eb, epi, grid, s);
+  if (pl.nb != 1) { return hipErrorNotSupported; }
+  return pl.pc <= 2 ? launch_up_i421(a, d_frag, pl.L, p.out_eb, epi, grid, s) : launch_up_i431(a, d_frag, pl.L, p.out_eb, epi, grid, s);
 }
+
+#endif   // ACDSP_UP_TU
 
 }  // namespace acdsp

@@ -187,12 +187,20 @@ def test_long_runs_take_the_branch_free_kernel(q, o):
     (8, 1, 5, A.Fmt(32, 16), A.Fmt(40, 24)),                      # narrower signed OUT_TYPE, still wider than 32 bits
     (8, 1, 5, A.Fmt(32, 16), A.Fmt(36, 20, False)),               # unsigned OUT_TYPE narrower than INT_TYPE (mask)
     (8, 1, 5, A.Fmt(32, 16), A.Fmt(50, 34, False)),               # unsigned and wider than INT_TYPE: generic conversion
-    (8, 1, 5, A.Fmt(32, 16), A.Fmt(24, 8, True, "RND", "SAT")),   # 4-byte containers: not compiled in, VALU kernel
+    (8, 1, 5, A.Fmt(32, 16), A.Fmt(24, 8, True, "RND", "SAT")),   # int32 samples into 4-byte containers: not compiled in, VALU kernel
     (16, 1, 4, A.Fmt(16, 1), None),                               # int16 samples, R = 16
     (8, 1, 5, A.Fmt(16, 1), A.Fmt(16, 1, True, "TRN", "WRAP")),   # int16 samples into 2-byte containers (generic conversion)
     (16, 1, 4, A.Fmt(16, 1), A.Fmt(16, 1, True, "RND", "SAT")),   # N - 1 = 3 skipped 2-byte outputs: unaligned runs, VALU kernel
     (4, 2, 5, A.Fmt(16, 4), None),                                # R = 4, differential delay 2
     (8, 2, 4, A.Fmt(30, 10, False), None),                        # unsigned input: 31-bit signed planes
+    (8, 1, 5, A.Fmt(16, 1), None),                                # int16 samples, INT_TYPE <28,13>: 4-byte containers, 32-bit wrap epilogue
+    (4, 1, 5, A.Fmt(16, 1), None),                                # ... R = 4: four steps per wave
+    (8, 1, 5, A.Fmt(16, 1), A.Fmt(20, 5, False)),                 # ... unsigned OUT_TYPE narrower than INT_TYPE (mask)
+    (8, 1, 5, A.Fmt(16, 1), A.Fmt(32, 17)),                       # ... signed OUT_TYPE wider than INT_TYPE, full container
+    (8, 1, 5, A.Fmt(16, 1), A.Fmt(24, 9, True, "RND", "SAT")),    # ... a real conversion into 4-byte containers (generic epilogue)
+    (16, 1, 5, A.Fmt(16, 1), None),                               # boxcar(16)^5 taps pass 2^15: three digit planes; INT_TYPE exactly 32 bits
+    (16, 1, 5, A.Fmt(32, 16), None),                              # three digit planes on int32 samples, INT_TYPE <48,32>
+    (16, 1, 5, A.Fmt(32, 16), A.Fmt(40, 24, False)),              # ... unsigned narrower OUT_TYPE
 ])
 def test_interpolator_matrix_core_path(R, M, N, fin, fout):
     rng = np.random.default_rng(R * 100 + N)
@@ -203,7 +211,8 @@ def test_interpolator_matrix_core_path(R, M, N, fin, fout):
     x = rand_raw(rng, fin, (3, n))
     x[1, :64] = (1 << (fin.W - 1)) - 1 if fin.S else (1 << fin.W) - 1
     x[2, :64] = -(1 << (fin.W - 1)) if fin.S else 0
-    want_mfma = A.torch_dtype_for(fo) in (torch.int64,) or (A.torch_dtype_for(fo) == torch.int16 and A.torch_dtype_for(fin) == torch.int16 and N == 5)
+    dt_i, dt_o = A.torch_dtype_for(fin), A.torch_dtype_for(fo)
+    want_mfma = dt_o == torch.int64 or (dt_i == torch.int16 and dt_o == torch.int32) or (dt_o == torch.int16 and dt_i == torch.int16 and N == 5)
     for splits in (None, [600], [16, 1200], [5, 1205]):
         cic = A.Cic(True, R, M, N, fin, fo, n_channels=3)
         y = run_engine(cic, x, splits)
