@@ -909,6 +909,10 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 3 && oeb == 8 && pl.R == 8) { ring_shape = 1; }          // CIC R8 N5 on int32 -> int64
     else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 2; }   // CIC R16 N5 on int16 -> int64
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && oeb == 2 && pl.R == 8) { ring_shape = 3; }    // 128-tap decimate-by-8 on int16 -> int16
+    // further CIC decimator shapes (tools/cic_sweep.py): no BASELINE config, same kernel
+    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 3 && oeb == 4 && pl.R == 8) { ring_shape = 4; }    // CIC R8 on int16 -> int32 (INT_TYPE <= 32 bits)
+    else if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 2 && oeb == 8 && pl.R == 4) { ring_shape = 5; if (!ring_env) { r_spw = 4; r_pf = 4; } }   // CIC R4 on int32: 4 KB per step
+    else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 6; if (!ring_env) { r_spw = 1; r_pf = 1; } }   // CIC R16 N5 on int32: 16 KB per step = one step per wave (LDS: 18 KB of planes per step)
   }
   if (ring_shape) {
     spw = r_spw; a.steps_per_wave = spw;
@@ -936,6 +940,9 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     if (ring_shape == 1) { e = launch_ring<int32_t, 4, 2, 3, 8, 8>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 2) { e = launch_ring<int16_t, 2, 3, 6, 16, 8>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 3) { e = launch_ring<int16_t, 2, 2, 4, 8, 2>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
+    else if (ring_shape == 4) { e = launch_ring<int16_t, 2, 2, 3, 8, 4>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
+    else if (ring_shape == 5) { e = launch_ring1<int32_t, 4, 2, 2, 4, 8, 4, 4, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 6) { e = launch_ring1<int32_t, 4, 3, 6, 16, 8, 1, 1, true, false>(grid, s, p, fr, a); }
     else if (in_eb == 4) { e = launch_fast<int32_t, 4, 2, 3, 9, 8>(grid, lds_bytes, s, p, fr, a); }
     else if (in_eb == 8) { e = launch_fast<int64_t, 5, 2, 3, 1, 4>(grid, lds_bytes, s, p, fr, a); }
     else if (oeb == 8) { e = launch_fast<int16_t, 2, 3, 6, 9, 8>(grid, lds_bytes, s, p, fr, a); }

@@ -180,6 +180,36 @@ def test_long_runs_take_the_branch_free_kernel(q, o):
     assert np.array_equal(y, run_oracle(False, 16, 1, 5, fin, fout, x))
 
 
+@pytest.mark.parametrize("R,N,fin,fout", [
+    (8, 4, A.Fmt(16, 1), None),                                   # int16 samples, INT_TYPE <28,13>: 4-byte containers
+    (8, 5, A.Fmt(16, 1), None),                                   # ... <31,16>
+    (8, 4, A.Fmt(16, 1), A.Fmt(24, 9, True, "RND", "SAT")),       # ... a narrowing conversion
+    (4, 3, A.Fmt(32, 16), None),                                  # R = 4 on int32: four steps of 4 KB per wave
+    (4, 5, A.Fmt(32, 16), None),
+    (16, 5, A.Fmt(32, 16), None),                                 # R = 16 on int32: three coefficient digits, one 16 KB step per wave
+    (16, 5, A.Fmt(32, 16), A.Fmt(40, 20, True, "TRN", "SAT")),
+])
+def test_decimator_ring_kernel_shapes_outside_the_baseline(R, N, fin, fout):
+    """The ring kernel (fir_gen_ring_kernel) serves more CIC decimator shapes than the BASELINE ones: whole chunks on it, the ragged
+    tail and the continuation calls (history in front of the first window) on the general kernel; every output against the oracle."""
+    rng = np.random.default_rng(7 * R + N)
+    probe = A.Cic(False, R, 1, N, fin, fin)
+    it = probe.int_type
+    fo = fout if fout is not None else A.Fmt(it.W, it.I)
+    n = R * (256 * 4 * 3 + 16 * 5) + 16                           # three chunks of four steps + a ragged tail, whole 16-sample slots
+    x = rand_raw(rng, fin, (3, n))
+    x[1, :R * 300] = (1 << (fin.W - 1)) - 1
+    x[2, :R * 300] = -(1 << (fin.W - 1))
+    for splits in (None, [R * 256 * 5 + 16 * R]):
+        cic = A.Cic(False, R, 1, N, fin, fo, n_channels=3)
+        y = run_engine(cic, x, splits)
+        assert cic.path == "mfma_gen"
+        yo = run_oracle(False, R, 1, N, fin, fo, x, splits)
+        assert y.shape == yo.shape
+        bad = np.argwhere(y != yo)
+        assert bad.size == 0, "%d mismatches, first at %s" % (len(bad), bad[0])
+
+
 # ---- interpolator on the matrix cores (fir_up.hip): whole steps of 512 inputs; head and tail on the polyphase VALU kernel ----
 
 @pytest.mark.parametrize("R,M,N,fin,fout", [
