@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   constexpr int PPB = 16 / S;                                 // samples of a 16-byte piece = bytes of one of its planes
   constexpr int SPK = 64 / S;                                 // slots per 1 KB load
   static_assert(S == 2 || S == 4, "ring kernel: 2- and 4-byte samples");
-  static_assert(R % 4 == 0 && SPK % R == 0 && H <= ADV && S * H <= 64 && NLD * SPK == ADV, "ring geometry");
+  static_assert(R % 2 == 0 && SPK % R == 0 && H <= ADV && S * H <= 64 && NLD * SPK == ADV && NLD >= 1, "ring geometry");
   constexpr int KSTEP = (SPK + 2 * (SPK / R)) * 16;           // LDS bytes from a piece of load k to the same lane's piece of load k + 1
   constexpr int PADV = (ADV + 2 * (ADV / R)) * 16;            // LDS bytes a step advances
   constexpr int RING = (SPW < 2 ? SPW : 2) * ADV + H;         // chunks of one or two steps never wrap
@@ -912,6 +912,11 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     // further CIC decimator shapes (tools/cic_sweep.py): no BASELINE config, same kernel
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 3 && oeb == 4 && pl.R == 8) { ring_shape = 4; }    // CIC R8 on int16 -> int32 (INT_TYPE <= 32 bits)
     else if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 2 && oeb == 8 && pl.R == 4) { ring_shape = 5; if (!ring_env) { r_spw = 4; r_pf = 4; } }   // CIC R4 on int32: 4 KB per step
+    // ac_poly_dec on int16 at other factors / output widths (tools/poly_shapes.py): about 8 KB of input per wave, every load up front
+    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 2 && (oeb == 2 || oeb == 8) && pl.R == 2 && !ring_env) { ring_shape = oeb == 2 ? 10 : 11; r_spw = 8; }
+    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 3 && (oeb == 2 || oeb == 8) && pl.R == 4 && !ring_env) { ring_shape = oeb == 2 ? 12 : 13; r_spw = 4; }
+    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && oeb == 8 && pl.R == 8 && !ring_env) { ring_shape = 14; r_spw = 2; }
+    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 8 && (oeb == 2 || oeb == 8) && pl.R == 16 && !ring_env) { ring_shape = oeb == 2 ? 15 : 16; r_spw = 2; }
     else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 6; if (!ring_env) { r_spw = 1; r_pf = 1; } }   // CIC R16 N5 on int32: 16 KB per step = one step per wave (LDS: 18 KB of planes per step)
   }
   if (ring_shape) {
@@ -943,6 +948,13 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     else if (ring_shape == 4) { e = launch_ring<int16_t, 2, 2, 3, 8, 4>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 5) { e = launch_ring1<int32_t, 4, 2, 2, 4, 8, 4, 4, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 6) { e = launch_ring1<int32_t, 4, 3, 6, 16, 8, 1, 1, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 10) { e = launch_ring1<int16_t, 2, 2, 2, 2, 2, 8, 8, true, true>(grid, s, p, fr, a); }
+    else if (ring_shape == 11) { e = launch_ring1<int16_t, 2, 2, 2, 2, 8, 8, 8, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 12) { e = launch_ring1<int16_t, 2, 2, 3, 4, 2, 4, 4, true, true>(grid, s, p, fr, a); }
+    else if (ring_shape == 13) { e = launch_ring1<int16_t, 2, 2, 3, 4, 8, 4, 4, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 14) { e = launch_ring1<int16_t, 2, 2, 4, 8, 8, 2, 2, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 15) { e = launch_ring1<int16_t, 2, 2, 8, 16, 2, 2, 2, true, true>(grid, s, p, fr, a); }
+    else if (ring_shape == 16) { e = launch_ring1<int16_t, 2, 2, 8, 16, 8, 2, 2, true, false>(grid, s, p, fr, a); }
     else if (in_eb == 4) { e = launch_fast<int32_t, 4, 2, 3, 9, 8>(grid, lds_bytes, s, p, fr, a); }
     else if (in_eb == 8) { e = launch_fast<int64_t, 5, 2, 3, 1, 4>(grid, lds_bytes, s, p, fr, a); }
     else if (oeb == 8) { e = launch_fast<int16_t, 2, 3, 6, 9, 8>(grid, lds_bytes, s, p, fr, a); }

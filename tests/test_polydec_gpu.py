@@ -64,3 +64,12 @@ def test_long_burst_takes_the_branch_free_kernel():
     check(16, 8, A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16), A.Fmt(16, 2, True, "RND", "SAT"), n_groups=4096 + 70, expect="mfma_gen",
           splits=[2048], seed=5)
     check(16, 8, A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16), A.Fmt(16, 4, True, "TRN", "WRAP"), n_groups=3000, expect="mfma_gen", seed=6)
+
+
+@pytest.mark.parametrize("nt,df", [(16, 2), (8, 2), (16, 4), (8, 4), (16, 8), (16, 16), (8, 16)])
+@pytest.mark.parametrize("fo", [A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(44, 16), A.Fmt(16, 3, True, "TRN", "WRAP")])
+def test_ring_kernel_shapes_outside_the_bench_row(nt, df, fo):
+    """Decimation factors 2 / 4 / 8 / 16 into 2- and 8-byte containers: whole chunks of 2 - 8 steps on fir_gen_ring_kernel, the ragged
+    tail and the second call's head (history in front of its first window) on the general kernel; every output against the oracle."""
+    groups = 256 * 8 * 3 + 200          # three chunks of the longest shape (eight 256-output steps) + a ragged tail
+    check(nt, df, A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16), fo, n_groups=groups, expect="mfma_gen", splits=[256 * 9 + 16], seed=nt * df + fo.W)
