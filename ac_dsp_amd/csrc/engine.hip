@@ -1795,8 +1795,11 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
     const int L = d.ifac;
     const int64_t out_off = -(int64_t)p.skip * L, slot_a = h->up_plan.hs;
     const int64_t n_steps = (n_in / 16 - slot_a) / 32;
-    const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0) && ((uintptr_t)d_out % 8 == 0) &&
-                         ((out_stride * h->out_eb) % 8 == 0) && ((out_off * h->out_eb) % 8 == 0);
+    // the tile stores need dword alignment only (gfx950 serves dword-aligned multi-dword stores): IF = 2 into 2-byte containers starts its
+    // first call one input's outputs = 4 bytes into the 8-byte grid
+    const int64_t oal = h->out_eb >= 8 ? 8 : 4;
+    const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0) && ((uintptr_t)d_out % oal == 0) &&
+                         ((out_stride * h->out_eb) % oal == 0) && ((out_off * h->out_eb) % oal == 0);
     if (aligned && n_steps > 0) {
       FirParams k;
       memset(&k, 0, sizeof k);

@@ -419,7 +419,7 @@ bool fir_up_plan(const int64_t *E, int L, int nt, int px, FirUpPlan *pl, std::ve
 }
 
 bool fir_up_shape_ok(int in_eb, int px, int nb, int L, int out_eb) {
-  if (nb < 1 || nb > 2 || (L != 4 && L != 8 && L != 16)) { return false; }
+  if (nb < 1 || nb > 2 || (L != 2 && L != 4 && L != 8 && L != 16)) { return false; }
   if (in_eb == 2 && px == 2) { return out_eb == 2 || (out_eb == 4 && nb == 1) || out_eb == 8; }
   if (in_eb == 4 && px == 4) { return nb == 1 && out_eb == 8; }
   return false;
@@ -430,9 +430,10 @@ bool fir_up_shape_ok(int in_eb, int px, int nb, int L, int out_eb) {
 // for int16 samples)
 #endif   // ACDSP_UP_TU
 
-// steps per wave: about 32 KB of outputs (a step writes 512 L OEB bytes); at most two for the branchy generic epilogue (code size, registers)
+// steps per wave: about 32 KB of outputs (a step writes 512 L OEB bytes); one for the branchy generic epilogue (two steps measured 1.8 x
+// SLOWER than one on ac_poly_intr IF = 4 into 8-byte outputs: profiles/r4_poly_shapes.txt)
 constexpr int up_nst(int L, int oeb, int epi) {
-  const int n = 32768 / (512 * L * oeb), cap = epi == 0 ? 2 : 4;
+  const int n = 32768 / (512 * L * oeb), cap = epi == 0 ? 1 : 4;
   return n < 1 ? 1 : (n > cap ? cap : n);
 }
 
@@ -468,6 +469,7 @@ template <typename TIN, int PX, int PCT, int NBT>
 static hipError_t launch_up_l(const UpArgs &a, const uint32_t *d_frag, int L, int out_eb, int epi, dim3 grid, hipStream_t s) {
   switch (L) {
 #ifndef ACDSP_UP_ONLY_L8   // A/B builds compile the bench shapes only (the full set takes five minutes)
+    case 2: return launch_up_oeb<TIN, PX, PCT, NBT, 2>(a, d_frag, out_eb, epi, grid, s);
     case 4: return launch_up_oeb<TIN, PX, PCT, NBT, 4>(a, d_frag, out_eb, epi, grid, s);
     case 16: return launch_up_oeb<TIN, PX, PCT, NBT, 16>(a, d_frag, out_eb, epi, grid, s);
 #endif

@@ -157,7 +157,7 @@ def check_up(n_taps, ifac, ftype, fo, n_ch=3, n=16 * 33 * 3 + 80, splits=None, s
 
 
 @pytest.mark.parametrize("ftype,n_taps", [("FOLD_EVEN", 16), ("FOLD_ODD", 15), ("FOLD_ANTI", 16), ("FOLD_EVEN", 12), ("FOLD_ODD", 9), ("FOLD_EVEN", 40)])
-@pytest.mark.parametrize("ifac", [4, 8, 16])
+@pytest.mark.parametrize("ifac", [2, 4, 8, 16])
 def test_matrix_core_path_all_cores(ftype, n_taps, ifac):
     fo = A.Fmt(16, 2, True, "RND", "SAT")
     check_up(n_taps, ifac, ftype, fo, seed=n_taps + ifac, pairs=True)
@@ -165,7 +165,7 @@ def test_matrix_core_path_all_cores(ftype, n_taps, ifac):
 
 
 @pytest.mark.parametrize("ftype,n_taps", [("FOLD_EVEN", 16), ("FOLD_ODD", 15), ("FOLD_ANTI", 16), ("FOLD_EVEN", 40)])
-@pytest.mark.parametrize("ifac", [4, 8, 16])
+@pytest.mark.parametrize("ifac", [2, 4, 8, 16])
 @pytest.mark.parametrize("coeff_bits", [15, 16])
 def test_matrix_core_path_three_digit_planes(ftype, n_taps, ifac, coeff_bits):
     """Full-range coefficients: the folded pair taps need 17 bits = three digit planes (the 13-bit sets above stay inside two and
@@ -190,4 +190,4 @@ def test_matrix_core_path_is_left_when_the_cores_are_not_linear():
     check_up(16, 8, "FOLD_EVEN", fo, seed=8, coeff_bits=16, fa=A.Fmt(40, 12))
     # interpolation factors that are not compiled in fall back as well
     check_up(16, 5, "FOLD_EVEN", fo, seed=9, expect="lossless64")
-    check_up(16, 2, "FOLD_EVEN", fo, seed=10, expect="lossless64")
+    check_up(16, 32, "FOLD_EVEN", fo, seed=10, expect="lossless64")
