@@ -188,6 +188,13 @@ struct acdsp_fir {
   void *d_hist[2] = {nullptr, nullptr};
   int64_t *d_rt[2] = {nullptr, nullptr};
   int cur = 0;
+  // TRANSPOSED with loadable coefficients, exact-sum class (rt_hybrid): reg_trans[] differs from an input history only while partial sums
+  // of an EARLIER coefficient set are still in it -- for the n_taps - 1 samples behind a coefficient change (or a loaded state blob).  Those
+  // samples run the exact-order kernel on reg_trans; everything else is the same dot product as SHIFT_REG and runs the matrix-core kernels
+  // on the input history, which is kept up to date by every call.  reg_trans is rebuilt from the history (rt_from_hist) when it is asked for.
+  bool rt_hybrid = false, rt_valid = true;
+  int64_t rt_since = 0;         // samples since the last coefficient change / state load, saturating at n_taps - 1
+  int cur_rt = 0;               // rt_hybrid: index of the current reg_trans buffer (the history has `cur`)
   int64_t *d_coeffs = nullptr;
   uint32_t *d_frag = nullptr;   // [n_sets][2][nb][64][4] Toeplitz byte-plane fragments
   int64_t *d_corr = nullptr;    // [n_sets] 128 * sum(c)
@@ -499,7 +506,10 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   const int fi = desc->in.W - desc->in.I, fc = desc->coeff.W - desc->coeff.I, fa = desc->acc.W - desc->acc.I;
   // exact-dot-product class: the kernels compute `sum << (fa - fi - fc)` in 64 bits, so the shift must be 0..63 (formats
   // with I outside [0, W] can ask for more: those stay on the per-tap path)
-  bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && !h->use_rt && !h->wide;
+  static const bool no_hybrid = getenv("ACDSP_NO_RT_HYBRID") != nullptr;   // A/B knob: reg_trans on the exact-order kernel for every sample
+  h->rt_hybrid = h->use_rt && !no_hybrid && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) && desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && !h->wide;
+  h->rt_since = desc->n_taps - 1;   // an all-zero state carries no coefficients
+  bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && (!h->use_rt || h->rt_hybrid) && !h->wide;
   const int ift = internal_ftype(desc->kind, desc->ftype);
   if (is_fold_odd(ift)) {
     // the ACC_TYPE `fold` must also keep every fraction bit of the pre-add (fc < 0 would let fa >= fi + fc pass with fa < fi)
@@ -555,6 +565,26 @@ int32_t acdsp_fir_destroy(acdsp_fir_t h) {
   return ACDSP_OK;
 }
 
+// rt_hybrid: reg_trans[] of every channel from the input history and the coefficients in d_coeffs (the reference's recurrence unrolled
+// in time: fir_rt_update_kernel with the history as a call of hl >= n_taps samples, so that no older partial sum enters).  Synchronous.
+static int32_t fir_rt_from_hist(acdsp_fir *h) {
+  const acdsp_fir_desc_t &d = h->d;
+  FirParams k;
+  memset(&k, 0, sizeof k);
+  k.n_taps = d.n_taps; k.ftype = internal_ftype(d.kind, d.ftype); k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
+  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+  k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl; k.use_rt = 1;
+  k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
+  k.x = h->d_hist[h->cur]; k.in_stride = h->hl; k.n = h->hl;
+  k.coeffs = h->d_coeffs; k.rt = h->d_rt[h->cur_rt];
+  const hipError_t e = launch_fir_rt_update(k, h->d_rt[h->cur_rt ^ 1], nullptr);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "reg_trans rebuild failed: %s", hipGetErrorString(e)); }
+  HIP_TRY(hipDeviceSynchronize());
+  h->cur_rt ^= 1;
+  h->rt_valid = true;
+  return ACDSP_OK;
+}
+
 int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   if (!h || !coeffs) { return fail(ACDSP_EINVAL, "null argument"); }
   const acdsp_fir_desc_t &d = h->d;
@@ -570,8 +600,15 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
       return fail(ACDSP_EINVAL, "coefficient %zu = %lld is not a COEFF_TYPE raw word", i, (long long)coeffs[i]);
     }
   }
+  // the same set again (ac_fir_prog_coeffs hands its coefficients to every one-sample call): nothing changes, no state event
+  if (h->coeffs_set && h->h_coeffs.size() == n_sets * d.n_taps && memcmp(h->h_coeffs.data(), coeffs, n_sets * d.n_taps * sizeof(int64_t)) == 0) { return ACDSP_OK; }
   // Kernels of earlier run() calls may still be reading d_coeffs / d_frag.
   HIP_TRY(hipDeviceSynchronize());
+  if (h->rt_hybrid && h->coeffs_set) {
+    // a change mid-stream: the partial sums of the next n_taps - 1 outputs keep the OLD coefficients' products (ac_fir_load_coeffs.h:265-278)
+    if (!h->rt_valid && (rc = fir_rt_from_hist(h))) { return rc; }
+    h->rt_since = 0;
+  }
   HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, n_sets * d.n_taps * sizeof(int64_t), hipMemcpyHostToDevice));
   h->mfma_ok = false;
   const bool i16_in = d.in.S ? d.in.W <= 16 : d.in.W <= 15;
@@ -644,9 +681,9 @@ int32_t acdsp_fir_clone(acdsp_fir_t h, acdsp_fir_t *out) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(c->d_hist[0], h->d_hist[h->cur], (size_t)h->d.n_channels * h->hl * h->in_eb, hipMemcpyDeviceToDevice));
   if (h->use_rt) {
-    HIP_TRY(hipMemcpy(c->d_rt[0], h->d_rt[h->cur], (size_t)h->d.n_channels * h->d.n_taps * h->rt_eb, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(c->d_rt[0], h->d_rt[h->rt_hybrid ? h->cur_rt : h->cur], (size_t)h->d.n_channels * h->d.n_taps * h->rt_eb, hipMemcpyDeviceToDevice));
   }
-  c->cur = 0;
+  c->cur = 0; c->cur_rt = 0; c->rt_valid = h->rt_valid; c->rt_since = h->rt_since;
   *out = c;
   return ACDSP_OK;
 }
@@ -671,11 +708,21 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff);
   if (h->wide) { memset(&k.acc, 0, sizeof k.acc); memset(&k.out, 0, sizeof k.out); k.acc.F = d.acc.W - d.acc.I; }
   else { k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out); }
-  k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl; k.use_rt = h->use_rt ? 1 : 0;
+  const bool hyb = h->rt_hybrid;
+  k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl; k.use_rt = (h->use_rt && !hyb) ? 1 : 0;
   k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
   k.in_stride = in_stride; k.out_stride = out_stride; k.n = n;
   k.x = d_in; k.y = d_out;
-  k.hist = h->d_hist[h->cur]; k.coeffs = h->d_coeffs; k.rt = h->d_rt[h->cur];
+  k.hist = h->d_hist[h->cur]; k.coeffs = h->d_coeffs; k.rt = h->d_rt[hyb ? h->cur_rt : h->cur];
+  // rt_hybrid: the first m outputs still carry partial sums of the previous coefficient set
+  int64_t m_rt = 0;
+  if (hyb) {
+    m_rt = (int64_t)d.n_taps - 1 - h->rt_since;
+    m_rt = m_rt < 0 ? 0 : (m_rt > n ? n : m_rt);
+    if (m_rt > 0 && stream_is_capturing(s)) {
+      return fail(ACDSP_ESTATE, "fir_run under graph capture: a TRANSPOSED filter within n_taps - 1 samples of a coefficient change keeps host-side state; run %lld more samples before capturing", (long long)m_rt);
+    }
+  }
 
   int path = h->path;
   if (h->wide) {
@@ -713,7 +760,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   // Small calls (the drop-in run() of one channel; ac_fir_prog_coeffs is ONE sample per call, reference ac_fir_prog_coeffs.h:281)
   // are launch-bound: no timing events, and the exact-order kernels write the next history themselves -- one launch per call.
   const bool small = h->small_call;
-  const bool fuse_hist = small && !h->use_rt && (path == ACDSP_PATH_LOSSLESS64 || path == ACDSP_PATH_GENERIC ||
+  const bool fuse_hist = small && (!h->use_rt || hyb) && (path == ACDSP_PATH_LOSSLESS64 || path == ACDSP_PATH_GENERIC ||
                                                 (path == ACDSP_PATH_MFMA_I8 && fir_mfma_register_resident(k, h->plan)));   // single-wave workgroups
   const int nxt_fused = hist_next_index(h->cur, false);
   if (fuse_hist) { k.hist_next = h->d_hist[nxt_fused]; }
@@ -728,13 +775,27 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
     HIP_TRY(hipEventRecord(h->tm.stop(), s));
     h->tm.commit();
   }
+  if (hyb) {
+    if (m_rt > 0) {
+      // exact-order pass over the call's first m samples, on reg_trans, behind the main kernel (it overwrites those outputs)
+      FirParams kt = k;
+      kt.use_rt = 1; kt.n = m_rt; kt.hist_next = nullptr;
+      e = launch_fir_generic(kt, s);
+      if (e == hipSuccess && m_rt == n) { e = launch_fir_rt_update(kt, h->d_rt[h->cur_rt ^ 1], s); }
+      if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR reg_trans kernel launch failed: %s", hipGetErrorString(e)); }
+      if (m_rt == n) { h->cur_rt ^= 1; h->rt_valid = true; } else { h->rt_valid = false; }   // past the transition reg_trans is rebuilt on demand
+    } else {
+      h->rt_valid = false;
+    }
+    h->rt_since = h->rt_since + n >= (int64_t)d.n_taps - 1 ? (int64_t)d.n_taps - 1 : h->rt_since + n;
+  }
   if (fuse_hist) { h->cur = nxt_fused; return ACDSP_OK; }
   // state carry.  A call of at least hl samples takes the new history from its input alone: written in place behind the
   // main kernel (same stream), no buffer flip -- the handle's host-side state is then the same after every call, which is what
   // lets any schedule of such calls be captured into a HIP graph.  Shorter calls (and reg_trans, which reads its old value)
   // go into the other buffer, then flip.
-  const int nxt = hist_next_index(h->cur, !h->use_rt && k.n >= k.hl);
-  if (h->use_rt) {
+  const int nxt = hist_next_index(h->cur, (!h->use_rt || hyb) && k.n >= k.hl);
+  if (h->use_rt && !hyb) {
     e = launch_fir_rt_update(k, h->d_rt[nxt], s);
   } else {
     e = launch_fir_hist_update(k, h->d_hist[nxt], s);
@@ -787,6 +848,7 @@ int32_t acdsp_fir_reset(acdsp_fir_t h) {
     HIP_TRY(hipMemset(h->d_hist[i], 0, (size_t)h->d.n_channels * h->hl * h->in_eb));
     if (h->d_rt[i]) { HIP_TRY(hipMemset(h->d_rt[i], 0, (size_t)h->d.n_channels * h->d.n_taps * h->rt_eb)); }
   }
+  h->rt_valid = true; h->rt_since = h->d.n_taps - 1;
   return ACDSP_OK;
 }
 
@@ -2252,8 +2314,9 @@ int32_t acdsp_fir_state_get(acdsp_fir_t h, void *buf, uint64_t cap_bytes) {
   int rc = check_device(h->d.device);
   if (rc) { return rc; }
   HIP_TRY(hipDeviceSynchronize());   // run() is asynchronous: the state of the last call must have landed
+  if (h->rt_hybrid && !h->rt_valid && (rc = fir_rt_from_hist(h))) { return rc; }
   memcpy(buf, &s, sizeof s);
-  HIP_TRY(hipMemcpy((char *)buf + sizeof s, h->use_rt ? (const void *)h->d_rt[h->cur] : h->d_hist[h->cur], pay, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy((char *)buf + sizeof s, h->use_rt ? (const void *)h->d_rt[h->rt_hybrid ? h->cur_rt : h->cur] : h->d_hist[h->cur], pay, hipMemcpyDeviceToHost));
   return ACDSP_OK;
 }
 
@@ -2284,7 +2347,11 @@ int32_t acdsp_fir_state_set(acdsp_fir_t h, const void *buf, uint64_t bytes) {
     HIP_TRY(hipMemcpy(h->d_hist[h->cur], img.data(), img.size(), hipMemcpyHostToDevice));
     return ACDSP_OK;
   }
-  HIP_TRY(hipMemcpy(h->use_rt ? (void *)h->d_rt[h->cur] : h->d_hist[h->cur], (const char *)buf + sizeof s, state_payload(mine), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->use_rt ? (void *)h->d_rt[h->rt_hybrid ? h->cur_rt : h->cur] : h->d_hist[h->cur], (const char *)buf + sizeof s, state_payload(mine), hipMemcpyHostToDevice));
+  if (h->rt_hybrid) {   // partial sums of unknown coefficients and samples: the next n_taps - 1 outputs come from them, the history starts empty
+    HIP_TRY(hipMemset(h->d_hist[h->cur], 0, (size_t)h->d.n_channels * h->hl * h->in_eb));
+    h->rt_valid = true; h->rt_since = 0;
+  }
   return ACDSP_OK;
 }
 

@@ -114,6 +114,40 @@ def test_transposed_coefficient_reload_mid_stream():
         assert np.array_equal(y, orc.run(c, x))
 
 
+@pytest.mark.parametrize("N,per_channel", [(13, False), (63, False), (255, False), (64, True), (300, False)])
+def test_transposed_reload_in_the_exact_sum_class_runs_the_matrix_cores(N, per_channel):
+    """TRANSPOSED with loadable coefficients and an accumulator that cannot lose bits: the n_taps - 1 outputs behind a coefficient change
+    come from reg_trans on the exact-order kernel, everything else from the input history on the matrix cores (engine.hip: rt_hybrid).
+    Reloads closer together than n_taps - 1 samples, calls of one sample, the same set handed over again, state blobs taken inside a
+    transition and in the steady state, all against the oracle's reg_trans recurrence."""
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14), A.Fmt(16, 2, True, "RND", "SAT")
+    rng = np.random.default_rng(N)
+    n_ch = 5
+    mk = lambda: A.Fir(N, "TRANSPOSED", fin, fc, fa, fo, n_channels=n_ch, kind="load", coeffs_per_channel=per_channel)
+    fir, other = mk(), None
+    orc = OracleFir(N, "TRANSPOSED", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    c = None
+    lens = (3 * N + 40, 5, max(N // 2, 1), 1, N - 1 if N > 1 else 1, 2 * N + 17, N // 3 + 1, 4 * N, 16, 2 * N)
+    new_set = (True, True, True, False, True, False, True, True, False, False)
+    for i, (n, change) in enumerate(zip(lens, new_set)):
+        if change or c is None:
+            c = np.minimum(rand_raw(rng, fc, (n_ch, N) if per_channel else (N,)), 32639)
+        fir.set_coeffs(c)                                  # unchanged sets are handed over again, as ac_fir_prog_coeffs does
+        if other is not None:
+            other.set_coeffs(c)
+        x = rand_raw(rng, fin, (n_ch, n))
+        want = orc.run(c, x)
+        assert np.array_equal(run_engine(fir, x), want), "call %d" % i
+        assert fir.path == "mfma_i8"
+        if other is not None:
+            assert np.array_equal(run_engine(other, x), want), "call %d after a state load" % i
+            other = None
+        if i in (1, 2, 5, 8):                              # 1, 2: inside a transition; 5, 8: steady state (reg_trans rebuilt from the history)
+            other = mk()
+            other.set_coeffs(c)
+            other.set_state(fir.state())
+
+
 @pytest.mark.parametrize("n_taps", [1, 2, 31, 32, 33, 63, 64, 65, 127, 255, 257])
 def test_mfma_path_tap_counts(n_taps):
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
