@@ -144,6 +144,12 @@ struct MfmaArgs {
   int32_t nb, hb0, hb1;       // big-NB kernel: K-blocks, and the range [hb0, hb1] of non-zero high-byte blocks
   int64_t step0;              // big-NB kernels: first 1024-sample step of this launch (split launches)
   const int64_t *corr;     // [n_sets] 128 * sum(c) per coefficient set
+  // OUT_TYPEs of W < 16 bits in the 32-bit epilogue classes (round 4).  With d = 16 - W the epilogue shifts by rs - d instead of rs, packs
+  // as for 16 bits (AC_SAT: saturating pack, AC_WRAP: truncating pack) and shifts the packed words right by d, arithmetically:
+  // sat16(q') >> d == sat_W(q' >> d) and the sign bit of the truncated q' is bit W - 1 of q.  One v_pk_ashrrev_i16 per two outputs, in the
+  // NAR instantiations of the pipelined body only; the edge chunks (fir_mfma_body) convert in registers: clamp to [nar_lo, nar_hi],
+  // sign-extend the low 32 - nar_sh bits.  nar_on = 0: 16-bit OUT_TYPEs, nothing of this runs.
+  int32_t nar_on, nar_d, nar_lo, nar_hi, nar_sh;
   int64_t *dbg;            // optional: per-wave {shader-clock ticks, 100 MHz real-time ticks} (ACDSP_DEBUG_CLOCK)
 };
 
@@ -160,9 +166,29 @@ __device__ __forceinline__ void epi32_t(const v16i &hh, const v16i &mid, const v
     o[r] = WIDE ? (hh[r] + (lo >> 16)) >> (rs - 16) : (int)((unsigned)hh[r] << (16 - rs)) + (lo >> rs);
   }
 }
-__device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16i &ll, int rs, int (&o)[16]) {
+__device__ __forceinline__ void epi32_narrow(const MfmaArgs &a, int (&o)[16]) {
+  if (a.nar_on) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      int q = o[r] >> a.nar_d;
+      q = q < a.nar_lo ? a.nar_lo : (q > a.nar_hi ? a.nar_hi : q);
+      o[r] = (int)((unsigned)q << a.nar_sh) >> a.nar_sh;
+    }
+  }
+}
+// packed form of the last step (MfmaArgs): four dwords of int16 pairs >> d, arithmetically
+__device__ __forceinline__ v4i pk16_ashr(const v4i &v, int d) {
+  typedef short v2s_ __attribute__((ext_vector_type(2)));
+  const v2s_ d2 = (v2s_){(short)d, (short)d};
+  v4i r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { r[i] = __builtin_bit_cast(int, __builtin_bit_cast(v2s_, v[i]) >> d2); }
+  return r;
+}
+__device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16i &ll, int rs, const MfmaArgs &a, int (&o)[16]) {
   if (rs <= 16) { epi32_t<false>(hh, mid, ll, rs, o); }   // one uniform branch per step, not one per output
   else { epi32_t<true>(hh, mid, ll, rs, o); }
+  epi32_narrow(a, o);
 }
 
 // EPI 4 (round 4; the LDS-resident kernels only): int16 OUT containers when the 32-bit epilogue's bounds fail -- dense or
@@ -379,7 +405,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
     // ---------------- phase O: epilogue, stores, staging of the next step, prefetch ----------------
     // D layout: lane (n_col, h), register r: sample T0 + 32 n_col + (r&3) + 8 (r>>2) + 4 h
     int o16[16];
-    if (EPI != 0) { epi32(hh, mid, ll, rs, o16); }
+    if (EPI != 0) { epi32(hh, mid, ll, rs - a.nar_d, a, o16); }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const int64_t t0 = T0 + 32 * n_col + 8 * g + 4 * h;
@@ -461,7 +487,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 // issue and the other work hides in their shadow (tools/mfma_probe.hip: 39 cycles/MFMA with the epilogue
 // interleaved vs 36 bare).  The loop is unrolled by two so the accumulator sets and the B-fragment
 // double buffer swap roles by renaming; it contains no branch.
-template <int NB, int EPI, int HS>
+template <int NB, int EPI, int HS, bool NAR = false>
 __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
                                                    unsigned char *lds) {
   static_assert(EPI >= 1 && EPI <= 3, "fast epilogue classes only");
@@ -633,7 +659,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       return;
     }
     int o[16];
-    epi32_t<decltype(wide_c)::value>(hh, mid, ll, rs, o);
+    epi32_t<decltype(wide_c)::value>(hh, mid, ll, NAR ? rs - a.nar_d : rs, o);
     // A lane holds rows 8 g + 4 h .. + 3 of column n: 8 bytes per g, and the 16 lanes of a ds_write_b64 group share h, so
     // they can reach only half of the 32 banks (2-way conflict on every store: the 16.6 % SQ_LDS_BANK_CONFLICT of round 1).
     // v_permlane32_swap trades g-odd of the h = 0 lanes for g-even of the h = 1 lanes: every lane then owns 16 contiguous
@@ -677,7 +703,8 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       const int P = 64 * half + lane;
-      const v4i val = *(const v4i *)(obuf + (P ^ ((P >> 3) & 3)) * 16);
+      v4i val = *(const v4i *)(obuf + (P ^ ((P >> 3) & 3)) * 16);
+      if constexpr (NAR) { val = pk16_ashr(val, a.nar_d); }   // OUT_TYPEs of fewer than 16 bits (MfmaArgs::nar_*)
 #if ACDSP_FIR_NT & 2
       __builtin_nontemporal_store(val, (v4i *)(yout + T0 + 512 * half + 8 * lane));
 #else
@@ -813,13 +840,13 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       }
     }
   };
-  if (EPI == 3 || rs <= 16) { go(integral_constant<bool, false>()); }
+  if (EPI == 3 || (NAR ? rs - a.nar_d : rs) <= 16) { go(integral_constant<bool, false>()); }
   else { go(integral_constant<bool, true>()); }
 }
 
 // NB > kMaxRegNB (the 1023-tap shape, NB = 33): one wave per SIMD with the whole 512-entry register file -- 2 * 33 Toeplitz
 // fragments are 264 registers (fewer with a high-byte band), next to two accumulator sets and the B-fragment double buffer.
-template <int NB, int EPI, int HS, int WAVES>
+template <int NB, int EPI, int HS, int WAVES, bool NAR = false>
 __global__ void __launch_bounds__(64 * WAVES, (NB > kMaxRegNB ? 1 : kOccupancy))
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   // WAVES == 1: the pipelined body keeps a 4-step ring of staged planes (4 arrays of 128 + NB - 1 slots), the plain body two windows
@@ -832,7 +859,7 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n && (s0 > 0 || s1 >= 2);
   const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (WAVES == 1 && EPI != 0) {
-    if (interior) { fir_mfma_pipe_body<NB, EPI, HS>(p, frag, a, lds); }
+    if (interior) { fir_mfma_pipe_body<NB, EPI, HS, NAR>(p, frag, a, lds); }
     else if constexpr (EPI == 3) { fir_mfma_body<NB, 0, 0, WAVES, false>(p, frag, a, lds); }   // edges: generic epilogue
     else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
   } else {
@@ -861,6 +888,13 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
 template <int NB, int HS, int WAVES>
 static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   const dim3 blk(64 * WAVES);
+  if constexpr (HS == 0 && WAVES == 1 && NB <= kMaxRegNB) {
+    if (a.nar_on && (epi == 1 || epi == 2)) {   // OUT_TYPEs of fewer than 16 bits: instantiated without a band skip only
+      if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, 0, 1, true>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
+      else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, 0, 1, true>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
+      return hipGetLastError();
+    }
+  }
   if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   else if (epi == 2) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   else if (epi == 3 && WAVES == 1 && NB <= kMaxRegNB) {
@@ -895,7 +929,7 @@ static int pick_hs(int nb, uint64_t hi_mask) {
 
 template <int NB>
 static hipError_t launch_nb(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
-  const int hs = epi ? pick_hs(NB, a.hi_mask) : 0;
+  const int hs = (epi && !a.nar_on) ? pick_hs(NB, a.hi_mask) : 0;
   if (NB >= 7) {
     constexpr int H33 = NB >= 7 ? 3 + 16 * 3 : 0, H32 = NB >= 7 ? 3 + 16 * 2 : 0, H23 = NB >= 7 ? 2 + 16 * 3 : 0;
     if (hs == 3 + 16 * 3) { return launch_nb_hs<NB, H33, kSmallWaves>(p, d_frag, a, epi, grid, s); }
@@ -1030,7 +1064,7 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
     // ---------------- phase O ----------------
     int o16[16];
     if (EPI == 4) { epi64(hh, mid, ll, e64, o16); }
-    else if (EPI != 0) { epi32(hh, mid, ll, rs, o16); }
+    else if (EPI != 0) { epi32(hh, mid, ll, rs - a.nar_d, a, o16); }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const int64_t t0 = T0 + 32 * n_col + 8 * g + 4 * h;
@@ -1213,7 +1247,7 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
     for (int set = 0; set < 2; set++) {
       int o[16];
       if (EPI == 4) { if (set == 0) { epi64(h0, m0, l0, e64, o); } else { epi64(h1, m1, l1, e64, o); } }
-      else if (set == 0) { epi32(h0, m0, l0, rs, o); } else { epi32(h1, m1, l1, rs, o); }
+      else if (set == 0) { epi32(h0, m0, l0, rs - a.nar_d, a, o); } else { epi32(h1, m1, l1, rs - a.nar_d, a, o); }
 #pragma unroll
       // (the permlane32-swap / ds_write_b128 tile of fir_mfma_pipe_body was tried here: conflicts 2.5e7 -> 0 but +0.8 % time,
       // the phase is not in the shadow of MFMAs)
@@ -1347,17 +1381,20 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   const int rs = p.in.F + p.cf.F - p.out.F;
   // |y| <= 32768 * sum|c| must fit the accumulator (no AC_WRAP event possible) ...
   const int acc_bits = p.acc.W - (p.acc.S ? 1 : 0) - p.lossless_shift;
-  const bool acc_wide = acc_bits >= 63 || plan.sum_abs * 32768 < (int64_t(1) << (acc_bits > 0 ? acc_bits : 0));
+  const int64_t x_max = int64_t(1) << (p.in.W > 1 && p.in.W <= 16 ? p.in.W - 1 : 15);   // |x| <= 2^(W_in - 1): narrow samples need a narrower accumulator
+  const bool acc_wide = acc_bits >= 63 || plan.sum_abs * x_max < (int64_t(1) << (acc_bits > 0 ? acc_bits : 0));
   // ... hh*256 + mid + carry must fit int32, and so must the low plane with corr + rounding constant preloaded
   const int64_t hh_max = 128 * plan.sum_abs_hi, mid_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo), ll_max = 128 * plan.sum_abs_lo;
   const int64_t rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs <= 38) ? (int64_t(1) << (rs - 1)) : 0;
   const int64_t corr_abs = (plan.corr < 0 ? -plan.corr : plan.corr) + rnd;
   // lo = 2^8 mid + ll (with the preloaded constant) and the shifted sum must stay inside int32
+  // (OUT_TYPEs of W < 16 bits shift by rse = rs - (16 - W) and finish on the packed words: MfmaArgs::nar_*)
+  const int nar_d = (p.out_eb == 2 && p.out.W >= 2 && p.out.W < 16) ? 16 - p.out.W : 0, rse = rs - nar_d;
   const bool small = mid_max * 256 + ll_max + corr_abs + 2 < (int64_t(1) << 31) &&
-                     (rs <= 16 ? (hh_max << (16 - (rs < 16 ? rs : 16))) + ((mid_max * 256 + ll_max + corr_abs) >> (rs > 0 ? rs : 0)) + 2
-                               : hh_max + ((mid_max * 256 + ll_max + corr_abs) >> 16) + 2) < (int64_t(1) << 31);
+                     (rse <= 16 ? (hh_max << (16 - (rse < 16 ? (rse > 0 ? rse : 0) : 16))) + ((mid_max * 256 + ll_max + corr_abs) >> (rse > 0 ? rse : 0)) + 2
+                                : hh_max + ((mid_max * 256 + ll_max + corr_abs) >> 16) + 2) < (int64_t(1) << 31);
   if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
-      rs >= 1 && rs <= 31 && acc_wide && small && p.out.W == 16) {
+      rse >= 1 && rs <= 31 && acc_wide && small && (p.out.W == 16 || (nar_d > 0 && plan.nb <= kMaxRegNB))) {
     return p.out.O == ACDSP_SAT ? 2 : 1;
   }
   // EPI 4: int16 containers past the 32-bit bounds, on the LDS-resident kernels (more than kMaxRegNB K-blocks): exact 64-bit recombination,
@@ -1414,6 +1451,12 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   if (p.n <= 0) { return hipSuccess; }
   const int epi = fir_mfma_epilogue_class(p, plan);
   MfmaArgs a;
+  a.nar_on = 0; a.nar_d = 0; a.nar_lo = INT32_MIN; a.nar_hi = INT32_MAX; a.nar_sh = 0;
+  if ((epi == 1 || epi == 2) && p.out_eb == 2 && p.out.W < 16) {   // (class 1 / 2 with fewer than 16 bits: at most kMaxRegNB K-blocks)
+    a.nar_on = 1; a.nar_d = 16 - p.out.W;
+    if (epi == 2) { a.nar_lo = (int32_t)p.out.lo; a.nar_hi = (int32_t)p.out.hi; }
+    else { a.nar_sh = 32 - p.out.W; }
+  }
   a.n_steps = (p.n + 1023) / 1024;
   a.n8 = (p.n + 7) / 8 * 8;
   // >= 16384 waves when the problem allows it; a chunk re-reads NB-1 halo blocks per step anyway

@@ -148,6 +148,23 @@ def test_transposed_reload_in_the_exact_sum_class_runs_the_matrix_cores(N, per_c
             other.set_state(fir.state())
 
 
+@pytest.mark.parametrize("n_taps", [15, 63, 127, 255, 300, 600])
+@pytest.mark.parametrize("fo", [A.Fmt(12, 1, True, "RND", "SAT"), A.Fmt(14, 2, True, "TRN", "SAT"), A.Fmt(8, 1, True, "RND", "SAT"),
+                                A.Fmt(12, 1, True, "RND", "WRAP"), A.Fmt(15, 2, True, "TRN", "WRAP"), A.Fmt(9, 3, True, "RND", "WRAP"),
+                                A.Fmt(2, 1, True, "RND", "SAT")])
+def test_output_types_of_fewer_than_16_bits_keep_the_32_bit_epilogue(n_taps, fo):
+    """ADC-width OUT_TYPEs (<12,..>, <14,..>, ...): AC_SAT clamps to the narrower range, AC_WRAP sign-extends the low W bits, both on the packed
+    tile words of the fast epilogue classes (up to 9 K-blocks; longer filters take the 64-bit branch-free epilogue).  Windowed-sinc sets
+    (band-limited high byte plane: the register-resident kernels) and dense random ones, unit gain and a gain that saturates."""
+    from bench import windowed_sinc_raw
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
+    for k, c in enumerate((windowed_sinc_raw(n_taps | 1, 0.1, fc.F)[:n_taps],
+                           np.minimum(rand_raw(np.random.default_rng(n_taps), fc, (n_taps,)), 32639) >> (6 if n_taps > 255 else 3))):
+        fir = check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=5, n=2048 + 3 * n_taps + 8, splits=[1024 + 16], seed=n_taps + fo.W + k,
+                         coeffs=np.asarray(c, dtype=np.int64), expect_path="mfma_i8")
+        del fir
+
+
 @pytest.mark.parametrize("n_taps", [1, 2, 31, 32, 33, 63, 64, 65, 127, 255, 257])
 def test_mfma_path_tap_counts(n_taps):
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
