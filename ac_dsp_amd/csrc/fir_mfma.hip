@@ -150,6 +150,10 @@ struct MfmaArgs {
   // NAR instantiations of the pipelined body only; the edge chunks (fir_mfma_body) convert in registers: clamp to [nar_lo, nar_hi],
   // sign-extend the low 32 - nar_sh bits.  nar_on = 0: 16-bit OUT_TYPEs, nothing of this runs.
   int32_t nar_on, nar_d, nar_lo, nar_hi, nar_sh;
+  // 4-byte containers in the wide class (W4 instantiations of the pipelined body): w4_sat = 1: AC_SAT bounds, 0: wrap to W_out bits in
+  // 64 bits, 2: wrap in 32-bit arithmetic (2^8 mid + ll and, for rs > 16, hh + carry exact in int32: host-checked)
+  int32_t w4_sat;
+  int64_t w4_lo, w4_hi;
   int64_t *dbg;            // optional: per-wave {shader-clock ticks, 100 MHz real-time ticks} (ACDSP_DEBUG_CLOCK)
 };
 
@@ -487,7 +491,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 // issue and the other work hides in their shadow (tools/mfma_probe.hip: 39 cycles/MFMA with the epilogue
 // interleaved vs 36 bare).  The loop is unrolled by two so the accumulator sets and the B-fragment
 // double buffer swap roles by renaming; it contains no branch.
-template <int NB, int EPI, int HS, bool NAR = false>
+template <int NB, int EPI, int HS, bool NAR = false, bool W4 = false>
 __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
                                                    unsigned char *lds) {
   static_assert(EPI >= 1 && EPI <= 3, "fast epilogue classes only");
@@ -636,6 +640,35 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   int64_t *yout64 = (int64_t *)p.y + (int64_t)ch * p.out_stride;
   const int e3_sr = rs > 0 ? rs : 0, e3_wl = 64 - p.out.W, e3_sl = (rs < 0 ? -rs : 0) + e3_wl;
   auto emit = [&](auto wide_c, int64_t T0, const v16i &hh, const v16i &mid, const v16i &ll, int prsel = 2) {
+    if constexpr (EPI == 3 && W4) {
+      // 4-byte containers (OUT_TYPEs of 17 .. 32 bits; round 4): the same 64-bit value, wrapped (AC_WRAP) or clamped (AC_SAT: MfmaArgs::w4_*)
+      // to W bits, as int32 -- a 4 KB tile of 16-byte slots, slot = 8 n + 2 g + h, XOR-swizzled with n >> 1 so that the ds_write_b128 here
+      // (16 lanes = columns n .. n + 15 of one (g, h): two 128-byte rows per column pair, eight distinct 16-byte bank groups in each) and
+      // the linear ds_read_b128 of flush() (16 consecutive slots = two whole column rows) are bank-conflict free.
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        int o[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int r = 4 * g + rr;
+          if (a.w4_sat == 2) {
+            // AC_WRAP needs the result mod 2^32 only: lo = 2^8 mid + ll is exact in int32 (host-checked), the rest may wrap
+            const int lo = (int)(((unsigned)mid[r] << 8) + (unsigned)ll[r]);
+            const unsigned q32 = rs <= 16 ? ((unsigned)hh[r] << (16 - rs)) + (unsigned)(lo >> rs) : (unsigned)((hh[r] + (lo >> 16)) >> (rs - 16));
+            o[rr] = (int)(q32 << (32 - p.out.W)) >> (32 - p.out.W);
+          } else {
+            const int64_t V = ((int64_t)hh[r] << 16) + ((int64_t)mid[r] << 8) + (int64_t)ll[r];
+            int64_t q = V >> e3_sr;
+            if (a.w4_sat) { q = q < a.w4_lo ? a.w4_lo : (q > a.w4_hi ? a.w4_hi : q); }
+            else { q = (int64_t)((uint64_t)q << e3_sl) >> e3_wl; }
+            o[rr] = (int)q;
+          }
+        }
+        const int slot = 8 * n_col + ((2 * g + h) ^ ((n_col >> 1) & 7));
+        *(v4i *)(obuf + slot * 16) = (v4i){o[0], o[1], o[2], o[3]};
+      }
+      return;
+    }
     if constexpr (EPI == 3) {
       // y = wrap_W((V + rnd) >> rs) (or V << -rs), V = 2^16 hh + 2^8 mid + ll.  The 1024 outputs of the step form an
       // 8 KB tile of 16-byte slots (slot = 16 n + 4 g + 2 h + half), XOR-swizzled with the column so that both the
@@ -687,6 +720,20 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   };
   // ... and its row-contiguous write-out: two coalesced 16-byte-per-lane stores
   auto flush = [&](int64_t T0) {
+    if constexpr (EPI == 3 && W4) {
+      char *yout32 = (char *)((int32_t *)p.y + (int64_t)ch * p.out_stride + T0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int P = 64 * k + lane;
+        const v4i val = *(const v4i *)(obuf + ((P & ~7) | ((P & 7) ^ ((P >> 4) & 7))) * 16);
+#if ACDSP_FIR_NT & 4
+        __builtin_nontemporal_store(val, (v4i *)(yout32 + (unsigned)(16 * P)));
+#else
+        *(v4i *)(yout32 + (unsigned)(16 * P)) = val;
+#endif
+      }
+      return;
+    }
     if constexpr (EPI == 3) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
@@ -846,7 +893,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
 
 // NB > kMaxRegNB (the 1023-tap shape, NB = 33): one wave per SIMD with the whole 512-entry register file -- 2 * 33 Toeplitz
 // fragments are 264 registers (fewer with a high-byte band), next to two accumulator sets and the B-fragment double buffer.
-template <int NB, int EPI, int HS, int WAVES, bool NAR = false>
+template <int NB, int EPI, int HS, int WAVES, bool NAR = false, bool W4 = false>
 __global__ void __launch_bounds__(64 * WAVES, (NB > kMaxRegNB ? 1 : kOccupancy))
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   // WAVES == 1: the pipelined body keeps a 4-step ring of staged planes (4 arrays of 128 + NB - 1 slots), the plain body two windows
@@ -859,7 +906,7 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n && (s0 > 0 || s1 >= 2);
   const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (WAVES == 1 && EPI != 0) {
-    if (interior) { fir_mfma_pipe_body<NB, EPI, HS, NAR>(p, frag, a, lds); }
+    if (interior) { fir_mfma_pipe_body<NB, EPI, HS, NAR, W4>(p, frag, a, lds); }
     else if constexpr (EPI == 3) { fir_mfma_body<NB, 0, 0, WAVES, false>(p, frag, a, lds); }   // edges: generic epilogue
     else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
   } else {
@@ -885,20 +932,22 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   }
 }
 
+// NAR (OUT_TYPEs of fewer than 16 bits; no band skip) and W4 (4-byte containers) instantiations of up to kMaxRegNB K-blocks live in a
+// translation unit of their own (fir_mfma_alt.hip) for compile time
+hipError_t launch_fir_mfma_alt(const FirParams &p, int nb, int hs, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s);
+
 template <int NB, int HS, int WAVES>
 static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   const dim3 blk(64 * WAVES);
-  if constexpr (HS == 0 && WAVES == 1 && NB <= kMaxRegNB) {
-    if (a.nar_on && (epi == 1 || epi == 2)) {   // OUT_TYPEs of fewer than 16 bits: instantiated without a band skip only
-      if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, 0, 1, true>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
-      else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, 0, 1, true>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
-      return hipGetLastError();
-    }
+  if constexpr (WAVES == 1 && NB <= kMaxRegNB) {
+    if ((HS == 0 && a.nar_on && (epi == 1 || epi == 2)) || (epi == 3 && p.out_eb == 4)) { return launch_fir_mfma_alt(p, NB, HS, d_frag, a, epi, grid, s); }
   }
   if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   else if (epi == 2) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   else if (epi == 3 && WAVES == 1 && NB <= kMaxRegNB) {
-    if constexpr (NB <= kMaxRegNB) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 3, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
+    if constexpr (NB <= kMaxRegNB) {
+      hipLaunchKernelGGL((fir_mfma_kernel<NB, 3, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a);
+    }
   }
   else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 0, 0, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   return hipGetLastError();
@@ -1304,6 +1353,41 @@ hipError_t launch_fir_mfma_mid2(const FirParams &p, int nb, const uint32_t *d_fr
     default: return hipErrorInvalidValue;
   }
 }
+#elif ACDSP_FIR_TU_MID == 4
+template <int NB, int HS>
+static hipError_t launch_alt_hs(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  const v4i *f = (const v4i *)d_frag;
+  if (epi == 3) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 3, HS, 1, false, true>), grid, dim3(64), 0, s, p, f, a); }
+  else if constexpr (HS == 0) {
+    if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, 0, 1, true>), grid, dim3(64), 0, s, p, f, a); }
+    else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, 0, 1, true>), grid, dim3(64), 0, s, p, f, a); }
+  } else { return hipErrorInvalidValue; }
+  return hipGetLastError();
+}
+template <int NB>
+static hipError_t launch_alt_nb(const FirParams &p, int hs, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  if constexpr (NB >= 7) {   // the band-skip codes launch_nb picks
+    if (hs == 3 + 16 * 3) { return launch_alt_hs<NB, 3 + 16 * 3>(p, d_frag, a, epi, grid, s); }
+    if (hs == 3 + 16 * 2) { return launch_alt_hs<NB, 3 + 16 * 2>(p, d_frag, a, epi, grid, s); }
+    if (hs == 2 + 16 * 3) { return launch_alt_hs<NB, 2 + 16 * 3>(p, d_frag, a, epi, grid, s); }
+  }
+  if constexpr (NB >= 5) { if (hs == 2 + 16 * 2) { return launch_alt_hs<NB, 2 + 16 * 2>(p, d_frag, a, epi, grid, s); } }
+  return hs == 0 ? launch_alt_hs<NB, 0>(p, d_frag, a, epi, grid, s) : hipErrorInvalidValue;
+}
+hipError_t launch_fir_mfma_alt(const FirParams &p, int nb, int hs, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  switch (nb) {
+    case 1: return launch_alt_nb<1>(p, hs, d_frag, a, epi, grid, s);
+    case 2: return launch_alt_nb<2>(p, hs, d_frag, a, epi, grid, s);
+    case 3: return launch_alt_nb<3>(p, hs, d_frag, a, epi, grid, s);
+    case 4: return launch_alt_nb<4>(p, hs, d_frag, a, epi, grid, s);
+    case 5: return launch_alt_nb<5>(p, hs, d_frag, a, epi, grid, s);
+    case 6: return launch_alt_nb<6>(p, hs, d_frag, a, epi, grid, s);
+    case 7: return launch_alt_nb<7>(p, hs, d_frag, a, epi, grid, s);
+    case 8: return launch_alt_nb<8>(p, hs, d_frag, a, epi, grid, s);
+    case 9: return launch_alt_nb<9>(p, hs, d_frag, a, epi, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
 #else
 hipError_t launch_fir_mfma_mid3(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   switch (nb) {
@@ -1405,6 +1489,11 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
       p.acc.F - p.out.F >= 1 && p.acc.F - p.out.F <= 62 && p.out.W >= 2 && p.out.W <= 16) {
     return 4;
   }
+  // 4-byte containers (W_out 17 .. 32): the wide class with an int32 tile; AC_WRAP or AC_SAT
+  if (p.out_eb == 4 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && acc_wide &&
+      rs >= 0 && rs <= 38 && p.out.W >= 2 && p.out.W <= 32 && ll_max + corr_abs + 2 < (int64_t(1) << 31) && plan.nb <= kMaxRegNB) {
+    return 3;
+  }
   // wide rows: 64-bit shift-and-wrap epilogue of the pipelined body (the low plane still carries C in 32 bits)
   if (p.out_eb == 8 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && p.out.O == ACDSP_WRAP && acc_wide &&
       rs >= -16 && rs <= 38 && p.out.W >= 2 && p.out.W <= 64 && (rs < 0 ? -rs : 0) + (64 - p.out.W) <= 63 && ll_max + corr_abs + 2 < (int64_t(1) << 31) && plan.nb <= kMaxRegNB) {
@@ -1422,7 +1511,8 @@ int fir_mfma_issued_per_step(const FirParams &p, const FirMfmaPlan &plan) {
   const int epi = fir_mfma_epilogue_class(p, plan), nb = plan.nb;
   int band = nb;
   if (nb <= kMaxRegNB) {
-    const int hs = epi ? pick_hs(nb, plan.hi_mask) : 0;
+    const bool no_skip = (epi == 1 || epi == 2) && p.out_eb == 2 && p.out.W < 16;   // NAR instantiations
+    const int hs = (epi && !no_skip) ? pick_hs(nb, plan.hi_mask) : 0;
     band = nb - (hs & 15) - (hs >> 4);
   } else if (epi) {
     int b0 = 0, b1 = nb - 1;
@@ -1452,6 +1542,13 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   const int epi = fir_mfma_epilogue_class(p, plan);
   MfmaArgs a;
   a.nar_on = 0; a.nar_d = 0; a.nar_lo = INT32_MIN; a.nar_hi = INT32_MAX; a.nar_sh = 0;
+  a.w4_sat = (epi == 3 && p.out_eb == 4 && p.out.O == ACDSP_SAT) ? 1 : 0; a.w4_lo = p.out.lo; a.w4_hi = p.out.hi;
+  if (epi == 3 && p.out_eb == 4 && p.out.O == ACDSP_WRAP) {
+    const int rs4 = p.in.F + p.cf.F - p.out.F;
+    const int64_t rnd4 = (p.out.Q == ACDSP_RND && rs4 > 0) ? (int64_t(1) << (rs4 - 1)) : 0;
+    const int64_t lo_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo) * 256 + 128 * plan.sum_abs_lo + (plan.corr < 0 ? -plan.corr : plan.corr) + rnd4 + 2;
+    if (rs4 >= 1 && rs4 <= 31 && lo_max < (int64_t(1) << 31) && 128 * plan.sum_abs_hi + (lo_max >> 16) + 2 < (int64_t(1) << 31)) { a.w4_sat = 2; }
+  }
   if ((epi == 1 || epi == 2) && p.out_eb == 2 && p.out.W < 16) {   // (class 1 / 2 with fewer than 16 bits: at most kMaxRegNB K-blocks)
     a.nar_on = 1; a.nar_d = 16 - p.out.W;
     if (epi == 2) { a.nar_lo = (int32_t)p.out.lo; a.nar_hi = (int32_t)p.out.hi; }

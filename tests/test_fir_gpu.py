@@ -165,6 +165,20 @@ def test_output_types_of_fewer_than_16_bits_keep_the_32_bit_epilogue(n_taps, fo)
         del fir
 
 
+@pytest.mark.parametrize("n_taps", [15, 63, 127, 255, 300])
+@pytest.mark.parametrize("fo", [A.Fmt(24, 6, True, "RND", "SAT"), A.Fmt(32, 12, True, "TRN", "WRAP"), A.Fmt(20, 4, True, "RND", "WRAP"),
+                                A.Fmt(32, 3, True, "RND", "SAT"), A.Fmt(18, 2, True, "TRN", "SAT"), A.Fmt(30, 2, True, "TRN", "WRAP")])
+def test_output_types_of_17_to_32_bits_take_the_wide_class_with_an_int32_tile(n_taps, fo):
+    """4-byte OUT containers: the wide (64-bit recombination) class of the pipelined kernel with a 4 KB int32 tile, AC_WRAP and AC_SAT; the
+    chunk edges and filters past 9 K-blocks on the generic epilogue.  Fraction counts from rs = 2 (fo.I = 2: 30 fraction bits kept) to 24."""
+    from bench import windowed_sinc_raw
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
+    for k, c in enumerate((windowed_sinc_raw(n_taps | 1, 0.1, fc.F)[:n_taps],
+                           np.minimum(rand_raw(np.random.default_rng(n_taps), fc, (n_taps,)), 32639) >> 2)):
+        check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=5, n=8 * 1024 + 3 * n_taps + 8, splits=[2048 + 16], seed=n_taps + fo.W + k,
+                   coeffs=np.asarray(c, dtype=np.int64), expect_path="mfma_i8")
+
+
 @pytest.mark.parametrize("n_taps", [1, 2, 31, 32, 33, 63, 64, 65, 127, 255, 257])
 def test_mfma_path_tap_counts(n_taps):
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
