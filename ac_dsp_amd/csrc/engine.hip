@@ -769,7 +769,10 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   if (path == ACDSP_PATH_MFMA_I8) { e = launch_fir_mfma(k, h->plan, d.coeffs_per_channel, h->d_frag, h->d_corr, s); }
   else if (path == ACDSP_PATH_MFMA_GEN) { e = launch_fir_gen(k, h->gplan, h->d_gfrag, 0, 0, 0, n, s); }
   else if (path == ACDSP_PATH_LOSSLESS64) { e = launch_fir_lossless64(k, s); }
-  else { e = launch_fir_generic(k, s); }
+  else {
+    static const bool no_lossy = getenv("ACDSP_NO_LOSSY_FAST") != nullptr;   // A/B knob: the exact-order kernel for every per-tap class
+    e = (!no_lossy && fir_lossy_fast_ok(k)) ? launch_fir_lossy(k, s) : launch_fir_generic(k, s);
+  }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR kernel launch failed: %s", hipGetErrorString(e)); }
   if (!small) {
     HIP_TRY(hipEventRecord(h->tm.stop(), s));

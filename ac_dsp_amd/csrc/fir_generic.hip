@@ -182,6 +182,100 @@ hipError_t launch_fir_lossless64(const FirParams &p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Class B on 16-bit types (lossy accumulator, AC_TRN / AC_RND into AC_WRAP): acc = sum_k Q(x[t-k] c[k]) mod 2^W_acc with
+// Q(p) = (p + rnd) >> s, s = F_in + F_c - F_acc in 1 .. 30.  `acc += p` quantises acc 2^s + p, and acc is a multiple of the quantum, so
+// every product is quantised on its own and the additions are exact: the sum has no order (SHIFT_REG, ROTATE_SHIFT, C_BUFF and the
+// ascending ac_fir_reg_share core alike) and AC_WRAP is applied once at the end.  The products fit int32 (16 x 16 bits).
+// One lane = 8 consecutive outputs; per 8 taps it takes ONE aligned 16-byte LDS read (the 8 samples in front of its window; the other
+// half of the 16-sample register window is the previous read), 64 x { v_mad_i32_i24, v_ashrrev_i32, v_add } and one 64-bit accumulate
+// per output (G8: eight quantised products cannot leave int32 for s >= 3; s = 1, 2 accumulate in 64 bits per tap).  Coefficients are
+// wave-uniform scalar loads.  A 256-thread block covers 2048 outputs of one channel.
+constexpr int kLossyOut = 8, kLossyTile = 256 * kLossyOut;
+
+bool fir_lossy_fast_ok(const FirParams &p) {
+  const int s = p.in.F + p.cf.F - p.acc.F;
+  const bool order_free = p.ftype == ACDSP_SHIFT_REG || p.ftype == ACDSP_ROTATE_SHIFT || p.ftype == ACDSP_C_BUFF || p.ftype == kRsShiftReg ||
+                          (p.ftype == ACDSP_TRANSPOSED && !p.use_rt);
+  return order_free && p.in_eb == 2 && (p.in.S ? p.in.W <= 16 : p.in.W <= 15) && (p.cf.S ? p.cf.W <= 16 : p.cf.W <= 15) &&
+         p.acc.O == ACDSP_WRAP && (p.acc.Q == ACDSP_TRN || p.acc.Q == ACDSP_RND) && p.acc.W <= 64 && s >= 1 && s <= 30 && p.n_taps <= 2048 &&
+         !p.hist_next;
+}
+
+template <bool G8>
+__global__ void __launch_bounds__(256) fir_lossy_kernel(FirParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int16_t *win = (int16_t *)smem_raw;                     // win[j] = x[t0 - NP + j], j in [0, NP + kLossyTile)
+  const int N = p.n_taps, N8 = (N + 7) & ~7, NP = N8 + 8;
+  const int ch = blockIdx.y, tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * kLossyTile;
+  const int16_t *xrow = (const int16_t *)p.x + (int64_t)ch * p.in_stride;
+  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)ch * p.hl + p.hl;
+  for (int j = tid; j < NP + kLossyTile; j += 256) {
+    const int64_t g = t0 - NP + j;
+    int16_t v = 0;
+    if (g >= 0) { if (g < p.n) { v = xrow[g]; } }
+    else if (!p.use_rt && g >= -(int64_t)p.hl) { v = hrow[g]; }
+    win[j] = v;
+  }
+  __syncthreads();
+  const int64_t *cg = p.coeffs + (p.coeffs_per_channel ? (int64_t)ch * N : 0);
+  const int s = p.in.F + p.cf.F - p.acc.F;
+  const int rnd = p.acc.Q == ACDSP_RND ? (1 << (s - 1)) : 0;
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  const int base = NP + kLossyOut * tid;                  // window index of this lane's first output
+  int64_t acc[kLossyOut];
+#pragma unroll
+  for (int j = 0; j < kLossyOut; j++) { acc[j] = 0; }
+  int xs[16];                                             // samples win[base - i0 - 8 .. base - i0 + 7]
+  {
+    const v4i_ hi = *(const v4i_ *)(win + base);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xs[8 + 2 * q] = (int)(int16_t)hi[q]; xs[9 + 2 * q] = hi[q] >> 16; }
+  }
+  for (int i0 = 0; i0 < N8; i0 += 8) {
+    const v4i_ lo = *(const v4i_ *)(win + base - i0 - 8);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xs[2 * q] = (int)(int16_t)lo[q]; xs[2 * q + 1] = lo[q] >> 16; }
+    int part[kLossyOut];
+#pragma unroll
+    for (int j = 0; j < kLossyOut; j++) { part[j] = 0; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int c = (i0 + k < N) ? (int)cg[i0 + k] : 0;   // wave-uniform
+      const int r = (i0 + k < N) ? rnd : 0;
+#pragma unroll
+      for (int j = 0; j < kLossyOut; j++) {
+        const int q = (xs[8 + j - k] * c + r) >> s;       // x[t + j - (i0 + k)]
+        if (G8) { part[j] += q; } else { acc[j] += q; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kLossyOut; j++) {
+      if (G8) { acc[j] += part[j]; }
+      xs[8 + j] = xs[j];                                   // the new low half is the next iteration's high half
+    }
+  }
+  const int64_t t = t0 + kLossyOut * tid;
+#pragma unroll
+  for (int j = 0; j < kLossyOut; j++) {
+    if (t + j < p.n) {
+      const int64_t a = wrap64(acc[j], p.acc.W, p.acc.S);
+      store_raw(p.y, (int64_t)ch * p.out_stride + t + j, p.out_eb, requant64(a, p.acc.F, p.out));
+    }
+  }
+}
+
+hipError_t launch_fir_lossy(const FirParams &p, hipStream_t s) {
+  if (p.n <= 0) { return hipSuccess; }
+  const int N8 = (p.n_taps + 7) & ~7;
+  const size_t lds = sizeof(int16_t) * (size_t)(N8 + 8 + kLossyTile);
+  dim3 grid((unsigned)((p.n + kLossyTile - 1) / kLossyTile), (unsigned)p.n_ch);
+  if (p.in.F + p.cf.F - p.acc.F >= 3) { hipLaunchKernelGGL(fir_lossy_kernel<true>, grid, dim3(256), lds, s, p); }
+  else { hipLaunchKernelGGL(fir_lossy_kernel<false>, grid, dim3(256), lds, s, p); }
+  return hipGetLastError();
+}
+
 // hist_next[ch][j] = sample at local time n - hl + j (from this call's input, or the old history).
 __global__ void fir_hist_update_kernel(FirParams p, void *hist_next) {
   const int ch = blockIdx.y;

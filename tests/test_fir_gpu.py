@@ -179,6 +179,24 @@ def test_output_types_of_17_to_32_bits_take_the_wide_class_with_an_int32_tile(n_
                    coeffs=np.asarray(c, dtype=np.int64), expect_path="mfma_i8")
 
 
+@pytest.mark.parametrize("n_taps", [1, 7, 8, 63, 255, 300])
+@pytest.mark.parametrize("ftype", ["SHIFT_REG", "ROTATE_SHIFT", "C_BUFF"])
+@pytest.mark.parametrize("fa", [A.Fmt(24, 8), A.Fmt(24, 8, True, "RND", "WRAP"), A.Fmt(40, 13, True, "RND", "WRAP"), A.Fmt(20, 3, False, "TRN", "WRAP"),
+                                A.Fmt(44, 18, True, "RND", "WRAP"), A.Fmt(46, 19), A.Fmt(12, 10, True, "RND", "WRAP")])
+def test_lossy_wrapping_accumulators_on_16_bit_types(n_taps, ftype, fa):
+    """Class B: every product is quantised into ACC_TYPE on its own (AC_TRN / AC_RND), the accumulator wraps -- the sum has no
+    order.  16-bit samples and coefficients run fir_lossy_kernel (8 outputs per lane, int32 products); shifts of 1 and 2 bits (64-bit
+    accumulation per tap), 12 bits, 28 + bits (everything rounds away but the largest products), an unsigned and a very narrow accumulator;
+    history across calls, a ragged last tile, per-channel coefficient sets.  Against the oracle's MAC loops in the reference's order."""
+    fin, fc = A.Fmt(16, 2), A.Fmt(16, 2)
+    fo = A.Fmt(16, 2, True, "RND", "SAT") if fa.S else A.Fmt(22, 5, True, "RND", "SAT")   # (signed containers: torch has no uint16)
+    n = 2048 + 600 + n_taps
+    check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=n, splits=[5, 1200], seed=n_taps + fa.W, expect_path="generic")
+    if ftype == "SHIFT_REG" and fa.F < 11 + 14:       # narrower sample / unsigned coefficient types: 25 fraction bits in a product
+        check_case(n_taps, ftype, A.Fmt(12, 1), A.Fmt(15, 1, False), fa, fo, n_ch=4, n=n, per_channel=True, splits=[2047], seed=n_taps + fa.F,
+                   expect_path="generic")
+
+
 @pytest.mark.parametrize("n_taps", [1, 2, 31, 32, 33, 63, 64, 65, 127, 255, 257])
 def test_mfma_path_tap_counts(n_taps):
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
