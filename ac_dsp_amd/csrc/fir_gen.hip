@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   constexpr int PPB = 16 / S;                                 // samples of a 16-byte piece = bytes of one of its planes
   constexpr int SPK = 64 / S;                                 // slots per 1 KB load
   static_assert(S == 2 || S == 4, "ring kernel: 2- and 4-byte samples");
-  static_assert(R % 2 == 0 && SPK % R == 0 && H <= ADV && S * H <= 64 && NLD * SPK == ADV && NLD >= 1, "ring geometry");
+  static_assert((R % 2 == 0 || R == 1) && SPK % R == 0 && H <= ADV && S * H <= 64 && NLD * SPK == ADV && NLD >= 1, "ring geometry");
   constexpr int KSTEP = (SPK + 2 * (SPK / R)) * 16;           // LDS bytes from a piece of load k to the same lane's piece of load k + 1
   constexpr int PADV = (ADV + 2 * (ADV / R)) * 16;            // LDS bytes a step advances
   constexpr int RING = (SPW < 2 ? SPW : 2) * ADV + H;         // chunks of one or two steps never wrap
@@ -917,6 +917,8 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 3 && (oeb == 2 || oeb == 8) && pl.R == 4 && !ring_env) { ring_shape = oeb == 2 ? 12 : 13; r_spw = 4; }
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && oeb == 8 && pl.R == 8 && !ring_env) { ring_shape = 14; r_spw = 2; }
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 8 && (oeb == 2 || oeb == 8) && pl.R == 16 && !ring_env) { ring_shape = oeb == 2 ? 15 : 16; r_spw = 2; }
+    // plain (R = 1) FIR on 32-bit samples, up to three coefficient digits and three K-blocks (~130 taps): one 1 KB load per 256-output step
+    else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 3 && (oeb == 8 || oeb == 4) && pl.R == 1 && !ring_env) { ring_shape = oeb == 8 ? 20 : 21; r_spw = 8; }
     else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 6; if (!ring_env) { r_spw = 1; r_pf = 1; } }   // CIC R16 N5 on int32: 16 KB per step = one step per wave (LDS: 18 KB of planes per step)
   }
   if (ring_shape) {
@@ -948,6 +950,8 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     else if (ring_shape == 4) { e = launch_ring<int16_t, 2, 2, 3, 8, 4>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 5) { e = launch_ring1<int32_t, 4, 2, 2, 4, 8, 4, 4, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 6) { e = launch_ring1<int32_t, 4, 3, 6, 16, 8, 1, 1, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 20) { e = launch_ring1<int32_t, 4, 3, 3, 1, 8, 8, 8, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 21) { e = launch_ring1<int32_t, 4, 3, 3, 1, 4, 8, 8, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 10) { e = launch_ring1<int16_t, 2, 2, 2, 2, 2, 8, 8, true, true>(grid, s, p, fr, a); }
     else if (ring_shape == 11) { e = launch_ring1<int16_t, 2, 2, 2, 2, 8, 8, 8, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 12) { e = launch_ring1<int16_t, 2, 2, 3, 4, 2, 4, 4, true, true>(grid, s, p, fr, a); }
