@@ -177,6 +177,25 @@ struct Staging {
 
 }  // namespace
 
+namespace {
+// dst[ch][j] = src[ch][j] ^ 0x8000 for the n samples of a call (row stride ds, multiple of 16: the tail up to ds is zero-filled in the
+// flipped domain's zero = 0x8000 ^ 0 ... it is never used by an output that exists) and for the hl history samples
+__global__ void flip16_kernel(const uint16_t *x, int64_t xs, int64_t n, uint16_t *dx, int64_t ds, const uint16_t *hist, uint16_t *dh, int hl) {
+  const int ch = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ds + hl; j += (int64_t)gridDim.x * blockDim.x) {
+    if (j < ds) { dx[(int64_t)ch * ds + j] = (uint16_t)((j < n ? x[(int64_t)ch * xs + j] : 0) ^ 0x8000u); }
+    else { dh[(int64_t)ch * hl + (j - ds)] = (uint16_t)(hist[(int64_t)ch * hl + (j - ds)] ^ 0x8000u); }
+  }
+}
+hipError_t launch_flip16(const void *x, int64_t xs, int64_t n, void *dx, int64_t ds, const void *hist, void *dh, int hl, int n_ch, hipStream_t s) {
+  int64_t blocks = (ds + hl + 1023) / 1024;
+  if (blocks > 4096) { blocks = 4096; }
+  hipLaunchKernelGGL(flip16_kernel, dim3((unsigned)blocks, (unsigned)n_ch), dim3(256), 0, s, (const uint16_t *)x, xs, n, (uint16_t *)dx, ds,
+                     (const uint16_t *)hist, (uint16_t *)dh, hl);
+  return hipGetLastError();
+}
+}  // namespace
+
 struct acdsp_fir {
   acdsp_fir_desc_t d;
   int in_eb, out_eb, hl;
@@ -192,6 +211,10 @@ struct acdsp_fir {
   // of an EARLIER coefficient set are still in it -- for the n_taps - 1 samples behind a coefficient change (or a loaded state blob).  Those
   // samples run the exact-order kernel on reg_trans; everything else is the same dot product as SHIFT_REG and runs the matrix-core kernels
   // on the input history, which is kept up to date by every call.  reg_trans is rebuilt from the history (rt_from_hist) when it is asked for.
+  // unsigned 16-bit samples on the int8 MFMA kernel (round 4): x_u = (x_u ^ 0x8000 as int16) + 32768, so a flipped copy of the call's samples
+  // and of the history goes through the signed kernel and 32768 * sum(c) rides in the correction constant; the state stays raw
+  bool in_flip = false;
+  Staging st_u;
   bool rt_hybrid = false, rt_valid = true;
   int64_t rt_since = 0;         // samples since the last coefficient change / state load, saturating at n_taps - 1
   int cur_rt = 0;               // rt_hybrid: index of the current reg_trans buffer (the history has `cur`)
@@ -507,7 +530,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   // exact-dot-product class: the kernels compute `sum << (fa - fi - fc)` in 64 bits, so the shift must be 0..63 (formats
   // with I outside [0, W] can ask for more: those stay on the per-tap path)
   static const bool no_hybrid = getenv("ACDSP_NO_RT_HYBRID") != nullptr;   // A/B knob: reg_trans on the exact-order kernel for every sample
-  h->rt_hybrid = h->use_rt && !no_hybrid && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) && desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && !h->wide;
+  h->rt_hybrid = h->use_rt && !no_hybrid && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) && (desc->in.S || desc->in.W <= 15) && desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && !h->wide;
   h->rt_since = desc->n_taps - 1;   // an all-zero state carries no coefficients
   bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && (!h->use_rt || h->rt_hybrid) && !h->wide;
   const int ift = internal_ftype(desc->kind, desc->ftype);
@@ -561,6 +584,7 @@ int32_t acdsp_fir_destroy(acdsp_fir_t h) {
   if (h->d_gfrag) { (void)hipFree(h->d_gfrag); }
   h->tm.destroy();
   h->st.destroy();
+  h->st_u.destroy();
   delete h;
   return ACDSP_OK;
 }
@@ -611,9 +635,12 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   }
   HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, n_sets * d.n_taps * sizeof(int64_t), hipMemcpyHostToDevice));
   h->mfma_ok = false;
-  const bool i16_in = d.in.S ? d.in.W <= 16 : d.in.W <= 15;
+  h->in_flip = false;
+  static const bool no_flip = getenv("ACDSP_NO_UNSIGNED16") != nullptr;   // A/B knob: unsigned 16-bit samples stay on the exact-sum VALU kernel
+  const bool flip = !d.in.S && d.in.W == 16 && !no_flip && !h->use_rt;
+  const bool i16_in = d.in.W <= 15 || (d.in.W == 16 && (d.in.S || flip));
   const bool i16_cf = d.coeff.S ? d.coeff.W <= 16 : d.coeff.W <= 15;
-  if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && i16_in && i16_cf && d.in.S && h->in_eb == 2 &&
+  if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && i16_in && i16_cf && h->in_eb == 2 &&
       fir_mfma_plan_blocks(d.n_taps) <= fir_mfma_max_blocks()) {
     const int nb = fir_mfma_plan_blocks(d.n_taps);
     const size_t per_set = (size_t)2 * nb * 64 * 4;
@@ -627,6 +654,11 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
       FirMfmaPlan pl;
       ok = fir_mfma_build_fragments(eff.data(), d.n_taps, &pl, frag.data() + st * per_set);
       if (!ok) { break; }
+      if (flip) {   // + 32768 * sum(c): the samples go through the kernel as x - 32768
+        int64_t sc = 0;
+        for (int64_t v : eff) { sc += v; }
+        pl.corr += 32768 * sc;
+      }
       corr[st] = pl.corr;
       worst.nb = pl.nb;
       worst.hi_mask |= pl.hi_mask; worst.lo_mask |= pl.lo_mask;
@@ -649,6 +681,7 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
       HIP_TRY(hipMemcpy(h->d_corr, corr.data(), corr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
       h->plan = worst;
       h->mfma_ok = true;
+      h->in_flip = flip;
     }
   }
   // wide inputs (more than 16 bits) / other misses of the int16 kernel: generalised multi-plane MFMA kernel
@@ -739,7 +772,18 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
     h->cur = nxw;
     return ACDSP_OK;
   }
-  if (path == ACDSP_PATH_MFMA_I8 || path == ACDSP_PATH_MFMA_GEN) {
+  FirParams kraw = k;   // the state kernels always see the caller's samples
+  const bool flipped = h->in_flip && path == ACDSP_PATH_MFMA_I8;
+  if (flipped) {
+    // unsigned 16-bit samples: a sign-flipped image of the call's rows and of the history (see acdsp_fir::in_flip)
+    const int64_t si = (n + 15) / 16 * 16;
+    if ((rc = h->st_u.ensure((size_t)d.n_channels * si * 2, (size_t)d.n_channels * h->hl * 2))) { return rc; }
+    const hipError_t ef = launch_flip16(d_in, in_stride, n, h->st_u.d_in, si, h->d_hist[h->cur], h->st_u.d_out, h->hl, d.n_channels, s);
+    if (ef != hipSuccess) { return fail(ACDSP_EHIP, "FIR sample staging kernel launch failed: %s", hipGetErrorString(ef)); }
+    k.x = h->st_u.d_in; k.in_stride = si; k.hist = h->st_u.d_out;
+    k.in.S = 1; k.in.lo = -32768; k.in.hi = 32767;
+  }
+  if (!flipped && (path == ACDSP_PATH_MFMA_I8 || path == ACDSP_PATH_MFMA_GEN)) {
     // The matrix-core kernels read rows with 16-byte vector loads (fir_gen: in whole 16-sample slots).  gfx950 serves a vector
     // access at any ELEMENT-aligned address, so the int8 kernel takes unaligned rows as they are (round 3: a row stride of 2^20 + 3
     // samples costs +12 %, profiles/r3_unaligned.txt; the staging copy below -- hipMemcpy2DAsync of misaligned rows -- cost 6.4 ms
@@ -760,7 +804,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   // Small calls (the drop-in run() of one channel; ac_fir_prog_coeffs is ONE sample per call, reference ac_fir_prog_coeffs.h:281)
   // are launch-bound: no timing events, and the exact-order kernels write the next history themselves -- one launch per call.
   const bool small = h->small_call;
-  const bool fuse_hist = small && (!h->use_rt || hyb) && (path == ACDSP_PATH_LOSSLESS64 || path == ACDSP_PATH_GENERIC ||
+  const bool fuse_hist = small && !flipped && (!h->use_rt || hyb) && (path == ACDSP_PATH_LOSSLESS64 || path == ACDSP_PATH_GENERIC ||
                                                 (path == ACDSP_PATH_MFMA_I8 && fir_mfma_register_resident(k, h->plan)));   // single-wave workgroups
   const int nxt_fused = hist_next_index(h->cur, false);
   if (fuse_hist) { k.hist_next = h->d_hist[nxt_fused]; }
@@ -801,7 +845,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   if (h->use_rt && !hyb) {
     e = launch_fir_rt_update(k, h->d_rt[nxt], s);
   } else {
-    e = launch_fir_hist_update(k, h->d_hist[nxt], s);
+    e = launch_fir_hist_update(flipped ? kraw : k, h->d_hist[nxt], s);
   }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR state kernel launch failed: %s", hipGetErrorString(e)); }
   h->cur = nxt;

@@ -1465,7 +1465,7 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   const int rs = p.in.F + p.cf.F - p.out.F;
   // |y| <= 32768 * sum|c| must fit the accumulator (no AC_WRAP event possible) ...
   const int acc_bits = p.acc.W - (p.acc.S ? 1 : 0) - p.lossless_shift;
-  const int64_t x_max = int64_t(1) << (p.in.W > 1 && p.in.W <= 16 ? p.in.W - 1 : 15);   // |x| <= 2^(W_in - 1): narrow samples need a narrower accumulator
+  const int64_t x_max = int64_t(1) << (p.in.W > 1 && p.in.W <= 16 ? p.in.W - (p.in.S ? 1 : 0) : 15);   // |x| <= 2^(W_in - 1) (unsigned: < 2^W_in): narrow samples need a narrower accumulator
   const bool acc_wide = acc_bits >= 63 || plan.sum_abs * x_max < (int64_t(1) << (acc_bits > 0 ? acc_bits : 0));
   // ... hh*256 + mid + carry must fit int32, and so must the low plane with corr + rounding constant preloaded
   const int64_t hh_max = 128 * plan.sum_abs_hi, mid_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo), ll_max = 128 * plan.sum_abs_lo;

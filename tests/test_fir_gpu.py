@@ -197,6 +197,42 @@ def test_lossy_wrapping_accumulators_on_16_bit_types(n_taps, ftype, fa):
                    expect_path="generic")
 
 
+@pytest.mark.parametrize("n_taps", [1, 31, 127, 255, 300])
+@pytest.mark.parametrize("ftype", ["SHIFT_REG", "C_BUFF", "FOLD_EVEN", "TRANSPOSED"])
+def test_unsigned_16_bit_samples_run_the_matrix_cores(n_taps, ftype):
+    """Offset-binary samples: <16,I,false> has 17 significant bits as a signed number.  The engine hands the int8 kernel a sign-flipped image of
+    the rows and of the history and adds 32768 * sum(c) to the correction constant; the state stays raw (blobs, reset, fallbacks).  Full-scale
+    samples, history across calls, a state blob carried into a second handle, per-channel sets; narrower unsigned types need no flip."""
+    kind = "const" if ftype == "TRANSPOSED" else "load"
+    fin, fc, fa = A.Fmt(16, 2, False), A.Fmt(16, 2), A.Fmt(44, 16)
+    nt = n_taps + (n_taps % 2 if ftype == "FOLD_EVEN" else 0)
+    from bench import windowed_sinc_raw
+    for k, fo in enumerate((A.Fmt(16, 3, True, "RND", "SAT"), A.Fmt(44, 16), A.Fmt(16, 3, True, "TRN", "WRAP"))):
+        cs = windowed_sinc_raw(max(nt | 1, 3), 0.1, fc.F)[:nt] >> 2 if k == 2 else np.minimum(rand_raw(np.random.default_rng(nt + k), fc, (nt,)), 32639)
+        check_case(nt, ftype, fin, fc, fa, fo, n_ch=4, n=2048 + 2 * nt + 24, kind=kind, splits=[5, 1100], seed=nt + fo.W, expect_path="mfma_i8",
+                   coeffs=np.asarray(cs, dtype=np.int64))
+    # state blob: raw samples
+    rng = np.random.default_rng(nt)
+    c = np.minimum(rand_raw(rng, fc, (nt,)), 32639)
+    a1 = A.Fir(nt, ftype, fin, fc, fa, A.Fmt(16, 3, True, "RND", "SAT"), n_channels=3, kind=kind)
+    a2 = A.Fir(nt, ftype, fin, fc, fa, A.Fmt(16, 3, True, "RND", "SAT"), n_channels=3, kind=kind)
+    a1.set_coeffs(c); a2.set_coeffs(c)
+    x = rand_raw(rng, fin, (3, 700 + nt))
+    x[0, :] = 65535
+    run_engine(a1, x[:, :333])
+    a2.set_state(a1.state())
+    assert np.array_equal(run_engine(a1, x[:, 333:]), run_engine(a2, x[:, 333:]))
+    orc = OracleFir(nt, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(A.Fmt(16, 3, True, "RND", "SAT")), n_ch=3)
+    yo = orc.run(c, x)
+    a1.reset()
+    assert np.array_equal(run_engine(a1, x, [333]), yo)
+    if ftype == "SHIFT_REG" and nt <= 257:             # (a dense set per channel beyond 9 K-blocks has no register-resident kernel)
+        check_case(nt, ftype, A.Fmt(15, 2, False), fc, fa, A.Fmt(16, 3, True, "RND", "SAT"), n_ch=4, n=1500, per_channel=True,
+                   coeffs=np.minimum(rand_raw(rng, fc, (4, nt)), 32639), splits=[777], seed=nt, expect_path="mfma_i8")
+        check_case(nt, ftype, fin, fc, fa, A.Fmt(16, 3, True, "RND", "SAT"), n_ch=4, n=1500, per_channel=True,
+                   coeffs=np.minimum(rand_raw(rng, fc, (4, nt)), 32639), splits=[777], seed=nt + 1, expect_path="mfma_i8")
+
+
 @pytest.mark.parametrize("n_taps", [1, 2, 31, 32, 33, 63, 64, 65, 127, 255, 257])
 def test_mfma_path_tap_counts(n_taps):
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
