@@ -94,8 +94,8 @@ __global__ void __launch_bounds__(kTile) mv_avg_kernel(MvAvgParams p) {
 // can wrap, else the 64-bit branch-free form) and stores 16 bytes per instruction.  The loads of the next tile are issued
 // before the arithmetic of the current one.  No workgroup barrier: waves never share data.
 struct MvStreamArgs {
-  int16_t c16[34];            // coefficients, zero padded (pairs (c[2q], c[2q+1]) are the v_dot2 operands of even outputs)
-  int16_t c16o[34];           // the same behind one zero: pairs (c[2q-1], c[2q]) for odd outputs, whose windows start in a high half
+  int16_t c16[66];            // coefficients, zero padded (pairs (c[2q], c[2q+1]) are the v_dot2 operands of even outputs)
+  int16_t c16o[66];           // the same behind one zero: pairs (c[2q-1], c[2q]) for odd outputs, whose windows start in a high half
   int32_t taps, h, hb, off, mode, nxg;
   int32_t linear, ls, e, rnd_e;
   int32_t cv32, s32, r32, lo32, hi32, ko32;   // 32-bit epilogue: q = (S + r32) >> s32, clamp, wrap (ko32 = 32 - W_out or 0)
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
 // true: launched.  Class and shape conditions of the streaming kernel (see above).
 static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   static const bool off = getenv("ACDSP_NO_MVAVG_STREAM") != nullptr;   // A/B knob
-  if (off || p.force_generic || !p.h_coeffs || p.taps > 33 || p.in_eb != 2 || !(p.in.S || p.in.W <= 15)) { return false; }
+  if (off || p.force_generic || !p.h_coeffs || p.taps > 65 || p.in_eb != 2 || !(p.in.S || p.in.W <= 15)) { return false; }
   if (p.n_sample < p.taps || p.n_sample % 8 != 0 || p.in_stride % 8 != 0 || ((uintptr_t)p.x % 16) != 0) { return false; }
   // the cast (ACC_TYPE) w[j] is exact and the accumulator wraps
   const int d = p.acc.F - p.in.F, sh = p.cf.F;
@@ -327,7 +327,10 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   if (p.out.O == ACDSP_SAT) { a.lo = p.out.lo; a.hi = p.out.hi; a.ko = 0; a.om = ~uint64_t(0); }
   else { a.lo = INT64_MIN; a.hi = INT64_MAX; a.ko = 64 - p.out.W; a.om = p.out.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.out.W)); }
   // 32-bit form: the accumulator cannot wrap (signed, W_acc >= 31 + ls) and the output shift swallows ls
-  a.cv32 = p.acc.S && p.acc.W >= 31 + a.ls && rs >= a.ls && rs - a.ls <= 30 && (p.out.S || p.out.W <= 31);
+  // (|sum| <= sum|c| * 2^(W_in - 1): samples narrower than 16 bits need a narrower accumulator)
+  int sum_bits = 0;
+  while (sum_bits < 62 && (int64_t(1) << sum_bits) <= sum_abs * (int64_t(1) << (p.in.W - (p.in.S ? 1 : 0)))) { sum_bits++; }   // |sum| < 2^sum_bits
+  a.cv32 = p.acc.S && p.acc.W >= sum_bits + 1 + a.ls && rs >= a.ls && rs - a.ls <= 30 && (p.out.S || p.out.W <= 31);
   if (a.cv32) {
     a.s32 = rs - a.ls;
     a.r32 = (p.out.Q == ACDSP_RND && a.s32 > 0) ? (1 << (a.s32 - 1)) : 0;
@@ -352,7 +355,7 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   if (blocks > 0x7FFFFFFF) { return false; }
   dim3 grid((unsigned)blocks);
   a.xcd_map = (xcd_map_wanted(false) && blocks % 8 == 0) ? 1 : 0;
-  const int nr = p.taps <= 9 ? 2 : (p.taps <= 17 ? 3 : (p.taps <= 25 ? 4 : 5));
+  const int nr = p.taps <= 9 ? 2 : (p.taps <= 17 ? 3 : (p.taps <= 25 ? 4 : (p.taps <= 33 ? 5 : (p.taps <= 49 ? 7 : 9))));   // taps <= 8 NR - 7
 #define ACDSP_MV_LAUNCH2(NR_, LIN_, CV_)                                                                                           \
   if (a.mode != 0) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true>), grid, dim3(256), 0, s, a); }                  \
   else { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, false>), grid, dim3(256), 0, s, a); }
@@ -366,7 +369,9 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
     case 2: ACDSP_MV_LAUNCH(2) break;
     case 3: ACDSP_MV_LAUNCH(3) break;
     case 4: ACDSP_MV_LAUNCH(4) break;
-    default: ACDSP_MV_LAUNCH(5) break;
+    case 5: ACDSP_MV_LAUNCH(5) break;
+    case 7: ACDSP_MV_LAUNCH(7) break;
+    default: ACDSP_MV_LAUNCH(9) break;
   }
 #undef ACDSP_MV_LAUNCH2
 #undef ACDSP_MV_LAUNCH

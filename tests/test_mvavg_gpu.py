@@ -93,7 +93,7 @@ STREAM_ACC = [
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("taps", [1, 3, 9, 11, 17, 25, 33])
+@pytest.mark.parametrize("taps", [1, 3, 9, 11, 17, 25, 33, 35, 49, 51, 65])
 def test_stream_kernel_classes(mode, taps):
     """16-bit samples / weights with sum |c| < 2^15, frames aligned to 16 bytes: the streaming kernel (path 'stream')."""
     rng = np.random.default_rng(100 + taps)
@@ -120,6 +120,17 @@ def test_stream_kernel_shapes(mode):
     check(9, mode, A.Fmt(16, 8), fc, fa, fo, 1024, 2, coeffs=c, seed=3, path="stream")
     c[:] = [-4095, 4095, -4095, 4095, -4095, 4095, -4095, 4095, -7]
     check(9, mode, A.Fmt(16, 8), fc, fa, fo, 1024, 2, coeffs=c, seed=4, path="stream")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_stream_kernel_narrow_sample_types_keep_the_32_bit_epilogue(mode):
+    """Samples of fewer than 16 bits bound the sums lower: an accumulator sized for THEM (W_acc < 31) cannot wrap either and keeps the 32-bit
+    conversion; one bit less and it may wrap (64-bit epilogue, same results)."""
+    rng = np.random.default_rng(12)
+    for fin, fa in ((A.Fmt(12, 4), A.Fmt(30, 10)), (A.Fmt(12, 4), A.Fmt(27, 7)), (A.Fmt(12, 4), A.Fmt(26, 6)), (A.Fmt(10, 2, False), A.Fmt(26, 4)),
+                    (A.Fmt(8, 1), A.Fmt(23, 2))):
+        for fo in (A.Fmt(12, 4, True, "RND", "SAT"), A.Fmt(16, 4, True, "TRN", "WRAP")):
+            check(9, mode, fin, A.Fmt(16, 2), fa, fo, 1024, 3, n_obj=3, seed=fa.W, coeffs=small_coeffs(rng, 9), path="stream")
 
 
 def test_stream_kernel_fallbacks():
