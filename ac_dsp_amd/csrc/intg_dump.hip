@@ -165,8 +165,10 @@ template <typename TS> __device__ inline TS id_xor32_sum(TS t) {
 // of CHN.  The half a lane keeps is chosen by lane bit 0 / 1 XOR lane bit 2, which makes the assignment symmetric under the
 // lane reversals of row_half_mirror and row_mirror; lanes 0 .. CHN-1 of a group end with channel 2 * bit0 + bit1 (CHN 4) or
 // bit0 (CHN 2) and store it.
+// lpb > 0 (round 4): blocks of lpb lane-loads that are NOT a multiple of 64 (NS = 1000 ...): one block per reduce, its loads start at
+// lane-load red * lpb wherever that falls, and the lanes of a block's last load that lie past its end contribute nothing.
 template <typename TIN, int CHN, bool SGN, bool SCAT>
-__global__ void __launch_bounds__(256) intg_dump_stream_kernel(IntgDumpParams p, IdConv cv, int gs, int lpr, int64_t reds_per_wave, int64_t n_reds) {
+__global__ void __launch_bounds__(256) intg_dump_stream_kernel(IntgDumpParams p, IdConv cv, int gs, int lpr, int64_t reds_per_wave, int64_t n_reds, int lpb = 0) {
   typedef typename std::conditional<sizeof(TIN) == 2, int, int64_t>::type TS;   // int16: rounds < 2^15 keep the sums inside int32
   constexpr int EPV = 16 / (int)sizeof(TIN);
 #ifndef ID_BATCH
@@ -191,14 +193,28 @@ __global__ void __launch_bounds__(256) intg_dump_stream_kernel(IntgDumpParams p,
 #pragma unroll
   for (int c = 0; c < CHN; c++) { acc[c] = 0; }
   const int64_t q0 = r0 * lpr, q1 = r1 * lpr;                   // 1 KB wave-loads of this wave
-  const v4i_t *src = (const v4i_t *)((const TIN *)p.x + (int64_t)obj * p.in_stride) + 64 * q0 + lane;
+  const v4i_t *row = (const v4i_t *)((const TIN *)p.x + (int64_t)obj * p.in_stride);
+  const v4i_t *src = row + 64 * q0 + lane;
   int k_in_red = 0;
   int64_t red = r0;
+  int64_t f_red = r0;                                            // ragged blocks: (block, load in block) of the next load to issue
+  int f_k = 0;
   for (int64_t q = q0; q < q1; q += BATCH, src += 64 * BATCH) {
     const int rem = (int)(q1 - q < BATCH ? q1 - q : BATCH);
     v4i_t v[BATCH];
+    if (lpb > 0) {
+#pragma unroll
+      for (int k = 0; k < BATCH; k++) {
+        const int in_blk = 64 * f_k + lane;
+        const bool ok = k < rem && in_blk < lpb;
+        const v4i_t t = __builtin_nontemporal_load(row + f_red * lpb + (ok ? in_blk : 0));
+        v[k] = ok ? t : (v4i_t){0, 0, 0, 0};
+        if (k < rem) { if (++f_k == lpr) { f_k = 0; f_red++; } }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < BATCH; k++) { v[k] = __builtin_nontemporal_load(src + 64 * (k < rem ? k : rem - 1)); }   // read once: streaming policy (6.05 -> 6.75 TB/s in tools/copy_probe)
+    }
 #pragma unroll
     for (int k = 0; k < BATCH; k++) {
       if (k >= rem) { break; }
@@ -437,18 +453,18 @@ static bool make_conv(const IntgDumpParams &p, IdConv &cv) {
 }
 
 template <typename TIN, int CHN>
-static bool launch_stream(const IntgDumpParams &p, int gs, int lpr, int64_t rpw, int64_t n_reds, dim3 grid, hipStream_t s) {
+static bool launch_stream(const IntgDumpParams &p, int gs, int lpr, int64_t rpw, int64_t n_reds, dim3 grid, hipStream_t s, int rag = 0) {
   IdConv cv;
   if (!make_conv(p, cv)) { return false; }                        // other modes: the tiled kernel and its general requant
   if constexpr (CHN == 2 || CHN == 4) {
     if (gs >= CHN) {
-      if (p.in.S) { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, true, true>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds); }
-      else { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, false, true>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds); }
+      if (p.in.S) { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, true, true>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds, rag); }
+      else { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, false, true>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds, rag); }
       return true;
     }
   }
-  if (p.in.S) { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, true, false>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds); }
-  else { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, false, false>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds); }
+  if (p.in.S) { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, true, false>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds, rag); }
+  else { hipLaunchKernelGGL((intg_dump_stream_kernel<TIN, CHN, false, false>), grid, dim3(256), 0, s, p, cv, gs, lpr, rpw, n_reds, rag); }
   return true;
 }
 
@@ -461,13 +477,19 @@ static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
   if (be % epv != 0 || ((uintptr_t)p.x % 16) != 0 || (p.in_stride * p.in_eb) % 16 != 0) { return false; }
   const int64_t lpb = be / epv;                                // lane-loads per block
   int gs, lpr;
-  if (lpb <= 64) { if (lpb & (lpb - 1)) { return false; } gs = (int)lpb; lpr = 1; }
-  else { if (lpb % 64) { return false; } gs = 64; lpr = (int)(lpb / 64); }
+  int rag = 0;   // blocks that are no multiple of a wave-load: one block per reduce, masked last load (at least half a wave-load per block)
+  if (lpb <= 64) {
+    if (lpb & (lpb - 1)) { if (lpb < 32) { return false; } gs = 64; lpr = 1; rag = (int)lpb; }
+    else { gs = (int)lpb; lpr = 1; }
+  } else if (lpb % 64) {
+    if (lpb > (1 << 20)) { return false; }
+    gs = 64; lpr = (int)((lpb + 63) / 64); rag = (int)lpb;
+  } else { gs = 64; lpr = (int)(lpb / 64); }
   const int bpr = 64 / gs;
   if (p.n_blocks % bpr != 0) { return false; }                 // (a ragged last reduce would read past the call's samples)
   const int64_t n_reds = p.n_blocks / bpr;
   static const bool no_batch = getenv("ACDSP_NO_INTG_BATCH") != nullptr;   // A/B knob: per-load kernel
-  if (!no_batch && p.in_eb == 2 && lpr == 1 && gs >= 8 && (p.chn == 1 || p.chn == 2 || p.chn == 4)) {
+  if (!no_batch && !rag && p.in_eb == 2 && lpr == 1 && gs >= 8 && (p.chn == 1 || p.chn == 2 || p.chn == 4)) {
     IdConv cv;
     if (!make_conv(p, cv)) { return false; }
     // 8 KB per wave (one 8-load batch; 8: 0.361 ms, 16: 0.373, 32: 0.375 on the bench row, profiles/r3_span_sweep.txt)
@@ -492,16 +514,16 @@ static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
   dim3 grid((unsigned)((waves + 3) / 4), (unsigned)p.n_obj);
   if (p.in_eb == 2) {
     switch (p.chn) {
-      case 1: return launch_stream<int16_t, 1>(p, gs, lpr, rpw, n_reds, grid, s);
-      case 2: return launch_stream<int16_t, 2>(p, gs, lpr, rpw, n_reds, grid, s);
-      case 4: return launch_stream<int16_t, 4>(p, gs, lpr, rpw, n_reds, grid, s);
-      default: return launch_stream<int16_t, 8>(p, gs, lpr, rpw, n_reds, grid, s);
+      case 1: return launch_stream<int16_t, 1>(p, gs, lpr, rpw, n_reds, grid, s, rag);
+      case 2: return launch_stream<int16_t, 2>(p, gs, lpr, rpw, n_reds, grid, s, rag);
+      case 4: return launch_stream<int16_t, 4>(p, gs, lpr, rpw, n_reds, grid, s, rag);
+      default: return launch_stream<int16_t, 8>(p, gs, lpr, rpw, n_reds, grid, s, rag);
     }
   } else {
     switch (p.chn) {
-      case 1: return launch_stream<int32_t, 1>(p, gs, lpr, rpw, n_reds, grid, s);
-      case 2: return launch_stream<int32_t, 2>(p, gs, lpr, rpw, n_reds, grid, s);
-      default: return launch_stream<int32_t, 4>(p, gs, lpr, rpw, n_reds, grid, s);
+      case 1: return launch_stream<int32_t, 1>(p, gs, lpr, rpw, n_reds, grid, s, rag);
+      case 2: return launch_stream<int32_t, 2>(p, gs, lpr, rpw, n_reds, grid, s, rag);
+      default: return launch_stream<int32_t, 4>(p, gs, lpr, rpw, n_reds, grid, s, rag);
     }
   }
 }

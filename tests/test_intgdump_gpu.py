@@ -66,6 +66,12 @@ def test_rejects_short_buffers():
     (256, 4, 256, 16, A.Fmt(32, 16), A.Fmt(44, 28), A.Fmt(44, 28)),                    # int32 containers, 64-bit sums
     (64, 2, 64, 32, A.Fmt(24, 8, False), A.Fmt(34, 18, False), A.Fmt(15, 9, False, "TRN", "WRAP")),
     (48, 4, 48, 64, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)),                       # 24 lanes per block: not a power of two -> tiled kernel
+    (1000, 4, 1000, 37, A.Fmt(16, 8), A.Fmt(40, 24), A.Fmt(40, 24)),                   # 500 lane-loads per block: ragged blocks, masked eighth load
+    (1000, 1, 1000, 41, A.Fmt(16, 8, False), A.Fmt(30, 14, False), A.Fmt(30, 14, False)),   # 125 lane-loads, unsigned
+    (100, 4, 100, 75, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(16, 8, True, "RND", "SAT")),  # 50 lane-loads: one masked load per block
+    (36, 8, 36, 130, A.Fmt(12, 4), A.Fmt(24, 12), A.Fmt(24, 12)),                      # 36 lane-loads, eight channels
+    (330, 2, 330, 51, A.Fmt(32, 16), A.Fmt(48, 32), A.Fmt(48, 32)),                    # int32 containers: 165 lane-loads
+    (1000, 2, 1000, 9, A.Fmt(16, 2), A.Fmt(27, 13, True, "TRN", "WRAP"), A.Fmt(20, 6, True, "RND", "SAT")),   # 250 lane-loads, few blocks
 ])
 def test_streaming_kernel_shapes(ns, chn, rounds, n_blk, fin, fa, fo):
     check(ns, chn, fin, fa, fo, [[rounds] * n_blk, [rounds] * (n_blk // 2)], n_obj=5, seed=ns + chn)
