@@ -87,6 +87,10 @@ struct UpArgs {
   // EPI 2 (mode 1, INT_TYPE and OUT_TYPE wider than 32 bits, same fraction, AC_WRAP): bit-field wraps of the high word
   int32_t e_rs, e_rnd, e_lo, e_hi, e_w;
   uint64_t e_mask;
+  // EPI 4 (mode 0 into 4- / 8-byte containers, AC_TRN / AC_RND into AC_WRAP / AC_SAT, signed OUT_TYPE): q = ((V + c_rnd) >> c_rs) << c_ls2,
+  // clamp to [c_lo, c_hi], sign-extend the low 64 - c_ko bits -- the generic conversion's result without its branches
+  int64_t c_rnd, c_lo, c_hi;
+  int32_t c_rs, c_ls2, c_ko;
   int32_t xcd_map;   // XCD-affine chunk order (acdsp_dev.hpp: xcd_remap)
 };
 
@@ -94,6 +98,7 @@ struct UpArgs {
 // EPI 1: poly_intr with every intermediate inside int32 and a shift / clamp / wrap conversion (host-checked).
 // EPI 2: CIC with a bit-field wrap conversion.  1, 2 and 3 are branch-free.
 // EPI 3: CIC whose INT_TYPE (and OUT_TYPE container) fit 32 bits: EPI 1's recombination mod 2^32, one sign-extending wrap, a mask.
+// EPI 4: poly_intr into 4- / 8-byte containers with a branch-free shift / clamp / wrap conversion in 64 bits (round 4).
 // PCT: coefficient digit planes compiled in (2 or 3; the fragment array always has 3 per K block).
 // NST: steps per wave (1 .. 4).  A wave is a short one-shot chunk: the samples of all its NST steps are loaded up front into NST register
 // sets, then the steps run back to back with nothing but their stores on the memory pipeline; no prefetch state is carried.  The host
@@ -315,6 +320,11 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
               // no wider than INT_TYPE: host-checked) = one bit-field extract of the high word + a mask for unsigned OUT_TYPEs
               const int hi = (int)__builtin_amdgcn_sbfe((int)(y >> 32), 0, (unsigned)a.e_w) & (int)a.e_mask;
               o[rr] = (int64_t)(((uint64_t)(unsigned)hi << 32) | (uint32_t)y);
+            } else if constexpr (EPI == 4) {
+              int64_t v = (int64_t)(y << p.lossless_shift) >> ((sh_t >> t) & 1u);
+              v = (int64_t)((uint64_t)((v + a.c_rnd) >> a.c_rs) << a.c_ls2);
+              v = v < a.c_lo ? a.c_lo : (v > a.c_hi ? a.c_hi : v);
+              o[rr] = (int64_t)((uint64_t)v << a.c_ko) >> a.c_ko;
             } else if (a.mode == 1) {
               o[rr] = requant64(wrap64((int64_t)y, a.w_int, 1), p.in.F, p.out);
             } else {
@@ -441,11 +451,16 @@ template <typename TIN, int PX, int PCT, int NBT, int L>
 static hipError_t launch_up_oeb(const UpArgs &a, const uint32_t *d_frag, int out_eb, int epi, dim3 grid, hipStream_t s) {
   const v4i *f = (const v4i *)d_frag;
   if (out_eb == 8) {
-    if (epi == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 2, up_nst(L, 8, 2)>), grid, dim3(64), 0, s, a, f); }
+    if (epi == 4) {
+      if constexpr (sizeof(TIN) == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 4, up_nst(L, 8, 4)>), grid, dim3(64), 0, s, a, f); }
+      else { return hipErrorNotSupported; }
+    }
+    else if (epi == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 2, up_nst(L, 8, 2)>), grid, dim3(64), 0, s, a, f); }
     else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 0, up_nst(L, 8, 0)>), grid, dim3(64), 0, s, a, f); }
   } else if (out_eb == 4) {
     if constexpr (sizeof(TIN) == 2 && NBT == 1) {   // CIC on 16-bit inputs: INT_TYPE of up to 32 bits
-      if (epi == 3) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 4, 3, up_nst(L, 4, 3)>), grid, dim3(64), 0, s, a, f); }
+      if (epi == 4) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 4, 4, up_nst(L, 4, 4)>), grid, dim3(64), 0, s, a, f); }
+      else if (epi == 3) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 4, 3, up_nst(L, 4, 3)>), grid, dim3(64), 0, s, a, f); }
       else if (epi == 0) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 4, 0, up_nst(L, 4, 0)>), grid, dim3(64), 0, s, a, f); }
       else { return hipErrorNotSupported; }
     } else { return hipErrorNotSupported; }
@@ -509,6 +524,7 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
   a.p = p; a.slot0 = slot0; a.n_steps = n_steps; a.out_off = out_off; a.mode = mode; a.w_int = w_int; a.out_simple = out_simple;
   a.sh_mask = sh_mask; a.corr = d_corr;
   a.e_rs = a.e_rnd = a.e_w = 0; a.e_lo = INT32_MIN; a.e_hi = INT32_MAX; a.e_mask = ~uint64_t(0);
+  a.c_rnd = 0; a.c_lo = INT64_MIN; a.c_hi = INT64_MAX; a.c_rs = a.c_ls2 = a.c_ko = 0;
   int epi = 0;
   const int rs = p.acc.F - p.out.F;
   if (mode == 0 && px == 2 && p.lossless_shift == 0 && rs >= 0 && rs <= 28 && p.out_eb == 2 &&
@@ -520,6 +536,15 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
     a.e_rs = rs;
     a.e_rnd = (p.out.Q == ACDSP_RND && rs > 0) ? (1 << (rs - 1)) : 0;
     if (p.out.O == ACDSP_SAT) { a.e_lo = (int32_t)p.out.lo; a.e_hi = (int32_t)p.out.hi; }
+  } else if (mode == 0 && px == 2 && (p.out_eb == 8 || (p.out_eb == 4 && pl.nb == 1)) && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) &&
+             (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && p.lossless_shift >= 0 && p.lossless_shift < 32 && rs >= -16 && rs <= 62 &&
+             p.acc.W + (rs < 0 ? -rs : 0) <= 63 && p.out.W >= 2 && p.out.W <= 8 * p.out_eb) {
+    // exact-accumulation class into wider containers: the conversion without the generic epilogue's branches
+    epi = 4;
+    a.c_rs = rs > 0 ? rs : 0; a.c_ls2 = rs < 0 ? -rs : 0;
+    a.c_rnd = (p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0;
+    if (p.out.O == ACDSP_SAT) { a.c_lo = p.out.lo; a.c_hi = p.out.hi; a.c_ko = 0; }
+    else { a.c_lo = INT64_MIN; a.c_hi = INT64_MAX; a.c_ko = 64 - p.out.W; }
   } else if (mode == 1 && out_simple >= 1) {
     // bit-field wrap of the high word: to INT_TYPE, then (out_simple 1) to an OUT_TYPE of the same fraction with AC_WRAP
     const int wo = out_simple == 2 ? w_int : p.out.W, so = out_simple == 2 ? 1 : p.out.S;

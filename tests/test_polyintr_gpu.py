@@ -174,11 +174,15 @@ def test_matrix_core_path_three_digit_planes(ftype, n_taps, ifac, coeff_bits):
         check_up(n_taps, ifac, ftype, fo, seed=100 + n_taps + ifac, coeff_bits=coeff_bits, splits=[8 + 16 * 36], n=16 * 33 * 3 + 160)
 
 
-@pytest.mark.parametrize("fo", [A.Fmt(40, 12), A.Fmt(16, 2, True, "TRN", "WRAP"), A.Fmt(24, 6, True, "RND_CONV", "SAT_SYM"), A.Fmt(12, 4, False, "RND", "SAT")])
+@pytest.mark.parametrize("fo", [A.Fmt(40, 12), A.Fmt(16, 2, True, "TRN", "WRAP"), A.Fmt(24, 6, True, "RND_CONV", "SAT_SYM"), A.Fmt(12, 4, False, "RND", "SAT"),
+                                A.Fmt(24, 6, True, "RND", "SAT"), A.Fmt(32, 10, True, "TRN", "WRAP"), A.Fmt(36, 9, True, "RND", "SAT"), A.Fmt(48, 20, True, "RND", "WRAP"),
+                                A.Fmt(50, 18, True, "TRN", "SAT"), A.Fmt(20, 3, True, "RND", "WRAP"), A.Fmt(33, 2, True, "TRN", "WRAP")])
 def test_matrix_core_path_output_types(fo):
     # 2-, 4- and 8-byte output containers (4-byte ones since round 4, one K block only)
     check_up(16, 8, "FOLD_EVEN", fo, seed=5, n=16 * 33 * 5)
     check_up(15, 8, "FOLD_ODD", fo, seed=6, n=16 * 33 * 2 + 8, pairs=False)
+    check_up(16, 2, "FOLD_EVEN", fo, seed=7, n=16 * 33 * 5, splits=[16 * 40])      # four steps per wave at IF = 2
+    check_up(16, 4, "FOLD_ANTI", fo, seed=8, n=16 * 33 * 4, coeff_bits=16)         # three digit planes
 
 
 def test_matrix_core_path_is_left_when_the_cores_are_not_linear():
