@@ -138,6 +138,46 @@ int main() {
     A last1; while (o1.available(1)) { last1 = o1.read(); }
     if (!(o2.read() == last1)) { std::cout << "copy semantics FAILED" << std::endl; fails++; }
   }
+  {
+    // TRANSPOSED with coefficients that change mid-stream (ac_fir_prog_coeffs hands a set to every one-sample call): reg_trans[] keeps the
+    // partial sums made with the coefficients of their time (ac_fir_prog_coeffs.h:233-247).  The model below is that recurrence on the same
+    // ac_fixed types; the engine serves the n_taps - 1 outputs behind a change from reg_trans and everything else from the input history.
+    typedef ac_fixed<16, 2, true> T;
+    typedef ac_fixed<40, 12, true> A;
+    const int N = 9;
+    T sets[3][N];
+    for (int k = 0; k < 3; k++) { for (int i = 0; i < N; i++) { sets[k][i] = T(0.03125 * ((i * 7 + k * 5) % 23 - 11)); } }
+    ac_fir_prog_coeffs<T, A, T, A, N, TRANSPOSED> f;
+    A rt[N];
+    for (int i = 0; i < N; i++) { rt[i] = 0; }
+    ac_channel<T> in;
+    ac_channel<A> out;
+    int bad = 0;
+    const int change_at[] = {0, 30, 33, 34, 60};            // changes closer together than n_taps - 1 samples, then a long steady run
+    int which = 0, nxt = 0;
+    for (int t = 0; t < 120; t++) {
+      if (nxt < 5 && t == change_at[nxt]) { which = nxt % 3; nxt++; }
+      const T x = T(0.001953125 * ((t * 37) % 1001 - 500));
+      in.write(x);
+      f.run(in, out, sets[which]);
+      for (int i = N - 1; i >= 0; i--) { rt[i] = x * sets[which][N - 1 - i] + (i ? rt[i - 1] : A(0)); }
+      if (!out.available(1) || !(out.read() == rt[N - 1])) { bad++; }
+      if (t == 32) {                                         // a copy taken inside a transition carries reg_trans along
+        ac_fir_prog_coeffs<T, A, T, A, N, TRANSPOSED> g(f);
+        ac_channel<T> in2;
+        ac_channel<A> out2;
+        A rt2[N];
+        for (int i = 0; i < N; i++) { rt2[i] = rt[i]; }
+        const T x2 = T(0.25);
+        in2.write(x2);
+        g.run(in2, out2, sets[2]);
+        for (int i = N - 1; i >= 0; i--) { rt2[i] = x2 * sets[2][N - 1 - i] + (i ? rt2[i - 1] : A(0)); }
+        if (!(out2.read() == rt2[N - 1])) { bad++; }
+      }
+    }
+    std::cout << "transposed, coefficient sets changing mid-stream: " << bad << " mismatches" << std::endl;
+    if (bad) { fails++; }
+  }
   std::cout << (fails ? "Test FAILED." : "Test PASSED.") << std::endl;
   return fails;
 }
