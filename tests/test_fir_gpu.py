@@ -233,6 +233,16 @@ def test_unsigned_16_bit_samples_run_the_matrix_cores(n_taps, ftype):
                    coeffs=np.minimum(rand_raw(rng, fc, (4, nt)), 32639), splits=[777], seed=nt + 1, expect_path="mfma_i8")
 
 
+@pytest.mark.parametrize("fo", [A.Fmt(12, 1, True, "RND", "SAT"), A.Fmt(14, 2, True, "TRN", "WRAP"), A.Fmt(24, 6, True, "RND", "SAT"), A.Fmt(32, 12)])
+def test_narrow_and_4_byte_outputs_with_a_coefficient_set_per_channel(fo):
+    """The NAR / W4 instantiations read per-channel Toeplitz fragments like the 16-bit kernels do."""
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
+    for n_taps in (31, 200):
+        c = np.minimum(rand_raw(np.random.default_rng(n_taps + fo.W), fc, (7, n_taps)), 32639) >> 3
+        check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=7, n=4096 + n_taps, per_channel=True, coeffs=c, splits=[1024 + 8], seed=fo.W,
+                   expect_path="mfma_i8")
+
+
 @pytest.mark.parametrize("n_taps", [1, 2, 31, 32, 33, 63, 64, 65, 127, 255, 257])
 def test_mfma_path_tap_counts(n_taps):
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
