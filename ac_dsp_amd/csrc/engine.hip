@@ -815,7 +815,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   else if (path == ACDSP_PATH_LOSSLESS64) { e = launch_fir_lossless64(k, s); }
   else {
     static const bool no_lossy = getenv("ACDSP_NO_LOSSY_FAST") != nullptr;   // A/B knob: the exact-order kernel for every per-tap class
-    e = (!no_lossy && fir_lossy_fast_ok(k)) ? launch_fir_lossy(k, s) : launch_fir_generic(k, s);
+    e = (!no_lossy && fir_lossy_fast_ok(k)) ? launch_fir_lossy(k, s) : ((!no_lossy && fir_satacc_fast_ok(k)) ? launch_fir_satacc(k, s) : launch_fir_generic(k, s));
   }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR kernel launch failed: %s", hipGetErrorString(e)); }
   if (!small) {

@@ -266,6 +266,96 @@ __global__ void __launch_bounds__(256) fir_lossy_kernel(FirParams p) {
   }
 }
 
+// Class C on 16-bit types, the common case of it: a SATURATING accumulator of up to 32 bits (AC_SAT; AC_TRN / AC_RND).  acc = sat(acc + Q(p)) after
+// every tap, in the reference's tap order -- i = N-1 .. 0 for SHIFT_REG / ROTATE_SHIFT (ac_fir_const_coeffs.h:190-220), ascending for C_BUFF
+// (:226-237) and ac_fir_reg_share's SHIFT_REG core -- so the chain of one output is serial, and a lane runs its 8 outputs' chains side by side:
+// v_mad_i32_i24, v_ashrrev_i32, v_add_i32 clamp (the sum of two in-range words cannot be told from a wrapped one otherwise), v_med3_i32.
+// Same register window as fir_lossy_kernel; DESC walks it from the oldest sample up.
+bool fir_satacc_fast_ok(const FirParams &p) {
+  const int s = p.in.F + p.cf.F - p.acc.F;
+  const bool order_ok = p.ftype == ACDSP_SHIFT_REG || p.ftype == ACDSP_ROTATE_SHIFT || p.ftype == ACDSP_C_BUFF || p.ftype == kRsShiftReg;
+  return order_ok && p.in_eb == 2 && (p.in.S ? p.in.W <= 16 : p.in.W <= 15) && (p.cf.S ? p.cf.W <= 16 : p.cf.W <= 15) &&
+         p.acc.O == ACDSP_SAT && (p.acc.Q == ACDSP_TRN || p.acc.Q == ACDSP_RND) && p.acc.W <= (p.acc.S ? 32 : 31) && s >= 0 && s <= 30 &&
+         p.n_taps <= 2048 && !p.hist_next && !p.use_rt;
+}
+
+template <bool DESC>
+__global__ void __launch_bounds__(256) fir_satacc_kernel(FirParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int16_t *win = (int16_t *)smem_raw;
+  const int N = p.n_taps, N8 = (N + 7) & ~7, NP = N8 + 8;
+  const int ch = blockIdx.y, tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * kLossyTile;
+  const int16_t *xrow = (const int16_t *)p.x + (int64_t)ch * p.in_stride;
+  const int16_t *hrow = (const int16_t *)p.hist + (int64_t)ch * p.hl + p.hl;
+  for (int j = tid; j < NP + kLossyTile; j += 256) {
+    const int64_t g = t0 - NP + j;
+    int16_t v = 0;
+    if (g >= 0) { if (g < p.n) { v = xrow[g]; } }
+    else if (g >= -(int64_t)p.hl) { v = hrow[g]; }
+    win[j] = v;
+  }
+  __syncthreads();
+  const int64_t *cg = p.coeffs + (p.coeffs_per_channel ? (int64_t)ch * N : 0);
+  const int s = p.in.F + p.cf.F - p.acc.F;
+  const int rnd = (p.acc.Q == ACDSP_RND && s > 0) ? (1 << (s - 1)) : 0;
+  const int lo = (int)p.acc.lo, hi = (int)p.acc.hi;
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  const int base = NP + kLossyOut * tid;
+  int acc[kLossyOut];
+#pragma unroll
+  for (int j = 0; j < kLossyOut; j++) { acc[j] = 0; }
+  int xs[16];                                             // samples win[base - i0 - 8 .. base - i0 + 7]
+  auto unpack = [&](const v4i_ &v, int at) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xs[at + 2 * q] = (int)(int16_t)v[q]; xs[at + 2 * q + 1] = v[q] >> 16; }
+  };
+  auto tap = [&](int i0, int k) {
+    const int c = (i0 + k < N) ? (int)cg[i0 + k] : 0;     // wave-uniform; padded taps add (0 + rnd) >> s = 0
+    const int r = (i0 + k < N) ? rnd : 0;
+#pragma unroll
+    for (int j = 0; j < kLossyOut; j++) {
+      const int q = (xs[8 + j - k] * c + r) >> s;
+      int a = __builtin_elementwise_add_sat(acc[j], q);
+      acc[j] = a < lo ? lo : (a > hi ? hi : a);
+    }
+  };
+  if (DESC) {
+    unpack(*(const v4i_ *)(win + base - (N8 - 8) - 8), 0);
+    for (int i0 = N8 - 8; i0 >= 0; i0 -= 8) {
+      unpack(*(const v4i_ *)(win + base - i0), 8);
+#pragma unroll
+      for (int k = 7; k >= 0; k--) { tap(i0, k); }
+#pragma unroll
+      for (int j = 0; j < 8; j++) { xs[j] = xs[8 + j]; }   // the high half is the next (newer) iteration's low half
+    }
+  } else {
+    unpack(*(const v4i_ *)(win + base), 8);
+    for (int i0 = 0; i0 < N8; i0 += 8) {
+      unpack(*(const v4i_ *)(win + base - i0 - 8), 0);
+#pragma unroll
+      for (int k = 0; k < 8; k++) { tap(i0, k); }
+#pragma unroll
+      for (int j = 0; j < 8; j++) { xs[8 + j] = xs[j]; }
+    }
+  }
+  const int64_t t = t0 + kLossyOut * tid;
+#pragma unroll
+  for (int j = 0; j < kLossyOut; j++) {
+    if (t + j < p.n) { store_raw(p.y, (int64_t)ch * p.out_stride + t + j, p.out_eb, requant64((int64_t)acc[j], p.acc.F, p.out)); }
+  }
+}
+
+hipError_t launch_fir_satacc(const FirParams &p, hipStream_t s) {
+  if (p.n <= 0) { return hipSuccess; }
+  const int N8 = (p.n_taps + 7) & ~7;
+  const size_t lds = sizeof(int16_t) * (size_t)(N8 + 8 + kLossyTile);
+  dim3 grid((unsigned)((p.n + kLossyTile - 1) / kLossyTile), (unsigned)p.n_ch);
+  if (p.ftype == ACDSP_SHIFT_REG || p.ftype == ACDSP_ROTATE_SHIFT) { hipLaunchKernelGGL(fir_satacc_kernel<true>, grid, dim3(256), lds, s, p); }
+  else { hipLaunchKernelGGL(fir_satacc_kernel<false>, grid, dim3(256), lds, s, p); }
+  return hipGetLastError();
+}
+
 hipError_t launch_fir_lossy(const FirParams &p, hipStream_t s) {
   if (p.n <= 0) { return hipSuccess; }
   const int N8 = (p.n_taps + 7) & ~7;

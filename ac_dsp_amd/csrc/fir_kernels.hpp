@@ -30,6 +30,9 @@ hipError_t launch_fir_lossless64(const FirParams &p, hipStream_t s);
 // class B on 16-bit types (lossy accumulator, AC_TRN / AC_RND into AC_WRAP, order-free ftypes): fir_generic.hip
 bool fir_lossy_fast_ok(const FirParams &p);
 hipError_t launch_fir_lossy(const FirParams &p, hipStream_t s);
+// class C on 16-bit types with a saturating accumulator of up to 32 bits, in the reference's tap order: fir_generic.hip
+bool fir_satacc_fast_ok(const FirParams &p);
+hipError_t launch_fir_satacc(const FirParams &p, hipStream_t s);
 // State carry: history ring (all ftypes but TRANSPOSED-with-rt) and reg_trans partial sums.
 hipError_t launch_fir_hist_update(const FirParams &p, void *hist_next, hipStream_t s);
 hipError_t launch_fir_rt_update(const FirParams &p, int64_t *rt_next, hipStream_t s);

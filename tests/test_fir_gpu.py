@@ -243,6 +243,21 @@ def test_narrow_and_4_byte_outputs_with_a_coefficient_set_per_channel(fo):
                    expect_path="mfma_i8")
 
 
+@pytest.mark.parametrize("n_taps", [1, 7, 8, 9, 63, 255, 300])
+@pytest.mark.parametrize("ftype", ["SHIFT_REG", "ROTATE_SHIFT", "C_BUFF"])
+@pytest.mark.parametrize("fa", [A.Fmt(30, 4, True, "TRN", "SAT"), A.Fmt(24, 8, True, "RND", "SAT"), A.Fmt(32, 6, True, "TRN", "SAT"), A.Fmt(30, 2, True, "TRN", "SAT"),
+                                A.Fmt(20, 3, False, "TRN", "SAT"), A.Fmt(14, 3, True, "RND", "SAT")])
+def test_saturating_accumulators_on_16_bit_types_keep_the_reference_tap_order(n_taps, ftype, fa):
+    """Class C: acc = sat(acc + Q(p)) after every tap; the clamp makes the order matter -- descending taps for SHIFT_REG / ROTATE_SHIFT,
+    ascending for C_BUFF.  Dense full-range coefficients drive the accumulator into both rails and back; shifts of 0, 2 and 12 + bits, an
+    unsigned and a very narrow accumulator; history across calls, a ragged last tile, per-channel sets.  Against the oracle's MAC loops."""
+    fin, fc = A.Fmt(16, 2), A.Fmt(16, 2)
+    fo = A.Fmt(16, 2, True, "RND", "SAT") if fa.S else A.Fmt(22, 5, True, "RND", "SAT")
+    n = 2048 + 600 + n_taps
+    check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=n, splits=[5, 1200], seed=n_taps + fa.W, expect_path="generic")
+    check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=4, n=n, per_channel=True, splits=[2047], seed=n_taps + fa.F, expect_path="generic")
+
+
 @pytest.mark.parametrize("n_taps", [1, 2, 31, 32, 33, 63, 64, 65, 127, 255, 257])
 def test_mfma_path_tap_counts(n_taps):
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
