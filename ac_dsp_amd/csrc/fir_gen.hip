@@ -599,11 +599,12 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   constexpr int LS = 8 / S;                                   // slots per 128-byte line
   constexpr int ADV = 16 * R, NSL = 15 * R + 4 * NBT;
   constexpr int H = (LS - 1 + NSL - ADV + LS - 1) / LS * LS;  // halo slots (line multiple): covers any delta
-  constexpr int NLD = R * S / 4;                              // 1 KB loads per step
+  constexpr int M = (R * S >= 4) ? 1 : 2;                     // steps per load group: a plain (R = 1) FIR on int16 advances half a 1 KB load per step
+  constexpr int NLD = R * S * M / 4;                          // 1 KB loads per group of M steps
   constexpr int PPB = 16 / S;                                 // samples of a 16-byte piece = bytes of one of its planes
   constexpr int SPK = 64 / S;                                 // slots per 1 KB load
   static_assert(S == 2 || S == 4, "ring kernel: 2- and 4-byte samples");
-  static_assert((R % 2 == 0 || R == 1) && SPK % R == 0 && H <= ADV && S * H <= 64 && NLD * SPK == ADV && NLD >= 1, "ring geometry");
+  static_assert((R % 2 == 0 || R == 1) && SPK % R == 0 && H <= ADV && S * H <= 64 && NLD * SPK == M * ADV && NLD >= 1 && SPW % M == 0, "ring geometry");
   constexpr int KSTEP = (SPK + 2 * (SPK / R)) * 16;           // LDS bytes from a piece of load k to the same lane's piece of load k + 1
   constexpr int PADV = (ADV + 2 * (ADV / R)) * 16;            // LDS bytes a step advances
   constexpr int RING = (SPW < 2 ? SPW : 2) * ADV + H;         // chunks of one or two steps never wrap
@@ -703,22 +704,27 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
 
   auto chunk = [&](auto fast_c) {
     v4i pre[PF][NLD];
-    auto fetch = [&](int j) {      // the 16 R new slots of step j
+    auto fetch = [&](int j) {      // the 16 R M new slots of step group j
 #pragma unroll
-      for (int k = 0; k < NLD; k++) { pre[j % PF][k] = piece(16 * (int64_t)(H + j * ADV) + (int64_t)(lane + 64 * k) * PPB, fast_c); }
+      for (int k = 0; k < NLD; k++) { pre[j % PF][k] = piece(16 * (int64_t)(H + j * M * ADV) + (int64_t)(lane + 64 * k) * PPB, fast_c); }
     };
+    constexpr int NG = SPW / M;                                // load groups of the chunk (M = 1: the steps)
     const v4i prm = piece((int64_t)pl_lane * PPB, fast_c);
 #pragma unroll
-    for (int j = 0; j < PF && j < SPW; j++) { fetch(j); }
+    for (int j = 0; j < PF && j < NG; j++) { fetch(j); }
     stage_piece(prm, pr_off);
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
       const int par = (k & 1) * PADV;
+      constexpr int dummy_m = M;
+      const int g = k / dummy_m;
+      if (k % M == 0) {   // (M = 2: one load covers the even step's region and the odd one's behind it)
 #pragma unroll
-      for (int q = 0; q < NLD; q++) { stage_piece(pre[k % PF][q], st_base + q * KSTEP + par); }
-      if ((k & 1) && k + 1 < SPW) { stage_piece(pre[k % PF][NLD - 1], mir_off); }   // the mirror is read by step k + 1
+        for (int q = 0; q < NLD; q++) { stage_piece(pre[g % PF][q], st_base + q * KSTEP + par); }
+      }
+      if ((k & 1) && k + 1 < SPW) { stage_piece(pre[g % PF][NLD - 1], mir_off); }   // the mirror is read by step k + 1
       if (!FB && k > 0) { flush(s0 + k - 1, 0); }
-      if (k + PF < SPW) { fetch(k + PF); }
+      if (k % M == 0 && g + PF < NG) { fetch(g + PF); }
       asm volatile("" ::: "memory");   // keep the loads in front of the step's arithmetic (see cascade_kernel)
 
       v4i acc[PX + PCT - 1];
@@ -917,6 +923,8 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 3 && (oeb == 2 || oeb == 8) && pl.R == 4 && !ring_env) { ring_shape = oeb == 2 ? 12 : 13; r_spw = 4; }
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && oeb == 8 && pl.R == 8 && !ring_env) { ring_shape = 14; r_spw = 2; }
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 8 && (oeb == 2 || oeb == 8) && pl.R == 16 && !ring_env) { ring_shape = oeb == 2 ? 15 : 16; r_spw = 2; }
+    // plain (R = 1) FIR on 16-bit samples whose coefficients need more than the int8 kernel's 16 bits (two load groups of two steps per ... )
+    else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 3 && (oeb == 8 || oeb == 4 || oeb == 2) && pl.R == 1 && !ring_env) { ring_shape = oeb == 8 ? 23 : (oeb == 4 ? 24 : 25); r_spw = 16; }
     // plain (R = 1) FIR on 32-bit samples, up to three coefficient digits and three K-blocks (~130 taps): one 1 KB load per 256-output step
     else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 3 && (oeb == 8 || oeb == 4) && pl.R == 1 && !ring_env) { ring_shape = oeb == 8 ? 20 : 21; r_spw = 8; }
     else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 6; if (!ring_env) { r_spw = 1; r_pf = 1; } }   // CIC R16 N5 on int32: 16 KB per step = one step per wave (LDS: 18 KB of planes per step)
@@ -950,6 +958,9 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     else if (ring_shape == 4) { e = launch_ring<int16_t, 2, 2, 3, 8, 4>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 5) { e = launch_ring1<int32_t, 4, 2, 2, 4, 8, 4, 4, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 6) { e = launch_ring1<int32_t, 4, 3, 6, 16, 8, 1, 1, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 23) { e = launch_ring1<int16_t, 2, 3, 3, 1, 8, 16, 8, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 24) { e = launch_ring1<int16_t, 2, 3, 3, 1, 4, 16, 8, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 25) { e = launch_ring1<int16_t, 2, 3, 3, 1, 2, 16, 8, true, true>(grid, s, p, fr, a); }
     else if (ring_shape == 20) { e = launch_ring1<int32_t, 4, 3, 3, 1, 8, 8, 8, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 21) { e = launch_ring1<int32_t, 4, 3, 3, 1, 4, 8, 8, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 10) { e = launch_ring1<int16_t, 2, 2, 2, 2, 2, 8, 8, true, true>(grid, s, p, fr, a); }

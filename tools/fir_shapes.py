@@ -19,6 +19,8 @@ CASES = [
     ("cfg1 types, 63 taps, OUT = ACC <38,10>", 63, "FOLD_ODD", F(16, 2), F(16, 2), F(38, 10), F(38, 10)),
     ("cfg1 types, 63 taps, OUT <16,2,RND,SAT>", 63, "FOLD_ODD", F(16, 2), F(16, 2), F(38, 10), F(16, 2, True, "RND", "SAT")),
     ("reference testbench types, 29 taps", 29, "FOLD_ODD", F(16, 8), F(32, 16), F(64, 32), F(64, 32)),
+    ("<16,8> x <32,16>, 29 taps, OUT <32,16,RND,SAT>", 29, "SHIFT_REG", F(16, 8), F(32, 16), F(60, 36), F(32, 16, True, "RND", "SAT")),
+    ("<16,8> x <32,16>, 127 taps, OUT <16,8,RND,SAT>", 127, "SHIFT_REG", F(16, 8), F(32, 16), F(60, 36), F(16, 8, True, "RND", "SAT")),
     ("DDC stage types, 127 taps <36,21> -> <32,17>", 127, "SHIFT_REG", F(36, 21), F(16, 1), F(59, 29), F(32, 17, True, "RND", "SAT")),
     ("<32,16> x <32,16>, 64 taps, ACC = OUT <64,32>", 64, "SHIFT_REG", F(32, 16), F(32, 16), F(64, 32), F(64, 32)),
     ("<32,16> x <16,2>, 127 taps, OUT <32,16,RND,SAT>", 127, "SHIFT_REG", F(32, 16), F(16, 2), F(56, 26), F(32, 16, True, "RND", "SAT")),
