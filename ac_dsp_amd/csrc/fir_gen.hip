@@ -840,7 +840,9 @@ static bool gen_conv_params(const FirParams &p, int out_mode, int w_int, GenArgs
   const int rs = f_src - p.out.F, src_w = out_mode == 1 ? w_int : p.acc.W;
   a->e_rs = rs > 0 ? rs : 0; a->e_ls2 = rs < 0 ? -rs : 0;
   a->e_rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs < 63) ? (int64_t(1) << (rs - 1)) : 0;
-  conv_ok = conv_ok && a->e_rs <= 62 && src_w + a->e_ls2 <= 62;     // neither the rounding add nor the left shift can leave int64
+  // neither the rounding add nor the left shift can leave int64 (a 63- / 64-bit source with neither of them -- AC_TRN or rs <= 0, no left shift:
+  // the reference testbench's ACC = OUT <64,32> -- is safe as it is)
+  conv_ok = conv_ok && a->e_rs <= 62 && (src_w + a->e_ls2 <= 62 || (a->e_rnd == 0 && a->e_ls2 == 0));
   if (p.out.O == ACDSP_SAT) {
     a->e_hi = (int64_t)((uint64_t(1) << (p.out.W - 1)) - 1); a->e_lo = -a->e_hi - 1; a->e_ko = 0;
   } else {
