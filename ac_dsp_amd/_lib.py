@@ -11,7 +11,8 @@ O_MODES = {"WRAP": 0, "SAT": 1, "SAT_ZERO": 2, "SAT_SYM": 3}
 FTYPES = {"SHIFT_REG": 0, "ROTATE_SHIFT": 1, "C_BUFF": 2, "FOLD_EVEN": 3, "FOLD_ODD": 4, "TRANSPOSED": 5,
           "FOLD_EVEN_ANTI": 6, "FOLD_ODD_ANTI": 7}
 KINDS = {"const": 0, "load": 1, "prog": 2, "reg_share": 3}
-PATHS = {0: "generic", 1: "lossless64", 2: "mfma_i8", 3: "mfma_gen", 4: "wide"}
+PATHS = {0: "generic", 1: "lossless64", 2: "mfma_i8", 3: "mfma_gen", 4: "wide", 5: "mfma_lossy"}
+KCLASSES = {**PATHS, 6: "lossy16", 7: "satacc16"}
 FLAG_FORCE_GENERIC = 1
 
 
@@ -119,6 +120,7 @@ SYMBOLS = {
     "acdsp_fir_run_host": (_i32, [_vp, _vp, _i64, _vp]),
     "acdsp_fir_reset": (_i32, [_vp]),
     "acdsp_fir_path": (_i32, [_vp]),
+    "acdsp_fir_kernel_class": (_i32, [_vp]),
     "acdsp_fir_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "acdsp_fir_kernel_stats": (_i32, [_vp, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "acdsp_fir_mfma_issued": (_i32, [_vp, C.POINTER(C.c_int32)]),

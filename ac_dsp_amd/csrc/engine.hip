@@ -226,6 +226,11 @@ struct acdsp_fir {
   uint32_t *d_gfrag = nullptr;  // fragments of the generalised (wide-input) MFMA kernel
   FirGenPlan gplan;
   bool gen_ok = false;
+  // class B on the matrix cores (fir_gen.hip, LZ ring shapes): gplan / d_gfrag hold the plan of the effective taps, lzp the residue table
+  bool lz_ok = false;
+  FirLossyPlan lzp;
+  uint32_t *d_lzcl = nullptr;
+  int kclass = 0;                 // acdsp_fir_kernel_class
   std::vector<int64_t> h_coeffs;  // last coefficient set (for clone)
   Timer tm;
   Staging st;
@@ -563,6 +568,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_corr, n_sets * sizeof(int64_t)); }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_gfrag, 3 * 8 * 64 * 4 * sizeof(uint32_t)); }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_lzcl, 128 * sizeof(uint32_t)); }
   if (e != hipSuccess || h->tm.init() != ACDSP_OK) {
     acdsp_fir_destroy(h);
     return fail(ACDSP_EHIP, "FIR state allocation failed: %s", hipGetErrorString(e));
@@ -582,6 +588,7 @@ int32_t acdsp_fir_destroy(acdsp_fir_t h) {
   if (h->d_frag) { (void)hipFree(h->d_frag); }
   if (h->d_corr) { (void)hipFree(h->d_corr); }
   if (h->d_gfrag) { (void)hipFree(h->d_gfrag); }
+  if (h->d_lzcl) { (void)hipFree(h->d_lzcl); }
   h->tm.destroy();
   h->st.destroy();
   h->st_u.destroy();
@@ -633,6 +640,10 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
     if (!h->rt_valid && (rc = fir_rt_from_hist(h))) { return rc; }
     h->rt_since = 0;
   }
+  // from here on the device side changes: a failure below must not leave the OLD set looking current (the early return above compares
+  // against h_coeffs), so the handle is without a set until the call succeeds
+  h->coeffs_set = false;
+  h->h_coeffs.clear();
   HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, n_sets * d.n_taps * sizeof(int64_t), hipMemcpyHostToDevice));
   h->mfma_ok = false;
   h->in_flip = false;
@@ -658,6 +669,9 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
         int64_t sc = 0;
         for (int64_t v : eff) { sc += v; }
         pl.corr += 32768 * sc;
+        // the kernel sees signed 16-bit samples (|x| <= 2^15) but the recombined sum is the UNSIGNED dot product, |y| <= 65535 * sum|c|:
+        // the no-wrap proof of the fast epilogues (fir_mfma_epilogue_class: sum_abs * x_max against ACC's range) must use that bound
+        pl.sum_abs *= 2;
       }
       corr[st] = pl.corr;
       worst.nb = pl.nb;
@@ -696,10 +710,71 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
       h->gen_ok = true;
     }
   }
+  // Class B (lossy accumulator, AC_TRN / AC_RND into AC_WRAP) on the matrix cores: sum_k Q(p_k) = (sum_k p_k + N h - sum_k ((p_k + h) mod 2^s)) >> s.
+  // The exact sum is class A on the effective taps; the residues need the low s bits of every (folded) sample and coefficient (fir_gen.hip, LZ).
+  // FOLD_ODD holds the pre-add in an ACC_TYPE variable (ac_fir_prog_coeffs.h:213-227): exact when ACC keeps the sample's fraction bits and
+  // cannot wrap on the sum of two samples, and the product c * fold then drops the same s bits as an unfolded tap.
+  h->lz_ok = false;
+  FirParams kq;
+  memset(&kq, 0, sizeof kq);
+  kq.n_taps = d.n_taps; kq.ftype = internal_ftype(d.kind, d.ftype); kq.n_ch = d.n_channels; kq.coeffs_per_channel = d.coeffs_per_channel;
+  kq.in = make_dfmt(d.in); kq.cf = make_dfmt(d.coeff);
+  if (!h->wide) { kq.acc = make_dfmt(d.acc); kq.out = make_dfmt(d.out); }
+  kq.in_eb = h->in_eb; kq.out_eb = h->out_eb; kq.hl = h->hl; kq.use_rt = (h->use_rt && !h->rt_hybrid) ? 1 : 0;
+  kq.lossless_shift = kq.acc.F - kq.in.F - kq.cf.F;
+  static const bool no_lz = getenv("ACDSP_NO_MFMA_LOSSY") != nullptr;        // A/B knob: class B stays on the VALU kernels
+  static const bool lz_first = getenv("ACDSP_MFMA_LOSSY_FIRST") != nullptr;  // A/B knob: ... also takes the 16-bit types fir_lossy_kernel serves
+  {
+    const int ift = internal_ftype(d.kind, d.ftype);
+    const int fi = kq.in.F, fc = kq.cf.F, fa = kq.acc.F, sbits = fi + fc - fa;
+    const bool fold_odd = is_fold_odd(ift), fold_even = ift == ACDSP_FOLD_EVEN || ift == kRsFoldEven || ift == kRsFoldEvenAnti;
+    const bool anti = ift == kRsFoldEvenAnti || ift == kRsFoldOddAnti;
+    bool ok = !no_lz && !no_gen && !h->wide && !h->lossless && !h->use_rt && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && !d.coeffs_per_channel &&
+              d.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && d.acc.S && d.acc.W <= 64 && sbits >= 1 && sbits <= 8 &&
+              (h->in_eb == 2 || h->in_eb == 4) && (d.in.W + (d.in.S ? 0 : 1) + 7) / 8 <= h->in_eb &&
+              (lz_first || !fir_lossy_fast_ok(kq));
+    if (ok && fold_odd) {
+      const int need_i = d.in.I + 1 + ((d.acc.S && !d.in.S) ? 1 : 0);
+      ok = fa >= fi && d.acc.I >= need_i;
+    }
+    const int n_pair = fold_odd ? (d.n_taps - 1) / 2 : (fold_even ? d.n_taps / 2 : 0);
+    const int n_single = fold_odd ? 1 : (fold_even ? 0 : d.n_taps);
+    const int n_ent = n_pair + n_single;
+    ok = ok && n_ent >= 1 && n_ent <= 128 && (int64_t)n_ent * ((1 << sbits) - 1) < 65536;
+    if (ok) {
+      std::vector<int64_t> eff = effective_coeffs(coeffs, d.n_taps, ift);
+      std::vector<uint32_t> gfrag;
+      ok = fir_gen_plan(eff.data(), d.n_taps, 1, 0, &h->gplan, &gfrag) && fir_gen_lossy_shape_ok(kq, h->gplan);
+      // the exact sum must not leave int64 (the shift by s follows it), unless ACC_TYPE only keeps bits that survive a wrap of 2^64
+      const int xb = d.in.W - (d.in.S ? 1 : 0);
+      ok = ok && (d.acc.W + sbits <= 64 || (h->gplan.sum_abs_h < (int64_t(1) << 61) && xb <= 61 && h->gplan.sum_abs_h <= ((int64_t(1) << 61) >> xb)));
+      if (ok) {
+        std::vector<uint32_t> cl(128, 0u);
+        const uint32_t m1 = (1u << sbits) - 1;
+        for (int i = 0; i < n_pair; i++) { const uint32_t v = (uint32_t)((uint64_t)coeffs[i] & m1); cl[i] = v | (v << 16); }
+        const int single0 = fold_odd ? (d.n_taps - 1) / 2 : 0;
+        for (int i = 0; i < n_single; i++) { const uint32_t v = (uint32_t)((uint64_t)coeffs[single0 + i] & m1); cl[n_pair + i] = v | (v << 16); }
+        const uint32_t hh = d.acc.Q == ACDSP_RND ? (1u << (sbits - 1)) : 0u;
+        h->lzp.s = sbits; h->lzp.n_pair = n_pair; h->lzp.n_single = n_single; h->lzp.single0 = single0; h->lzp.neg = anti ? 1 : 0; h->lzp.n_taps = d.n_taps;
+        h->lzp.h2 = hh | (hh << 16); h->lzp.m2 = m1 | (m1 << 16); h->lzp.k = (int64_t)n_ent * hh; h->lzp.d_cl = h->d_lzcl;
+        HIP_TRY(hipMemcpy(h->d_gfrag, gfrag.data(), gfrag.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_lzcl, cl.data(), cl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        h->lz_ok = true;
+      }
+    }
+  }
   h->path = h->wide ? ACDSP_PATH_WIDE
             : h->mfma_ok ? ACDSP_PATH_MFMA_I8
             : h->gen_ok ? ACDSP_PATH_MFMA_GEN
+            : h->lz_ok ? ACDSP_PATH_MFMA_LOSSY
                         : ((h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC)) ? ACDSP_PATH_LOSSLESS64 : ACDSP_PATH_GENERIC);
+  {
+    static const bool no_lossy = getenv("ACDSP_NO_LOSSY_FAST") != nullptr;
+    h->kclass = h->path;
+    if (h->path == ACDSP_PATH_GENERIC && !no_lossy && !(d.flags & ACDSP_FLAG_FORCE_GENERIC)) {
+      h->kclass = fir_lossy_fast_ok(kq) ? ACDSP_KCLASS_LOSSY16 : (fir_satacc_fast_ok(kq) ? ACDSP_KCLASS_SATACC16 : ACDSP_PATH_GENERIC);
+    }
+  }
   h->coeffs_set = true;
   h->h_coeffs.assign(coeffs, coeffs + n_sets * d.n_taps);
   return ACDSP_OK;
@@ -722,6 +797,7 @@ int32_t acdsp_fir_clone(acdsp_fir_t h, acdsp_fir_t *out) {
 }
 
 int32_t acdsp_fir_path(acdsp_fir_t h) { return h ? h->path : -1; }
+int32_t acdsp_fir_kernel_class(acdsp_fir_t h) { return (h && h->coeffs_set) ? h->kclass : -1; }
 
 int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_t n, void *d_out, int64_t out_stride,
                       void *stream) {
@@ -736,7 +812,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   if (rc) { return rc; }
   hipStream_t s = (hipStream_t)stream;
   FirParams k;
-  k.hist_next = nullptr;
+  k.hist_next = nullptr; k.t_begin = 0;
   k.n_taps = d.n_taps; k.ftype = internal_ftype(d.kind, d.ftype); k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
   k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff);
   if (h->wide) { memset(&k.acc, 0, sizeof k.acc); memset(&k.out, 0, sizeof k.out); k.acc.F = d.acc.W - d.acc.I; }
@@ -777,13 +853,18 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   if (flipped) {
     // unsigned 16-bit samples: a sign-flipped image of the call's rows and of the history (see acdsp_fir::in_flip)
     const int64_t si = (n + 15) / 16 * 16;
-    if ((rc = h->st_u.ensure((size_t)d.n_channels * si * 2, (size_t)d.n_channels * h->hl * 2))) { return rc; }
+    const size_t ub_in = (size_t)d.n_channels * si * 2, ub_h = (size_t)d.n_channels * h->hl * 2;
+    if ((ub_in > h->st_u.cap_in || ub_h > h->st_u.cap_out) && stream_is_capturing(s)) {
+      return fail(ACDSP_ESTATE, "fir_run under graph capture: the staging image of unsigned 16-bit samples must grow (run one call of this length before capturing)");
+    }
+    if ((rc = h->st_u.ensure(ub_in, ub_h))) { return rc; }
+    if (!h->small_call) { HIP_TRY(hipEventRecord(h->tm.start(), s)); }   // the flip is part of this path's cost: inside the timed region
     const hipError_t ef = launch_flip16(d_in, in_stride, n, h->st_u.d_in, si, h->d_hist[h->cur], h->st_u.d_out, h->hl, d.n_channels, s);
     if (ef != hipSuccess) { return fail(ACDSP_EHIP, "FIR sample staging kernel launch failed: %s", hipGetErrorString(ef)); }
     k.x = h->st_u.d_in; k.in_stride = si; k.hist = h->st_u.d_out;
     k.in.S = 1; k.in.lo = -32768; k.in.hi = 32767;
   }
-  if (!flipped && (path == ACDSP_PATH_MFMA_I8 || path == ACDSP_PATH_MFMA_GEN)) {
+  if (!flipped && (path == ACDSP_PATH_MFMA_I8 || path == ACDSP_PATH_MFMA_GEN || path == ACDSP_PATH_MFMA_LOSSY)) {
     // The matrix-core kernels read rows with 16-byte vector loads (fir_gen: in whole 16-sample slots).  gfx950 serves a vector
     // access at any ELEMENT-aligned address, so the int8 kernel takes unaligned rows as they are (round 3: a row stride of 2^20 + 3
     // samples costs +12 %, profiles/r3_unaligned.txt; the staging copy below -- hipMemcpy2DAsync of misaligned rows -- cost 6.4 ms
@@ -808,10 +889,16 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
                                                 (path == ACDSP_PATH_MFMA_I8 && fir_mfma_register_resident(k, h->plan)));   // single-wave workgroups
   const int nxt_fused = hist_next_index(h->cur, false);
   if (fuse_hist) { k.hist_next = h->d_hist[nxt_fused]; }
-  if (!small) { HIP_TRY(hipEventRecord(h->tm.start(), s)); }
+  if (!small && !flipped) { HIP_TRY(hipEventRecord(h->tm.start(), s)); }
   hipError_t e;
   if (path == ACDSP_PATH_MFMA_I8) { e = launch_fir_mfma(k, h->plan, d.coeffs_per_channel, h->d_frag, h->d_corr, s); }
   else if (path == ACDSP_PATH_MFMA_GEN) { e = launch_fir_gen(k, h->gplan, h->d_gfrag, 0, 0, 0, n, s); }
+  else if (path == ACDSP_PATH_MFMA_LOSSY) {
+    // complete chunks on the matrix cores, the ragged rest (and calls shorter than a chunk) on the exact-order kernel
+    int64_t cov = 0;
+    e = launch_fir_gen(k, h->gplan, h->d_gfrag, 0, 0, 0, n, s, &h->lzp, &cov);
+    if (e == hipSuccess && cov < n) { FirParams kt = k; kt.t_begin = cov; e = launch_fir_generic(kt, s); }
+  }
   else if (path == ACDSP_PATH_LOSSLESS64) { e = launch_fir_lossless64(k, s); }
   else {
     static const bool no_lossy = getenv("ACDSP_NO_LOSSY_FAST") != nullptr;   // A/B knob: the exact-order kernel for every per-tap class

@@ -131,6 +131,13 @@ struct GenArgs {
   int32_t dig[8];
   int32_t l_hb_lo, l_hb_hi;   // stage B, AC_SAT: clamp of the high limb in front of the funnel shift
   int32_t l_lo, l_hi, l_w;    // stage B: OUT range (AC_SAT) / OUT width (AC_WRAP: l_lo = l_hi = 0)
+  // class B on the ring kernel (LZ instantiations, see fir_gen_ring_kernel): acc = (S + K - sum_e r_e) >> lz_s with S the exact sum of the
+  // matrix cores, r_e = (f_e * cl_e + h) mod 2^s the bits the reference's per-tap quantisation drops, K = entries * h
+  int32_t lz_s;               // s = F_in + F_c - F_acc (1 .. 8)
+  int32_t lz_n_pair, lz_n_single, lz_single0, lz_neg, lz_ntaps;   // folded pairs (i, N-1-i) [difference when lz_neg], then single taps from lz_single0 on
+  uint32_t lz_h2, lz_m2;      // rounding constant and mask of the dropped bits, in both 16-bit fields
+  int64_t lz_k;
+  const uint32_t *lz_cl;      // [128] per-entry c mod 2^s in both 16-bit fields, pairs first; zero-padded
 };
 
 
@@ -593,7 +600,13 @@ static hipError_t launch_fast(dim3 grid, size_t lds_bytes, hipStream_t s, const 
 //   of one 1 KB load are multiples of R.
 //   PF = steps the loads run ahead (1 or 2); NT = non-temporal window loads.
 //   FB = the output tiles of the whole chunk wait in LDS and leave in one burst at its end (SPW tiles instead of one).
-template <typename TIN, int PX, int PCT, int NBT, int R, int OEB, int SPW, int PF, bool NT, bool FB>
+//   LZ = class B (lossy accumulator, AC_TRN / AC_RND into AC_WRAP -- reference ac_fir_prog_coeffs.h:147-227 at the types of its
+//        own testbench, <28,6> x <23,7> into <64,32>).  sum_k Q(p_k) = (sum_k p_k + N h - sum_k ((p_k + h) mod 2^s)) / 2^s: the first sum is
+//        the exact product of the matrix cores, and the dropped bits of a tap only need the low s bits of its operands.  The low s bits of
+//        every sample are staged a second time as a plain ring of 16-bit fields (no holes), so that the four consecutive outputs of a lane
+//        read the four samples of a tap with ONE (2-byte aligned) 8-byte LDS read; per tap and four outputs: v_pk_mad_u16 x 2, v_and x 2,
+//        add x 2 (+ v_pk_add_u16 x 2 for the pre-add of a folded pair), coefficients as uniform LDS reads.  R = 1 only.
+template <typename TIN, int PX, int PCT, int NBT, int R, int OEB, int SPW, int PF, bool NT, bool FB, bool LZ = false>
 __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const v4i *__restrict__ frag, GenArgs a) {
   constexpr int S = (int)sizeof(TIN);
   constexpr int LS = 8 / S;                                   // slots per 128-byte line
@@ -616,11 +629,19 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   constexpr int PLANE = (RING + 2 * ((RING + PH) / R) + 2) * 16;   // + one dump slot (mirror writes of the lanes that have none)
   constexpr int DUMP = PLANE - 16;
   constexpr int TILE = 256 * OEB;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[PX * PLANE + (FB ? SPW : 1) * TILE];
+  static_assert(!LZ || R == 1, "class-B residues: plain FIR only");
+  constexpr int LZP = LZ ? (RING + 1) * 32 : 0;               // low-bit ring: 16 samples x 2 bytes per slot, + one dump slot
+  constexpr int LZ_DUMP = RING * 32, KSTEP_L = SPK * 32, PADV_L = ADV * 32;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PX * PLANE + (FB ? SPW : 1) * TILE + LZP + (LZ ? 512 : 0)];
   const int lane = threadIdx.x;
   const int n_col = lane & 15, kg = lane >> 4;
   int bx, ch;
   xcd_remap(a.xcd_map, bx, ch);
+  unsigned char *const lzr = lds + PX * PLANE + (FB ? SPW : 1) * TILE;   // low-bit ring, then the 128 coefficient words
+  if constexpr (LZ) {
+    ((uint32_t *)(lzr + LZP))[lane] = a.lz_cl[lane];
+    ((uint32_t *)(lzr + LZP))[lane + 64] = a.lz_cl[lane + 64];
+  }
   const int NB = a.pl.nb, PC = a.pl.pc;
   auto phys = [](int s) { return s + 2 * ((s + PH) / R); };
 
@@ -641,6 +662,10 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   const int pr_off = phys(pl_lane / S) * 16 + (pl_lane % S) * PPB;
   const int st_base = phys(H + lane / S) * 16 + (lane % S) * PPB;
   const int mir_off = lane >= 64 - S * H ? st_base - KSTEP : DUMP;
+  // the same three places in the low-bit ring (linear slots of 32 bytes)
+  const int pr_lin = (pl_lane / S) * 32 + (pl_lane % S) * PPB * 2;
+  const int st_lin = (H + lane / S) * 32 + (lane % S) * PPB * 2;
+  const int mir_lin = lane >= 64 - S * H ? st_lin - KSTEP_L : LZ_DUMP;
   int xs[NBT];
 #pragma unroll
   for (int b = 0; b < NBT; b++) { xs[b] = phys(a.ring_delta + R * n_col + 4 * b + kg) * 16; }
@@ -659,7 +684,16 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
       return ld((const v4i *)src);
     }
   };
-  auto stage_piece = [&](const v4i &v, int off) {
+  auto stage_piece = [&](const v4i &v, int off, int loff) {
+    if constexpr (LZ) {
+      if constexpr (S == 2) {     // 8 samples: the dwords already hold two 16-bit fields
+        *(v4i *)(lzr + loff) = (v4i){(int)((unsigned)v.x & a.lz_m2), (int)((unsigned)v.y & a.lz_m2), (int)((unsigned)v.z & a.lz_m2), (int)((unsigned)v.w & a.lz_m2)};
+      } else {                    // 4 samples: low halves of two dwords side by side
+        typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+        *(v2u_ *)(lzr + loff) = (v2u_){__builtin_amdgcn_perm((unsigned)v.y, (unsigned)v.x, 0x05040100u) & a.lz_m2,
+                                       __builtin_amdgcn_perm((unsigned)v.w, (unsigned)v.z, 0x05040100u) & a.lz_m2};
+      }
+    }
 #pragma unroll
     for (int pp = 0; pp < PX; pp++) {
       if constexpr (S == 2) {
@@ -712,17 +746,18 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
     const v4i prm = piece((int64_t)pl_lane * PPB, fast_c);
 #pragma unroll
     for (int j = 0; j < PF && j < NG; j++) { fetch(j); }
-    stage_piece(prm, pr_off);
+    stage_piece(prm, pr_off, pr_lin);
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
       const int par = (k & 1) * PADV;
+      const int par_l = (k & 1) * PADV_L;
       constexpr int dummy_m = M;
       const int g = k / dummy_m;
       if (k % M == 0) {   // (M = 2: one load covers the even step's region and the odd one's behind it)
 #pragma unroll
-        for (int q = 0; q < NLD; q++) { stage_piece(pre[g % PF][q], st_base + q * KSTEP + par); }
+        for (int q = 0; q < NLD; q++) { stage_piece(pre[g % PF][q], st_base + q * KSTEP + par, st_lin + q * KSTEP_L + par_l); }
       }
-      if ((k & 1) && k + 1 < SPW) { stage_piece(pre[g % PF][NLD - 1], mir_off); }   // the mirror is read by step k + 1
+      if ((k & 1) && k + 1 < SPW) { stage_piece(pre[g % PF][NLD - 1], mir_off, mir_lin); }   // the mirror is read by step k + 1
       if (!FB && k > 0) { flush(s0 + k - 1, 0); }
       if (k % M == 0 && g + PF < NG) { fetch(g + PF); }
       asm volatile("" ::: "memory");   // keep the loads in front of the step's arithmetic (see cascade_kernel)
@@ -741,6 +776,38 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
           for (int pp = 0; pp < PX; pp++) { acc[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b][q], X[pp], acc[pp + q], 0, 0, 0); }
         }
       }
+      // class B: the dropped bits of every tap, for this lane's four outputs (fields: outputs 0 | 1 in rA, 2 | 3 in rB)
+      unsigned rA = 0, rB = 0;
+      if constexpr (LZ) {
+        typedef unsigned short v2us_ __attribute__((ext_vector_type(2)));
+        typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+        // sample of output r, tap i: ring position 16 (delta + n_col) + off + 4 kg + r - i  (+ the step's parity)
+        const unsigned char *xb = lzr + 2 * (16 * (a.ring_delta + n_col) + a.pl.off + 4 * kg) + par_l;
+        const uint32_t *clt = (const uint32_t *)(lzr + LZP);
+        const v2us_ h2 = __builtin_bit_cast(v2us_, a.lz_h2);
+        auto ld4 = [&](const unsigned char *q) -> v2u_ { v2u_ w; __builtin_memcpy(&w, q, 8); return w; };
+        auto term = [&](unsigned f, unsigned c2) -> unsigned {
+          const v2us_ m = __builtin_bit_cast(v2us_, f) * __builtin_bit_cast(v2us_, c2) + h2;
+          return __builtin_bit_cast(unsigned, m) & a.lz_m2;
+        };
+        const int np = a.lz_n_pair, ns = a.lz_n_single, nt1 = a.lz_ntaps - 1;
+#pragma unroll 2
+        for (int i = 0; i < np; i++) {
+          const v2u_ wa = ld4(xb - 2 * i), wb = ld4(xb - 2 * (nt1 - i));
+          const unsigned ax = wa.x, ay = wa.y, bx_ = wb.x, by = wb.y, c2 = clt[i];
+          unsigned f0, f1;
+          if (a.lz_neg) { f0 = __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, ax) - __builtin_bit_cast(v2us_, bx_))); f1 = __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, ay) - __builtin_bit_cast(v2us_, by))); }
+          else { f0 = __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, ax) + __builtin_bit_cast(v2us_, bx_))); f1 = __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, ay) + __builtin_bit_cast(v2us_, by))); }
+          rA += term(f0, c2); rB += term(f1, c2);
+        }
+        const unsigned char *xs1 = xb - 2 * a.lz_single0;
+#pragma unroll 4
+        for (int i = 0; i < ns; i++) {
+          const v2u_ wa = ld4(xs1 - 2 * i);
+          const unsigned ax = wa.x, ay = wa.y, c2 = clt[np + i];
+          rA += term(ax, c2); rB += term(ay, c2);
+        }
+      }
       int64_t o[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -748,6 +815,11 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
 #pragma unroll
         for (int w = 0; w < PX + PCT - 1; w++) {
           if (w < 8) { y += (uint64_t)(int64_t)acc[w][r] << (8 * w); }
+        }
+        if constexpr (LZ) {
+          const unsigned rr = r < 2 ? rA : rB;
+          const unsigned res = (r & 1) ? (rr >> 16) : (rr & 0xffffu);
+          y = (uint64_t)((int64_t)(y + (uint64_t)a.lz_k - (uint64_t)res) >> a.lz_s);
         }
         int64_t v = (int64_t)(y << a.e_ls);
         v = (int64_t)((uint64_t)v << a.e_ka) >> a.e_ka;
@@ -779,9 +851,9 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   if (interior) { chunk(std::integral_constant<bool, true>()); } else { chunk(std::integral_constant<bool, false>()); }
 }
 
-template <typename TIN, int PX, int PCT, int NBT, int R, int OEB, int SPW, int PF, bool NT, bool FB>
+template <typename TIN, int PX, int PCT, int NBT, int R, int OEB, int SPW, int PF, bool NT, bool FB, bool LZ = false>
 static hipError_t launch_ring1(dim3 grid, hipStream_t s, const FirParams &p, const v4i *frag, const GenArgs &a) {
-  hipLaunchKernelGGL((fir_gen_ring_kernel<TIN, PX, PCT, NBT, R, OEB, SPW, PF, NT, FB>), grid, dim3(64), 0, s, p, frag, a);
+  hipLaunchKernelGGL((fir_gen_ring_kernel<TIN, PX, PCT, NBT, R, OEB, SPW, PF, NT, FB, LZ>), grid, dim3(64), 0, s, p, frag, a);
   return hipGetLastError();
 }
 // variant = spw (steps per chunk), pf (steps the loads run ahead), nt (non-temporal loads), fb (chunk-end store burst)
@@ -857,9 +929,26 @@ static int64_t gen_rebias_corr(int px, int64_t sum_h) {   // 128 * sum(h) * sum_
   return (int64_t)(unsigned long long)((unsigned __int128)128 * bias * (unsigned long long)sum_h);
 }
 
+// class-B ring shapes (the R = 1 shapes 20 / 21 / 23 / 24 / 25 below with the residue loop compiled in)
+static int lossy_ring_shape(int in_eb, int oeb, const FirGenPlan &pl) {
+  if (pl.R != 1 || pl.pc > 3 || pl.nb > 3) { return 0; }
+  if (in_eb == 2) { return oeb == 8 ? 23 : (oeb == 4 ? 24 : (oeb == 2 ? 25 : 0)); }
+  if (in_eb == 4) { return oeb == 8 ? 20 : (oeb == 4 ? 21 : 0); }
+  return 0;
+}
+bool fir_gen_lossy_shape_ok(const FirParams &p, const FirGenPlan &pl) {
+  GenArgs a;
+  FirParams q = p;
+  q.lossless_shift = 0;
+  return lossy_ring_shape(p.in_eb, p.out_eb, pl) != 0 && gen_conv_params(q, 0, 0, &a);
+}
+
 // p.n = inputs of this call; outputs m with first + m*R < n.  hist must hold >= off + 16 samples.
-hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32_t *d_frag, int out_mode, int w_int,
-                          int64_t first, int64_t n_out, hipStream_t s) {
+hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uint32_t *d_frag, int out_mode, int w_int,
+                          int64_t first, int64_t n_out, hipStream_t s, const FirLossyPlan *lz, int64_t *covered) {
+  FirParams p = p_in;
+  if (covered) { *covered = 0; }
+  if (lz) { p.lossless_shift = 0; }   // class B: the exact sum is shifted RIGHT by lz->s in front of the ACC_TYPE wrap
   // (out_mode 1) OUT_TYPE with INT_TYPE's fraction and AC_WRAP converts by bit-field wraps only
   const int out_simple = (out_mode == 1 && p.out.F == p.in.F && p.out.O == ACDSP_WRAP) ? ((p.out.S && p.out.W >= w_int) ? 2 : 1) : 0;
   if (n_out <= 0) { return hipSuccess; }
@@ -869,6 +958,13 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
   const int in_bits = p.in.W + (p.in.S ? 0 : 1);
   a.px = (in_bits + 7) / 8;
   if (a.px > p.in_eb) { return hipErrorInvalidValue; }
+  if (lz) {
+    a.px = p.in_eb;                    // the containers are sign-extended: every byte of them is a plane (the ring shapes are compiled for that)
+    a.lz_s = lz->s; a.lz_n_pair = lz->n_pair; a.lz_n_single = lz->n_single; a.lz_single0 = lz->single0; a.lz_neg = lz->neg; a.lz_ntaps = lz->n_taps;
+    a.lz_h2 = lz->h2; a.lz_m2 = lz->m2; a.lz_k = lz->k; a.lz_cl = lz->d_cl;
+  } else {
+    a.lz_s = 0; a.lz_n_pair = a.lz_n_single = a.lz_single0 = a.lz_neg = a.lz_ntaps = 0; a.lz_h2 = a.lz_m2 = 0; a.lz_k = 0; a.lz_cl = nullptr;
+  }
   a.n_slots = 15 * pl.R + 4 * pl.nb;
   a.out_mode = out_mode; a.w_int = w_int; a.out_simple = out_simple;
   a.corr = gen_rebias_corr(a.px, pl.sum_h);
@@ -913,7 +1009,10 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     if (sscanf(ring_env, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) { r_spw = v[0]; r_pf = v[1]; r_nt = v[2]; r_fb = v[3]; }
     else { ring_on = atoi(ring_env) != 0; }
   }
-  if (ring_on && conv_ok && a.out_vec_ok) {
+  if (lz) {
+    if (!conv_ok || !a.out_vec_ok || !(ring_shape = lossy_ring_shape(in_eb, oeb, pl))) { return hipSuccess; }   // nothing covered: the caller's exact-order kernel takes the call
+    r_spw = in_eb == 2 ? 16 : 8;
+  } else if (ring_on && conv_ok && a.out_vec_ok) {
     if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 3 && oeb == 8 && pl.R == 8) { ring_shape = 1; }          // CIC R8 N5 on int32 -> int64
     else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 2; }   // CIC R16 N5 on int16 -> int64
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && oeb == 2 && pl.R == 8) { ring_shape = 3; }    // 128-tap decimate-by-8 on int16 -> int16
@@ -954,7 +1053,13 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     // int32, 8 KB of input per step) +2.5 % every time, poly_dec -0.6 % twice and +6.6 % once, the fused DDC -3 %: on for the
     // int32 decimator shape only.  ACDSP_XCD_MAP=0 / 1 forces it off / on for every shape (A/B knob).
     a.xcd_map = (xcd_map_wanted(out_mode == 1 && in_eb == 4) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
-    if (ring_shape == 1) { e = launch_ring<int32_t, 4, 2, 3, 8, 8>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
+    if (lz && ring_shape == 23) { e = launch_ring1<int16_t, 2, 3, 3, 1, 8, 16, 8, true, false, true>(grid, s, p, fr, a); }
+    else if (lz && ring_shape == 24) { e = launch_ring1<int16_t, 2, 3, 3, 1, 4, 16, 8, true, false, true>(grid, s, p, fr, a); }
+    else if (lz && ring_shape == 25) { e = launch_ring1<int16_t, 2, 3, 3, 1, 2, 16, 8, true, true, true>(grid, s, p, fr, a); }
+    else if (lz && ring_shape == 20) { e = launch_ring1<int32_t, 4, 3, 3, 1, 8, 8, 8, true, false, true>(grid, s, p, fr, a); }
+    else if (lz && ring_shape == 21) { e = launch_ring1<int32_t, 4, 3, 3, 1, 4, 8, 8, true, false, true>(grid, s, p, fr, a); }
+    else if (lz) { e = hipErrorInvalidValue; }
+    else if (ring_shape == 1) { e = launch_ring<int32_t, 4, 2, 3, 8, 8>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 2) { e = launch_ring<int16_t, 2, 3, 6, 16, 8>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 3) { e = launch_ring<int16_t, 2, 2, 4, 8, 2>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 4) { e = launch_ring<int16_t, 2, 2, 3, 8, 4>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
@@ -977,6 +1082,10 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
     else if (oeb == 8) { e = launch_fast<int16_t, 2, 3, 6, 9, 8>(grid, lds_bytes, s, p, fr, a); }
     else { e = launch_fast<int16_t, 2, 2, 4, 5, 2>(grid, lds_bytes, s, p, fr, a); }
     if (e != hipSuccess) { return e; }
+  }
+  if (lz) {
+    if (covered) { *covered = fast_chunks * spw * 256; }
+    return hipSuccess;
   }
   if (fast_chunks >= n_chunks) { return hipSuccess; }
   a.xcd_map = 0;

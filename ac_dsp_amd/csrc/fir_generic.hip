@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(kTile) fir_direct_kernel(FirParams p) {
   int64_t *win = smem;                 // [kTile + N - 1]: win[j] = x[t0 - (N-1) + j]
   int64_t *cf = smem + kTile + N - 1;  // [N]
   const int ch = blockIdx.y;
-  const int64_t t0 = (int64_t)blockIdx.x * kTile;
+  const int64_t t0 = p.t_begin + (int64_t)blockIdx.x * kTile;
   const int tid = threadIdx.x;
 
   const int64_t *cg = p.coeffs + (p.coeffs_per_channel ? (int64_t)ch * N : 0);
@@ -169,8 +169,8 @@ __global__ void __launch_bounds__(kTile) fir_direct_kernel(FirParams p) {
 static size_t fir_smem_bytes(const FirParams &p) { return sizeof(int64_t) * (size_t)(kTile + 2 * p.n_taps - 1); }
 
 hipError_t launch_fir_generic(const FirParams &p, hipStream_t s) {
-  if (p.n <= 0) { return hipSuccess; }
-  dim3 grid((unsigned)((p.n + kTile - 1) / kTile), (unsigned)p.n_ch);
+  if (p.n <= p.t_begin) { return hipSuccess; }
+  dim3 grid((unsigned)((p.n - p.t_begin + kTile - 1) / kTile), (unsigned)p.n_ch);
   hipLaunchKernelGGL(fir_direct_kernel<false>, grid, dim3(kTile), fir_smem_bytes(p), s, p);
   return hipGetLastError();
 }

@@ -21,6 +21,7 @@ struct FirParams {
   const int64_t *coeffs;       // [n_sets][n_taps] raw words
   const int64_t *rt;           // [n_ch][n_taps] ACC raw words (use_rt)
   void *hist_next;             // small calls: the exact-order kernels write the next history themselves (one launch per call); else null
+  int64_t t_begin;             // exact-order kernels: outputs [t_begin, n) only (the ragged rest behind a matrix-core launch); normally 0
 };
 
 // Exact per-tap emulation in the reference's loop order (any Q/O, any widths <= 64).
@@ -75,8 +76,20 @@ struct FirGenPlan {
 bool fir_gen_plan(const int64_t *h, int n_taps, int R, int first_mod16, FirGenPlan *pl, std::vector<uint32_t> *frag);
 // out_mode 0: FIR class A epilogue (p.lossless_shift, p.acc wrap, requant to p.out);
 // out_mode 1: CIC epilogue (wrap to w_int, requant from p.in.F to p.out).  p.n = inputs, p.hist holds >= off samples.
+// Class B on the ring kernel (lossy accumulator, AC_TRN / AC_RND into AC_WRAP; fir_gen.hip: LZ instantiations).  pl / d_frag are the
+// plan of the EFFECTIVE tap vector (the exact sum), this struct the per-tap residues.
+struct FirLossyPlan {
+  int32_t s;                           // F_in + F_c - F_acc, 1 .. 8
+  int32_t n_pair, n_single, single0, neg, n_taps;
+  uint32_t h2, m2;                     // rounding constant / mask of the dropped bits in both 16-bit fields
+  int64_t k;                           // entries * h
+  const uint32_t *d_cl;                // device [128]: c mod 2^s per entry in both 16-bit fields (pairs, then singles), zero-padded
+};
+// are this handle's (formats, plan) compiled as a class-B ring shape?  (decided at set_coeffs time: acdsp_fir_path reports it)
+bool fir_gen_lossy_shape_ok(const FirParams &p, const FirGenPlan &pl);
+// lz != nullptr: class B -- only complete chunks run here; *covered = outputs written (the caller runs the exact-order kernel on the rest)
 hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32_t *d_frag, int out_mode, int w_int,
-                          int64_t first, int64_t n_out, hipStream_t s);
+                          int64_t first, int64_t n_out, hipStream_t s, const FirLossyPlan *lz = nullptr, int64_t *covered = nullptr);
 
 // Fused decimator -> FIR cascade on the matrix cores (fir_gen.hip).  pa = stage A as for launch_fir_gen with
 // out_mode 1 (history of >= 256*R + off + 16 samples), pb = stage B formats + output buffer (int32 containers).

@@ -186,7 +186,13 @@ __device__ __forceinline__ v4i pk16_ashr(const v4i &v, int d) {
   const v2s_ d2 = (v2s_){(short)d, (short)d};
   v4i r;
 #pragma unroll
-  for (int i = 0; i < 4; i++) { r[i] = __builtin_bit_cast(int, __builtin_bit_cast(v2s_, v[i]) >> d2); }
+  for (int i = 0; i < 4; i++) {
+    // (the element goes through a scalar first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 whatever the
+    // index -- clang 22 / ROCm 7.2 -- and every lane stored four copies of its first dword: round 5, found by disassembly; the round-4
+    // parity tests of the narrow OUT_TYPEs never reached this pipelined body)
+    const int e = v[i];
+    r[i] = __builtin_bit_cast(int, __builtin_bit_cast(v2s_, e) >> d2);
+  }
   return r;
 }
 __device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16i &ll, int rs, const MfmaArgs &a, int (&o)[16]) {

@@ -207,7 +207,9 @@ __global__ void __launch_bounds__(256) intg_dump_stream_kernel(IntgDumpParams p,
       for (int k = 0; k < BATCH; k++) {
         const int in_blk = 64 * f_k + lane;
         const bool ok = k < rem && in_blk < lpb;
-        const v4i_t t = __builtin_nontemporal_load(row + f_red * lpb + (ok ? in_blk : 0));
+        // dead loads of a partial last batch (k >= rem) re-read the wave's first block: behind the last valid load f_red == r1, whose
+        // first lane-load is past the consumed samples -- and past the allocation for the last object of a dense block
+        const v4i_t t = __builtin_nontemporal_load(row + (k < rem ? f_red : r0) * lpb + (ok ? in_blk : 0));
         v[k] = ok ? t : (v4i_t){0, 0, 0, 0};
         if (k < rem) { if (++f_k == lpr) { f_k = 0; f_red++; } }
       }

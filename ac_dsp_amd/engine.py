@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, PolyIntrDesc, IntgDumpDesc, MvAvgDesc, StreamHdr, FTYPES, KINDS, PATHS
+from ._lib import lib, check, Fmt, FirDesc, CicDesc, PolyDecDesc, PolyIntrDesc, IntgDumpDesc, MvAvgDesc, StreamHdr, FTYPES, KINDS, PATHS, KCLASSES
 
 
 def device_count():
@@ -115,6 +115,11 @@ class Fir:
     @property
     def path(self):
         return PATHS[lib.acdsp_fir_path(self._h)]
+
+    @property
+    def kernel(self):
+        """path, with the VALU fast kernels inside "generic" told apart ("lossy16", "satacc16"): acdsp_fir_kernel_class"""
+        return KCLASSES[lib.acdsp_fir_kernel_class(self._h)]
 
     def run(self, x, out=None):
         """x: [n_channels][n] device tensor of IN containers -> [n_channels][n] OUT containers."""
@@ -528,6 +533,10 @@ class _Node:
             assert t.is_cuda and _dev_index(t.device) == d and t.shape[0] == hi - lo and t.dtype == torch_dtype_for(fmt), (t.shape, t.device, lo, hi, d)
         strides = {_row_stride(t, fmt) for t in tensors}
         assert len(strides) == 1, "every shard's block must have the same row stride"
+        # The node handle launches on its workers' own non-blocking streams, which do not order with torch's streams: the blocks must be
+        # complete (inputs) / free (outputs recycled by the caching allocator) before acdsp_node_*_run -- the precondition include/acdsp.h states.
+        for d in set(self.devices):
+            torch.cuda.current_stream(d).synchronize()
         return (C.c_void_p * self.n_shards)(*[t.data_ptr() for t in tensors]), strides.pop()
 
     def alloc(self, fmt, n, fill=None):

@@ -64,7 +64,11 @@ enum {
 
 /* which kernel family a FIR handle resolved to (acdsp_fir_path) */
 enum { ACDSP_PATH_GENERIC = 0, ACDSP_PATH_LOSSLESS64 = 1, ACDSP_PATH_MFMA_I8 = 2, ACDSP_PATH_MFMA_GEN = 3,
-       ACDSP_PATH_WIDE = 4 /* a format wider than 64 bits: exact-order kernels on 128-bit words, 256-bit intermediates */ };
+       ACDSP_PATH_WIDE = 4 /* a format wider than 64 bits: exact-order kernels on 128-bit words, 256-bit intermediates */,
+       ACDSP_PATH_MFMA_LOSSY = 5 /* lossy wrapping accumulator (per-tap AC_TRN / AC_RND): exact sum on the matrix cores minus the dropped bits */ };
+/* finer: the kernel family inside ACDSP_PATH_GENERIC (acdsp_fir_kernel_class; the other values equal the path) */
+enum { ACDSP_KCLASS_LOSSY16 = 6 /* fir_lossy_kernel: class B on 16-bit types, int32 VALU */,
+       ACDSP_KCLASS_SATACC16 = 7 /* fir_satacc_kernel: saturating accumulator of <= 32 bits on 16-bit types, reference tap order */ };
 
 typedef struct {
   int32_t kind;               /* ACDSP_FIR_*: which reference class this mirrors (informational) */
@@ -203,6 +207,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
 int32_t acdsp_fir_run_host(acdsp_fir_t h, const void *h_in, int64_t n_samples, void *h_out);
 int32_t acdsp_fir_reset(acdsp_fir_t h);        /* back to the freshly constructed state (coefficients kept) */
 int32_t acdsp_fir_path(acdsp_fir_t h);         /* ACDSP_PATH_* chosen for the current coefficients */
+int32_t acdsp_fir_kernel_class(acdsp_fir_t h); /* the same, with ACDSP_KCLASS_* inside ACDSP_PATH_GENERIC; -1 before set_coeffs */
 /* Duration of the main kernel of the most recent TIMED run(), from HIP events
  * recorded on the launch stream (blocks until that kernel has finished).  Small host-side
  * calls (run_host of at most 64 KB: the drop-in classes' one-channel path) are launch-bound
@@ -335,6 +340,8 @@ int32_t acdsp_ddc_state_set(acdsp_ddc_t h, const void *h_buf, uint64_t bytes);
  * run():      d_in[s] / d_out[s] = device pointers ON shard s's device to its [ch_hi - ch_lo][stride] block; every shard's thread
  *             launches its slice on its stream and waits for it; the call returns when all have.  Aggregate rate of a call =
  *             n_channels * n / acdsp_node_last_ms's maximum (per-shard times: the engine handles' own HIP events).
+ *             PRECONDITION: the shard streams are non-blocking and order with no other stream -- every d_in block must be complete
+ *             and every d_out block unused by pending work of other streams when run() is called (synchronise the producer first).
  * run_host(): dense host block [n_channels][n]: every thread moves and filters its rows (acdsp_fir_run_host of the slice).
  * The shard handles (acdsp_node_shard_info) take every per-handle call of this header: state get / set, reset, path, kernel_stats. */
 typedef struct acdsp_node *acdsp_node_t;

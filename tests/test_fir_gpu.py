@@ -160,7 +160,9 @@ def test_output_types_of_fewer_than_16_bits_keep_the_32_bit_epilogue(n_taps, fo)
     fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
     for k, c in enumerate((windowed_sinc_raw(n_taps | 1, 0.1, fc.F)[:n_taps],
                            np.minimum(rand_raw(np.random.default_rng(n_taps), fc, (n_taps,)), 32639) >> (6 if n_taps > 255 else 3))):
-        fir = check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=5, n=2048 + 3 * n_taps + 8, splits=[1024 + 16], seed=n_taps + fo.W + k,
+        # calls of at least two complete 1024-sample steps: the software-pipelined body (round 4's sizes -- 1040 + 1008 + ... samples -- only
+        # ever ran the edge body, and the pipelined write-out of these types stored every lane's first dword four times: round 5)
+        fir = check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=5, n=6 * 1024 + 3 * n_taps + 8, splits=[1024 + 16, 4096 + 16], seed=n_taps + fo.W + k,
                          coeffs=np.asarray(c, dtype=np.int64), expect_path="mfma_i8")
         del fir
 
@@ -231,6 +233,75 @@ def test_unsigned_16_bit_samples_run_the_matrix_cores(n_taps, ftype):
                    coeffs=np.minimum(rand_raw(rng, fc, (4, nt)), 32639), splits=[777], seed=nt, expect_path="mfma_i8")
         check_case(nt, ftype, fin, fc, fa, A.Fmt(16, 3, True, "RND", "SAT"), n_ch=4, n=1500, per_channel=True,
                    coeffs=np.minimum(rand_raw(rng, fc, (4, nt)), 32639), splits=[777], seed=nt + 1, expect_path="mfma_i8")
+
+
+LOSSY_MFMA_TYPES = [
+    # (IN, COEFF, ACC): s = F_in + F_c - F_acc dropped bits per tap
+    (A.Fmt(28, 6), A.Fmt(23, 7), A.Fmt(64, 32)),                      # the reference's prog testbench (rtest_ac_fir_prog_coeffs.cpp:47-54): s = 6
+    (A.Fmt(28, 6), A.Fmt(23, 7), A.Fmt(64, 32, True, "RND", "WRAP")),
+    (A.Fmt(32, 16), A.Fmt(24, 8), A.Fmt(56, 28, True, "RND", "WRAP")),  # s = 4
+    (A.Fmt(32, 16), A.Fmt(24, 8), A.Fmt(40, 16)),                     # s = 8, an accumulator that wraps (40 + 8 <= 64: mod-2^64 sums suffice)
+    (A.Fmt(20, 4), A.Fmt(18, 2), A.Fmt(50, 19, True, "RND", "WRAP")),  # s = 1, 20-bit samples in 4-byte containers (all four byte planes)
+    (A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(48, 28)),                     # 16-bit samples, wide coefficients: s = 4
+    (A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(48, 31, True, "RND", "WRAP")),  # s = 7
+    (A.Fmt(15, 3, False), A.Fmt(24, 4), A.Fmt(46, 16)),               # unsigned 15-bit samples: s = 2
+]
+
+
+@pytest.mark.parametrize("ftype", FTYPES6)
+@pytest.mark.parametrize("types", range(len(LOSSY_MFMA_TYPES)))
+def test_lossy_wrapping_accumulators_on_the_matrix_cores(ftype, types):
+    """Class B beyond 16-bit types and through the folds (reference ac_fir_prog_coeffs.h:147-227): sum_k Q(p_k) = (sum_k p_k + N h -
+    sum_k ((p_k + h) mod 2^s)) >> s -- the exact sum on the matrix cores (effective taps of the ftype), the dropped bits from the low s bits of
+    every (folded) sample and coefficient.  Calls that are whole chunks (the ring kernel), ragged calls (its exact-order tail), history across
+    calls, odd and even tap counts (FOLD_EVEN drops the centre tap of an odd count, FOLD_ODD ignores reg[N/2] of an even one), OUT = ACC and
+    narrower saturating OUT_TYPEs.  TRANSPOSED keeps reg_trans outside the const class: those handles stay on the exact-order kernel."""
+    fin, fc, fa = LOSSY_MFMA_TYPES[types]
+    chunk = 4096 if fin.W <= 16 else 2048
+    kind = "const" if ftype == "TRANSPOSED" else "prog"
+    for k, (n_taps, fo) in enumerate(((27, fa), (28, A.Fmt(32, 12, True, "RND", "SAT")), (97, A.Fmt(fa.W, fa.I)), (6, A.Fmt(30, 9, True, "TRN", "WRAP")))):
+        if fin.W <= 16 and k == 1:
+            fo = A.Fmt(16, 6, True, "RND", "SAT")
+        rng = np.random.default_rng(100 * types + k)
+        c = rand_raw(rng, fc, (n_taps,)) >> (max(fc.W - 22, 0) + (2 if n_taps > 30 else 0))    # three balanced base-256 digits per tap
+        fir = check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=4 * chunk + 333, kind=kind, splits=[2 * chunk, 2 * chunk + 77], seed=types + k,
+                         coeffs=c, expect_path="mfma_lossy")
+        del fir
+    if ftype == "TRANSPOSED":
+        check_case(27, ftype, fin, fc, fa, fa, n_ch=2, n=chunk + 50, kind="load", splits=[chunk], seed=types, expect_path="generic")
+
+
+def test_lossy_matrix_core_class_bounds():
+    """What the class refuses: more than 8 dropped bits, a 64-bit sum that could leave int64 while ACC_TYPE keeps its top bits, sign-dependent
+    rounding, a saturating accumulator, a coefficient set per channel -- all of them bit-exact on the other kernels."""
+    x28, c23 = A.Fmt(28, 6), A.Fmt(23, 7)
+    for fa, fc, want in ((A.Fmt(64, 40), c23, "generic"),                               # s = 14
+                         (A.Fmt(64, 32, True, "TRN_ZERO", "WRAP"), c23, "generic"),
+                         (A.Fmt(64, 32, True, "TRN", "SAT"), c23, "generic"),
+                         (A.Fmt(64, 32, False, "TRN", "WRAP"), c23, "generic"),
+                         (A.Fmt(64, 32), A.Fmt(40, 7), "generic")):                     # 2^27 * 27 * 2^39 passes 2^62 and ACC keeps all 64 bits
+        check_case(27, "FOLD_ODD", x28, fc, fa, A.Fmt(fa.W, fa.I, fa.S), n_ch=2, n=2048 + 100, kind="prog", splits=[2048], seed=fa.I, expect_path=want)
+    check_case(27, "SHIFT_REG", x28, c23, A.Fmt(64, 32), A.Fmt(64, 32), n_ch=3, n=2048 + 100, kind="prog", per_channel=True, splits=[2048], expect_path="generic")
+
+
+@pytest.mark.parametrize("acc_w", [27, 28, 29, 30])
+def test_unsigned_16_bit_samples_against_an_accumulator_inside_twice_the_signed_bound(acc_w):
+    """The flipped image is signed (|x| <= 2^15) but the recombined sum is the unsigned dot product, up to 65535 * sum|c|: an ACC_TYPE that holds
+    32768 * sum|c| and not 65535 * sum|c| wraps in the reference and must wrap here (round-4 advisor finding: the no-wrap proof of the fast
+    epilogues used the signed bound).  32 taps of +100, full-scale samples: <28,0> wraps 6399 -> -1792."""
+    fin, fc = A.Fmt(16, 2, False), A.Fmt(16, 2)
+    c = np.full(32, 100, dtype=np.int64)
+    for fo in (A.Fmt(16, 3, True, "RND", "SAT"), A.Fmt(16, 3, True, "TRN", "WRAP"), A.Fmt(acc_w, 0), A.Fmt(24, 4, True, "RND", "SAT")):
+        rng = np.random.default_rng(acc_w)
+        x = rand_raw(rng, fin, (3, 1500))
+        x[0, :] = 65535
+        x[1, ::2] = 65535
+        fir = A.Fir(32, "SHIFT_REG", fin, fc, A.Fmt(acc_w, 0), fo, n_channels=3)
+        fir.set_coeffs(c)
+        assert fir.path == "mfma_i8", fir.path
+        y = run_engine(fir, x, [700])
+        yo = OracleFir(32, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(A.Fmt(acc_w, 0)), ofmt(fo), n_ch=3).run(c, x)
+        assert np.array_equal(y, yo), (acc_w, fo.W, y[0, 40:44], yo[0, 40:44])
 
 
 @pytest.mark.parametrize("fo", [A.Fmt(12, 1, True, "RND", "SAT"), A.Fmt(14, 2, True, "TRN", "WRAP"), A.Fmt(24, 6, True, "RND", "SAT"), A.Fmt(32, 12)])
