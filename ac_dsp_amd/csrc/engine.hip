@@ -568,7 +568,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_corr, n_sets * sizeof(int64_t)); }
   if (e == hipSuccess) { e = hipMalloc((void **)&h->d_gfrag, 3 * 8 * 64 * 4 * sizeof(uint32_t)); }
-  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_lzcl, 128 * sizeof(uint32_t)); }
+  if (e == hipSuccess) { e = hipMalloc((void **)&h->d_lzcl, kLossyTabWords * sizeof(uint32_t)); }
   if (e != hipSuccess || h->tm.init() != ACDSP_OK) {
     acdsp_fir_destroy(h);
     return fail(ACDSP_EHIP, "FIR state allocation failed: %s", hipGetErrorString(e));
@@ -739,26 +739,29 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
     }
     const int n_pair = fold_odd ? (d.n_taps - 1) / 2 : (fold_even ? d.n_taps / 2 : 0);
     const int n_single = fold_odd ? 1 : (fold_even ? 0 : d.n_taps);
-    const int n_ent = n_pair + n_single;
-    ok = ok && n_ent >= 1 && n_ent <= 128 && (int64_t)n_ent * ((1 << sbits) - 1) < 65536;
+    ok = ok && n_pair + n_single >= 1;
     if (ok) {
       std::vector<int64_t> eff = effective_coeffs(coeffs, d.n_taps, ift);
-      std::vector<uint32_t> gfrag;
-      ok = fir_gen_plan(eff.data(), d.n_taps, 1, 0, &h->gplan, &gfrag) && fir_gen_lossy_shape_ok(kq, h->gplan);
+      std::vector<uint32_t> gfrag, tab;
+      ok = fir_gen_plan(eff.data(), d.n_taps, 1, 0, &h->gplan, &gfrag);
       // the exact sum must not leave int64 (the shift by s follows it), unless ACC_TYPE only keeps bits that survive a wrap of 2^64
       const int xb = d.in.W - (d.in.S ? 1 : 0);
-      ok = ok && (d.acc.W + sbits <= 64 || (h->gplan.sum_abs_h < (int64_t(1) << 61) && xb <= 61 && h->gplan.sum_abs_h <= ((int64_t(1) << 61) >> xb)));
+      const bool bounded = ok && h->gplan.sum_abs_h < (int64_t(1) << 61) && xb <= 61 && h->gplan.sum_abs_h <= ((int64_t(1) << 61) >> xb);
+      ok = ok && (d.acc.W + sbits <= 64 || bounded);
+      int acc_bits = d.acc.W;       // |acc| <= sum|c| 2^xb / 2^s + 1 when the sum is bounded: lets a 64-bit ACC_TYPE round into OUT_TYPE in int64
+      if (bounded) {
+        int sb = 0;
+        while (sb < 62 && (int64_t(1) << sb) <= h->gplan.sum_abs_h) { sb++; }
+        const int vb = sb + xb - sbits + 2;
+        if (vb < acc_bits) { acc_bits = vb < 2 ? 2 : vb; }
+      }
+      ok = ok && fir_gen_lossy_shape_ok(kq, h->gplan, acc_bits);
+      const int single0 = fold_odd ? (d.n_taps - 1) / 2 : 0;
+      ok = ok && fir_gen_lossy_table(h->gplan, coeffs, d.n_taps, n_pair, n_single, single0, anti ? 1 : 0, sbits, d.acc.Q == ACDSP_RND, &h->lzp, &tab);
       if (ok) {
-        std::vector<uint32_t> cl(128, 0u);
-        const uint32_t m1 = (1u << sbits) - 1;
-        for (int i = 0; i < n_pair; i++) { const uint32_t v = (uint32_t)((uint64_t)coeffs[i] & m1); cl[i] = v | (v << 16); }
-        const int single0 = fold_odd ? (d.n_taps - 1) / 2 : 0;
-        for (int i = 0; i < n_single; i++) { const uint32_t v = (uint32_t)((uint64_t)coeffs[single0 + i] & m1); cl[n_pair + i] = v | (v << 16); }
-        const uint32_t hh = d.acc.Q == ACDSP_RND ? (1u << (sbits - 1)) : 0u;
-        h->lzp.s = sbits; h->lzp.n_pair = n_pair; h->lzp.n_single = n_single; h->lzp.single0 = single0; h->lzp.neg = anti ? 1 : 0; h->lzp.n_taps = d.n_taps;
-        h->lzp.h2 = hh | (hh << 16); h->lzp.m2 = m1 | (m1 << 16); h->lzp.k = (int64_t)n_ent * hh; h->lzp.d_cl = h->d_lzcl;
+        h->lzp.d_tab = h->d_lzcl; h->lzp.acc_bits = acc_bits;
         HIP_TRY(hipMemcpy(h->d_gfrag, gfrag.data(), gfrag.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_lzcl, cl.data(), cl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_lzcl, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         h->lz_ok = true;
       }
     }

@@ -78,6 +78,11 @@ bool fir_gen_plan(const int64_t *h, int n_taps, int R, int first_mod16, FirGenPl
   for (int k = 0; k < n_taps; k++) { sum += (__int128)h[k]; sum_abs += h[k] < 0 ? -(__int128)h[k] : (__int128)h[k]; }
   pl->sum_h = (int64_t)(unsigned long long)sum;  // mod 2^64
   pl->sum_abs_h = sum_abs < ((__int128)1 << 62) ? (int64_t)sum_abs : (int64_t(1) << 62);
+  for (int q = 0; q < kGenMaxPC; q++) {
+    int64_t sa = 0;
+    for (int k = 0; k < n_taps; k++) { sa += dig[q][k] < 0 ? -(int64_t)dig[q][k] : (int64_t)dig[q][k]; }
+    pl->dig_abs[q] = sa;
+  }
   frag->assign((size_t)pc * nb * 64 * 4, 0u);
   for (int q = 0; q < pc; q++) {
     for (int b = 0; b < nb; b++) {
@@ -126,6 +131,9 @@ struct GenArgs {
   int32_t e_ls, e_ka, e_rs, e_ls2, e_ko;
   int64_t e_rnd, e_lo, e_hi;
   int32_t out_vec_ok;         // output rows are 16-byte aligned: whole steps leave as 1 KB-per-instruction stores
+  // ring kernel: which stages of that conversion do anything (bit 0 shift / wrap to ACC_TYPE, 1 rounding shift, 2 clamp, 3 final wrap) -- OUT =
+  // ACC = <64,32> of the reference testbenches needs none of them -- and whether neighbouring plane accumulators may be combined in 32 bits
+  int32_t e_stages, pw;
   // 32-bit limb epilogues of the cascade kernel (host-verified bounds, see launch_cascade): the constant of the
   // recombination (re-bias correction + rounding) enters as balanced base-256 digits = the initial accumulator values
   int32_t dig[8];
@@ -134,10 +142,10 @@ struct GenArgs {
   // class B on the ring kernel (LZ instantiations, see fir_gen_ring_kernel): acc = (S + K - sum_e r_e) >> lz_s with S the exact sum of the
   // matrix cores, r_e = (f_e * cl_e + h) mod 2^s the bits the reference's per-tap quantisation drops, K = entries * h
   int32_t lz_s;               // s = F_in + F_c - F_acc (1 .. 8)
-  int32_t lz_n_pair, lz_n_single, lz_single0, lz_neg, lz_ntaps;   // folded pairs (i, N-1-i) [difference when lz_neg], then single taps from lz_single0 on
+  int32_t lz_neg, lz_var_y, lz_p_n, lz_p_woff, lz_p_voff, lz_s_n, lz_s_woff;   // FirLossyPlan
   uint32_t lz_h2, lz_m2;      // rounding constant and mask of the dropped bits, in both 16-bit fields
   int64_t lz_k;
-  const uint32_t *lz_cl;      // [128] per-entry c mod 2^s in both 16-bit fields, pairs first; zero-padded
+  const uint32_t *lz_tab;     // [kLossyTabWords] slot coefficients (c_S, c_D) per iteration, pair loop first
 };
 
 
@@ -632,15 +640,15 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   static_assert(!LZ || R == 1, "class-B residues: plain FIR only");
   constexpr int LZP = LZ ? (RING + 1) * 32 : 0;               // low-bit ring: 16 samples x 2 bytes per slot, + one dump slot
   constexpr int LZ_DUMP = RING * 32, KSTEP_L = SPK * 32, PADV_L = ADV * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[PX * PLANE + (FB ? SPW : 1) * TILE + LZP + (LZ ? 512 : 0)];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PX * PLANE + (FB ? SPW : 1) * TILE + LZP + (LZ ? 4 * kLossyTabWords : 0)];
   const int lane = threadIdx.x;
   const int n_col = lane & 15, kg = lane >> 4;
   int bx, ch;
   xcd_remap(a.xcd_map, bx, ch);
   unsigned char *const lzr = lds + PX * PLANE + (FB ? SPW : 1) * TILE;   // low-bit ring, then the 128 coefficient words
   if constexpr (LZ) {
-    ((uint32_t *)(lzr + LZP))[lane] = a.lz_cl[lane];
-    ((uint32_t *)(lzr + LZP))[lane + 64] = a.lz_cl[lane + 64];
+#pragma unroll
+    for (int q = 0; q < kLossyTabWords / 64; q++) { ((uint32_t *)(lzr + LZP))[lane + 64 * q] = a.lz_tab[lane + 64 * q]; }
   }
   const int NB = a.pl.nb, PC = a.pl.pc;
   auto phys = [](int s) { return s + 2 * ((s + PH) / R); };
@@ -776,56 +784,123 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
           for (int pp = 0; pp < PX; pp++) { acc[pp + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b][q], X[pp], acc[pp + q], 0, 0, 0); }
         }
       }
-      // class B: the dropped bits of every tap, for this lane's four outputs (fields: outputs 0 | 1 in rA, 2 | 3 in rB)
+      // class B: the dropped bits of every tap, for this lane's four outputs (fields: outputs 0 | 1 in rA, 2 | 3 in rB).
+      // The low-bit ring holds sample p as a 16-bit field at byte 2 p.  An LDS access off its natural alignment is replayed lane by lane
+      // (~75 cycles per wave read measured, profiles/r5_lds_align.txt; the first form of this loop read 8 bytes per tap at 2-byte alignment
+      // and ran 13 lane-ops per tap and output), so every read here is an aligned dword of a sliding three-dword window, two taps
+      // per iteration: the "direct" slot D takes its four samples as (w1, w2), the "shifted" slot S one sample earlier through two
+      // v_alignbit.  Which tap sits in which slot depends on the parity of the window against the taps -- host-side (fir_gen_lossy_table),
+      // as slot coefficients; a slot without a tap has coefficient 0 and contributes exactly h, which K counts.
       unsigned rA = 0, rB = 0;
       if constexpr (LZ) {
         typedef unsigned short v2us_ __attribute__((ext_vector_type(2)));
         typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
-        // sample of output r, tap i: ring position 16 (delta + n_col) + off + 4 kg + r - i  (+ the step's parity)
-        const unsigned char *xb = lzr + 2 * (16 * (a.ring_delta + n_col) + a.pl.off + 4 * kg) + par_l;
-        const uint32_t *clt = (const uint32_t *)(lzr + LZP);
+        // byte address of the sample of output r = 0, tap 0: ring position 16 (delta + n_col) + off + 4 kg  (+ the step's parity)
+        const unsigned char *p0 = lzr + 2 * (16 * (a.ring_delta + n_col) + a.pl.off + 4 * kg) + par_l;
+        const v2u_ *ctab = (const v2u_ *)(lzr + LZP);
         const v2us_ h2 = __builtin_bit_cast(v2us_, a.lz_h2);
-        auto ld4 = [&](const unsigned char *q) -> v2u_ { v2u_ w; __builtin_memcpy(&w, q, 8); return w; };
+        auto ld32 = [&](const unsigned char *q) -> unsigned { return *(const unsigned *)q; };
         auto term = [&](unsigned f, unsigned c2) -> unsigned {
           const v2us_ m = __builtin_bit_cast(v2us_, f) * __builtin_bit_cast(v2us_, c2) + h2;
           return __builtin_bit_cast(unsigned, m) & a.lz_m2;
         };
-        const int np = a.lz_n_pair, ns = a.lz_n_single, nt1 = a.lz_ntaps - 1;
-#pragma unroll 2
-        for (int i = 0; i < np; i++) {
-          const v2u_ wa = ld4(xb - 2 * i), wb = ld4(xb - 2 * (nt1 - i));
-          const unsigned ax = wa.x, ay = wa.y, bx_ = wb.x, by = wb.y, c2 = clt[i];
-          unsigned f0, f1;
-          if (a.lz_neg) { f0 = __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, ax) - __builtin_bit_cast(v2us_, bx_))); f1 = __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, ay) - __builtin_bit_cast(v2us_, by))); }
-          else { f0 = __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, ax) + __builtin_bit_cast(v2us_, bx_))); f1 = __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, ay) + __builtin_bit_cast(v2us_, by))); }
-          rA += term(f0, c2); rB += term(f1, c2);
+        auto sh = [](unsigned lo, unsigned hi) -> unsigned { return __builtin_amdgcn_alignbit(hi, lo, 16); };   // fields (lo.hi, hi.lo)
+        auto fold = [&](unsigned x, unsigned y, auto neg_c) -> unsigned {
+          if constexpr (decltype(neg_c)::value) { return __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, x) - __builtin_bit_cast(v2us_, y))); }
+          else { return __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, x) + __builtin_bit_cast(v2us_, y))); }
+        };
+        auto pairs = [&](auto neg_c, auto vary_c) {
+          const unsigned char *wp = p0 + 2 * a.lz_p_woff, *vp = p0 + 2 * a.lz_p_voff;
+          unsigned w1 = ld32(wp + 4), w2 = ld32(wp + 8), v0 = ld32(vp), v1 = ld32(vp + 4);
+          for (int m = 0; m < a.lz_p_n; m++) {
+            const unsigned w0 = ld32(wp - 4 * m), v2 = ld32(vp + 4 * m + 8);
+            const v2u_ c = ctab[m];
+            const unsigned cS = c.x, cD = c.y;
+            unsigned fS0, fS1, fD0, fD1;
+            if constexpr (decltype(vary_c)::value) {   // even tap count: the mirror of the shifted slot is direct (v1, v2), of the direct slot shifted
+              fS0 = fold(sh(w0, w1), v1, neg_c); fS1 = fold(sh(w1, w2), v2, neg_c);
+              fD0 = fold(w1, sh(v0, v1), neg_c); fD1 = fold(w2, sh(v1, v2), neg_c);
+            } else {
+              fS0 = fold(sh(w0, w1), sh(v0, v1), neg_c); fS1 = fold(sh(w1, w2), sh(v1, v2), neg_c);
+              fD0 = fold(w1, v0, neg_c); fD1 = fold(w2, v1, neg_c);
+            }
+            rA += term(fS0, cS) + term(fD0, cD);
+            rB += term(fS1, cS) + term(fD1, cD);
+            w2 = w1; w1 = w0; v0 = v1; v1 = v2;
+          }
+        };
+        if (a.lz_p_n > 0) {
+          typedef std::integral_constant<bool, true> T_; typedef std::integral_constant<bool, false> F_;
+          if (a.lz_neg) { if (a.lz_var_y) { pairs(T_(), T_()); } else { pairs(T_(), F_()); } }
+          else { if (a.lz_var_y) { pairs(F_(), T_()); } else { pairs(F_(), F_()); } }
         }
-        const unsigned char *xs1 = xb - 2 * a.lz_single0;
-#pragma unroll 4
-        for (int i = 0; i < ns; i++) {
-          const v2u_ wa = ld4(xs1 - 2 * i);
-          const unsigned ax = wa.x, ay = wa.y, c2 = clt[np + i];
-          rA += term(ax, c2); rB += term(ay, c2);
+        {
+          const unsigned char *wp = p0 + 2 * a.lz_s_woff;
+          const v2u_ *tab = ctab + a.lz_p_n;
+          unsigned w1 = ld32(wp + 4), w2 = ld32(wp + 8);
+#pragma unroll 2
+          for (int m = 0; m < a.lz_s_n; m++) {
+            const unsigned w0 = ld32(wp - 4 * m);
+            const v2u_ c = tab[m];
+            const unsigned cS = c.x, cD = c.y;
+            rA += term(sh(w0, w1), cS) + term(w1, cD);
+            rB += term(sh(w1, w2), cS) + term(w2, cD);
+            w2 = w1; w1 = w0;
+          }
         }
       }
       int64_t o[4];
+      constexpr int NACC = PX + PCT - 1, NPR = (NACC + 1) / 2;
+      if (a.pw) {
+        // |acc[w]| small enough (host: dig_abs) that acc[2m] + (acc[2m+1] << 8) is exact in int32: pairs first, then 32-bit limbs with
+        // carries -- 8 instead of ~24 VALU instructions per output against a 64-bit shift-and-add per plane
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        uint64_t y = (uint64_t)a.corr;
+        for (int r = 0; r < 4; r++) {
+          int pr[NPR];
 #pragma unroll
-        for (int w = 0; w < PX + PCT - 1; w++) {
-          if (w < 8) { y += (uint64_t)(int64_t)acc[w][r] << (8 * w); }
+          for (int m = 0; m < NPR; m++) { pr[m] = (2 * m + 1 < NACC) ? (int)(((unsigned)acc[2 * m + 1][r] << 8) + (unsigned)acc[2 * m][r]) : acc[2 * m][r]; }
+          unsigned lo = (unsigned)a.corr, hi = (unsigned)((uint64_t)a.corr >> 32);
+          { const unsigned s0 = lo + (unsigned)pr[0]; hi += (unsigned)(pr[0] >> 31) + (s0 < lo); lo = s0; }
+          if constexpr (NPR > 1) { const unsigned t1 = (unsigned)pr[1] << 16, s1 = lo + t1; hi += (unsigned)(pr[1] >> 16) + (s1 < lo); lo = s1; }
+          if constexpr (NPR > 2) { hi += (unsigned)pr[2]; }
+          if constexpr (NPR > 3) { hi += (unsigned)pr[3] << 16; }
+          o[r] = (int64_t)(((uint64_t)hi << 32) | lo);
         }
-        if constexpr (LZ) {
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          uint64_t y = (uint64_t)a.corr;
+#pragma unroll
+          for (int w = 0; w < NACC; w++) {
+            if (w < 8) { y += (uint64_t)(int64_t)acc[w][r] << (8 * w); }
+          }
+          o[r] = (int64_t)y;
+        }
+      }
+      if constexpr (LZ) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
           const unsigned rr = r < 2 ? rA : rB;
           const unsigned res = (r & 1) ? (rr >> 16) : (rr & 0xffffu);
-          y = (uint64_t)((int64_t)(y + (uint64_t)a.lz_k - (uint64_t)res) >> a.lz_s);
+          o[r] = (int64_t)((uint64_t)o[r] + (uint64_t)a.lz_k - (uint64_t)res) >> a.lz_s;
         }
-        int64_t v = (int64_t)(y << a.e_ls);
-        v = (int64_t)((uint64_t)v << a.e_ka) >> a.e_ka;
-        v = (int64_t)((uint64_t)((v + a.e_rnd) >> a.e_rs) << a.e_ls2);
-        v = v < a.e_lo ? a.e_lo : (v > a.e_hi ? a.e_hi : v);
-        o[r] = (int64_t)((uint64_t)v << a.e_ko) >> a.e_ko;
+      }
+      // the conversion, stage by stage (uniform branches: a stage whose constants are trivial is skipped for all four outputs)
+      if (a.e_stages & 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { o[r] = (int64_t)(((uint64_t)o[r] << a.e_ls) << a.e_ka) >> a.e_ka; }
+      }
+      if (a.e_stages & 2) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { o[r] = (int64_t)((uint64_t)((o[r] + a.e_rnd) >> a.e_rs) << a.e_ls2); }
+      }
+      if (a.e_stages & 4) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { o[r] = o[r] < a.e_lo ? a.e_lo : (o[r] > a.e_hi ? a.e_hi : o[r]); }
+      }
+      if (a.e_stages & 8) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { o[r] = (int64_t)((uint64_t)o[r] << a.e_ko) >> a.e_ko; }
       }
       typedef long v2l __attribute__((ext_vector_type(2)));
       unsigned char *ob = ob0 + (FB ? k * TILE : 0);
@@ -900,7 +975,7 @@ static hipError_t launch_px(int px, dim3 grid, size_t lds_bytes, hipStream_t s, 
 }
 
 // Branch-free output conversion of the fast kernels (GenArgs::e_*): false if the formats need the general requant64.
-static bool gen_conv_params(const FirParams &p, int out_mode, int w_int, GenArgs *a) {
+static bool gen_conv_params(const FirParams &p, int out_mode, int w_int, GenArgs *a, int src_bits = 0) {
   bool conv_ok = p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
                  p.out.W >= 2 && p.out.W <= 64;
   int f_src = 0;
@@ -909,7 +984,8 @@ static bool gen_conv_params(const FirParams &p, int out_mode, int w_int, GenArgs
     a->e_ls = p.lossless_shift; a->e_ka = 64 - p.acc.W; f_src = p.acc.F;
     conv_ok = conv_ok && p.acc.S && p.acc.W >= 2 && p.acc.W <= 64 && p.lossless_shift >= 0 && p.lossless_shift < 64;
   }
-  const int rs = f_src - p.out.F, src_w = out_mode == 1 ? w_int : p.acc.W;
+  // src_bits > 0: the host has bounded the accumulator VALUE to that many bits (sign included), whatever its type's width
+  const int rs = f_src - p.out.F, src_w0 = out_mode == 1 ? w_int : p.acc.W, src_w = (src_bits > 0 && src_bits < src_w0) ? src_bits : src_w0;
   a->e_rs = rs > 0 ? rs : 0; a->e_ls2 = rs < 0 ? -rs : 0;
   a->e_rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs < 63) ? (int64_t(1) << (rs - 1)) : 0;
   // neither the rounding add nor the left shift can leave int64 (a 63- / 64-bit source with neither of them -- AC_TRN or rs <= 0, no left shift:
@@ -929,6 +1005,41 @@ static int64_t gen_rebias_corr(int px, int64_t sum_h) {   // 128 * sum(h) * sum_
   return (int64_t)(unsigned long long)((unsigned __int128)128 * bias * (unsigned long long)sum_h);
 }
 
+// Slot tables of the LZ residue loops (see fir_gen_ring_kernel).  With P0 the ring sample of (output r = 0, tap 0) of a lane -- parity
+// b = off & 1 for every lane -- iteration m of a loop over taps T0 + i' reads the dwords holding samples P0 + woff - 2 m .. + 5:
+//   b' = (b - T0) & 1;  woff = -T0 + b' - 2;  b' = 0: slot D = tap 2m, slot S = tap 2m + 1;  b' = 1: slot S = tap 2m, slot D = tap 2m - 1.
+// The mirror sample of tap i is P0 - (N-1-i): a second window that slides UP from voff = -N + 1 - b (N odd: the mirror of a direct
+// slot is direct) or -N - b (N even: it is the shifted one and vice versa).
+bool fir_gen_lossy_table(const FirGenPlan &pl, const int64_t *coeffs, int n_taps, int n_pair, int n_single, int single0, int neg, int s, bool rnd,
+                         FirLossyPlan *out, std::vector<uint32_t> *tab) {
+  const uint32_t m1 = (1u << s) - 1, hh = rnd ? (1u << (s - 1)) : 0u;
+  auto cl2 = [&](int tap) -> uint32_t { const uint32_t v = (uint32_t)((uint64_t)coeffs[tap] & m1); return v | (v << 16); };
+  tab->assign(kLossyTabWords, 0u);
+  const int b = pl.off & 1;
+  // one loop over `cnt` taps from T0 on: iterations and slot taps
+  auto build = [&](int T0, int cnt, int word0, int *n_it, int *woff) {
+    const int bp = (b - T0) & 1;
+    *woff = -T0 + bp - 2;
+    *n_it = cnt <= 0 ? 0 : (bp == 0 ? (cnt + 1) / 2 : cnt / 2 + 1);
+    for (int m = 0; m < *n_it; m++) {
+      const int iS = bp == 0 ? 2 * m + 1 : 2 * m, iD = bp == 0 ? 2 * m : 2 * m - 1;
+      if (word0 + 2 * m + 1 >= kLossyTabWords) { return false; }
+      (*tab)[word0 + 2 * m] = (iS >= 0 && iS < cnt) ? cl2(T0 + iS) : 0u;
+      (*tab)[word0 + 2 * m + 1] = (iD >= 0 && iD < cnt) ? cl2(T0 + iD) : 0u;
+    }
+    return true;
+  };
+  int p_n = 0, p_woff = 0, s_n = 0, s_woff = 0;
+  if (!build(0, n_pair, 0, &p_n, &p_woff) || !build(single0, n_single, 2 * p_n, &s_n, &s_woff)) { return false; }
+  const int slots = 2 * (p_n + s_n);
+  if (slots < 1 || (int64_t)slots * m1 >= 65536) { return false; }
+  out->s = s; out->neg = neg; out->var_y = (n_taps & 1) ? 0 : 1;
+  out->p_n = p_n; out->p_woff = p_woff; out->p_voff = (n_taps & 1) ? -n_taps + 1 - b : -n_taps - b;
+  out->s_n = s_n; out->s_woff = s_woff;
+  out->h2 = hh | (hh << 16); out->m2 = m1 | (m1 << 16); out->k = (int64_t)slots * hh;
+  return true;
+}
+
 // class-B ring shapes (the R = 1 shapes 20 / 21 / 23 / 24 / 25 below with the residue loop compiled in)
 static int lossy_ring_shape(int in_eb, int oeb, const FirGenPlan &pl) {
   if (pl.R != 1 || pl.pc > 3 || pl.nb > 3) { return 0; }
@@ -936,11 +1047,11 @@ static int lossy_ring_shape(int in_eb, int oeb, const FirGenPlan &pl) {
   if (in_eb == 4) { return oeb == 8 ? 20 : (oeb == 4 ? 21 : 0); }
   return 0;
 }
-bool fir_gen_lossy_shape_ok(const FirParams &p, const FirGenPlan &pl) {
+bool fir_gen_lossy_shape_ok(const FirParams &p, const FirGenPlan &pl, int acc_bits) {
   GenArgs a;
   FirParams q = p;
   q.lossless_shift = 0;
-  return lossy_ring_shape(p.in_eb, p.out_eb, pl) != 0 && gen_conv_params(q, 0, 0, &a);
+  return lossy_ring_shape(p.in_eb, p.out_eb, pl) != 0 && gen_conv_params(q, 0, 0, &a, acc_bits);
 }
 
 // p.n = inputs of this call; outputs m with first + m*R < n.  hist must hold >= off + 16 samples.
@@ -960,10 +1071,11 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
   if (a.px > p.in_eb) { return hipErrorInvalidValue; }
   if (lz) {
     a.px = p.in_eb;                    // the containers are sign-extended: every byte of them is a plane (the ring shapes are compiled for that)
-    a.lz_s = lz->s; a.lz_n_pair = lz->n_pair; a.lz_n_single = lz->n_single; a.lz_single0 = lz->single0; a.lz_neg = lz->neg; a.lz_ntaps = lz->n_taps;
-    a.lz_h2 = lz->h2; a.lz_m2 = lz->m2; a.lz_k = lz->k; a.lz_cl = lz->d_cl;
+    a.lz_s = lz->s; a.lz_neg = lz->neg; a.lz_var_y = lz->var_y; a.lz_p_n = lz->p_n; a.lz_p_woff = lz->p_woff; a.lz_p_voff = lz->p_voff;
+    a.lz_s_n = lz->s_n; a.lz_s_woff = lz->s_woff;
+    a.lz_h2 = lz->h2; a.lz_m2 = lz->m2; a.lz_k = lz->k; a.lz_tab = lz->d_tab;
   } else {
-    a.lz_s = 0; a.lz_n_pair = a.lz_n_single = a.lz_single0 = a.lz_neg = a.lz_ntaps = 0; a.lz_h2 = a.lz_m2 = 0; a.lz_k = 0; a.lz_cl = nullptr;
+    a.lz_s = 0; a.lz_neg = a.lz_var_y = a.lz_p_n = a.lz_p_woff = a.lz_p_voff = a.lz_s_n = a.lz_s_woff = 0; a.lz_h2 = a.lz_m2 = 0; a.lz_k = 0; a.lz_tab = nullptr;
   }
   a.n_slots = 15 * pl.R + 4 * pl.nb;
   a.out_mode = out_mode; a.w_int = w_int; a.out_simple = out_simple;
@@ -993,7 +1105,20 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
   else if (in_eb == 8 && px == 5 && pc <= 2 && nb <= 3 && spl == 1 && oeb == 4) { nbt = 3; }   // 127-tap FIR on 36-bit words -> int32
   else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && spl == 3 && npc <= 5 && oeb == 2) { nbt = 4; }   // 128-tap decimate-by-8 on int16 -> int16
   // ... and a conversion the branch-free form covers: signed wrapping accumulator, signed OUT, TRN/RND, WRAP/SAT
-  const bool conv_ok = gen_conv_params(p, out_mode, w_int, &a);
+  const bool conv_ok = gen_conv_params(p, out_mode, w_int, &a, lz ? lz->acc_bits : 0);
+  a.e_stages = ((a.e_ls != 0 || a.e_ka != 0) ? 1 : 0) | ((a.e_rnd != 0 || a.e_rs != 0 || a.e_ls2 != 0) ? 2 : 0) |
+               ((a.e_lo != INT64_MIN || a.e_hi != INT64_MAX) ? 4 : 0) | (a.e_ko != 0 ? 8 : 0);
+  {
+    // plane accumulator w sums the products of (input plane pp, coefficient digit q), pp + q = w, |plane byte| <= 128
+    int64_t bw[kGenMaxPX + kGenMaxPC] = {0};
+    for (int w = 0; w < a.px + pl.pc - 1; w++) {
+      for (int q = 0; q < pl.pc; q++) { if (w - q >= 0 && w - q < a.px) { bw[w] += 128 * pl.dig_abs[q]; } }
+    }
+    bool pw_ok = true;
+    for (int w = 0; w + 1 < kGenMaxPX + kGenMaxPC; w += 2) { pw_ok = pw_ok && (bw[w + 1] * 256 + bw[w] < (int64_t(1) << 31)); }
+    static const bool no_pw = getenv("ACDSP_GEN_NO_PW") != nullptr;   // A/B knob
+    a.pw = (pw_ok && !no_pw) ? 1 : 0;
+  }
 
   // Ring variant (fir_gen_ring_kernel) for the decimating BASELINE shapes.  ACDSP_GEN_RING=0: the window-per-step kernel (A/B
   // reference); ACDSP_GEN_RING=spw,pf,nt,fb picks another compiled variant (steps per chunk, load distance, non-temporal loads,
@@ -1053,11 +1178,11 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
     // int32, 8 KB of input per step) +2.5 % every time, poly_dec -0.6 % twice and +6.6 % once, the fused DDC -3 %: on for the
     // int32 decimator shape only.  ACDSP_XCD_MAP=0 / 1 forces it off / on for every shape (A/B knob).
     a.xcd_map = (xcd_map_wanted(out_mode == 1 && in_eb == 4) && ((int64_t)grid.x * grid.y) % 8 == 0) ? 1 : 0;
-    if (lz && ring_shape == 23) { e = launch_ring1<int16_t, 2, 3, 3, 1, 8, 16, 8, true, false, true>(grid, s, p, fr, a); }
-    else if (lz && ring_shape == 24) { e = launch_ring1<int16_t, 2, 3, 3, 1, 4, 16, 8, true, false, true>(grid, s, p, fr, a); }
-    else if (lz && ring_shape == 25) { e = launch_ring1<int16_t, 2, 3, 3, 1, 2, 16, 8, true, true, true>(grid, s, p, fr, a); }
-    else if (lz && ring_shape == 20) { e = launch_ring1<int32_t, 4, 3, 3, 1, 8, 8, 8, true, false, true>(grid, s, p, fr, a); }
-    else if (lz && ring_shape == 21) { e = launch_ring1<int32_t, 4, 3, 3, 1, 4, 8, 8, true, false, true>(grid, s, p, fr, a); }
+    if (lz && ring_shape == 23) { e = nb == 1 ? launch_ring1<int16_t, 2, 3, 1, 1, 8, 16, 8, true, false, true>(grid, s, p, fr, a) : launch_ring1<int16_t, 2, 3, 3, 1, 8, 16, 8, true, false, true>(grid, s, p, fr, a); }
+    else if (lz && ring_shape == 24) { e = nb == 1 ? launch_ring1<int16_t, 2, 3, 1, 1, 4, 16, 8, true, false, true>(grid, s, p, fr, a) : launch_ring1<int16_t, 2, 3, 3, 1, 4, 16, 8, true, false, true>(grid, s, p, fr, a); }
+    else if (lz && ring_shape == 25) { e = nb == 1 ? launch_ring1<int16_t, 2, 3, 1, 1, 2, 16, 8, true, true, true>(grid, s, p, fr, a) : launch_ring1<int16_t, 2, 3, 3, 1, 2, 16, 8, true, true, true>(grid, s, p, fr, a); }
+    else if (lz && ring_shape == 20) { e = nb == 1 ? launch_ring1<int32_t, 4, 3, 1, 1, 8, 8, 8, true, false, true>(grid, s, p, fr, a) : launch_ring1<int32_t, 4, 3, 3, 1, 8, 8, 8, true, false, true>(grid, s, p, fr, a); }
+    else if (lz && ring_shape == 21) { e = nb == 1 ? launch_ring1<int32_t, 4, 3, 1, 1, 4, 8, 8, true, false, true>(grid, s, p, fr, a) : launch_ring1<int32_t, 4, 3, 3, 1, 4, 8, 8, true, false, true>(grid, s, p, fr, a); }
     else if (lz) { e = hipErrorInvalidValue; }
     else if (ring_shape == 1) { e = launch_ring<int32_t, 4, 2, 3, 8, 8>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 2) { e = launch_ring<int16_t, 2, 3, 6, 16, 8>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
@@ -1065,11 +1190,13 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
     else if (ring_shape == 4) { e = launch_ring<int16_t, 2, 2, 3, 8, 4>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 5) { e = launch_ring1<int32_t, 4, 2, 2, 4, 8, 4, 4, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 6) { e = launch_ring1<int32_t, 4, 3, 6, 16, 8, 1, 1, true, false>(grid, s, p, fr, a); }
-    else if (ring_shape == 23) { e = launch_ring1<int16_t, 2, 3, 3, 1, 8, 16, 8, true, false>(grid, s, p, fr, a); }
-    else if (ring_shape == 24) { e = launch_ring1<int16_t, 2, 3, 3, 1, 4, 16, 8, true, false>(grid, s, p, fr, a); }
-    else if (ring_shape == 25) { e = launch_ring1<int16_t, 2, 3, 3, 1, 2, 16, 8, true, true>(grid, s, p, fr, a); }
-    else if (ring_shape == 20) { e = launch_ring1<int32_t, 4, 3, 3, 1, 8, 8, 8, true, false>(grid, s, p, fr, a); }
-    else if (ring_shape == 21) { e = launch_ring1<int32_t, 4, 3, 3, 1, 4, 8, 8, true, false>(grid, s, p, fr, a); }
+    // (plans of ONE K-block -- up to ~49 taps: the reference testbenches' 27 / 29 -- have their own instantiations: the three-block shapes
+    // issue 3 x the MFMAs on zero fragments, 36 instead of 12 per 256 outputs on 32-bit samples -- the matrix pipe, not HBM, bounded them)
+    else if (ring_shape == 23) { e = nb == 1 ? launch_ring1<int16_t, 2, 3, 1, 1, 8, 16, 8, true, false>(grid, s, p, fr, a) : launch_ring1<int16_t, 2, 3, 3, 1, 8, 16, 8, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 24) { e = nb == 1 ? launch_ring1<int16_t, 2, 3, 1, 1, 4, 16, 8, true, false>(grid, s, p, fr, a) : launch_ring1<int16_t, 2, 3, 3, 1, 4, 16, 8, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 25) { e = nb == 1 ? launch_ring1<int16_t, 2, 3, 1, 1, 2, 16, 8, true, true>(grid, s, p, fr, a) : launch_ring1<int16_t, 2, 3, 3, 1, 2, 16, 8, true, true>(grid, s, p, fr, a); }
+    else if (ring_shape == 20) { e = nb == 1 ? launch_ring1<int32_t, 4, 3, 1, 1, 8, 8, 8, true, false>(grid, s, p, fr, a) : launch_ring1<int32_t, 4, 3, 3, 1, 8, 8, 8, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 21) { e = nb == 1 ? launch_ring1<int32_t, 4, 3, 1, 1, 4, 8, 8, true, false>(grid, s, p, fr, a) : launch_ring1<int32_t, 4, 3, 3, 1, 4, 8, 8, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 10) { e = launch_ring1<int16_t, 2, 2, 2, 2, 2, 8, 8, true, true>(grid, s, p, fr, a); }
     else if (ring_shape == 11) { e = launch_ring1<int16_t, 2, 2, 2, 2, 8, 8, 8, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 12) { e = launch_ring1<int16_t, 2, 2, 3, 4, 2, 4, 4, true, true>(grid, s, p, fr, a); }

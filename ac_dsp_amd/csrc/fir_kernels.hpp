@@ -70,6 +70,7 @@ struct FirGenPlan {
   int32_t pc, nb, off, R;   // coefficient byte planes, 64-sample K blocks, T_n - W_n, decimation
   int64_t sum_h;            // sum of the taps mod 2^64 (re-bias correction)
   int64_t sum_abs_h;        // sum of |taps|, saturating at 2^62 (bounds of the 32-bit limb epilogues)
+  int64_t dig_abs[3];       // sum over the taps of |digit q| (bounds of the int32 plane accumulators)
 };
 // y[m] = sum_k h[k] x[first + m R - k] mod 2^64.  Builds the A fragments for first % 16 == first_mod16;
 // false if the taps need more than 3 byte planes or more than 8 K blocks.
@@ -80,13 +81,21 @@ bool fir_gen_plan(const int64_t *h, int n_taps, int R, int first_mod16, FirGenPl
 // plan of the EFFECTIVE tap vector (the exact sum), this struct the per-tap residues.
 struct FirLossyPlan {
   int32_t s;                           // F_in + F_c - F_acc, 1 .. 8
-  int32_t n_pair, n_single, single0, neg, n_taps;
+  int32_t neg, var_y;                  // folded pairs: difference instead of sum (ac_fir_reg_share's anti-symmetric cores); even tap count
+  int32_t p_n, p_woff, p_voff;         // pair loop: iterations (two pairs each), window offsets in samples relative to the output's own sample
+  int32_t s_n, s_woff;                 // single-tap loop: iterations (two taps each), window offset
   uint32_t h2, m2;                     // rounding constant / mask of the dropped bits in both 16-bit fields
-  int64_t k;                           // entries * h
-  const uint32_t *d_cl;                // device [128]: c mod 2^s per entry in both 16-bit fields (pairs, then singles), zero-padded
+  int64_t k;                           // slots * h
+  int32_t acc_bits;                    // bits (sign included) the accumulator VALUE can reach, <= W_acc: bounds the OUT_TYPE rounding add
+  const uint32_t *d_tab;               // device [kLossyTabWords]: per iteration (c_S, c_D) = c mod 2^s in both 16-bit fields; pair loop first
 };
+constexpr int kLossyTabWords = 256;
+// Slot tables of the residue loops (fir_gen.hip): taps [0, n_pair) fold with their mirror N-1-i, taps [single0, single0 + n_single) stand alone;
+// pl = plan of the effective taps (its window offset fixes the sample parities).  false: more slots than the table / the 16-bit sums hold.
+bool fir_gen_lossy_table(const FirGenPlan &pl, const int64_t *coeffs, int n_taps, int n_pair, int n_single, int single0, int neg, int s, bool rnd,
+                         FirLossyPlan *out, std::vector<uint32_t> *tab);
 // are this handle's (formats, plan) compiled as a class-B ring shape?  (decided at set_coeffs time: acdsp_fir_path reports it)
-bool fir_gen_lossy_shape_ok(const FirParams &p, const FirGenPlan &pl);
+bool fir_gen_lossy_shape_ok(const FirParams &p, const FirGenPlan &pl, int acc_bits);   // acc_bits: FirLossyPlan::acc_bits
 // lz != nullptr: class B -- only complete chunks run here; *covered = outputs written (the caller runs the exact-order kernel on the rest)
 hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32_t *d_frag, int out_mode, int w_int,
                           int64_t first, int64_t n_out, hipStream_t s, const FirLossyPlan *lz = nullptr, int64_t *covered = nullptr);

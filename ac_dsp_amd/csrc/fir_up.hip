@@ -66,9 +66,13 @@ __device__ inline unsigned up_gather4(unsigned d0, unsigned d1, unsigned d2, uns
   return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
-// index into the per-lane phase table of accumulator register r (row i = (r & 3) + 8 (r >> 2) + 4 h, phase i % L)
-template <int L> __device__ constexpr int up_tab_idx(int r) { return L >= 32 ? r : (L == 16 ? (r & 3) + 4 * ((r >> 2) & 1) : (r & 3)); }
-template <int L> constexpr int up_tab_size() { return L >= 32 ? 16 : (L == 16 ? 8 : 4); }
+// index into the per-lane phase table of accumulator register r (row i = (r & 3) + 8 (r >> 2) + 4 h, phase i % L); factors that do not
+// divide 32 have no period inside the 16 registers: one entry per register
+template <int L> __device__ constexpr int up_tab_idx(int r) { return (L >= 32 || 32 % L != 0) ? r : (L == 16 ? (r & 3) + 4 * ((r >> 2) & 1) : (r & 3)); }
+template <int L> constexpr int up_tab_size() { return (L >= 32 || 32 % L != 0) ? 16 : (L == 16 ? 8 : 4); }
+// input samples per MFMA column: the largest power of two with SPC * L <= 32 rows (L = 7: 4 samples x 7 phases = 28 of the 32 rows; the
+// Toeplitz fragments of the idle rows are zero and their outputs are never written)
+constexpr int up_spc(int L) { return L <= 2 ? 16 : (L <= 4 ? 8 : (L <= 8 ? 4 : 2)); }
 
 }  // namespace
 
@@ -108,9 +112,10 @@ template <typename TIN, int PX, int PCT, int NBT, int L, int OEB, int EPI, int N
 // (two waves per SIMD where the fragments + the register sets + accumulators need more than 168 registers: spills inside a step are
 // VMEM operations that every store-counting wait would have to drain)
 __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_kernel(UpArgs a, const v4i *__restrict__ frag) {
-  constexpr int SPC = 32 / L;                                 // input samples per MFMA column
+  constexpr int SPC = up_spc(L);                              // input samples per MFMA column
+  constexpr int ROWS = SPC * L;                               // live rows of a tile (32 when L divides 32)
   constexpr int SS = 512;                                     // samples per step
-  constexpr int G = L / 2;                                    // MFMA groups (1024 outputs each) per step
+  constexpr int G = 16 / SPC;                                 // MFMA groups (32 ROWS outputs each) per step
   constexpr int NLD = (int)sizeof(TIN) / 2;                   // 1 KB loads per step
   static_assert(NST >= 1 && NST <= 4, "up to four steps loaded up front");
   constexpr int HP = 32 * NBT;                                // history samples staged in front of a step
@@ -118,13 +123,14 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
   constexpr int NHL = HP / SPL;                               // lanes that load history
   constexpr int PLB = HP + SS + 16;                           // bytes of one plane array
   constexpr int FU = OEB == 8 ? 1 : ((OEB == 4 ? 2 : 4) < G ? (OEB == 4 ? 2 : 4) : G);   // groups per write-out
-  constexpr int RUN = 32 * OEB;                               // output bytes of one column
-  constexpr int RUNP = RUN + (OEB == 2 ? 8 : 16);             // padded column pitch of the tile (conflict-free writes)
+  constexpr int RUN = ROWS * OEB;                             // output bytes of one column
+  constexpr int UNIT = OEB == 2 ? 8 : 16;                     // bytes a lane writes per tile store
+  constexpr int RUNP = RUN + ((RUN / UNIT) % 2 == 0 ? UNIT : 0);   // column pitch of the tile: an odd number of store units (conflict-free writes)
   constexpr int NACC = PX + PCT - 1;
   constexpr int TS = up_tab_size<L>();
-  static constexpr int XAL = SPC >= 16 ? 16 : SPC;                  // alignment of the fragment reads
-  static_assert(32 % L == 0 && L >= 2, "L divides 32");
+  static_assert(L >= 2 && L <= 16 && ROWS % 4 == 0 && ROWS <= 32, "live rows come in the accumulator groups of four");
   static_assert(G % FU == 0, "groups per write-out must divide the groups of a step");
+  static_assert((FU * 32 * RUN) % (OEB == 2 ? 1024 : 512) == 0, "whole store instructions per write-out");
   __shared__ __attribute__((aligned(16))) unsigned char lds[PX * PLB + 64 * 16 + FU * 32 * RUNP];
   unsigned char *sink = lds + PX * PLB;                       // private dump of the lanes without a history load
   unsigned char *tile = sink + 64 * 16;
@@ -210,11 +216,13 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
     if constexpr (OEB == 2) {
 #pragma unroll
       for (int k = 0; k < FU * 32 * RUN / 1024; k++) {
+        // two aligned 8-byte reads: the column pitch (72 bytes at 32 rows) is a multiple of 8, not of 16, and a DS access off its natural
+        // alignment is replayed lane by lane (~85 instead of ~8 cycles per wave read: profiles/r5_lds_align.txt; round 4 read 16 bytes here)
         const int lin = (k * 64 + lane) * 16;
-        const int cc = lin / RUN, w = lin % RUN;
-        v4i val;
-        __builtin_memcpy(&val, (const unsigned char *)__builtin_assume_aligned(tile + cc * RUNP + w, 8), 16);   // column pitch 72: 8-byte aligned
-        __builtin_nontemporal_store(val, (v4i *)(yrow + e_unit * OEB + lin));
+        const int c0 = lin / RUN, w0 = lin % RUN, c1 = (lin + 8) / RUN, w1 = (lin + 8) % RUN;
+        typedef long v2l_ __attribute__((ext_vector_type(2)));
+        const v2l_ val = (v2l_){*(const long *)(tile + c0 * RUNP + w0), *(const long *)(tile + c1 * RUNP + w1)};
+        __builtin_nontemporal_store(val, (v2l_ *)(yrow + e_unit * OEB + lin));
       }
     } else {
 #pragma unroll
@@ -238,8 +246,25 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
       for (int b = 0; b < NBT; b++) {
 #pragma unroll
         for (int pp = 0; pp < PX; pp++) {
-          const unsigned char *src = (const unsigned char *)__builtin_assume_aligned(lds + pp * PLB + SPC * (32 * g + c + 1) + 32 * b + 16 * h, XAL);
-          __builtin_memcpy(&X[b][pp], src, 16);
+          // 16 bytes at byte offset SPC (32 g + c + 1) + ...: only SPC-aligned, and a DS read off its natural alignment is replayed lane by
+          // lane (round 4 issued one 16-byte read here: 26 % SQ_LDS_BANK_CONFLICT on the L = 8 rows was this).  Aligned pieces instead.
+          const unsigned char *src = lds + pp * PLB + SPC * (32 * g + c + 1) + 32 * b + 16 * h;
+          if constexpr (SPC >= 16) { X[b][pp] = *(const v4i *)src; }
+          else if constexpr (SPC == 8) {
+            typedef int v2i_ __attribute__((ext_vector_type(2)));
+            const v2i_ lo = *(const v2i_ *)src, hi = *(const v2i_ *)(src + 8);
+            X[b][pp] = (v4i){lo.x, lo.y, hi.x, hi.y};
+          } else if constexpr (SPC == 4) {
+            X[b][pp] = (v4i){*(const int *)src, *(const int *)(src + 4), *(const int *)(src + 8), *(const int *)(src + 12)};
+          } else {
+            // 2-byte steps: five aligned dwords, realigned per lane (odd columns start two bytes into a dword)
+            const unsigned sh = 2u * ((unsigned)(c + 1) & 1u);
+            const unsigned char *al = src - sh;
+            const unsigned d0 = *(const unsigned *)al, d1 = *(const unsigned *)(al + 4), d2 = *(const unsigned *)(al + 8), d3 = *(const unsigned *)(al + 12),
+                           d4 = *(const unsigned *)(al + 16);
+            X[b][pp] = (v4i){(int)__builtin_amdgcn_alignbyte(d1, d0, sh), (int)__builtin_amdgcn_alignbyte(d2, d1, sh),
+                             (int)__builtin_amdgcn_alignbyte(d3, d2, sh), (int)__builtin_amdgcn_alignbyte(d4, d3, sh)};
+          }
         }
       }
       v16i acc[NACC];
@@ -334,6 +359,7 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
           }
         }
         unsigned char *dst = tile + ((g % FU) * 32 + c) * RUNP + (8 * g4 + 4 * h) * OEB;
+        if (ROWS < 32 && 8 * g4 + 4 * h >= ROWS) { continue; }   // idle rows of a factor that does not divide 32
         if (EPI == 1 || EPI == 3) {
           if (OEB == 4) { *(v4i *)dst = (v4i){o32[0], o32[1], o32[2], o32[3]}; }
           else {
@@ -352,7 +378,7 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
           *(v4s *)dst = (v4s){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
         }
       }
-      if ((g + 1) % FU == 0) { flush(e_step + 1024 * (int64_t)(g + 1 - FU)); }
+      if ((g + 1) % FU == 0) { flush(e_step + 32 * ROWS * (int64_t)(g + 1 - FU)); }
       // keep the groups apart: interleaved, their accumulators and temporaries exceed the register budget
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -377,9 +403,9 @@ __global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_ker
 // host: digit planes, Toeplitz fragments, correction table
 // ---------------------------------------------------------------------------------------------
 bool fir_up_plan(const int64_t *E, int L, int nt, int px, FirUpPlan *pl, std::vector<uint32_t> *frag, std::vector<int64_t> *corr) {
-  if (L < 2 || L > 32 || (32 % L) != 0 || nt < 1 || px < 1 || px > 4) { return false; }
-  // K blocks: the window of a column spans its SPC = 32 / L samples and nt - 1 earlier ones
-  const int SPC = 32 / L;
+  if (L < 2 || L > 16 || (up_spc(L) * L) % 4 != 0 || nt < 1 || px < 1 || px > 4) { return false; }
+  // K blocks: the window of a column spans its SPC samples and nt - 1 earlier ones
+  const int SPC = up_spc(L);
   int nb = 1;
   while (32 * nb - SPC < nt - 1) { nb++; }
   if (nb > 2) { return false; }
@@ -408,7 +434,7 @@ bool fir_up_plan(const int64_t *E, int L, int nt, int px, FirUpPlan *pl, std::ve
           for (int bj = 0; bj < 4; bj++) {
             const int kappa = 32 * b + 16 * kg + 4 * dw + bj;
             const int tap = 32 * nb - SPC + d - kappa;
-            const int8_t val = (tap >= 0 && tap < nt) ? dig[q][(size_t)j * nt + tap] : (int8_t)0;
+            const int8_t val = (d < SPC && tap >= 0 && tap < nt) ? dig[q][(size_t)j * nt + tap] : (int8_t)0;   // rows past SPC * L: idle
             word |= (uint32_t)(uint8_t)val << (8 * bj);
           }
           (*frag)[((((size_t)b * kUpMaxPC) + q) * 64 + lane) * 4 + dw] = word;
@@ -429,7 +455,7 @@ bool fir_up_plan(const int64_t *E, int L, int nt, int px, FirUpPlan *pl, std::ve
 }
 
 bool fir_up_shape_ok(int in_eb, int px, int nb, int L, int out_eb) {
-  if (nb < 1 || nb > 2 || (L != 2 && L != 4 && L != 8 && L != 16)) { return false; }
+  if (nb < 1 || nb > 2 || (L != 2 && L != 4 && L != 8 && L != 16 && L != 7 && L != 3 && L != 5 && L != 6)) { return false; }
   if (in_eb == 2 && px == 2) { return out_eb == 2 || (out_eb == 4 && nb == 1) || out_eb == 8; }
   if (in_eb == 4 && px == 4) { return nb == 1 && out_eb == 8; }
   return false;
@@ -487,6 +513,11 @@ static hipError_t launch_up_l(const UpArgs &a, const uint32_t *d_frag, int L, in
     case 2: return launch_up_oeb<TIN, PX, PCT, NBT, 2>(a, d_frag, out_eb, epi, grid, s);
     case 4: return launch_up_oeb<TIN, PX, PCT, NBT, 4>(a, d_frag, out_eb, epi, grid, s);
     case 16: return launch_up_oeb<TIN, PX, PCT, NBT, 16>(a, d_frag, out_eb, epi, grid, s);
+    // factors that do not divide 32 (the reference's own CIC testbench: R = 7, ac_cic_intr_full_param.h:33-47): SPC * L live rows of 32
+    case 3: return launch_up_oeb<TIN, PX, PCT, NBT, 3>(a, d_frag, out_eb, epi, grid, s);
+    case 5: return launch_up_oeb<TIN, PX, PCT, NBT, 5>(a, d_frag, out_eb, epi, grid, s);
+    case 6: return launch_up_oeb<TIN, PX, PCT, NBT, 6>(a, d_frag, out_eb, epi, grid, s);
+    case 7: return launch_up_oeb<TIN, PX, PCT, NBT, 7>(a, d_frag, out_eb, epi, grid, s);
 #endif
     case 8: return launch_up_oeb<TIN, PX, PCT, NBT, 8>(a, d_frag, out_eb, epi, grid, s);
     default: return hipErrorNotSupported;

@@ -64,6 +64,48 @@ def test_interpolator_reference_vector_exact():
     assert len(y) == 6990 and np.array_equal(y, ref[:6990])
 
 
+def test_reference_vectors_many_channels_distinct_delays():
+    """The reference's two exact CIC vectors (tests/ac_cic_{dec,intr}_full_{input,ref}.txt) as a bank: channel c carries the testbench stream
+    behind its own number of leading zeros, so every channel must reproduce the reference outputs at its own delay -- on the batched kernels
+    the bank takes (decimator R = 7: the matrix-core FIR identity; interpolator R = 7: fir_up_kernel's 28-row tiles, whole 512-input steps
+    on the matrix cores and the head / tail on the polyphase kernel), one call and ragged calls."""
+    n_ch = 48
+    # interpolator: R=7 M=2 N=5 (rtest_ac_cic_intr_full.cpp, ac_cic_intr_full_param.h:33-47)
+    fin, fout = A.Fmt(32, 16), A.Fmt(49, 33)
+    xi = to_raw(read_fracs("ac_cic_intr_full_input.txt"), 16)[:1000]
+    ref = to_raw(read_fracs("ac_cic_intr_full_ref.txt"), 16)[5:][:6990]
+    n = 1000 + n_ch + 8
+    n += (-n) % 16
+    x = np.zeros((n_ch, n), dtype=np.int64)
+    for c in range(n_ch):
+        x[c, c:c + 1000] = xi
+    for splits in (None, [600], [33, 34, 1000]):
+        cic = A.Cic(True, 7, 2, 5, fin, fout, n_channels=n_ch)
+        y = run_engine(cic, x, splits)
+        if splits is None:
+            assert cic.path == "mfma_gen", cic.path
+        for c in range(n_ch):
+            assert not y[c, :7 * c].any(), c
+            assert np.array_equal(y[c, 7 * c:7 * c + 6990], ref), (c, splits)
+    # decimator: R=7 M=2 N=4 (rtest_ac_cic_dec_full.cpp; one extra leading zero :84-85); delays in whole decimation periods keep the phase
+    fin, fout = A.Fmt(32, 16), A.Fmt(48, 32)
+    xd = np.concatenate([[0], to_raw(read_fracs("ac_cic_dec_full_input.txt"), 16)])
+    refd = to_raw(read_fracs("ac_cic_dec_full_ref.txt"), 16)
+    n = len(xd) + 7 * n_ch
+    n += (-n) % 16
+    x = np.zeros((n_ch, n), dtype=np.int64)
+    for c in range(n_ch):
+        x[c, 7 * c:7 * c + len(xd)] = xd
+    for splits in (None, [4096], [7, 700, 5000]):
+        cic = A.Cic(False, 7, 2, 4, fin, fout, n_channels=n_ch)
+        y = run_engine(cic, x, splits)
+        if splits is None:
+            assert cic.path == "mfma_gen", cic.path
+        for c in range(n_ch):
+            assert not y[c, :c].any(), c
+            assert np.array_equal(y[c, c:c + len(refd)], refd), (c, splits)
+
+
 @pytest.mark.parametrize("interp", [False, True])
 @pytest.mark.parametrize("R,M,N", [(8, 1, 5), (16, 1, 5), (2, 1, 1), (3, 2, 3), (5, 3, 2), (4, 4, 3), (2, 1, 8), (13, 1, 4)])
 def test_parameter_sweep_vs_oracle(interp, R, M, N):
@@ -231,6 +273,14 @@ def test_decimator_ring_kernel_shapes_outside_the_baseline(R, N, fin, fout):
     (16, 1, 5, A.Fmt(16, 1), None),                               # boxcar(16)^5 taps pass 2^15: three digit planes; INT_TYPE exactly 32 bits
     (16, 1, 5, A.Fmt(32, 16), None),                              # three digit planes on int32 samples, INT_TYPE <48,32>
     (16, 1, 5, A.Fmt(32, 16), A.Fmt(40, 24, False)),              # ... unsigned narrower OUT_TYPE
+    (7, 2, 5, A.Fmt(32, 16), None),                               # the reference testbench's parameters: 28 live rows per tile
+    (7, 2, 5, A.Fmt(32, 16), A.Fmt(49, 33)),
+    (7, 2, 5, A.Fmt(16, 1), None),                                # ... on int16 samples: INT_TYPE <36,21>
+    (7, 1, 4, A.Fmt(16, 1), None),                                # INT_TYPE <26,11>: 4-byte containers
+    (3, 1, 4, A.Fmt(16, 2), None),                                # R = 3: 8 samples x 3 phases = 24 rows
+    (5, 2, 3, A.Fmt(32, 16), None),                               # R = 5: 20 rows
+    (6, 1, 5, A.Fmt(16, 1), None),                                # R = 6: 24 rows
+    (6, 1, 5, A.Fmt(32, 16), A.Fmt(40, 24, False)),
 ])
 def test_interpolator_matrix_core_path(R, M, N, fin, fout):
     rng = np.random.default_rng(R * 100 + N)

@@ -264,8 +264,10 @@ def test_lossy_wrapping_accumulators_on_the_matrix_cores(ftype, types):
             fo = A.Fmt(16, 6, True, "RND", "SAT")
         rng = np.random.default_rng(100 * types + k)
         c = rand_raw(rng, fc, (n_taps,)) >> (max(fc.W - 22, 0) + (2 if n_taps > 30 else 0))    # three balanced base-256 digits per tap
+        # FOLD_ODD keeps the pre-add in ACC_TYPE: an accumulator without the extra integer bit lets it wrap -- exact-order kernel
+        want = "generic" if (ftype == "FOLD_ODD" and fa.I < fin.I + 1 + (0 if fin.S else 1)) else "mfma_lossy"
         fir = check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=4 * chunk + 333, kind=kind, splits=[2 * chunk, 2 * chunk + 77], seed=types + k,
-                         coeffs=c, expect_path="mfma_lossy")
+                         coeffs=c, expect_path=want)
         del fir
     if ftype == "TRANSPOSED":
         check_case(27, ftype, fin, fc, fa, fa, n_ch=2, n=chunk + 50, kind="load", splits=[chunk], seed=types, expect_path="generic")
@@ -278,7 +280,7 @@ def test_lossy_matrix_core_class_bounds():
     for fa, fc, want in ((A.Fmt(64, 40), c23, "generic"),                               # s = 14
                          (A.Fmt(64, 32, True, "TRN_ZERO", "WRAP"), c23, "generic"),
                          (A.Fmt(64, 32, True, "TRN", "SAT"), c23, "generic"),
-                         (A.Fmt(64, 32, False, "TRN", "WRAP"), c23, "generic"),
+                         (A.Fmt(60, 28, False, "TRN", "WRAP"), c23, "generic"),
                          (A.Fmt(64, 32), A.Fmt(40, 7), "generic")):                     # 2^27 * 27 * 2^39 passes 2^62 and ACC keeps all 64 bits
         check_case(27, "FOLD_ODD", x28, fc, fa, A.Fmt(fa.W, fa.I, fa.S), n_ch=2, n=2048 + 100, kind="prog", splits=[2048], seed=fa.I, expect_path=want)
     check_case(27, "SHIFT_REG", x28, c23, A.Fmt(64, 32), A.Fmt(64, 32), n_ch=3, n=2048 + 100, kind="prog", per_channel=True, splits=[2048], expect_path="generic")
@@ -842,8 +844,24 @@ def test_reg_share_lossless_runs_on_the_matrix_cores(ftype):
 @pytest.mark.parametrize("q,o", [("TRN", "WRAP"), ("RND_CONV", "SAT"), ("TRN_ZERO", "SAT_SYM")])
 def test_reg_share_lossy_accumulator_keeps_the_ascending_mac_order(ftype, q, o):
     n_taps = 21 if "ODD" in ftype else 22
+    # (TRN into WRAP has no order: the folds run the matrix-core class-B kernel, SHIFT_REG the 16-bit VALU kernel; the others keep the exact order)
+    want = "mfma_lossy" if ((q, o) == ("TRN", "WRAP") and ftype != "SHIFT_REG") else "generic"
     check_reg_share(n_taps, ftype, A.Fmt(14, 4), A.Fmt(12, 2), A.Fmt(20, 8, True, q, o), A.Fmt(10, 5, True, q, o), splits=[7, 300],
-                    expect_path="generic", seed=5)
+                    expect_path=want, seed=5)
+
+
+@pytest.mark.parametrize("ftype", RS_FTYPES)
+@pytest.mark.parametrize("rnd", ["TRN", "RND"])
+def test_reg_share_lossy_wrapping_accumulator_on_the_matrix_cores(ftype, rnd):
+    """ac_fir_reg_share's cores in class B (ac_fir_reg_share.h:136-260): the anti-symmetric folds subtract the mirrored sample, so the dropped
+    bits come from (x[i] - x[N-1-i]) mod 2^s; whole chunks on the ring kernel, ragged calls on the exact-order kernel, odd and even tap counts."""
+    for n_taps, fin, fc, fa in ((27 if "ODD" in ftype else 28, A.Fmt(28, 6), A.Fmt(23, 7), A.Fmt(64, 32, True, rnd, "WRAP")),
+                                (61 if "ODD" in ftype else 60, A.Fmt(16, 8), A.Fmt(24, 6), A.Fmt(48, 26, True, rnd, "WRAP")),
+                                (28 if "ODD" in ftype else 27, A.Fmt(32, 16), A.Fmt(20, 4), A.Fmt(50, 22, True, rnd, "WRAP"))):
+        chunk = 4096 if fin.W <= 16 else 2048
+        c = rand_raw(np.random.default_rng(n_taps), fc, (n_taps,)) >> max(fc.W - 22, 1)
+        check_reg_share(n_taps, ftype, fin, fc, fa, A.Fmt(fa.W, fa.I), n_ch=3, n=3 * chunk + 211, coeffs=c, splits=[2 * chunk, 2 * chunk + 100],
+                        expect_path="mfma_lossy", seed=n_taps)
 
 
 def test_reg_share_rejects_ftypes_without_a_branch():

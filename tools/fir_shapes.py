@@ -19,6 +19,12 @@ CASES = [
     ("cfg1 types, 63 taps, OUT = ACC <38,10>", 63, "FOLD_ODD", F(16, 2), F(16, 2), F(38, 10), F(38, 10)),
     ("cfg1 types, 63 taps, OUT <16,2,RND,SAT>", 63, "FOLD_ODD", F(16, 2), F(16, 2), F(38, 10), F(16, 2, True, "RND", "SAT")),
     ("reference testbench types, 29 taps", 29, "FOLD_ODD", F(16, 8), F(32, 16), F(64, 32), F(64, 32)),
+    ("rtest load types <32,16> x <32,16> -> <64,32>, 27 taps", 27, "FOLD_ODD", F(32, 16), F(32, 16), F(64, 32), F(64, 32)),
+    ("rtest prog types <28,6> x <23,7> -> <64,32>, 27 taps", 27, "FOLD_ODD", F(28, 6), F(23, 7), F(64, 32), F(64, 32)),
+    ("prog types, 27 taps SHIFT_REG (class B)", 27, "SHIFT_REG", F(28, 6), F(23, 7), F(64, 32), F(64, 32)),
+    ("prog types, 27 taps FOLD_ODD, OUT <32,8,RND,SAT>", 27, "FOLD_ODD", F(28, 6), F(23, 7), F(64, 32), F(32, 8, True, "RND", "SAT")),
+    ("prog types, 127 taps SHIFT_REG (class B)", 127, "SHIFT_REG", F(28, 6), F(23, 7), F(64, 32), F(64, 32)),
+    ("<16,8> x <32,16> -> ACC <48,28> lossy s=4, 29 taps", 29, "FOLD_ODD", F(16, 8), F(32, 16), F(48, 28), F(48, 28)),
     ("<16,8> x <32,16>, 29 taps, OUT <32,16,RND,SAT>", 29, "SHIFT_REG", F(16, 8), F(32, 16), F(60, 36), F(32, 16, True, "RND", "SAT")),
     ("<16,8> x <32,16>, 127 taps, OUT <16,8,RND,SAT>", 127, "SHIFT_REG", F(16, 8), F(32, 16), F(60, 36), F(16, 8, True, "RND", "SAT")),
     ("DDC stage types, 127 taps <36,21> -> <32,17>", 127, "SHIFT_REG", F(36, 21), F(16, 1), F(59, 29), F(32, 17, True, "RND", "SAT")),
@@ -69,5 +75,5 @@ for name, taps, ftype, fin, fc, fa, fo in CASES:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     gb = (x.numel() * x.element_size() + y.numel() * y.element_size()) / 1e9
-    print("%-52s %8.3f ms  %5.2f TB/s  %.3f of 8 TB/s  path %s" % (name, ms, gb / ms, gb / ms / 8, eng.path), flush=True)
+    print("%-52s %8.3f ms  %5.2f TB/s  %.3f of 8 TB/s  path %s" % (name, ms, gb / ms, gb / ms / 8, eng.kernel), flush=True)
     del eng, x, y
