@@ -1759,6 +1759,8 @@ struct acdsp_polyintr {
   uint8_t *d_sign = nullptr, *d_corr = nullptr;
   // exact-accumulation class on the matrix cores (fir_up.hip): folded per-phase taps of the current control words
   bool up_ok = false;
+  bool acc64_ok = false;        // a 64-bit ACC_TYPE whose sums the current control words keep inside 62 bits: the exact-accumulation class applies
+  int up_px = 2;                // input byte planes of the matrix-core kernel (= container bytes)
   FirUpPlan up_plan;
   uint32_t up_shmask = 0;
   int64_t up_max_abs = -1;      // bound on |z| of the folded taps (enables the 32-bit epilogue)
@@ -1911,8 +1913,19 @@ int32_t acdsp_polyintr_set_ctrl(acdsp_polyintr_t h, const int64_t *coeffs, const
   h->up_ok = false;
   static const bool no_gen = getenv("ACDSP_NO_GEN") != nullptr;
   const int fi = d.in.W - d.in.I, fc = d.coeff.W - d.coeff.I, fa = d.acc.W - d.acc.I, ls = fa - fi - fc;
-  const bool lossless = d.in.S && d.acc.S && d.acc.O == ACDSP_WRAP && ls >= 0 && ls < 64 && fa >= fi && d.acc.I >= d.in.I + 1 && d.acc.W <= 63;
-  if (lossless && !no_gen && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && d.in.W <= 16 && h->in_eb == 2 && d.ifac <= 32) {
+  // (a 64-bit ACC_TYPE -- the header's own usage example, ac_poly_intr.h:45-48: <32,16> samples and coefficients into <64,32> -- belongs to
+  // the class when the control words bound every sub-filter sum to 62 bits: nothing can wrap and the pair sum t1 -/+ t2 stays inside int64)
+  const bool lossless = d.in.S && d.acc.S && d.acc.O == ACDSP_WRAP && ls >= 0 && ls < 64 && fa >= fi && d.acc.I >= d.in.I + 1 && d.acc.W <= 64;
+  h->acc64_ok = false;
+  if (lossless && d.acc.W == 64) {
+    std::vector<int64_t> E;
+    int nt = 0;
+    uint32_t shm = 0;
+    __int128 sa = 0;
+    h->acc64_ok = polyintr_linear_taps(d, coeffs, sign, corr, &E, &nt, &shm, &sa) && d.in.W - 1 + ls < 100 && (sa << (d.in.W - 1 + ls)) < ((__int128)1 << 62);
+  }
+  const int upx = h->in_eb;
+  if (lossless && (d.acc.W <= 63 || h->acc64_ok) && !no_gen && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && (h->in_eb == 2 || h->in_eb == 4) && d.ifac <= 32) {
     std::vector<int64_t> E;
     int nt = 0;
     uint32_t shm = 0;
@@ -1922,15 +1935,15 @@ int32_t acdsp_polyintr_set_ctrl(acdsp_polyintr_t h, const int64_t *coeffs, const
     FirUpPlan pl;
     if (polyintr_linear_taps(d, coeffs, sign, corr, &E, &nt, &shm, &sa) &&
         // |acc| <= sum|taps| * 2^(W_in - 1) << ls must stay inside ACC_TYPE; a pair sum then fits one more bit
-        (sa << (d.in.W - 1 + ls)) < ((__int128)1 << (d.acc.W - 1)) &&
-        fir_up_plan(E.data(), d.ifac, nt, 2, &pl, &frag, &ucorr) && fir_up_shape_ok(h->in_eb, 2, pl.nb, d.ifac, h->out_eb)) {
+        (sa << (d.in.W - 1 + ls)) < ((__int128)1 << ((d.acc.W < 64 ? d.acc.W : 63) - 1)) &&
+        fir_up_plan(E.data(), d.ifac, nt, upx, &pl, &frag, &ucorr) && fir_up_shape_ok(h->in_eb, upx, pl.nb, d.ifac, h->out_eb)) {
       if (h->d_upfrag) { (void)hipFree(h->d_upfrag); h->d_upfrag = nullptr; }
       if (h->d_upcorr) { (void)hipFree(h->d_upcorr); h->d_upcorr = nullptr; }
       HIP_TRY(hipMalloc((void **)&h->d_upfrag, frag.size() * sizeof(uint32_t)));
       HIP_TRY(hipMalloc((void **)&h->d_upcorr, ucorr.size() * sizeof(int64_t)));
       HIP_TRY(hipMemcpy(h->d_upfrag, frag.data(), frag.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy(h->d_upcorr, ucorr.data(), ucorr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-      h->up_plan = pl; h->up_shmask = shm; h->up_ok = true;
+      h->up_plan = pl; h->up_shmask = shm; h->up_ok = true; h->up_px = upx;
       {  // |z| <= max_j sum_k |E_j[k]| * 2^(W_in - 1)
         __int128 worst = 0;
         for (int j = 0; j < d.ifac; j++) {
@@ -1979,7 +1992,7 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
     const int fi = p.in.F, fc = p.cf.F, fa = p.acc.F;
     p.lossless_shift = fa - fi - fc;
     p.lossless = !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && d.in.S && d.acc.S && d.acc.O == ACDSP_WRAP && p.lossless_shift >= 0 && p.lossless_shift < 64 && fa >= fi &&
-                 d.acc.I >= d.in.I + 1 && d.acc.W <= 63 && (d.in.O == ACDSP_WRAP || d.in.O == ACDSP_SAT || d.in.O == ACDSP_SAT_SYM || d.in.O == ACDSP_SAT_ZERO);
+                 d.acc.I >= d.in.I + 1 && (d.acc.W <= 63 || h->acc64_ok) && (d.in.O == ACDSP_WRAP || d.in.O == ACDSP_SAT || d.in.O == ACDSP_SAT_SYM || d.in.O == ACDSP_SAT_ZERO);
   }
   p.in_stride = in_stride; p.out_stride = out_stride; p.n = n_in; p.n_out = no;
   p.x = d_in; p.y = d_out; p.hist = h->d_hist[h->cur];
@@ -2004,7 +2017,7 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
       memset(&k, 0, sizeof k);
       k.n_ch = d.n_channels; k.in = p.in; k.cf = p.cf; k.acc = p.acc; k.out = p.out; k.in_eb = h->in_eb; k.out_eb = h->out_eb;
       k.lossless_shift = p.lossless_shift; k.in_stride = in_stride; k.out_stride = out_stride; k.n = n_in; k.x = d_in; k.y = d_out;
-      e = launch_fir_up(k, h->up_plan, 2, h->d_upfrag, h->d_upcorr, 0, 0, 0, h->up_shmask, h->up_max_abs, slot_a, n_steps, out_off, s);
+      e = launch_fir_up(k, h->up_plan, h->up_px, h->d_upfrag, h->d_upcorr, 0, 0, 0, h->up_shmask, h->up_max_abs, slot_a, n_steps, out_off, s);
       if (e == hipSuccess) {
         o_a = 16 * slot_a * L + out_off; o_b = 16 * (slot_a + 32 * n_steps) * L + out_off;
         h->last_path = ACDSP_PATH_MFMA_GEN;

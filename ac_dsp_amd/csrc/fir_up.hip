@@ -477,10 +477,7 @@ template <typename TIN, int PX, int PCT, int NBT, int L>
 static hipError_t launch_up_oeb(const UpArgs &a, const uint32_t *d_frag, int out_eb, int epi, dim3 grid, hipStream_t s) {
   const v4i *f = (const v4i *)d_frag;
   if (out_eb == 8) {
-    if (epi == 4) {
-      if constexpr (sizeof(TIN) == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 4, up_nst(L, 8, 4)>), grid, dim3(64), 0, s, a, f); }
-      else { return hipErrorNotSupported; }
-    }
+    if (epi == 4) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 4, up_nst(L, 8, 4)>), grid, dim3(64), 0, s, a, f); }
     else if (epi == 2) { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 2, up_nst(L, 8, 2)>), grid, dim3(64), 0, s, a, f); }
     else { hipLaunchKernelGGL((fir_up_kernel<TIN, PX, PCT, NBT, L, 8, 0, up_nst(L, 8, 0)>), grid, dim3(64), 0, s, a, f); }
   } else if (out_eb == 4) {
@@ -558,6 +555,13 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
   a.c_rnd = 0; a.c_lo = INT64_MIN; a.c_hi = INT64_MAX; a.c_rs = a.c_ls2 = a.c_ko = 0;
   int epi = 0;
   const int rs = p.acc.F - p.out.F;
+  // bits (sign included) the accumulator value can reach: the host's bound on |V| where it has one, else ACC_TYPE's width
+  int acc_bits = p.acc.W;
+  if (mode == 0 && max_abs_v >= 0 && p.lossless_shift >= 0 && p.lossless_shift < 32) {
+    int vb = 0;
+    while (vb < 62 && (int64_t(1) << vb) <= max_abs_v) { vb++; }
+    if (vb + p.lossless_shift + 1 < acc_bits) { acc_bits = vb + p.lossless_shift + 1; }
+  }
   if (mode == 0 && px == 2 && p.lossless_shift == 0 && rs >= 0 && rs <= 28 && p.out_eb == 2 &&
       (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_SAT || (p.out.O == ACDSP_WRAP && p.out.W == 16)) &&
       max_abs_v >= 0 && max_abs_v < (int64_t(1) << 30)) {
@@ -567,9 +571,9 @@ hipError_t launch_fir_up(const FirParams &p, const FirUpPlan &pl, int px, const 
     a.e_rs = rs;
     a.e_rnd = (p.out.Q == ACDSP_RND && rs > 0) ? (1 << (rs - 1)) : 0;
     if (p.out.O == ACDSP_SAT) { a.e_lo = (int32_t)p.out.lo; a.e_hi = (int32_t)p.out.hi; }
-  } else if (mode == 0 && px == 2 && (p.out_eb == 8 || (p.out_eb == 4 && pl.nb == 1)) && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) &&
+  } else if (mode == 0 && (px == 2 || (px == 4 && p.out_eb == 8)) && (p.out_eb == 8 || (p.out_eb == 4 && pl.nb == 1)) && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) &&
              (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && p.lossless_shift >= 0 && p.lossless_shift < 32 && rs >= -16 && rs <= 62 &&
-             p.acc.W + (rs < 0 ? -rs : 0) <= 63 && p.out.W >= 2 && p.out.W <= 8 * p.out_eb) {
+             acc_bits + (rs < 0 ? -rs : 0) <= 63 && p.out.W >= 2 && p.out.W <= 8 * p.out_eb) {
     // exact-accumulation class into wider containers: the conversion without the generic epilogue's branches
     epi = 4;
     a.c_rs = rs > 0 ? rs : 0; a.c_ls2 = rs < 0 ? -rs : 0;

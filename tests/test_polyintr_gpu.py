@@ -129,22 +129,21 @@ def test_lossless_class_int64_kernel(ftype, n_taps, in_o):
 # ---- matrix-core path (fir_up.hip): exact-accumulation class, int16 samples, all phases with sign set ----
 
 def check_up(n_taps, ifac, ftype, fo, n_ch=3, n=16 * 33 * 3 + 80, splits=None, seed=0, pairs=True, coeff_bits=13, expect="mfma_gen", sign=None,
-             fa=A.Fmt(40, 12)):
-    fin, fc = A.Fmt(16, 2), A.Fmt(16, 2)
+             fa=A.Fmt(40, 12), fin=A.Fmt(16, 2), fc=A.Fmt(16, 2)):
     rng = np.random.default_rng(seed)
     csz = table_size(n_taps, ifac, ftype) + 1
     c = rng.integers(-(1 << (coeff_bits - 1)), 1 << (coeff_bits - 1), size=csz, dtype=np.int64)
     sg = np.ones(ifac, dtype=np.int64) if sign is None else np.asarray(sign)
     corr = (ifac - 1 - np.arange(ifac)) if pairs else np.arange(ifac)
     x = rand_raw(rng, fin, (n_ch, n))
-    x[0, :40] = -32768                                      # the most negative word everywhere in one window
+    x[0, :40] = -(1 << (fin.W - 1))                         # the most negative word everywhere in one window
     eng = A.PolyIntr(n_taps, csz, ifac, ftype, fin, fc, fa, fo, n_channels=n_ch)
     eng.set_ctrl(c, sg, corr)
     orc = OraclePolyIntr(n_taps, csz, ifac, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
     bounds = [0] + list(splits or []) + [n]
     seen = set()
     for a, b in zip(bounds[:-1], bounds[1:]):
-        xd = torch.from_numpy(x[:, a:b].copy()).to(torch.int16).cuda()
+        xd = torch.from_numpy(x[:, a:b].copy()).to(A.torch_dtype_for(fin)).cuda()
         y = eng.run(xd).cpu().numpy().astype(np.int64)
         seen.add(eng.path)
         yo = orc.run(c, sg, corr, x[:, a:b])
@@ -193,5 +192,30 @@ def test_matrix_core_path_is_left_when_the_cores_are_not_linear():
     check_up(16, 8, "FOLD_EVEN", fo, seed=8, coeff_bits=16, expect="lossless64", fa=A.Fmt(34, 6))
     check_up(16, 8, "FOLD_EVEN", fo, seed=8, coeff_bits=16, fa=A.Fmt(40, 12))
     # interpolation factors that are not compiled in fall back as well
-    check_up(16, 5, "FOLD_EVEN", fo, seed=9, expect="lossless64")
+    check_up(16, 9, "FOLD_EVEN", fo, seed=9, expect="lossless64")
     check_up(16, 32, "FOLD_EVEN", fo, seed=10, expect="lossless64")
+
+
+@pytest.mark.parametrize("ftype,n_taps", [("FOLD_EVEN", 16), ("FOLD_ODD", 15), ("FOLD_ANTI", 12)])
+@pytest.mark.parametrize("ifac", [2, 4, 8, 16, 3, 6, 7])
+def test_matrix_core_path_on_the_usage_example_types(ftype, n_taps, ifac):
+    """The header's own example (ac_poly_intr.h:44-48): <32,16> samples and coefficients, ACC = OUT = <64,32>.  Four input byte planes; a
+    64-bit accumulator belongs to the exact-accumulation class when the control words bound every sub-filter sum to 62 bits.  Factors that
+    do not divide 32 run SPC * IF live rows of the 32-row tile."""
+    f32, a64 = A.Fmt(32, 16), A.Fmt(64, 32)
+    n = 16 * 33 * 3 + 80
+    check_up(n_taps, ifac, ftype, a64, seed=ifac + n_taps, coeff_bits=17, fa=a64, fin=f32, fc=f32, n=n, splits=[16 * 40])
+    check_up(n_taps, ifac, ftype, A.Fmt(48, 20, True, "RND", "SAT"), seed=ifac, coeff_bits=16, fa=a64, fin=f32, fc=f32, pairs=False, n=n)
+    # full-range 32-bit coefficients: sums past 62 bits -- the accumulator may wrap, exact-order kernel
+    check_up(n_taps, ifac, ftype, a64, seed=ifac + 1, coeff_bits=32, fa=a64, fin=f32, fc=f32, n=700, expect="generic")
+    # 4-byte containers on 4-byte samples are not compiled in
+    check_up(n_taps, ifac, ftype, A.Fmt(32, 16, True, "RND", "SAT"), seed=ifac + 2, coeff_bits=16, fa=a64, fin=f32, fc=f32, n=n, expect="lossless64")
+
+
+@pytest.mark.parametrize("ifac", [3, 5, 6, 7])
+def test_matrix_core_path_factors_that_do_not_divide_32(ifac):
+    for fo in (A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(40, 12), A.Fmt(24, 6, True, "RND", "SAT")):
+        # (odd factors: the first call of a folded stream starts IF outputs early -- 2-byte runs then leave the 4-byte grid and stay on the VALU kernel;
+        # a second call of whole steps is aligned again)
+        check_up(16, ifac, "FOLD_EVEN", fo, seed=ifac, n=16 * 33 * 4 + 16, splits=[16 * 36], expect=None)
+        check_up(12, ifac, "FOLD_ANTI", fo, seed=ifac + 1, n=16 * 33 * 3 + 8)

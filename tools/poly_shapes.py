@@ -59,3 +59,20 @@ if which in ("both", "intr"):
             gb = (x.numel() * 2 + n_ch * n * ifac * (A.torch_dtype_for(fo).itemsize)) / 1e9
             print("poly_intr NTAPS=%2d IF=%2d -> %-15s %.3f ms  %.2f TB/s  %.3f of 8 TB/s  path %s" % (tp, ifac, oname, ms, gb / ms, gb / ms / 8, eng.path), flush=True)
             del eng, x
+
+if which in ("both", "intr", "hdr"):
+    # the header's usage-example types (ac_poly_intr.h:44-48): <32,16> samples and coefficients, ACC = OUT = <64,32>
+    f32, a64 = A.Fmt(32, 16), A.Fmt(64, 32)
+    for ifac, tp in ((2, 16), (4, 16), (8, 16), (16, 16), (7, 16)):
+        n = (1 << 20) // ifac
+        csz = tp * ifac // 2
+        eng = A.PolyIntr(tp, csz, ifac, "FOLD_EVEN", f32, f32, a64, a64, n_channels=n_ch)
+        hh = bench.windowed_sinc_raw(tp * ifac - 1, 0.4 / ifac, 16)
+        eng.set_ctrl(np.concatenate([hh, [0] * csz])[:csz], [1] * ifac, list(range(ifac)))
+        x = torch.empty((n_ch, n), dtype=torch.int32, device="cuda")
+        A.fill_stimulus(x, 1, 32)
+        eng.run(x[:, :16])
+        ms = timed(lambda: eng.run(x))
+        gb = (x.numel() * 4 + n_ch * n * ifac * 8) / 1e9
+        print("poly_intr <32,16> x <32,16> -> <64,32> NTAPS=%2d IF=%2d  %.3f ms  %.2f TB/s  %.3f of 8 TB/s  path %s" % (tp, ifac, ms, gb / ms, gb / ms / 8, eng.path), flush=True)
+        del eng, x
