@@ -124,7 +124,7 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 #endif
 template <int NR, bool LINEAR, bool CV32, bool EDGE>
 __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
-  constexpr int REGION = 512 + 8 * NR;          // samples of one wave's LDS image
+  constexpr int REGION = 512 + 8 * NR + 8;      // samples of one wave's LDS image (+ 8: the odd-offset window reads one dword further)
   constexpr int NQ = 4 * NR - 3;                // coefficient pairs covering 8 NR - 7 taps (+ a zero)
   __shared__ __attribute__((aligned(16))) int16_t sm[4][REGION];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -182,12 +182,31 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // The window starts a.off samples into the image: any even byte offset.  A DS read off its natural alignment is replayed lane by lane
+    // (~85 instead of ~8 cycles per wave read, profiles/r5_lds_align.txt; rounds 2 - 4 read 16 bytes at 2-byte alignment here -- 8 bytes into
+    // a 16-byte granule on the bench row), so the widest reads the offset is aligned for (the offset is wave-uniform: uniform branches).
     uint32_t R[4 * NR + 1];
+    {
+      const unsigned char *wb = reinterpret_cast<const unsigned char *>(img + 8 * lane) + 2 * a.off;
+      const int bo = 2 * a.off;
+      if ((bo & 15) == 0) {
 #pragma unroll
-    for (int r = 0; r < NR; r++) {
-      uint4 v;
-      __builtin_memcpy(&v, img + 8 * lane + a.off + 8 * r, 16);   // 2-byte aligned: the LDS takes unaligned b128 reads
-      R[4 * r] = v.x; R[4 * r + 1] = v.y; R[4 * r + 2] = v.z; R[4 * r + 3] = v.w;
+        for (int r = 0; r < NR; r++) { const uint4 v = *reinterpret_cast<const uint4 *>(wb + 16 * r); R[4 * r] = v.x; R[4 * r + 1] = v.y; R[4 * r + 2] = v.z; R[4 * r + 3] = v.w; }
+      } else if ((bo & 7) == 0) {
+#pragma unroll
+        for (int r = 0; r < 2 * NR; r++) { const uint2 v = *reinterpret_cast<const uint2 *>(wb + 8 * r); R[2 * r] = v.x; R[2 * r + 1] = v.y; }
+      } else if ((bo & 3) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4 * NR; r++) { R[r] = *reinterpret_cast<const uint32_t *>(wb + 4 * r); }
+      } else {   // an odd sample offset: aligned dwords one sample early, shifted down by 16 bits
+        uint32_t prev = *reinterpret_cast<const uint32_t *>(wb - 2);
+#pragma unroll
+        for (int r = 0; r < 4 * NR; r++) {
+          const uint32_t nxt = *reinterpret_cast<const uint32_t *>(wb + 2 + 4 * r);
+          R[r] = __builtin_amdgcn_alignbit(nxt, prev, 16);
+          prev = nxt;
+        }
+      }
     }
     R[4 * NR] = 0;
     int S[8];

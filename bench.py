@@ -69,6 +69,18 @@ def cpu_baseline_fir(n_taps, coeffs, fin, fc, fa, fo, seed):
                       "(ctypes releases the GIL), %.1f s wall" % (cores, n, reps, dt)}
 
 
+def reference_cfg_coeffs(which, fc):
+    """Raw words of the coefficient set of tests/rtest_ac_fir_<which>_coeffs.cpp (tests/golden/ref_txt/ac_fir_<which>_coeffs_cfg.txt: data,
+    see NOTICE); every value is exactly representable in its COEFF_TYPE."""
+    from fractions import Fraction
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "ref_txt", "ac_fir_%s_coeffs_cfg.txt" % which)
+    with open(path) as f:
+        vals = [Fraction(t) for t in f.read().replace(",", " ").split()]
+    raw = [v * (1 << (fc.W - fc.I)) for v in vals]
+    assert all(r.denominator == 1 for r in raw), "cfg value not representable in COEFF_TYPE"
+    return np.array([int(r) for r in raw], dtype=np.int64)
+
+
 def build_workload(workload, args, world, rank, local_rank):
     """Allocate one workload's engine handle and device buffers (per-rank channel slice) and return its description:
     step() = one pass of the hot path over the resident [channels][samples] block."""
@@ -113,6 +125,66 @@ def build_workload(workload, args, world, rank, local_rank):
             eng.run(x, y)
         path = eng.path
         samples_per_step = (hi - lo) * n
+    elif workload in ("rtest_const_types", "rtest_load_types", "rtest_prog_types"):
+        # The reference's OWN shipped parameterisations (the only FIR configurations with reference-held vectors), at batch scale:
+        #   tests/rtest_ac_fir_const_coeffs.cpp:50-74,160   29 taps FOLD_ODD, <16,8> x <32,16> -> ACC = OUT <64,32> (exact sums)
+        #   tests/rtest_ac_fir_load_coeffs.cpp:50-74,135    27 taps FOLD_ODD, <32,16> x <32,16> -> <64,32>            (exact sums)
+        #   tests/rtest_ac_fir_prog_coeffs.cpp:47-54        27 taps FOLD_ODD, <28,6> x <23,7> -> <64,32>: 6 bits dropped per tap (class B)
+        # with the coefficient sets of the testbenches (tests/golden/ref_txt/*_cfg.txt, attributed in NOTICE)
+        which = workload.split("_")[1]
+        n_taps = 29 if which == "const" else 27
+        fin = {"const": A.Fmt(16, 8), "load": A.Fmt(32, 16), "prog": A.Fmt(28, 6)}[which]
+        fc = {"const": A.Fmt(32, 16), "load": A.Fmt(32, 16), "prog": A.Fmt(23, 7)}[which]
+        fa = fo = A.Fmt(64, 32)
+        ch_per_gpu = args.channels or (1024 if which == "const" else 512)
+        n = args.samples or (1 << 20)
+        coeffs = reference_cfg_coeffs(which, fc)
+        assert len(coeffs) == n_taps
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        eng = A.Fir(n_taps, "FOLD_ODD", fin, fc, fa, fo, n_channels=hi - lo, kind=which, device=local_rank)
+        eng.set_coeffs(coeffs)
+        x = torch.empty((hi - lo, n + args.pad), dtype=A.torch_dtype_for(fin), device=dev)[:, :n]
+        A.fill_stimulus(x, seed, fin.W, ch0=lo)
+        y = torch.empty((hi - lo, n + args.pad), dtype=torch.int64, device=dev)[:, :n]
+        bytes_per_sample = float(x.element_size() + 8)
+        macs_per_sample = 0.0
+        name = "ac_fir_%s_coeffs %d-tap FOLD_ODD <%d,%d> x <%d,%d> -> ACC = OUT <64,32> (the types and coefficients of tests/rtest_ac_fir_%s_coeffs.cpp), " \
+               "%d ch x %d samples per GPU" % (which, n_taps, fin.W, fin.I, fc.W, fc.I, which, ch_per_gpu, n)
+        dtype = "int64 (exact multi-plane int8 MFMA sums%s)" % (" minus the per-tap dropped bits: class B" if which == "prog" else "")
+        coeffs = None
+
+        def step():
+            eng.run(x, y)
+        path = eng.kernel
+        samples_per_step = (hi - lo) * n
+    elif workload in ("cic_dec_r7m2n4", "cic_intr_r7m2n5"):
+        # the reference's CIC testbench parameters (tests/ac_cic_dec_full_param.h:33-47, ac_cic_intr_full_param.h:33-47) at batch scale
+        interp = workload.startswith("cic_intr")
+        N = 5 if interp else 4
+        fin = A.Fmt(32, 16)
+        ch_per_gpu = args.channels or (1024 if interp else 4096)
+        n = args.samples or ((1 << 18) if interp else 7 * (1 << 17))
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        it = A.Cic(interp, 7, 2, N, fin, fin, n_channels=1, device=local_rank).int_type
+        fo = A.Fmt(it.W, it.I)                   # <49,33> / <48,32>: the testbenches' OUT_TYPEs
+        eng = A.Cic(interp, 7, 2, N, fin, fo, n_channels=hi - lo, device=local_rank)
+        x = torch.empty((hi - lo, n), dtype=torch.int32, device=dev)
+        A.fill_stimulus(x, seed, 32, ch0=lo)
+        y = torch.empty((hi - lo, (n * 7 + 64) if interp else (n // 7 + 8)), dtype=torch.int64, device=dev)
+        if interp:
+            eng.run(x[:, :64], y)                # steady state: later calls emit R outputs per input
+        bytes_per_sample = 4.0 + (8.0 * 7 if interp else 8.0 / 7)
+        macs_per_sample = 0.0
+        name = "ac_cic_%s_full N=%d R=7 M=2 ac_fixed<32,16> -> <%d,%d> (the parameters of tests/rtest_ac_cic_%s_full.cpp), %d ch x %d input samples per GPU" % (
+            "intr" if interp else "dec", N, it.W, it.I, "intr" if interp else "dec", ch_per_gpu, n)
+        dtype = "int64 (wrap arithmetic mod 2^%d)" % it.W
+        coeffs = None
+
+        def step():
+            eng.run(x, y)
+        samples_per_step = (hi - lo) * n
+        step()
+        path = ("cic_intr_" if interp else "cic_dec_") + eng.path
     elif workload == "polydec":
         # ac_poly_dec, 16 taps per branch x DF = 8 (128-tap decimate-by-8), ac_fixed<16,2>
         ch_per_gpu = args.channels or 1024
@@ -477,7 +549,10 @@ def mfma_roofline_of(w, k_avg):
 
 # every other workload, measured in the same process after the headline (N = 1 only): the other BASELINE configurations
 # first, then the SURVEY 8 (f) rows
-SECONDARY = ["fir255_dense", "fir255_wide", "fir1023", "cic_dec", "ddc", "cic_intr", "polydec", "polyintr", "intgdump", "mvavg"]
+SECONDARY = ["fir255_dense", "fir255_wide", "fir1023", "cic_dec", "ddc", "cic_intr", "polydec", "polyintr", "intgdump", "mvavg",
+             # round 5: the reference's own shipped testbench parameterisations at batch scale
+             "rtest_const_types", "rtest_load_types", "rtest_prog_types", "cic_dec_r7m2n4", "cic_intr_r7m2n5"]
+ALL_WORKLOADS = ["fir255"] + SECONDARY
 
 
 def main():
@@ -485,7 +560,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "cic_intr", "ddc", "polydec", "polyintr", "intgdump", "mvavg"])
+    ap.add_argument("--workload", default="fir255", choices=ALL_WORKLOADS)
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the BASELINE config)")
     ap.add_argument("--samples", type=int, default=0, help="samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
