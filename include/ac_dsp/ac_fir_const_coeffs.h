@@ -43,9 +43,8 @@ public:
     std::vector<IN_TYPE> burst;
     while (data_in.available(1)) { burst.push_back(data_in.read()); }
     if (burst.empty()) { return; }
-    engine.set_coeffs(coeffs);  // uploaded on first use / when the pointed-to values changed
     std::vector<OUT_TYPE> result;
-    engine.run_values(burst, result);
+    engine.run_values_c(burst, result, coeffs);  // (coefficients uploaded on first use / when the pointed-to values changed; tiny bursts stay on the host)
     for (size_t i = 0; i < result.size(); i++) { data_out.write(result[i]); }
   }
 

@@ -48,9 +48,8 @@ public:
     std::vector<IN_TYPE> burst;
     while (data_in.available(1)) { burst.push_back(data_in.read()); }
     if (burst.empty()) { return; }
-    engine.set_coeffs(coeffs);
     std::vector<OUT_TYPE> result;
-    engine.run_values(burst, result);
+    engine.run_values_c(burst, result, coeffs);
     for (size_t i = 0; i < result.size(); i++) { data_out.write(result[i]); }
   }
 

@@ -32,9 +32,8 @@ public:
   void CCS_BLOCK(run)(ac_channel<IN_TYPE> &data_in, ac_channel<OUT_TYPE> &data_out, const COEFF_TYPE coeffs[N_TAPS]) {
     if (data_in.available(1)) {
       std::vector<IN_TYPE> one(1, data_in.read());
-      engine.set_coeffs(coeffs);
       std::vector<OUT_TYPE> result;
-      engine.run_values(one, result);
+      engine.run_values_c(one, result, coeffs);   // one sample: below the break-even of a launch, the host-side loop of acdsp_engine.h
       data_out.write(result[0]);
     }
   }

@@ -141,12 +141,12 @@ class fir_engine {
 public:
   fir_engine(int kind, int ftype, int n_taps, int n_channels = 1, bool coeffs_per_channel = false, int device = -1)
       : h_(0), kind_(kind), ftype_(ftype), n_taps_(n_taps), n_ch_(n_channels), per_ch_(coeffs_per_channel),
-        device_(device < 0 ? default_device() : device) {}
+        device_(device < 0 ? default_device() : device), head_(0), host_valid_(true), host_ahead_(false) {}
   ~fir_engine() { if (h_) { acdsp_fir_destroy(h_); } }
   // The reference objects are plain aggregates: copying one copies its state.
   fir_engine(const fir_engine &o)
       : h_(0), kind_(o.kind_), ftype_(o.ftype_), n_taps_(o.n_taps_), n_ch_(o.n_ch_), per_ch_(o.per_ch_), device_(o.device_),
-        coeffs_(o.coeffs_) {
+        coeffs_(o.coeffs_), ring_(o.ring_), rt_(o.rt_), head_(o.head_), host_valid_(o.host_valid_), host_ahead_(o.host_ahead_) {
     if (o.h_) { check(acdsp_fir_clone(o.h_, &h_), "acdsp_fir_clone"); }
   }
   fir_engine &operator=(const fir_engine &o) {
@@ -154,6 +154,7 @@ public:
       if (h_) { acdsp_fir_destroy(h_); h_ = 0; }
       kind_ = o.kind_; ftype_ = o.ftype_; n_taps_ = o.n_taps_; n_ch_ = o.n_ch_; per_ch_ = o.per_ch_; device_ = o.device_;
       coeffs_ = o.coeffs_;
+      ring_ = o.ring_; rt_ = o.rt_; head_ = o.head_; host_valid_ = o.host_valid_; host_ahead_ = o.host_ahead_;
       if (o.h_) { check(acdsp_fir_clone(o.h_, &h_), "acdsp_fir_clone"); }
     }
     return *this;
@@ -162,7 +163,8 @@ public:
   int n_channels() const { return n_ch_; }
   int in_bytes() const { return acdsp_elem_bytes(IN_TYPE::width); }
   int out_bytes() const { return acdsp_elem_bytes(OUT_TYPE::width); }
-  acdsp_fir_t handle() { ensure(); return h_; }
+  // the raw engine handle (state blobs, kernel statistics ...): the device becomes the authority on the filter state
+  acdsp_fir_t handle() { ensure(); to_device(); host_valid_ = false; return h_; }
 
   // raw coefficient words, [n_taps] or [n_channels][n_taps]; uploaded only when they changed
   void set_coeffs_raw(const std::vector<int64_t> &c) {
@@ -178,28 +180,140 @@ public:
   }
   // device-resident streams (the hot path): containers of in_bytes()/out_bytes(), strides in elements
   void run_device(const void *d_in, int64_t in_stride, int64_t n, void *d_out, int64_t out_stride, void *stream = 0) {
-    ensure();
+    ensure(); to_device(); host_valid_ = false;
     check(acdsp_fir_run(h_, d_in, in_stride, n, d_out, out_stride, stream), "acdsp_fir_run");
   }
   // host-resident dense [n_channels][n] containers
   void run_host(const void *h_in, int64_t n, void *h_out) {
-    ensure();
+    ensure(); to_device(); host_valid_ = false;
     check(acdsp_fir_run_host(h_, h_in, n, h_out), "acdsp_fir_run_host");
   }
   // one channel of ac_fixed values in, ac_fixed values out (used by the drop-in run() bodies)
   void run_values(const std::vector<IN_TYPE> &x, std::vector<OUT_TYPE> &y) {
-    std::vector<int64_t> r(x.size());
-    for (size_t i = 0; i < x.size(); i++) { r[i] = raw_of(x[i]); }
-    std::vector<unsigned char> bi, bo(x.size() * (size_t)out_bytes());
-    pack(r, in_bytes(), bi);
+    std::vector<unsigned char> bi(x.size() * (size_t)in_bytes()), bo(x.size() * (size_t)out_bytes());
+    for (size_t i = 0; i < x.size(); i++) { container_io<IN_TYPE>::store(x[i], &bi[i * in_bytes()], in_bytes()); }
     run_host(bi.data(), (int64_t)x.size(), bo.data());
     y.resize(x.size());
     for (size_t i = 0; i < x.size(); i++) { y[i] = container_io<OUT_TYPE>::load(&bo[i * out_bytes()], out_bytes()); }
   }
-  void reset() { if (h_) { check(acdsp_fir_reset(h_), "acdsp_fir_reset"); } }
+  void reset() {
+    if (h_) { check(acdsp_fir_reset(h_), "acdsp_fir_reset"); }
+    ring_.clear(); rt_.clear(); head_ = 0; host_valid_ = true; host_ahead_ = false;
+  }
+
+  // ---- the drop-in classes' entry point: one channel, the coefficient array of THIS call --------------------------------------------
+  // A burst below the break-even of a kernel launch (~25 us: ac_fir_prog_coeffs::run is ONE sample per call, reference
+  // ac_fir_prog_coeffs.h:281) runs HERE, on the caller's own ac_fixed arithmetic -- `acc += x * c` in the tap order of the
+  // architecture, over a ring of the last N_TAPS samples (or the partial sums of TRANSPOSED) -- and the filter state moves between the
+  // two sides as an engine state blob whenever the other side runs next.  Larger bursts (and every batched entry point above) go to
+  // the GPU.  ACDSP_HOST_SMALL_MACS = samples x taps below which a call stays on the host (default 8192; 0: never).
+  void run_values_c(const std::vector<IN_TYPE> &x, std::vector<OUT_TYPE> &y, const COEFF_TYPE *c) {
+    if (host_path_ok() && (int64_t)x.size() * n_taps_ <= small_macs()) {
+      to_host();
+      y.resize(x.size());
+      for (size_t i = 0; i < x.size(); i++) { y[i] = host_step(x[i], c); }
+      host_ahead_ = true;
+      return;
+    }
+    set_coeffs(c);
+    run_values(x, y);
+  }
+  static int64_t small_macs() {
+    static const int64_t v = getenv("ACDSP_HOST_SMALL_MACS") ? atoll(getenv("ACDSP_HOST_SMALL_MACS")) : 8192;
+    return v;
+  }
 
 private:
-  void ensure() {
+  bool host_path_ok() const {
+    return n_ch_ == 1 && !per_ch_ && (kind_ == ACDSP_FIR_CONST || kind_ == ACDSP_FIR_LOAD || kind_ == ACDSP_FIR_PROG) &&
+           ftype_ >= ACDSP_SHIFT_REG && ftype_ <= ACDSP_TRANSPOSED && n_taps_ >= 1;
+  }
+  // reg_trans partial sums are the state of TRANSPOSED with coefficients that can change (the const class keeps an input history: DESIGN 3)
+  bool chain_state() const { return ftype_ == ACDSP_TRANSPOSED && kind_ != ACDSP_FIR_CONST; }
+  // sample x[n-k] of the ring, k = 0 .. N-1
+  const IN_TYPE &w(int k) const { return ring_[(size_t)((head_ + k) % n_taps_)]; }
+  OUT_TYPE host_step(const IN_TYPE &xin, const COEFF_TYPE *c) {
+    const int N = n_taps_;
+    OUT_TYPE out;
+    if (chain_state()) {   // every partial sum takes this sample's product at its own coefficient (ac_fir_load_coeffs.h:265-278)
+      for (int i = N - 1; i >= 0; i--) {
+        ACC_TYPE below = 0;
+        if (i > 0) { below = rt_[(size_t)(i - 1)]; }
+        rt_[(size_t)i] = xin * c[N - 1 - i] + below;
+      }
+      out = rt_[(size_t)(N - 1)];
+      return out;
+    }
+    head_ = (head_ + N - 1) % N;
+    ring_[(size_t)head_] = xin;
+    ACC_TYPE acc = 0;
+    switch (ftype_) {
+      case ACDSP_C_BUFF:                                   // newest sample first
+        for (int k = 0; k < N; k++) { acc += w(k) * c[k]; }
+        break;
+      case ACDSP_FOLD_EVEN:                                // mirrored samples share a coefficient: exact pre-add
+        for (int k = N / 2 - 1; k >= 0; k--) { acc += c[k] * (w(k) + w(N - 1 - k)); }
+        break;
+      case ACDSP_FOLD_ODD: {                               // ... with the pre-add held in an ACC_TYPE variable, the centre tap alone
+        const int mid = (N - 1) / 2;
+        for (int k = 0; k <= mid; k++) {
+          ACC_TYPE folded;
+          if (k == mid) { folded = w(k); } else { folded = w(k) + w(N - 1 - k); }
+          acc += c[k] * folded;
+        }
+        break;
+      }
+      default:                                             // SHIFT_REG, ROTATE_SHIFT, TRANSPOSED with bound coefficients: oldest sample first
+        for (int k = N - 1; k >= 0; k--) { acc += w(k) * c[k]; }
+        break;
+    }
+    out = acc;
+    return out;
+  }
+  // host mirror <- engine state blob (64-byte header, then the words of the one channel: include/acdsp.h)
+  void to_host() {
+    const size_t N = (size_t)n_taps_;
+    if (host_valid_ && (ring_.size() == N || rt_.size() == N)) { return; }
+    ring_.assign(chain_state() ? 0 : N, IN_TYPE(0));
+    rt_.assign(chain_state() ? N : 0, ACC_TYPE(0));
+    head_ = 0;
+    if (h_ && !host_valid_) {
+      const int64_t sz = acdsp_fir_state_size(h_);
+      std::vector<unsigned char> blob((size_t)sz);
+      check(acdsp_fir_state_get(h_, blob.data(), (uint64_t)sz), "acdsp_fir_state_get");
+      const unsigned char *pay = blob.data() + 64;
+      if (chain_state()) {
+        const size_t eb = ((size_t)sz - 64) / N;           // 8-byte ACC raw words, 16 above 64 bits
+        for (size_t i = 0; i < N; i++) { rt_[i] = container_io<ACC_TYPE>::load(pay + i * eb, (int)eb); }
+      } else {
+        const size_t eb = (size_t)in_bytes(), hl = ((size_t)sz - 64) / eb;   // oldest first: entry hl-1-k is x[n-k]
+        for (size_t k = 0; k < N && k < hl; k++) { ring_[k] = container_io<IN_TYPE>::load(pay + (hl - 1 - k) * eb, (int)eb); }
+      }
+    }
+    host_valid_ = true;
+  }
+  // engine state <- host mirror, when the host ran last
+  void to_device() {
+    if (!host_ahead_) { return; }
+    ensure_raw();
+    const size_t N = (size_t)n_taps_;
+    const int64_t sz = acdsp_fir_state_size(h_);
+    std::vector<unsigned char> blob((size_t)sz);
+    check(acdsp_fir_state_get(h_, blob.data(), (uint64_t)sz), "acdsp_fir_state_get");   // the header of this handle's blobs
+    unsigned char *pay = blob.data() + 64;
+    memset(pay, 0, (size_t)sz - 64);
+    if (chain_state()) {
+      const size_t eb = ((size_t)sz - 64) / N;
+      for (size_t i = 0; i < N; i++) { container_io<ACC_TYPE>::store(rt_[i], pay + i * eb, (int)eb); }
+    } else {
+      const size_t eb = (size_t)in_bytes(), hl = ((size_t)sz - 64) / eb;
+      for (size_t k = 0; k < N && k < hl; k++) { container_io<IN_TYPE>::store(w((int)k), pay + (hl - 1 - k) * eb, (int)eb); }
+    }
+    check(acdsp_fir_state_set(h_, blob.data(), (uint64_t)sz), "acdsp_fir_state_set");
+    host_ahead_ = false;
+  }
+  void ensure() { ensure_raw(); }
+  void ensure_raw() {
     if (h_) { return; }
     acdsp_fir_desc_t d;
     d.kind = kind_; d.ftype = ftype_; d.n_taps = n_taps_; d.n_channels = n_ch_; d.coeffs_per_channel = per_ch_ ? 1 : 0;
@@ -212,6 +326,12 @@ private:
   bool per_ch_;
   int device_;
   std::vector<int64_t> coeffs_;
+  // host-side mirror of the one-channel state (tiny calls): ring of the last N_TAPS samples, or the TRANSPOSED partial sums
+  std::vector<IN_TYPE> ring_;
+  std::vector<ACC_TYPE> rt_;
+  int head_;
+  bool host_valid_;   // the mirror holds the current state
+  bool host_ahead_;   // ... and the device does not (the host ran last)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ def run(exe):
     return p.returncode, p.stdout.decode(errors="replace")
 
 
-TBS = ("tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg", "tb_wide", "tb_node")
+TBS = ("tb_tiny", "tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg", "tb_wide", "tb_node")
 # tests/_bin arrived prebuilt (the snapshot of a build container that ran __graft_entry__.build()): then the reference's rtest_*
 # binaries must have arrived with it -- a lost binary is a failure there, not a skip
 PREBUILT = all(os.path.exists(os.path.join(BIN, t)) for t in TBS)
