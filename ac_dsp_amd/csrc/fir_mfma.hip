@@ -150,6 +150,11 @@ struct MfmaArgs {
   // NAR instantiations of the pipelined body only; the edge chunks (fir_mfma_body) convert in registers: clamp to [nar_lo, nar_hi],
   // sign-extend the low 32 - nar_sh bits.  nar_on = 0: 16-bit OUT_TYPEs, nothing of this runs.
   int32_t nar_on, nar_d, nar_lo, nar_hi, nar_sh;
+  // 16-bit OUT_TYPEs with a sign- / parity-dependent rounding mode or AC_SAT_SYM / AC_SAT_ZERO (round 5), also in the NAR instantiations
+  // (nar_d = 0): the truncated quotient of the 32-bit epilogue plus the increment the dropped bits ask for (acdsp_dev.hpp: q_increment),
+  // then gq_o = 1: clamp to +-(2^15 - 1), 2: zero outside the int16 range.  gq_on = 0: AC_TRN / AC_RND, the rounding constant rides in ll.
+  // gq_q: mask word of the mode (epi32_gq).
+  int32_t gq_on, gq_q, gq_o;
   // 4-byte containers in the wide class (W4 instantiations of the pipelined body): w4_sat = 1: AC_SAT bounds, 0: wrap to W_out bits in
   // 64 bits, 2: wrap in 32-bit arithmetic (2^8 mid + ll and, for rs > 16, hh + carry exact in int32: host-checked)
   int32_t w4_sat;
@@ -168,6 +173,39 @@ __device__ __forceinline__ void epi32_t(const v16i &hh, const v16i &mid, const v
   for (int r = 0; r < 16; r++) {
     const int lo = (int)(((unsigned)mid[r] << 8) + (unsigned)ll[r]);
     o[r] = WIDE ? (hh[r] + (lo >> 16)) >> (rs - 16) : (int)((unsigned)hh[r] << (16 - rs)) + (lo >> rs);
+  }
+}
+// The same with the increment of a general rounding mode: the dropped bits of V >> rs are the low rs bits of lo (rs <= 16: 2^16 hh is a
+// multiple of 2^rs) or the low rs - 16 bits of hh + (lo >> 16) above the low half of lo.  ~10 VALU per output more than AC_TRN.
+// gq_q is a mask word, not the mode (one code path for all eight modes -- a switch over template instances of the mode multiplied the compile
+// time of every instantiation of this file by four): bit 0: the mode rounds on the half bit qb; bits 1 .. 5: what makes qb count beside the
+// other dropped bits r -- always (AC_RND), x < 0, x >= 0, an odd quotient, an even quotient; bit 6: AC_TRN_ZERO (x < 0 and any dropped bit).
+template <bool WIDE>
+__device__ __forceinline__ void epi32_gq(const v16i &hh, const v16i &mid, const v16i &ll, int rs, const MfmaArgs &a, int (&o)[16]) {
+  const int m = a.gq_q, om = a.gq_o;
+  const int m_half = m & 1, m_one = (m >> 1) & 1, m_neg = (m >> 2) & 1, m_pos = (m >> 3) & 1, m_odd = (m >> 4) & 1, m_even = (m >> 5) & 1, m_tz = (m >> 6) & 1;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int lo = (int)(((unsigned)mid[r] << 8) + (unsigned)ll[r]);
+    int q, qb, rest;
+    if (!WIDE) {
+      q = (int)((unsigned)hh[r] << (16 - rs)) + (lo >> rs);
+      const unsigned rem = (unsigned)lo & ((1u << rs) - 1u);
+      qb = (int)(rem >> (rs - 1)) & 1;
+      rest = (rem & ((1u << (rs - 1)) - 1u)) != 0;
+    } else {
+      const int t = hh[r] + (lo >> 16), s2 = rs - 16;
+      q = t >> s2;
+      const unsigned rem = (unsigned)t & ((1u << s2) - 1u);
+      qb = (int)(rem >> (s2 - 1)) & 1;
+      rest = ((rem & ((1u << (s2 - 1)) - 1u)) | ((unsigned)lo & 0xffffu)) != 0;
+    }
+    const int neg = (int)((unsigned)q >> 31), odd = q & 1;      // V < 0 exactly when its floor quotient is
+    const int why = rest | m_one | (neg & m_neg) | ((neg ^ 1) & m_pos) | (odd & m_odd) | ((odd ^ 1) & m_even);
+    q += (qb & why & m_half) | (neg & (qb | rest) & m_tz);
+    if (om == 1) { q = q < -32767 ? -32767 : (q > 32767 ? 32767 : q); }
+    else if (om == 2) { q = (q < -32768 || q > 32767) ? 0 : q; }
+    o[r] = q;
   }
 }
 __device__ __forceinline__ void epi32_narrow(const MfmaArgs &a, int (&o)[16]) {
@@ -196,6 +234,10 @@ __device__ __forceinline__ v4i pk16_ashr(const v4i &v, int d) {
   return r;
 }
 __device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16i &ll, int rs, const MfmaArgs &a, int (&o)[16]) {
+  if (a.gq_on) {
+    if (rs <= 16) { epi32_gq<false>(hh, mid, ll, rs, a, o); } else { epi32_gq<true>(hh, mid, ll, rs, a, o); }
+    return;
+  }
   if (rs <= 16) { epi32_t<false>(hh, mid, ll, rs, o); }   // one uniform branch per step, not one per output
   else { epi32_t<true>(hh, mid, ll, rs, o); }
   epi32_narrow(a, o);
@@ -698,7 +740,8 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       return;
     }
     int o[16];
-    epi32_t<decltype(wide_c)::value>(hh, mid, ll, NAR ? rs - a.nar_d : rs, o);
+    if (NAR && a.gq_on) { epi32_gq<decltype(wide_c)::value>(hh, mid, ll, rs, a, o); }   // (general rounding modes: 16-bit OUT_TYPEs only, nar_d = 0)
+    else { epi32_t<decltype(wide_c)::value>(hh, mid, ll, NAR ? rs - a.nar_d : rs, o); }
     // A lane holds rows 8 g + 4 h .. + 3 of column n: 8 bytes per g, and the 16 lanes of a ds_write_b64 group share h, so
     // they can reach only half of the 32 banks (2-way conflict on every store: the 16.6 % SQ_LDS_BANK_CONFLICT of round 1).
     // v_permlane32_swap trades g-odd of the h = 0 lanes for g-even of the h = 1 lanes: every lane then owns 16 contiguous
@@ -1464,6 +1507,10 @@ static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArg
 }
 
 // Can the all-32-bit epilogue be used for this plan / type combination?  0: no, 1: WRAP, 2: SAT
+// a rounding / overflow mode beyond the AC_TRN / AC_RND x AC_WRAP / AC_SAT of the plain fast classes
+static bool fir_mfma_general_q(const FirParams &p) {
+  return !((p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT));
+}
 int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   // an unsigned AC_WRAP accumulator turns every negative sum into 2^W - |v| before OUT_TYPE sees it (the reference's
   // `acc += ...` assignment): only the generic epilogue wraps to ACC_TYPE, the fast ones convert the signed sum
@@ -1486,6 +1533,12 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
       rse >= 1 && rs <= 31 && acc_wide && small && (p.out.W == 16 || (nar_d > 0 && plan.nb <= kMaxRegNB))) {
     return p.out.O == ACDSP_SAT ? 2 : 1;
+  }
+  // the other rounding modes and AC_SAT_SYM / AC_SAT_ZERO on full 16-bit OUT_TYPEs: the same classes with the increment of the dropped
+  // bits (MfmaArgs::gq_*; NAR instantiations: register-resident shapes of up to kMaxRegNB K-blocks).  ACDSP_NO_GQ: generic class (A/B knob)
+  static const bool no_gq = getenv("ACDSP_NO_GQ") != nullptr;
+  if (!no_gq && fir_mfma_general_q(p) && p.out_eb == 2 && p.out.S && p.out.W == 16 && rs >= 1 && rs <= 31 && acc_wide && small && plan.nb <= kMaxRegNB) {
+    return p.out.O == ACDSP_WRAP ? 1 : 2;
   }
   // EPI 4: int16 containers past the 32-bit bounds, on the LDS-resident kernels (more than kMaxRegNB K-blocks): exact 64-bit recombination,
   // ACC_TYPE wrap included, branch-free (epi64).  ACDSP_NO_EPI4: the generic class instead (A/B knob).
@@ -1517,7 +1570,7 @@ int fir_mfma_issued_per_step(const FirParams &p, const FirMfmaPlan &plan) {
   const int epi = fir_mfma_epilogue_class(p, plan), nb = plan.nb;
   int band = nb;
   if (nb <= kMaxRegNB) {
-    const bool no_skip = (epi == 1 || epi == 2) && p.out_eb == 2 && p.out.W < 16;   // NAR instantiations
+    const bool no_skip = (epi == 1 || epi == 2) && p.out_eb == 2 && (p.out.W < 16 || fir_mfma_general_q(p));   // NAR instantiations
     const int hs = (epi && !no_skip) ? pick_hs(nb, plan.hi_mask) : 0;
     band = nb - (hs & 15) - (hs >> 4);
   } else if (epi) {
@@ -1548,6 +1601,13 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   const int epi = fir_mfma_epilogue_class(p, plan);
   MfmaArgs a;
   a.nar_on = 0; a.nar_d = 0; a.nar_lo = INT32_MIN; a.nar_hi = INT32_MAX; a.nar_sh = 0;
+  a.gq_on = 0; a.gq_q = 0; a.gq_o = 0;
+  if ((epi == 1 || epi == 2) && p.out_eb == 2 && fir_mfma_general_q(p)) {   // W_out = 16 (fir_mfma_epilogue_class)
+    // (AC_RND keeps its constant in ll like the plain classes: no increment on top of it)
+    static const int kMask[8] = {0 /* TRN */, 0 /* RND: preloaded */, 64 /* TRN_ZERO */, 1 | 4 /* RND_ZERO */, 1 | 8 /* RND_INF */, 1 /* RND_MIN_INF */,
+                                 1 | 16 /* RND_CONV */, 1 | 32 /* RND_CONV_ODD */};
+    a.nar_on = 1; a.gq_on = 1; a.gq_q = kMask[p.out.Q & 7]; a.gq_o = p.out.O == ACDSP_SAT_SYM ? 1 : (p.out.O == ACDSP_SAT_ZERO ? 2 : 0);
+  }
   a.w4_sat = (epi == 3 && p.out_eb == 4 && p.out.O == ACDSP_SAT) ? 1 : 0; a.w4_lo = p.out.lo; a.w4_hi = p.out.hi;
   if (epi == 3 && p.out_eb == 4 && p.out.O == ACDSP_WRAP) {
     const int rs4 = p.in.F + p.cf.F - p.out.F;

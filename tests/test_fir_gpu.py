@@ -73,6 +73,31 @@ def test_all_q_o_modes_in_accumulator_and_output(q, o):
                    seed=hash((q, o)) % 1000, splits=[5])
 
 
+@pytest.mark.parametrize("q", list(A.Q_MODES))
+@pytest.mark.parametrize("o", list(A.O_MODES))
+def test_all_q_o_modes_of_a_16_bit_output_on_the_matrix_core_epilogue(q, o):
+    """Every rounding / overflow mode of a full 16-bit OUT_TYPE behind an exact accumulator: the 32-bit epilogue of the int8 kernel with the
+    increment of the dropped bits (round 5; these ran the generic epilogue with element-wise stores at 0.12 of the roofline).  Whole
+    1024-sample steps (the software-pipelined body) and ragged calls (the edge body), shifts on both sides of 16, gains that saturate, values
+    on the rounding ties (samples and coefficients that are multiples of large powers of two), 63 and 255 taps."""
+    fin, fc, fa = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14)
+    for k, (n_taps, fo) in enumerate(((63, A.Fmt(16, 2, True, q, o)), (255, A.Fmt(16, 3, True, q, o)), (31, A.Fmt(16, 9, True, q, o)), (127, A.Fmt(16, 0, True, q, o)))):
+        rng = np.random.default_rng(n_taps)
+        c = windowed_sinc(n_taps, 0.1, fc) if k != 3 else (rand_raw(rng, fc, (n_taps,)) >> 4)
+        if k == 2:
+            c = (c >> 6) << 6                               # products that land on the ties of the dropped bits
+        x = rand_raw(rng, fin, (3, 5 * 1024 + 77))
+        x[1, :] = (x[1, :] >> 9) << 9
+        x[2, 1000:3000] = 32767
+        fir = A.Fir(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_channels=3)
+        fir.set_coeffs(c)
+        assert fir.path == "mfma_i8", fir.path
+        y = run_engine(fir, x, [1024 + 16, 4096 + 16])     # 1040 (edge body), 3072 = three whole steps (pipelined body), the ragged rest
+        yo = OracleFir(n_taps, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=3).run(c, x)
+        bad = np.argwhere(y != yo)
+        assert bad.size == 0, "%s %s case %d: %d mismatches, first at %s: got %d want %d" % (q, o, k, len(bad), bad[0], y[tuple(bad[0])], yo[tuple(bad[0])])
+
+
 def test_unsigned_types():
     check_case(8, "FOLD_EVEN", A.Fmt(10, 3, False), A.Fmt(9, 1, False), A.Fmt(24, 8, False), A.Fmt(12, 6, False, "RND", "SAT"))
     check_case(8, "SHIFT_REG", A.Fmt(10, 3, False), A.Fmt(9, 1, True), A.Fmt(24, 8, True), A.Fmt(12, 6, False, "RND", "SAT"))

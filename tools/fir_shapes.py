@@ -41,6 +41,7 @@ CASES = [
     ("255 taps, OUT <24,6,RND,SAT> (4-byte containers)", 255, "SHIFT_REG", F(16, 2), F(16, 2), F(40, 12), F(24, 6, True, "RND", "SAT")),
     ("255 taps, OUT <32,12,TRN,WRAP> (4-byte containers)", 255, "SHIFT_REG", F(16, 2), F(16, 2), F(40, 12), F(32, 12)),
     ("255 taps, OUT = ACC <40,12> (8-byte containers)", 255, "SHIFT_REG", F(16, 2), F(16, 2), F(40, 12), F(40, 12)),
+    ("255 taps, OUT <16,2,RND_ZERO,SAT>", 255, "SHIFT_REG", F(16, 2), F(16, 2), F(40, 12), F(16, 2, True, "RND_ZERO", "SAT")),
     ("255 taps, OUT <16,2,RND_CONV,SAT_SYM>", 255, "SHIFT_REG", F(16, 2), F(16, 2), F(40, 12), F(16, 2, True, "RND_CONV", "SAT_SYM")),
     ("63 taps, lossy ACC <24,8,TRN,WRAP> (class B)", 63, "SHIFT_REG", F(16, 2), F(16, 2), F(24, 8), F(16, 2, True, "RND", "SAT")),
     ("63 taps, lossy ACC <24,8,RND,WRAP> (class B)", 63, "SHIFT_REG", F(16, 2), F(16, 2), F(24, 8, True, "RND", "WRAP"), F(16, 2, True, "RND", "SAT")),
