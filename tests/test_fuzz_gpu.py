@@ -37,9 +37,20 @@ FIR_TYPES = [
     (A.Fmt(14, 4), A.Fmt(12, 2), A.Fmt(20, 8, True, "RND", "SAT")),    # lossy accumulator: exact-order VALU kernel
     (A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12, False)),                # unsigned wrapping accumulator under signed data
     (A.Fmt(12, 4, False), A.Fmt(14, 1), A.Fmt(36, 12)),                # unsigned input
+    # round 5: the families of the R = 1 ring shapes, the class-B matrix-core kernel and the flipped unsigned-16 path
+    (A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(64, 32)),                      # the reference const testbench's types
+    (A.Fmt(32, 16), A.Fmt(32, 16), A.Fmt(64, 32)),                     # ... load
+    (A.Fmt(32, 16), A.Fmt(24, 8), A.Fmt(60, 28)),
+    (A.Fmt(28, 6), A.Fmt(23, 7), A.Fmt(64, 32)),                       # ... prog: 6 bits dropped per tap (class B)
+    (A.Fmt(28, 6), A.Fmt(23, 7), A.Fmt(60, 31, True, "RND", "WRAP")),  # 7 bits dropped, rounded
+    (A.Fmt(16, 8), A.Fmt(24, 6), A.Fmt(48, 26)),                       # class B on 16-bit samples with wide coefficients
+    (A.Fmt(16, 2, False), A.Fmt(16, 2), A.Fmt(44, 16)),                # unsigned 16-bit samples: sign-flipped image
+    (A.Fmt(16, 2, False), A.Fmt(16, 2), A.Fmt(34, 6)),                 # ... against an accumulator that may wrap
+    (A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(24, 8)),                        # class B on 16-bit types (VALU kernel)
 ]
 FIR_OUTS = [A.Fmt(16, 2, True, "RND", "SAT"), A.Fmt(16, 2, True, "TRN", "WRAP"), A.Fmt(16, 6, True, "RND", "SAT"), A.Fmt(40, 12),
-            A.Fmt(24, 9, True, "RND", "SAT"), A.Fmt(34, 4, True, "TRN", "WRAP"), A.Fmt(12, 5, True, "RND_CONV", "SAT_SYM")]
+            A.Fmt(24, 9, True, "RND", "SAT"), A.Fmt(34, 4, True, "TRN", "WRAP"), A.Fmt(12, 5, True, "RND_CONV", "SAT_SYM"),
+            A.Fmt(16, 3, True, "RND_ZERO", "SAT_ZERO"), A.Fmt(16, 2, True, "TRN_ZERO", "SAT_SYM"), A.Fmt(16, 4, True, "RND_INF", "WRAP"), A.Fmt(64, 32)]
 
 
 @pytest.mark.parametrize("seed", range(CASES))
@@ -55,30 +66,39 @@ def test_fir_random_shapes(seed):
         n_taps = min(n_taps, 100)                                       # keep the oracle's i128 loops short
     n_ch = int(rng.choice([1, 2, 7, 8, 9, 17]))
     per_ch = bool(rng.integers(2)) and n_taps <= 257 and fin.W <= 16
-    n_total = int(rng.choice([1, 5, 100, 1023, 1024, 1025, 2048, 3000, 5000, 9000]))
+    n_total = int(rng.choice([1, 5, 100, 1023, 1024, 1025, 2048, 3000, 5000, 9000, 8192, 12288, 10240 + 77]))
     scale = 1 if rng.integers(3) else 8                                 # sometimes small coefficients (zero high-byte planes)
     c = rand_raw(rng, fc, (n_ch, n_taps) if per_ch else (n_taps,)) // scale
+    if fc.W > 22:
+        c = c >> (fc.W - 22)                                            # three balanced base-256 digits: the matrix-core classes of wide coefficients
+    # the fast bodies of every family run WHOLE chunks of aligned rows only (1024 .. 4096 outputs): half of the cases cut the stream at
+    # multiples of 1024 and leave the rows aligned, so that the differential test reaches them (round 4's fuzz almost never did)
+    whole = bool(rng.integers(2))
     x = rand_raw(rng, fin, (n_ch, n_total))
     fir = A.Fir(n_taps, ftype, fin, fc, fa, fo, n_channels=n_ch, kind=kind, coeffs_per_channel=per_ch)
     fir.set_coeffs(c)
     orc = OracleFir(n_taps, ftype, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch, reg_share=(1, 1, 0) if kind == "reg_share" else None)
     yo = orc.run(c, x)
     cuts = sorted(set(int(v) for v in rng.integers(0, n_total + 1, size=rng.integers(0, 3))))
+    if whole:
+        cuts = sorted(set(min(n_total, (v // 1024) * 1024) for v in cuts))
     bounds = [0] + cuts + [n_total]
     dt_in, dt_out = A.torch_dtype_for(fin), A.torch_dtype_for(fo)
     outs = []
     for a, b in zip(bounds[:-1], bounds[1:]):
         if b == a:
             continue
-        xv = padded_view(x[:, a:b], dt_in, int(rng.integers(0, 9)), int(rng.integers(0, 9)))
-        out = torch.zeros((n_ch, b - a + int(rng.integers(0, 9))), dtype=dt_out, device="cuda")
-        out = out[:, int(rng.integers(0, min(4, out.shape[1] - (b - a) + 1))):]
+        pad = 8 if whole else 1                                         # whole: rows start on 16-byte boundaries, strides are multiples of 16 bytes
+        xv = padded_view(x[:, a:b], dt_in, pad * int(rng.integers(0, 9 // pad + 1)), pad * int(rng.integers(0, 9 // pad + 1)) + ((-(b - a)) % 8 if whole else 0))
+        out = torch.zeros((n_ch, b - a + (((-(b - a)) % 8) if whole else int(rng.integers(0, 9)))), dtype=dt_out, device="cuda")
+        if not whole:
+            out = out[:, int(rng.integers(0, min(4, out.shape[1] - (b - a) + 1))):]
         y = fir.run(xv, out)[:, :b - a].cpu().numpy().astype(np.int64)
         outs.append(y)
     y = np.concatenate(outs, axis=1)
     bad = np.argwhere(y != yo)
-    assert bad.size == 0, "seed %d: %d mismatches, first %s (path %s, %s %s taps %d ch %d n %d cuts %s per_ch %s)" % (
-        seed, len(bad), bad[0], fir.path, kind, ftype, n_taps, n_ch, n_total, cuts, per_ch)
+    assert bad.size == 0, "seed %d: %d mismatches, first %s (kernel %s, %s %s taps %d ch %d n %d cuts %s per_ch %s whole %s types %s)" % (
+        seed, len(bad), bad[0], fir.kernel, kind, ftype, n_taps, n_ch, n_total, cuts, per_ch, whole, (fin.W, fc.W, fa.W, fo.W))
 
 
 @pytest.mark.parametrize("seed", range(max(CASES // 2, 1)))   # the oracle needs ~1 s per case at these lengths
