@@ -110,6 +110,18 @@ SYMBOLS = {
     "acdsp_node_ddc_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
     "acdsp_node_ddc_out_count": (_i64, [_vp, _i64]),
     "acdsp_node_ddc_run": (_i32, [_vp, C.POINTER(_vp), _i64, _i64, C.POINTER(_vp), _i64, C.POINTER(_i64)]),
+    "acdsp_node_polydec_create": (_i32, [C.POINTER(PolyDecDesc), _i32, C.POINTER(_i32), C.POINTER(_vp)]),
+    "acdsp_node_polydec_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
+    "acdsp_node_polydec_run": (_i32, [_vp, C.POINTER(_vp), _i64, _i64, C.POINTER(_vp), _i64]),
+    "acdsp_node_polyintr_create": (_i32, [C.POINTER(PolyIntrDesc), _i32, C.POINTER(_i32), C.POINTER(_vp)]),
+    "acdsp_node_polyintr_set_ctrl": (_i32, [_vp, C.POINTER(_i64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
+    "acdsp_node_polyintr_out_count": (_i64, [_vp, _i64]),
+    "acdsp_node_polyintr_run": (_i32, [_vp, C.POINTER(_vp), _i64, _i64, C.POINTER(_vp), _i64, C.POINTER(_i64)]),
+    "acdsp_node_intgdump_create": (_i32, [C.POINTER(IntgDumpDesc), _i32, C.POINTER(_i32), C.POINTER(_vp)]),
+    "acdsp_node_intgdump_run": (_i32, [_vp, C.POINTER(_vp), _i64, C.POINTER(_i64), _i64, C.POINTER(_vp), _i64, C.POINTER(_i64)]),
+    "acdsp_node_mvavg_create": (_i32, [C.POINTER(MvAvgDesc), _i32, C.POINTER(_i32), C.POINTER(_vp)]),
+    "acdsp_node_mvavg_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
+    "acdsp_node_mvavg_run": (_i32, [_vp, C.POINTER(_vp), _i64, _i64, _i64, C.POINTER(_vp), _i64, C.POINTER(_i64)]),
     "acdsp_diag_copy_ms": (_i32, [_i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_diag_fir_envelope_ms": (_i32, [_i32, C.POINTER(_i64), _i32, _i32, _i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_fir_create": (_i32, [C.POINTER(FirDesc), C.POINTER(_vp)]),

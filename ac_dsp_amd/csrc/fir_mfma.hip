@@ -206,6 +206,7 @@ __device__ __forceinline__ void epi32_gq(const v16i &hh, const v16i &mid, const 
     if (om == 1) { q = q < -32767 ? -32767 : (q > 32767 ? 32767 : q); }
     else if (om == 2) { q = (q < -32768 || q > 32767) ? 0 : q; }
     o[r] = q;
+    if ((r & 3) == 3) { __builtin_amdgcn_sched_barrier(0); }   // four outputs at a time: interleaved, the temporaries of all sixteen spill at 256 registers
   }
 }
 __device__ __forceinline__ void epi32_narrow(const MfmaArgs &a, int (&o)[16]) {
@@ -233,8 +234,9 @@ __device__ __forceinline__ v4i pk16_ashr(const v4i &v, int d) {
   }
   return r;
 }
+template <bool GQ = true>   // GQ = false: the kernels of more than kMaxRegNB K-blocks, which the general-rounding class never reaches
 __device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16i &ll, int rs, const MfmaArgs &a, int (&o)[16]) {
-  if (a.gq_on) {
+  if (GQ && a.gq_on) {
     if (rs <= 16) { epi32_gq<false>(hh, mid, ll, rs, a, o); } else { epi32_gq<true>(hh, mid, ll, rs, a, o); }
     return;
   }
@@ -539,7 +541,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 // issue and the other work hides in their shadow (tools/mfma_probe.hip: 39 cycles/MFMA with the epilogue
 // interleaved vs 36 bare).  The loop is unrolled by two so the accumulator sets and the B-fragment
 // double buffer swap roles by renaming; it contains no branch.
-template <int NB, int EPI, int HS, bool NAR = false, bool W4 = false>
+template <int NB, int EPI, int HS, int NAR = 0, bool W4 = false>   // NAR: 1 = OUT_TYPEs of fewer than 16 bits, 2 = general rounding / overflow modes of a 16-bit OUT_TYPE
 __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
                                                    unsigned char *lds) {
   static_assert(EPI >= 1 && EPI <= 3, "fast epilogue classes only");
@@ -740,8 +742,8 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       return;
     }
     int o[16];
-    if (NAR && a.gq_on) { epi32_gq<decltype(wide_c)::value>(hh, mid, ll, rs, a, o); }   // (general rounding modes: 16-bit OUT_TYPEs only, nar_d = 0)
-    else { epi32_t<decltype(wide_c)::value>(hh, mid, ll, NAR ? rs - a.nar_d : rs, o); }
+    if constexpr (NAR == 2) { epi32_gq<decltype(wide_c)::value>(hh, mid, ll, rs, a, o); }   // (general rounding modes: 16-bit OUT_TYPEs only)
+    else { epi32_t<decltype(wide_c)::value>(hh, mid, ll, NAR == 1 ? rs - a.nar_d : rs, o); }
     // A lane holds rows 8 g + 4 h .. + 3 of column n: 8 bytes per g, and the 16 lanes of a ds_write_b64 group share h, so
     // they can reach only half of the 32 banks (2-way conflict on every store: the 16.6 % SQ_LDS_BANK_CONFLICT of round 1).
     // v_permlane32_swap trades g-odd of the h = 0 lanes for g-even of the h = 1 lanes: every lane then owns 16 contiguous
@@ -800,7 +802,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     for (int half = 0; half < 2; half++) {
       const int P = 64 * half + lane;
       v4i val = *(const v4i *)(obuf + (P ^ ((P >> 3) & 3)) * 16);
-      if constexpr (NAR) { val = pk16_ashr(val, a.nar_d); }   // OUT_TYPEs of fewer than 16 bits (MfmaArgs::nar_*)
+      if constexpr (NAR == 1) { val = pk16_ashr(val, a.nar_d); }   // OUT_TYPEs of fewer than 16 bits (MfmaArgs::nar_*)
 #if ACDSP_FIR_NT & 2
       __builtin_nontemporal_store(val, (v4i *)(yout + T0 + 512 * half + 8 * lane));
 #else
@@ -936,13 +938,13 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       }
     }
   };
-  if (EPI == 3 || (NAR ? rs - a.nar_d : rs) <= 16) { go(integral_constant<bool, false>()); }
+  if (EPI == 3 || (NAR == 1 ? rs - a.nar_d : rs) <= 16) { go(integral_constant<bool, false>()); }
   else { go(integral_constant<bool, true>()); }
 }
 
 // NB > kMaxRegNB (the 1023-tap shape, NB = 33): one wave per SIMD with the whole 512-entry register file -- 2 * 33 Toeplitz
 // fragments are 264 registers (fewer with a high-byte band), next to two accumulator sets and the B-fragment double buffer.
-template <int NB, int EPI, int HS, int WAVES, bool NAR = false, bool W4 = false>
+template <int NB, int EPI, int HS, int WAVES, int NAR = 0, bool W4 = false>
 __global__ void __launch_bounds__(64 * WAVES, (NB > kMaxRegNB ? 1 : kOccupancy))
 fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   // WAVES == 1: the pipelined body keeps a 4-step ring of staged planes (4 arrays of 128 + NB - 1 slots), the plain body two windows
@@ -1162,7 +1164,7 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
     // ---------------- phase O ----------------
     int o16[16];
     if (EPI == 4) { epi64(hh, mid, ll, e64, o16); }
-    else if (EPI != 0) { epi32(hh, mid, ll, rs - a.nar_d, a, o16); }
+    else if (EPI != 0) { epi32<false>(hh, mid, ll, rs - a.nar_d, a, o16); }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const int64_t t0 = T0 + 32 * n_col + 8 * g + 4 * h;
@@ -1345,7 +1347,7 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
     for (int set = 0; set < 2; set++) {
       int o[16];
       if (EPI == 4) { if (set == 0) { epi64(h0, m0, l0, e64, o); } else { epi64(h1, m1, l1, e64, o); } }
-      else if (set == 0) { epi32(h0, m0, l0, rs - a.nar_d, a, o); } else { epi32(h1, m1, l1, rs - a.nar_d, a, o); }
+      else if (set == 0) { epi32<false>(h0, m0, l0, rs - a.nar_d, a, o); } else { epi32<false>(h1, m1, l1, rs - a.nar_d, a, o); }
 #pragma unroll
       // (the permlane32-swap / ds_write_b128 tile of fir_mfma_pipe_body was tried here: conflicts 2.5e7 -> 0 but +0.8 % time,
       // the phase is not in the shadow of MFMAs)
@@ -1406,10 +1408,15 @@ hipError_t launch_fir_mfma_mid2(const FirParams &p, int nb, const uint32_t *d_fr
 template <int NB, int HS>
 static hipError_t launch_alt_hs(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   const v4i *f = (const v4i *)d_frag;
-  if (epi == 3) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 3, HS, 1, false, true>), grid, dim3(64), 0, s, p, f, a); }
+  if (epi == 3) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 3, HS, 1, 0, true>), grid, dim3(64), 0, s, p, f, a); }
   else if constexpr (HS == 0) {
-    if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, 0, 1, true>), grid, dim3(64), 0, s, p, f, a); }
-    else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, 0, 1, true>), grid, dim3(64), 0, s, p, f, a); }
+    // (the general-rounding epilogue has instantiations of its own: inside the narrow-type kernels it spilled 5 - 13 registers at 6 and 9 K-blocks)
+    if (a.gq_on) {
+      if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, 0, 1, 2>), grid, dim3(64), 0, s, p, f, a); }
+      else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, 0, 1, 2>), grid, dim3(64), 0, s, p, f, a); }
+    }
+    else if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, 0, 1, 1>), grid, dim3(64), 0, s, p, f, a); }
+    else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, 0, 1, 1>), grid, dim3(64), 0, s, p, f, a); }
   } else { return hipErrorInvalidValue; }
   return hipGetLastError();
 }

@@ -111,7 +111,7 @@ struct UpArgs {
 template <typename TIN, int PX, int PCT, int NBT, int L, int OEB, int EPI, int NST>
 // (two waves per SIMD where the fragments + the register sets + accumulators need more than 168 registers: spills inside a step are
 // VMEM operations that every store-counting wait would have to drain)
-__global__ void __launch_bounds__(64, (PX * PCT * NBT >= 12 ? 2 : 3)) fir_up_kernel(UpArgs a, const v4i *__restrict__ frag) {
+__global__ void __launch_bounds__(64, ((PX * PCT * NBT >= 12 || 32 % L != 0) ? 2 : 3)) fir_up_kernel(UpArgs a, const v4i *__restrict__ frag) {   // (factors that do not divide 32: sixteen-entry phase tables)
   constexpr int SPC = up_spc(L);                              // input samples per MFMA column
   constexpr int ROWS = SPC * L;                               // live rows of a tile (32 when L divides 32)
   constexpr int SS = 512;                                     // samples per step

@@ -33,6 +33,7 @@ namespace {
 struct Worker {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // kinds whose engine handle keeps no kernel timer: the shard's call on its stream
   std::thread th;
   std::mutex m;
   std::condition_variable cv;
@@ -43,7 +44,8 @@ struct Worker {
 
   void loop() {
     int rc0 = ACDSP_OK;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { rc0 = ACDSP_EHIP; }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { rc0 = ACDSP_EHIP; }
     {
       std::lock_guard<std::mutex> lk(m);
       init_rc = rc0; ready = true;
@@ -65,6 +67,8 @@ struct Worker {
       }
       cv.notify_all();
     }
+    if (ev0) { (void)hipEventDestroy(ev0); }
+    if (ev1) { (void)hipEventDestroy(ev1); }
     if (stream) { (void)hipStreamDestroy(stream); }
   }
   int start(int dev) {
@@ -97,7 +101,7 @@ struct Worker {
   }
 };
 
-enum { kNodeFir = 1, kNodeCic = 2, kNodeDdc = 3 };
+enum { kNodeFir = 1, kNodeCic = 2, kNodeDdc = 3, kNodePolyDec = 4, kNodePolyIntr = 5, kNodeIntgDump = 6, kNodeMvAvg = 7 };
 
 struct Shard {
   int device = 0;
@@ -171,7 +175,11 @@ void destroy_handle(int kind, void *p) {
   if (!p) { return; }
   if (kind == kNodeFir) { (void)acdsp_fir_destroy((acdsp_fir_t)p); }
   else if (kind == kNodeCic) { (void)acdsp_cic_destroy((acdsp_cic_t)p); }
-  else { (void)acdsp_ddc_destroy((acdsp_ddc_t)p); }
+  else if (kind == kNodeDdc) { (void)acdsp_ddc_destroy((acdsp_ddc_t)p); }
+  else if (kind == kNodePolyDec) { (void)acdsp_polydec_destroy((acdsp_polydec_t)p); }
+  else if (kind == kNodePolyIntr) { (void)acdsp_polyintr_destroy((acdsp_polyintr_t)p); }
+  else if (kind == kNodeIntgDump) { (void)acdsp_intgdump_destroy((acdsp_intgdump_t)p); }
+  else { (void)acdsp_mvavg_destroy((acdsp_mvavg_t)p); }
 }
 
 int free_node(acdsp_node *h) {
@@ -197,6 +205,37 @@ int finish_timed(Shard &s, int kind) {
   int rc = kind == kNodeFir ? acdsp_fir_last_kernel_ms((acdsp_fir_t)s.handle, &ms)
                             : (kind == kNodeCic ? acdsp_cic_last_kernel_ms((acdsp_cic_t)s.handle, &ms) : acdsp_ddc_kernel_stats((acdsp_ddc_t)s.handle, 1, &ms, &mn));
   s.last_ms = rc == ACDSP_OK ? ms : 0.f;   // calls too small to be timed leave 0
+  return ACDSP_OK;
+}
+
+// the f-row classes (poly_dec, poly_intr, intg_dump, mv_avg): run `call` on the shard's stream between two events of that stream
+template <typename F>
+int run_timed(Shard &s, F call) {
+  if (hipEventRecord(s.w->ev0, s.w->stream) != hipSuccess) { return set_error(ACDSP_EHIP, "node: event record failed"); }
+  const int r = call();
+  if (r) { return r; }
+  hipError_t e = hipEventRecord(s.w->ev1, s.w->stream);
+  if (e == hipSuccess) { e = hipStreamSynchronize(s.w->stream); }
+  float ms = 0;
+  if (e == hipSuccess) { e = hipEventElapsedTime(&ms, s.w->ev0, s.w->ev1); }
+  if (e != hipSuccess) { return set_error(ACDSP_EHIP, hipGetErrorString(e)); }
+  s.last_ms = ms;
+  return ACDSP_OK;
+}
+
+// create one engine handle per shard with `make(desc with this slice's row count and device)`
+template <typename D, typename H, typename MK>
+int create_shards(acdsp_node *h, const D &d0, int32_t D::*rows, MK make) {
+  const int rc = run_all(h, [h, d0, rows, make](int i) {
+    Shard &s = h->shards[(size_t)i];
+    D d = d0;
+    d.*rows = (int32_t)(s.hi - s.lo); d.device = s.device;
+    H e = nullptr;
+    const int r = make(&d, &e);
+    s.handle = e;
+    return r;
+  });
+  if (rc) { const std::string keep = acdsp_last_error(); free_node(h); return set_error(rc, keep.c_str()); }
   return ACDSP_OK;
 }
 
@@ -379,6 +418,119 @@ int32_t acdsp_node_ddc_run(acdsp_node_t h, const void *const *d_in, int64_t in_s
     Shard &s = h->shards[(size_t)i];
     const int r = acdsp_ddc_run((acdsp_ddc_t)s.handle, d_in[i], in_stride, n_in, d_out[i], out_stride, &no[(size_t)i], (void *)s.w->stream);
     return r ? r : finish_timed(s, kNodeDdc);
+  });
+  if (rc == ACDSP_OK && n_out) { *n_out = no[0]; }
+  return rc;
+}
+
+// ---- the f-row classes (round 5): same slicing, one engine handle of the class per shard ----
+int32_t acdsp_node_polydec_create(const acdsp_polydec_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out) {
+  if (!desc) { return set_error(ACDSP_EINVAL, "node_polydec_create: null descriptor"); }
+  acdsp_node *h = nullptr;
+  int rc = make_node(kNodePolyDec, desc->n_channels, n_devices, devices, &h);
+  if (rc) { return rc; }
+  h->in_eb = acdsp_elem_bytes(desc->in.W); h->out_eb = acdsp_elem_bytes(desc->out.W);
+  if ((rc = create_shards<acdsp_polydec_desc_t, acdsp_polydec_t>(h, *desc, &acdsp_polydec_desc_t::n_channels, acdsp_polydec_create))) { return rc; }
+  *out = h;
+  return ACDSP_OK;
+}
+int32_t acdsp_node_polydec_set_coeffs(acdsp_node_t h, const int64_t *coeffs) {
+  int rc = check_node(h, kNodePolyDec, "not a poly_dec node handle");
+  if (rc) { return rc; }
+  if (!coeffs) { return set_error(ACDSP_EINVAL, "node_polydec_set_coeffs: null coefficients"); }
+  return run_all(h, [h, coeffs](int i) { return (int)acdsp_polydec_set_coeffs((acdsp_polydec_t)h->shards[(size_t)i].handle, coeffs); });
+}
+int32_t acdsp_node_polydec_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_in, void *const *d_out, int64_t out_stride) {
+  int rc = check_node(h, kNodePolyDec, "not a poly_dec node handle");
+  if (rc) { return rc; }
+  if (!d_in || !d_out) { return set_error(ACDSP_EINVAL, "node_polydec_run: null pointer arrays"); }
+  return run_all(h, [=](int i) {
+    Shard &s = h->shards[(size_t)i];
+    return run_timed(s, [&] { return (int)acdsp_polydec_run((acdsp_polydec_t)s.handle, d_in[i], in_stride, n_in, d_out[i], out_stride, (void *)s.w->stream); });
+  });
+}
+
+int32_t acdsp_node_polyintr_create(const acdsp_polyintr_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out) {
+  if (!desc) { return set_error(ACDSP_EINVAL, "node_polyintr_create: null descriptor"); }
+  acdsp_node *h = nullptr;
+  int rc = make_node(kNodePolyIntr, desc->n_channels, n_devices, devices, &h);
+  if (rc) { return rc; }
+  h->in_eb = acdsp_elem_bytes(desc->in.W); h->out_eb = acdsp_elem_bytes(desc->out.W);
+  if ((rc = create_shards<acdsp_polyintr_desc_t, acdsp_polyintr_t>(h, *desc, &acdsp_polyintr_desc_t::n_channels, acdsp_polyintr_create))) { return rc; }
+  *out = h;
+  return ACDSP_OK;
+}
+int32_t acdsp_node_polyintr_set_ctrl(acdsp_node_t h, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr) {
+  int rc = check_node(h, kNodePolyIntr, "not a poly_intr node handle");
+  if (rc) { return rc; }
+  return run_all(h, [=](int i) { return (int)acdsp_polyintr_set_ctrl((acdsp_polyintr_t)h->shards[(size_t)i].handle, coeffs, sign, corr); });
+}
+int64_t acdsp_node_polyintr_out_count(acdsp_node_t h, int64_t n_in) {
+  if (!h || h->kind != kNodePolyIntr || h->shards.empty()) { return -1; }
+  return acdsp_polyintr_out_count((acdsp_polyintr_t)h->shards[0].handle, n_in);
+}
+int32_t acdsp_node_polyintr_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_in, void *const *d_out, int64_t out_stride, int64_t *n_out) {
+  int rc = check_node(h, kNodePolyIntr, "not a poly_intr node handle");
+  if (rc) { return rc; }
+  if (!d_in || !d_out) { return set_error(ACDSP_EINVAL, "node_polyintr_run: null pointer arrays"); }
+  std::vector<int64_t> no(h->shards.size(), 0);
+  rc = run_all(h, [&, h](int i) {
+    Shard &s = h->shards[(size_t)i];
+    return run_timed(s, [&] { return (int)acdsp_polyintr_run((acdsp_polyintr_t)s.handle, d_in[i], in_stride, n_in, d_out[i], out_stride, &no[(size_t)i], (void *)s.w->stream); });
+  });
+  if (rc == ACDSP_OK && n_out) { *n_out = no[0]; }
+  return rc;
+}
+
+int32_t acdsp_node_intgdump_create(const acdsp_intgdump_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out) {
+  if (!desc) { return set_error(ACDSP_EINVAL, "node_intgdump_create: null descriptor"); }
+  acdsp_node *h = nullptr;
+  int rc = make_node(kNodeIntgDump, desc->n_objects, n_devices, devices, &h);
+  if (rc) { return rc; }
+  h->in_eb = acdsp_elem_bytes(desc->in.W); h->out_eb = acdsp_elem_bytes(desc->out.W);
+  if ((rc = create_shards<acdsp_intgdump_desc_t, acdsp_intgdump_t>(h, *desc, &acdsp_intgdump_desc_t::n_objects, acdsp_intgdump_create))) { return rc; }
+  *out = h;
+  return ACDSP_OK;
+}
+int32_t acdsp_node_intgdump_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, const int64_t *n_sample, int64_t n_blocks, void *const *d_out,
+                                int64_t out_stride, int64_t *n_out) {
+  int rc = check_node(h, kNodeIntgDump, "not an intg_dump node handle");
+  if (rc) { return rc; }
+  if (!d_in || !d_out) { return set_error(ACDSP_EINVAL, "node_intgdump_run: null pointer arrays"); }
+  std::vector<int64_t> no(h->shards.size(), 0);
+  rc = run_all(h, [&, h](int i) {
+    Shard &s = h->shards[(size_t)i];
+    return run_timed(s, [&] { return (int)acdsp_intgdump_run((acdsp_intgdump_t)s.handle, d_in[i], in_stride, n_sample, n_blocks, d_out[i], out_stride, &no[(size_t)i], (void *)s.w->stream); });
+  });
+  if (rc == ACDSP_OK && n_out) { *n_out = no[0]; }
+  return rc;
+}
+
+int32_t acdsp_node_mvavg_create(const acdsp_mvavg_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out) {
+  if (!desc) { return set_error(ACDSP_EINVAL, "node_mvavg_create: null descriptor"); }
+  acdsp_node *h = nullptr;
+  int rc = make_node(kNodeMvAvg, desc->n_objects, n_devices, devices, &h);
+  if (rc) { return rc; }
+  h->in_eb = acdsp_elem_bytes(desc->in.W); h->out_eb = acdsp_elem_bytes(desc->out.W);
+  if ((rc = create_shards<acdsp_mvavg_desc_t, acdsp_mvavg_t>(h, *desc, &acdsp_mvavg_desc_t::n_objects, acdsp_mvavg_create))) { return rc; }
+  *out = h;
+  return ACDSP_OK;
+}
+int32_t acdsp_node_mvavg_set_coeffs(acdsp_node_t h, const int64_t *coeffs) {
+  int rc = check_node(h, kNodeMvAvg, "not a mv_avg node handle");
+  if (rc) { return rc; }
+  if (!coeffs) { return set_error(ACDSP_EINVAL, "node_mvavg_set_coeffs: null coefficients"); }
+  return run_all(h, [h, coeffs](int i) { return (int)acdsp_mvavg_set_coeffs((acdsp_mvavg_t)h->shards[(size_t)i].handle, coeffs); });
+}
+int32_t acdsp_node_mvavg_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_sample, int64_t n_frames, void *const *d_out,
+                             int64_t out_stride, int64_t *n_out) {
+  int rc = check_node(h, kNodeMvAvg, "not a mv_avg node handle");
+  if (rc) { return rc; }
+  if (!d_in || !d_out) { return set_error(ACDSP_EINVAL, "node_mvavg_run: null pointer arrays"); }
+  std::vector<int64_t> no(h->shards.size(), 0);
+  rc = run_all(h, [&, h](int i) {
+    Shard &s = h->shards[(size_t)i];
+    return run_timed(s, [&] { return (int)acdsp_mvavg_run((acdsp_mvavg_t)s.handle, d_in[i], in_stride, n_sample, n_frames, d_out[i], out_stride, &no[(size_t)i], (void *)s.w->stream); });
   });
   if (rc == ACDSP_OK && n_out) { *n_out = no[0]; }
   return rc;

@@ -667,6 +667,113 @@ class NodeDdc(_Node):
         return [o[:, :n_out.value] for o in outs]
 
 
+class NodePolyDec(_Node):
+    """A PolyDec bank sharded over `devices` (acdsp_node_polydec_*)."""
+
+    def __init__(self, n_taps, df, fin, fcoeff, facc, fout, n_channels, devices):
+        self.fin, self.fout, self.n_channels, self.n_taps, self.df = fin, fout, n_channels, n_taps, df
+        d = PolyDecDesc(n_taps, df, n_channels, fin, fcoeff, facc, fout, 0, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_node_polydec_create(C.byref(d), len(devices), self._dev_array(devices), C.byref(self._h)))
+        self._finish_create(devices)
+
+    def set_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert c.shape == (self.n_taps * self.df,)
+        check(lib.acdsp_node_polydec_set_coeffs(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def run(self, xs, outs=None):
+        n_in = xs[0].shape[1]
+        assert n_in % self.df == 0
+        if outs is None:
+            outs = self.alloc(self.fout, n_in // self.df + 8)
+        pin, sin = self._ptrs(xs, self.fin)
+        pout, sout = self._ptrs(outs, self.fout)
+        check(lib.acdsp_node_polydec_run(self._h, pin, sin, n_in, pout, sout))
+        return [o[:, :n_in // self.df] for o in outs]
+
+
+class NodePolyIntr(_Node):
+    """A PolyIntr bank sharded over `devices` (acdsp_node_polyintr_*)."""
+
+    def __init__(self, n_taps, coeff_sz, ifac, ftype, fin, fcoeff, facc, fout, n_channels, devices):
+        self.fin, self.fout, self.n_channels, self.ifac, self.coeff_sz = fin, fout, n_channels, ifac, coeff_sz
+        d = PolyIntrDesc(n_taps, coeff_sz, ifac, POLY_FTYPES[ftype] if isinstance(ftype, str) else ftype, n_channels, fin, fcoeff, facc, fout, 0, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_node_polyintr_create(C.byref(d), len(devices), self._dev_array(devices), C.byref(self._h)))
+        self._finish_create(devices)
+
+    def set_ctrl(self, coeffs, sign, corr):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        sg, cr = np.ascontiguousarray(sign, dtype=np.uint8), np.ascontiguousarray(corr, dtype=np.uint8)
+        assert c.shape == (self.coeff_sz,) and sg.shape == (self.ifac,) and cr.shape == (self.ifac,)
+        check(lib.acdsp_node_polyintr_set_ctrl(self._h, c.ctypes.data_as(C.POINTER(C.c_int64)), sg.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                               cr.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def out_count(self, n_in):
+        return lib.acdsp_node_polyintr_out_count(self._h, n_in)
+
+    def run(self, xs, outs=None):
+        n_in = xs[0].shape[1]
+        no = self.out_count(n_in)
+        if outs is None:
+            outs = self.alloc(self.fout, (max(no, 1) + 7) // 8 * 8)
+        pin, sin = self._ptrs(xs, self.fin)
+        pout, sout = self._ptrs(outs, self.fout)
+        n_out = C.c_int64()
+        check(lib.acdsp_node_polyintr_run(self._h, pin, sin, n_in, pout, sout, C.byref(n_out)))
+        return [o[:, :n_out.value] for o in outs]
+
+
+class NodeIntgDump(_Node):
+    """An IntgDump bank (rows = objects) sharded over `devices` (acdsp_node_intgdump_*)."""
+
+    def __init__(self, ns, chn, fin, facc, fout, n_objects, devices):
+        self.fin, self.fout, self.n_objects, self.ns, self.chn = fin, fout, n_objects, ns, chn
+        d = IntgDumpDesc(ns, chn, n_objects, fin, facc, fout, 0, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_node_intgdump_create(C.byref(d), len(devices), self._dev_array(devices), C.byref(self._h)))
+        self._finish_create(devices)
+
+    def run(self, xs, n_sample, outs=None):
+        ns = np.ascontiguousarray(n_sample, dtype=np.int64)
+        n_dump = int(((ns >= 1) & (ns <= self.ns)).sum()) * self.chn
+        if outs is None:
+            outs = self.alloc(self.fout, (max(n_dump, 1) + 7) // 8 * 8)
+        pin, sin = self._ptrs(xs, self.fin)
+        pout, sout = self._ptrs(outs, self.fout)
+        n_out = C.c_int64()
+        check(lib.acdsp_node_intgdump_run(self._h, pin, sin, ns.ctypes.data_as(C.POINTER(C.c_int64)), len(ns), pout, sout, C.byref(n_out)))
+        return [o[:, :n_out.value] for o in outs]
+
+
+class NodeMvAvg(_Node):
+    """A MvAvg bank (rows = objects) sharded over `devices` (acdsp_node_mvavg_*)."""
+
+    def __init__(self, max_sample, taps, win_mode, fin, fcoeff, facc, fout, n_objects, devices):
+        self.fin, self.fout, self.n_objects, self.taps = fin, fout, n_objects, taps
+        d = MvAvgDesc(max_sample, taps, WIN_MODES[win_mode] if isinstance(win_mode, str) else win_mode, n_objects, fin, fcoeff, facc, fout, 0, 0)
+        self._h = C.c_void_p()
+        check(lib.acdsp_node_mvavg_create(C.byref(d), len(devices), self._dev_array(devices), C.byref(self._h)))
+        self._finish_create(devices)
+
+    def set_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert c.shape == (self.taps,)
+        check(lib.acdsp_node_mvavg_set_coeffs(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def run(self, xs, n_sample, outs=None):
+        n = xs[0].shape[1]
+        assert n % n_sample == 0
+        if outs is None:
+            outs = self.alloc(self.fout, n)
+        pin, sin = self._ptrs(xs, self.fin)
+        pout, sout = self._ptrs(outs, self.fout)
+        n_out = C.c_int64()
+        check(lib.acdsp_node_mvavg_run(self._h, pin, sin, n_sample, n // n_sample, pout, sout, C.byref(n_out)))
+        return [o[:, :n_out.value] for o in outs]
+
+
 def save_stream(path, x, fmt):
     """[n_channels][n] raw words (numpy, any integer dtype) -> ACDSPRAW file (include/acdsp.h: acdsp_stream_hdr_t)."""
     a = np.ascontiguousarray(np.atleast_2d(x), dtype=_np_dtype_for(fmt))

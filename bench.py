@@ -359,20 +359,46 @@ def build_node_workload(workload, args, n_shards, one_gpu):
 
     def fill(bits):
         return lambda t, lo: A.fill_stimulus(t, seed, bits, ch0=lo)
-    if workload in ("fir255", "fir1023"):
+    run_extra = ()
+    if workload in ("fir255", "fir255_dense", "fir255_wide", "fir1023"):
         n_taps = 1023 if workload == "fir1023" else 255
         ch, n = args.channels or 1024, args.samples or (1 << 20)
         fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(42, 14) if workload == "fir1023" else A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+        if workload == "fir255_wide":
+            fo = fa
         node = A.NodeFir(n_taps, "SHIFT_REG", fin, fc, fa, fo, ch * n_shards, devices, kind="prog" if workload == "fir1023" else "load")
-        node.set_coeffs(windowed_sinc_raw(n_taps, 0.05 if workload == "fir1023" else 0.1, fc.F))
+        node.set_coeffs(np.random.default_rng(1).integers(-32768, 32640, size=n_taps, dtype=np.int64) if workload == "fir255_dense"
+                        else windowed_sinc_raw(n_taps, 0.05 if workload == "fir1023" else 0.1, fc.F))
         xs, ys = node.alloc(fin, n, fill(16)), node.alloc(fo, n)
-        bps, name = 4.0, "ac_fir_%s_coeffs %d-tap ac_fixed<16,2> -> <16,2,RND,SAT>, %d ch x %d samples per GPU" % ("prog" if workload == "fir1023" else "load", n_taps, ch, n)
-    elif workload == "cic_dec":
-        ch, n = args.channels or 4096, args.samples or (1 << 22)
-        fin, fo = A.Fmt(32, 16), A.Fmt(47, 31)
-        node = A.NodeCic(False, 8, 1, 5, fin, fo, ch * n_shards, devices)
-        xs, ys = node.alloc(fin, n, fill(32)), node.alloc(fo, n // 8 + 8)
-        bps, name = 5.0, "ac_cic_dec_full N=5 R=8 M=1 ac_fixed<32,16> -> <47,31>, %d ch x %d samples per GPU" % (ch, n)
+        bps = 2.0 + ys[0].element_size()
+        name = "ac_fir_%s_coeffs %d-tap ac_fixed<16,2> -> <%d,%d>, %d ch x %d samples per GPU (%s)" % ("prog" if workload == "fir1023" else "load", n_taps, fo.W, fo.I, ch, n, workload)
+    elif workload in ("rtest_const_types", "rtest_load_types", "rtest_prog_types"):
+        which = workload.split("_")[1]
+        n_taps = 29 if which == "const" else 27
+        fin = {"const": A.Fmt(16, 8), "load": A.Fmt(32, 16), "prog": A.Fmt(28, 6)}[which]
+        fc = {"const": A.Fmt(32, 16), "load": A.Fmt(32, 16), "prog": A.Fmt(23, 7)}[which]
+        fa = fo = A.Fmt(64, 32)
+        ch, n = args.channels or (1024 if which == "const" else 512), args.samples or (1 << 20)
+        node = A.NodeFir(n_taps, "FOLD_ODD", fin, fc, fa, fo, ch * n_shards, devices, kind=which)
+        node.set_coeffs(reference_cfg_coeffs(which, fc))
+        xs, ys = node.alloc(fin, n, fill(fin.W)), node.alloc(fo, n)
+        bps = xs[0].element_size() + 8.0
+        name = "ac_fir_%s_coeffs %d-tap FOLD_ODD, the types and coefficients of tests/rtest_ac_fir_%s_coeffs.cpp, %d ch x %d samples per GPU" % (which, n_taps, which, ch, n)
+    elif workload in ("cic_dec", "cic_intr", "cic_dec_r7m2n4", "cic_intr_r7m2n5"):
+        interp = "intr" in workload
+        R, M, N = (7, 2, 5 if interp else 4) if "r7" in workload else (8, 1, 5)
+        fin = A.Fmt(32, 16)
+        ch = args.channels or (1024 if interp else 4096)
+        n = args.samples or ((1 << 18) if interp else (7 * (1 << 17) if R == 7 else (1 << 22)))
+        it = A.Cic(interp, R, M, N, fin, fin, n_channels=1).int_type
+        fo = A.Fmt(it.W, it.I)
+        node = A.NodeCic(interp, R, M, N, fin, fo, ch * n_shards, devices)
+        xs = node.alloc(fin, n, fill(32))
+        ys = node.alloc(fo, (n * R + 64) if interp else (n // R + 8))
+        if interp:
+            node.run([x[:, :64] for x in xs], ys)      # steady state: later calls emit R outputs per input
+        bps = 4.0 + (8.0 * R if interp else 8.0 / R)
+        name = "ac_cic_%s_full N=%d R=%d M=%d ac_fixed<32,16> -> <%d,%d>, %d ch x %d input samples per GPU" % ("intr" if interp else "dec", N, R, M, it.W, it.I, ch, n)
     elif workload == "ddc":
         ch, n = args.channels or 4096, args.samples or (1 << 20)
         cin, fc, fa, fo = A.Fmt(16, 1), A.Fmt(16, 1), A.Fmt(60, 30), A.Fmt(24, 9, True, "RND", "SAT")
@@ -380,11 +406,42 @@ def build_node_workload(workload, args, n_shards, one_gpu):
         node.set_coeffs(windowed_sinc_raw(127, 0.2, fc.F))
         xs, ys = node.alloc(cin, n, fill(16)), node.alloc(fo, n // 16 + 8)
         bps, name = 2.25, "DDC: ac_cic_dec_full R=16 N=5 <16,1> -> 127-tap ac_fir_const_coeffs, %d real streams x %d samples per GPU" % (ch, n)
+    elif workload == "polydec":
+        ch, n = args.channels or 1024, args.samples or (1 << 22)
+        fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+        node = A.NodePolyDec(16, 8, fin, fc, fa, fo, ch * n_shards, devices)
+        hh = np.concatenate([windowed_sinc_raw(127, 0.05, fc.F), [0]])
+        node.set_coeffs(np.array([hh[df + tp * 8] for df in range(8) for tp in range(16)], dtype=np.int64))
+        xs, ys = node.alloc(fin, n, fill(16)), node.alloc(fo, n // 8 + 8)
+        bps, name = 2.25, "ac_poly_dec NTAPS=16 DF=8 ac_fixed<16,2> -> <16,2,RND,SAT>, %d ch x %d samples per GPU" % (ch, n)
+    elif workload == "polyintr":
+        ch, n = args.channels or 1024, args.samples or (1 << 18)
+        fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+        node = A.NodePolyIntr(16, 64, 8, "FOLD_EVEN", fin, fc, fa, fo, ch * n_shards, devices)
+        node.set_ctrl(windowed_sinc_raw(127, 0.05, fc.F)[:64], [1] * 8, list(range(8)))
+        xs, ys = node.alloc(fin, n, fill(16)), node.alloc(fo, n * 8 + 8)
+        node.run([x[:, :16] for x in xs], ys)          # past the stream's first sample
+        bps, name = 18.0, "ac_poly_intr FOLD_EVEN NTAPS=16 IF=8 ac_fixed<16,2> -> <16,2,RND,SAT>, %d ch x %d input samples per GPU" % (ch, n)
+    elif workload == "intgdump":
+        ch, n = args.channels or 1024, args.samples or (1 << 20)
+        fin, fa, fo = A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)
+        node = A.NodeIntgDump(64, 4, fin, fa, fo, ch * n_shards, devices)
+        xs, ys = node.alloc(fin, n, fill(16)), node.alloc(fo, n // 64 + 8)
+        run_extra = (np.full(n // (64 * 4), 64, dtype=np.int64),)
+        bps, name = 2.0 + 4.0 / 64, "ac_intg_dump NS=64 CHN=4 ac_fixed<16,8> -> <32,16>, %d objects x %d interleaved samples per GPU" % (ch, n)
+    elif workload == "mvavg":
+        ch, n = args.channels or 1024, args.samples or (1 << 20)
+        fin, fc, fa, fo = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18), A.Fmt(16, 8, True, "RND", "SAT")
+        node = A.NodeMvAvg(1024, 9, "MIRROR", fin, fc, fa, fo, ch * n_shards, devices)
+        node.set_coeffs(np.round(np.hanning(11)[1:-1] / np.hanning(11).sum() * 2.0 ** fc.F).astype(np.int64))
+        xs, ys = node.alloc(fin, n, fill(16)), node.alloc(fo, n)
+        run_extra = (1024,)
+        bps, name = 4.0, "ac_mv_avg TAPS=9 AC_MIRROR ac_fixed<16,8> -> <16,8,RND,SAT>, %d objects x %d frames x 1024 samples per GPU" % (ch, n // 1024)
     else:
-        raise SystemExit("bench.py --inproc: workloads fir255, fir1023, cic_dec, ddc")
+        raise SystemExit("bench.py --inproc: unknown workload %s" % workload)
     for d in set(devices):
         torch.cuda.synchronize(d)
-    return {"node": node, "step": lambda: node.run(xs, ys), "name": name, "samples_per_step": ch * n_shards * n, "samples_per_gpu": ch * n,
+    return {"node": node, "step": lambda: node.run(xs, *run_extra, ys), "name": name, "samples_per_step": ch * n_shards * n, "samples_per_gpu": ch * n,
             "bytes_per_sample": bps, "ch_per_gpu": ch, "n": n, "devices": devices}
 
 

@@ -364,6 +364,23 @@ int32_t acdsp_node_ddc_set_coeffs(acdsp_node_t h, const int64_t *coeffs);
 int64_t acdsp_node_ddc_out_count(acdsp_node_t h, int64_t n_in);
 int32_t acdsp_node_ddc_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_in, void *const *d_out, int64_t out_stride,
                            int64_t *n_out);
+/* the f-row classes: rows = channels (poly_dec, poly_intr) or objects (intg_dump, mv_avg), sliced the same way; coefficients /
+ * control words / block counts are replicated.  acdsp_node_last_ms: the shard's whole call between two events of its stream. */
+int32_t acdsp_node_polydec_create(const acdsp_polydec_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out);
+int32_t acdsp_node_polydec_set_coeffs(acdsp_node_t h, const int64_t *coeffs);
+int32_t acdsp_node_polydec_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_in, void *const *d_out, int64_t out_stride);
+int32_t acdsp_node_polyintr_create(const acdsp_polyintr_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out);
+int32_t acdsp_node_polyintr_set_ctrl(acdsp_node_t h, const int64_t *coeffs, const uint8_t *sign, const uint8_t *corr);
+int64_t acdsp_node_polyintr_out_count(acdsp_node_t h, int64_t n_in);
+int32_t acdsp_node_polyintr_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_in, void *const *d_out, int64_t out_stride,
+                                int64_t *n_out);
+int32_t acdsp_node_intgdump_create(const acdsp_intgdump_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out);
+int32_t acdsp_node_intgdump_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, const int64_t *n_sample, int64_t n_blocks,
+                                void *const *d_out, int64_t out_stride, int64_t *n_out);
+int32_t acdsp_node_mvavg_create(const acdsp_mvavg_desc_t *desc, int32_t n_devices, const int32_t *devices, acdsp_node_t *out);
+int32_t acdsp_node_mvavg_set_coeffs(acdsp_node_t h, const int64_t *coeffs);
+int32_t acdsp_node_mvavg_run(acdsp_node_t h, const void *const *d_in, int64_t in_stride, int64_t n_sample, int64_t n_frames, void *const *d_out,
+                             int64_t out_stride, int64_t *n_out);
 
 /* ---- raw-integer stream files (host side; no device needed) ---- */
 int32_t acdsp_stream_write(const char *path, const acdsp_stream_hdr_t *hdr, const void *data);

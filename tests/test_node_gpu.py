@@ -11,7 +11,7 @@ import torch
 
 import ac_dsp_amd as A
 from helpers import ofmt
-from oracle import OracleCic, OracleFir, stimulus
+from oracle import OracleCic, OracleFir, OracleIntgDump, OracleMvAvg, OraclePolyDec, OraclePolyIntr, stimulus
 
 pytestmark = pytest.mark.gpu
 
@@ -85,6 +85,61 @@ def test_fused_ddc_bank_sharded_on_one_device():
     got = gather(node.run(xs))
     want = oracle_cascade(16, 1, 5, cin, node.int_type, 127, "SHIFT_REG", fc, fa, fo, c, stimulus(SEED, n_ch, n, 16))
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n_shards", [1, 3, 8])
+def test_f_row_banks_sharded_on_one_device(n_shards):
+    """The SURVEY 8(f) classes behind the same node layer (round 5): ac_poly_dec, ac_poly_intr, ac_intg_dump, ac_mv_avg -- rows (channels or
+    objects) in contiguous slices, coefficients / control words / block counts replicated, two calls each (state carry where the class has
+    state), every slice against the unsharded oracle."""
+    import bench
+    devs = [0] * n_shards
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+    n_ch = 19
+    # ac_poly_dec: 16 taps per branch x DF 8 (the bench row's filter)
+    hh = np.concatenate([bench.windowed_sinc_raw(127, 0.05, fc.F), [0]])
+    cd = np.array([hh[df + tp * 8] for df in range(8) for tp in range(16)], dtype=np.int64)
+    node = A.NodePolyDec(16, 8, fin, fc, fa, fo, n_ch, devs)
+    node.set_coeffs(cd)
+    ora = OraclePolyDec(16, 8, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    xs = node.alloc(fin, 8 * 2600, fill(16))
+    xo = stimulus(SEED, n_ch, 8 * 2600, 16)
+    pos = 0
+    for k in (8 * 2048, 8 * 552):
+        assert np.array_equal(gather(node.run([x[:, pos:pos + k] for x in xs])), ora.run(cd, xo[:, pos:pos + k]))
+        pos += k
+    # ac_poly_intr: FOLD_EVEN, 16 taps x IF 8 (the bench row's filter)
+    ci = bench.windowed_sinc_raw(127, 0.05, fc.F)[:64]
+    node = A.NodePolyIntr(16, 64, 8, "FOLD_EVEN", fin, fc, fa, fo, n_ch, devs)
+    node.set_ctrl(ci, [1] * 8, list(range(8)))
+    ora = OraclePolyIntr(16, 64, 8, "FOLD_EVEN", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=n_ch)
+    xs = node.alloc(fin, 16 * 80, fill(16))
+    xo = stimulus(SEED, n_ch, 16 * 80, 16)
+    pos = 0
+    for k in (16 * 70, 16 * 10):
+        assert np.array_equal(gather(node.run([x[:, pos:pos + k] for x in xs])), ora.run(ci, [1] * 8, list(range(8)), xo[:, pos:pos + k]))
+        pos += k
+    # ac_intg_dump: 4 interleaved channels, a block that carries its sums on (n_sample = 0) between dumping ones
+    gin, ga, go = A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)
+    node = A.NodeIntgDump(64, 4, gin, ga, go, n_ch, devs)
+    ora = OracleIntgDump(64, 4, ofmt(gin), ofmt(ga), ofmt(go), n_obj=n_ch)
+    ns = np.array([64] * 9 + [0] + [17, 64], dtype=np.int64)
+    n_in = int(sum(64 if (v < 1 or v > 64) else v for v in ns)) * 4
+    xs = node.alloc(gin, (n_in + 7) // 8 * 8, fill(16))
+    xo = stimulus(SEED, n_ch, (n_in + 7) // 8 * 8, 16)
+    for _ in range(2):
+        assert np.array_equal(gather(node.run(xs, ns)), ora.run(xo[:, :n_in], ns))
+    # ac_mv_avg: 9 taps, AC_MIRROR, frames of 256 samples
+    mo, mc, ma = A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(16, 2), A.Fmt(40, 18)
+    wts = np.round(np.hanning(11)[1:-1] / np.hanning(11).sum() * 2.0 ** mc.F).astype(np.int64)
+    node = A.NodeMvAvg(1024, 9, "MIRROR", gin, mc, ma, mo, n_ch, devs)
+    node.set_coeffs(wts)
+    ora = OracleMvAvg(9, "MIRROR", ofmt(gin), ofmt(mc), ofmt(ma), ofmt(mo), n_obj=n_ch)
+    xs = node.alloc(gin, 256 * 12, fill(16))
+    xo = stimulus(SEED, n_ch, 256 * 12, 16)
+    assert np.array_equal(gather(node.run(xs, 256)), ora.run(wts, xo, 256))
+    per, mx = node.last_ms()
+    assert len(per) == n_shards and mx > 0
 
 
 def test_node_argument_errors_are_loud():
