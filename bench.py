@@ -295,6 +295,7 @@ def build_workload(workload, args, world, rank, local_rank):
         def step():
             eng.run(x, y)
         samples_per_step = (hi - lo) * n
+        step()
         path = "cic_intr_" + eng.path
     elif workload == "ddc":
         # BASELINE configs[4]: CIC R=16 N=5 on ac_fixed<16,1> -> lossless INT <36,21> -> 127-tap FIR (IN <36,21>,

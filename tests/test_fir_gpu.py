@@ -318,16 +318,16 @@ def test_unsigned_16_bit_samples_against_an_accumulator_inside_twice_the_signed_
     epilogues used the signed bound).  32 taps of +100, full-scale samples: <28,0> wraps 6399 -> -1792."""
     fin, fc = A.Fmt(16, 2, False), A.Fmt(16, 2)
     c = np.full(32, 100, dtype=np.int64)
-    for fo in (A.Fmt(16, 3, True, "RND", "SAT"), A.Fmt(16, 3, True, "TRN", "WRAP"), A.Fmt(acc_w, 0), A.Fmt(24, 4, True, "RND", "SAT")):
+    for fo in (A.Fmt(16, 3, True, "RND", "SAT"), A.Fmt(16, 3, True, "TRN", "WRAP"), A.Fmt(acc_w, acc_w - 28), A.Fmt(24, 4, True, "RND", "SAT")):   # ACC keeps all 28 fraction bits
         rng = np.random.default_rng(acc_w)
         x = rand_raw(rng, fin, (3, 1500))
         x[0, :] = 65535
         x[1, ::2] = 65535
-        fir = A.Fir(32, "SHIFT_REG", fin, fc, A.Fmt(acc_w, 0), fo, n_channels=3)
+        fir = A.Fir(32, "SHIFT_REG", fin, fc, A.Fmt(acc_w, acc_w - 28), fo, n_channels=3)
         fir.set_coeffs(c)
         assert fir.path == "mfma_i8", fir.path
         y = run_engine(fir, x, [700])
-        yo = OracleFir(32, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(A.Fmt(acc_w, 0)), ofmt(fo), n_ch=3).run(c, x)
+        yo = OracleFir(32, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(A.Fmt(acc_w, acc_w - 28)), ofmt(fo), n_ch=3).run(c, x)
         assert np.array_equal(y, yo), (acc_w, fo.W, y[0, 40:44], yo[0, 40:44])
 
 
