@@ -123,6 +123,7 @@ SYMBOLS = {
     "acdsp_node_mvavg_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
     "acdsp_node_mvavg_run": (_i32, [_vp, C.POINTER(_vp), _i64, _i64, _i64, C.POINTER(_vp), _i64, C.POINTER(_i64)]),
     "acdsp_diag_copy_ms": (_i32, [_i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
+    "acdsp_diag_shader_clock_mhz": (_i32, [_i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_diag_fir_envelope_ms": (_i32, [_i32, C.POINTER(_i64), _i32, _i32, _i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_fir_create": (_i32, [C.POINTER(FirDesc), C.POINTER(_vp)]),
     "acdsp_fir_destroy": (_i32, [_vp]),

@@ -94,4 +94,24 @@ hipError_t launch_diag_envelope(const uint32_t *d_frag, const void *x, void *y, 
   return hipErrorInvalidValue;
 }
 
+// Shader clock right behind a workload (bench.py: `clock_mhz_after` beside every row): one wave per XCD-sized slice of the chip spins on
+// dependent VALU adds for ~40 us and compares the shader-clock counter with the constant 100 MHz real-time counter; launched on the
+// workload's stream immediately behind its last timed step, before the power management has moved the clock (it reacts in milliseconds).
+__global__ void diag_clock_kernel(float *mhz) {
+  const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned v = threadIdx.x;
+  uint64_t r1;
+  do {
+#pragma unroll
+    for (int i = 0; i < 256; i++) { v = v * 3u + 1u; }
+    r1 = __builtin_amdgcn_s_memrealtime();
+  } while (r1 - r0 < 4000);
+  const uint64_t c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == (v & 0u)) { mhz[blockIdx.x] = (float)((double)(c1 - c0) / (double)(r1 - r0) * 100.0); }
+}
+hipError_t launch_diag_clock(float *d_mhz, int n_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(diag_clock_kernel, dim3((unsigned)n_blocks), dim3(64), 0, s, d_mhz);
+  return hipGetLastError();
+}
+
 }  // namespace acdsp

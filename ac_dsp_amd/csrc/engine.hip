@@ -176,6 +176,24 @@ extern "C" int32_t acdsp_diag_copy_ms(int32_t device, const void *d_src, void *d
   return time_launches([&] { return launch_diag_copy(d_src, d_dst, (int64_t)bytes, s); }, warmup, reps, s, ms_avg);
 }
 
+extern "C" int32_t acdsp_diag_shader_clock_mhz(int32_t device, void *stream, float *mhz) {
+  if (!mhz) { return fail(ACDSP_EINVAL, "diag_shader_clock: null output"); }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  static thread_local float *d_buf = nullptr;
+  if (!d_buf) { HIP_TRY(hipMalloc((void **)&d_buf, 8 * sizeof(float))); }
+  hipStream_t s = (hipStream_t)stream;
+  const hipError_t e = launch_diag_clock(d_buf, 8, s);
+  if (e != hipSuccess) { return fail(ACDSP_EHIP, "diag clock launch failed: %s", hipGetErrorString(e)); }
+  float h[8];
+  HIP_TRY(hipMemcpyAsync(h, d_buf, sizeof h, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  float sum = 0;
+  for (int i = 0; i < 8; i++) { sum += h[i]; }
+  *mhz = sum / 8;
+  return ACDSP_OK;
+}
+
 extern "C" int32_t acdsp_diag_fir_envelope_ms(int32_t device, const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, int32_t mfma_hi_per_step,
                                               const void *d_x, void *d_y, uint64_t bytes, int32_t warmup, int32_t reps, void *stream, float *ms_avg) {
   if (!d_x || !d_y || bytes < 16 || bytes % 16 || ((uintptr_t)d_x | (uintptr_t)d_y) % 16) { return fail(ACDSP_EINVAL, "diag_fir_envelope: 16-byte aligned buffers of a multiple of 16 bytes"); }

@@ -322,14 +322,16 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   kq.in_eb = h->in_eb; kq.out_eb = h->out_eb; kq.hl = h->hl; kq.use_rt = (h->use_rt && !h->rt_hybrid) ? 1 : 0;
   kq.lossless_shift = kq.acc.F - kq.in.F - kq.cf.F;
   static const bool no_lz = getenv("ACDSP_NO_MFMA_LOSSY") != nullptr;        // A/B knob: class B stays on the VALU kernels
-  static const bool lz_first = getenv("ACDSP_MFMA_LOSSY_FIRST") != nullptr;  // A/B knob: ... also takes the 16-bit types fir_lossy_kernel serves
+  // 16-bit types: fir_lossy_kernel (int32 VALU, 12 instructions per tap and four outputs) serves them too; the matrix-core kernel needs 6
+  // (measured 1.7 - 1.8 x faster at 63 / 127 taps, profiles/r5_shapes.txt) and goes first; ACDSP_LOSSY16_FIRST restores round 4's choice (A/B knob)
+  static const bool lz_first = getenv("ACDSP_LOSSY16_FIRST") == nullptr;
   {
     const int ift = internal_ftype(d.kind, d.ftype);
     const int fi = kq.in.F, fc = kq.cf.F, fa = kq.acc.F, sbits = fi + fc - fa;
     const bool fold_odd = is_fold_odd(ift), fold_even = ift == ACDSP_FOLD_EVEN || ift == kRsFoldEven || ift == kRsFoldEvenAnti;
     const bool anti = ift == kRsFoldEvenAnti || ift == kRsFoldOddAnti;
     bool ok = !no_lz && !no_gen && !h->wide && !h->lossless && !h->use_rt && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && !d.coeffs_per_channel &&
-              d.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && d.acc.S && d.acc.W <= 64 && sbits >= 1 && sbits <= 8 &&
+              d.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && d.acc.S && d.acc.W <= 64 && sbits >= 1 && sbits <= 15 &&
               (h->in_eb == 2 || h->in_eb == 4) && (d.in.W + (d.in.S ? 0 : 1) + 7) / 8 <= h->in_eb &&
               (lz_first || !fir_lossy_fast_ok(kq));
     if (ok && fold_odd) {

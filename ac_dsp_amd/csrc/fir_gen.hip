@@ -141,8 +141,8 @@ struct GenArgs {
   int32_t l_lo, l_hi, l_w;    // stage B: OUT range (AC_SAT) / OUT width (AC_WRAP: l_lo = l_hi = 0)
   // class B on the ring kernel (LZ instantiations, see fir_gen_ring_kernel): acc = (S + K - sum_e r_e) >> lz_s with S the exact sum of the
   // matrix cores, r_e = (f_e * cl_e + h) mod 2^s the bits the reference's per-tap quantisation drops, K = entries * h
-  int32_t lz_s;               // s = F_in + F_c - F_acc (1 .. 8)
-  int32_t lz_neg, lz_var_y, lz_p_n, lz_p_woff, lz_p_voff, lz_s_n, lz_s_woff;   // FirLossyPlan
+  int32_t lz_s;               // s = F_in + F_c - F_acc (1 .. 15)
+  int32_t lz_neg, lz_var_y, lz_p_n, lz_p_woff, lz_p_voff, lz_s_n, lz_s_woff, lz_flush;   // FirLossyPlan
   uint32_t lz_h2, lz_m2;      // rounding constant and mask of the dropped bits, in both 16-bit fields
   int64_t lz_k;
   const uint32_t *lz_tab;     // [kLossyTabWords] slot coefficients (c_S, c_D) per iteration, pair loop first
@@ -792,6 +792,7 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
       // v_alignbit.  Which tap sits in which slot depends on the parity of the window against the taps -- host-side (fir_gen_lossy_table),
       // as slot coefficients; a slot without a tap has coefficient 0 and contributes exactly h, which K counts.
       unsigned rA = 0, rB = 0;
+      unsigned rT[4] = {0, 0, 0, 0};   // 32-bit totals per output: the packed fields are emptied into them every lz_flush iterations
       if constexpr (LZ) {
         typedef unsigned short v2us_ __attribute__((ext_vector_type(2)));
         typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
@@ -809,7 +810,11 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
           if constexpr (decltype(neg_c)::value) { return __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, x) - __builtin_bit_cast(v2us_, y))); }
           else { return __builtin_bit_cast(unsigned, (v2us_)(__builtin_bit_cast(v2us_, x) + __builtin_bit_cast(v2us_, y))); }
         };
-        auto pairs = [&](auto neg_c, auto vary_c) {
+        // 16-bit fields hold two slots of up to 2^s - 1 per iteration: emptied into the 32-bit totals before they can wrap (never inside a
+        // loop for s <= 8 at these tap counts; every iteration at s = 15)
+        int cnt = 0;
+        auto flush = [&]() { rT[0] += rA & 0xffffu; rT[1] += rA >> 16; rT[2] += rB & 0xffffu; rT[3] += rB >> 16; rA = 0; rB = 0; cnt = 0; };
+        auto pairs = [&](auto neg_c, auto vary_c, auto fl_c) {
           const unsigned char *wp = p0 + 2 * a.lz_p_woff, *vp = p0 + 2 * a.lz_p_voff;
           unsigned w1 = ld32(wp + 4), w2 = ld32(wp + 8), v0 = ld32(vp), v1 = ld32(vp + 4);
           for (int m = 0; m < a.lz_p_n; m++) {
@@ -827,14 +832,22 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
             rA += term(fS0, cS) + term(fD0, cD);
             rB += term(fS1, cS) + term(fD1, cD);
             w2 = w1; w1 = w0; v0 = v1; v1 = v2;
+            if constexpr (decltype(fl_c)::value) { if (++cnt == a.lz_flush) { flush(); } }
           }
         };
+        typedef std::integral_constant<bool, true> T_; typedef std::integral_constant<bool, false> F_;
+        // (the counter and its branch cost the loops 25 % when they were unconditional: only sets that need a flush inside a loop pay for it)
+        const bool fl = a.lz_flush < a.lz_p_n + a.lz_s_n;
         if (a.lz_p_n > 0) {
-          typedef std::integral_constant<bool, true> T_; typedef std::integral_constant<bool, false> F_;
-          if (a.lz_neg) { if (a.lz_var_y) { pairs(T_(), T_()); } else { pairs(T_(), F_()); } }
-          else { if (a.lz_var_y) { pairs(F_(), T_()); } else { pairs(F_(), F_()); } }
+          if (fl) {
+            if (a.lz_neg) { if (a.lz_var_y) { pairs(T_(), T_(), T_()); } else { pairs(T_(), F_(), T_()); } }
+            else { if (a.lz_var_y) { pairs(F_(), T_(), T_()); } else { pairs(F_(), F_(), T_()); } }
+          } else {
+            if (a.lz_neg) { if (a.lz_var_y) { pairs(T_(), T_(), F_()); } else { pairs(T_(), F_(), F_()); } }
+            else { if (a.lz_var_y) { pairs(F_(), T_(), F_()); } else { pairs(F_(), F_(), F_()); } }
+          }
         }
-        {
+        auto singles = [&](auto fl_c) {
           const unsigned char *wp = p0 + 2 * a.lz_s_woff;
           const v2u_ *tab = ctab + a.lz_p_n;
           unsigned w1 = ld32(wp + 4), w2 = ld32(wp + 8);
@@ -846,8 +859,11 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
             rA += term(sh(w0, w1), cS) + term(w1, cD);
             rB += term(sh(w1, w2), cS) + term(w2, cD);
             w2 = w1; w1 = w0;
+            if constexpr (decltype(fl_c)::value) { if (++cnt == a.lz_flush) { flush(); } }
           }
-        }
+        };
+        if (fl) { singles(T_()); } else { singles(F_()); }
+        flush();
       }
       int64_t o[4];
       constexpr int NACC = PX + PCT - 1, NPR = (NACC + 1) / 2;
@@ -880,9 +896,7 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
       if constexpr (LZ) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const unsigned rr = r < 2 ? rA : rB;
-          const unsigned res = (r & 1) ? (rr >> 16) : (rr & 0xffffu);
-          o[r] = (int64_t)((uint64_t)o[r] + (uint64_t)a.lz_k - (uint64_t)res) >> a.lz_s;
+          o[r] = (int64_t)((uint64_t)o[r] + (uint64_t)a.lz_k - (uint64_t)rT[r]) >> a.lz_s;
         }
       }
       // the conversion, stage by stage (uniform branches: a stage whose constants are trivial is skipped for all four outputs)
@@ -1032,7 +1046,8 @@ bool fir_gen_lossy_table(const FirGenPlan &pl, const int64_t *coeffs, int n_taps
   int p_n = 0, p_woff = 0, s_n = 0, s_woff = 0;
   if (!build(0, n_pair, 0, &p_n, &p_woff) || !build(single0, n_single, 2 * p_n, &s_n, &s_woff)) { return false; }
   const int slots = 2 * (p_n + s_n);
-  if (slots < 1 || (int64_t)slots * m1 >= 65536) { return false; }
+  if (slots < 1 || s > 15) { return false; }
+  out->flush = (int32_t)(65535u / (2u * m1));      // iterations (two slots each) a 16-bit field holds: >= 1 for s <= 15
   out->s = s; out->neg = neg; out->var_y = (n_taps & 1) ? 0 : 1;
   out->p_n = p_n; out->p_woff = p_woff; out->p_voff = (n_taps & 1) ? -n_taps + 1 - b : -n_taps - b;
   out->s_n = s_n; out->s_woff = s_woff;
@@ -1072,10 +1087,10 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
   if (lz) {
     a.px = p.in_eb;                    // the containers are sign-extended: every byte of them is a plane (the ring shapes are compiled for that)
     a.lz_s = lz->s; a.lz_neg = lz->neg; a.lz_var_y = lz->var_y; a.lz_p_n = lz->p_n; a.lz_p_woff = lz->p_woff; a.lz_p_voff = lz->p_voff;
-    a.lz_s_n = lz->s_n; a.lz_s_woff = lz->s_woff;
+    a.lz_s_n = lz->s_n; a.lz_s_woff = lz->s_woff; a.lz_flush = lz->flush;
     a.lz_h2 = lz->h2; a.lz_m2 = lz->m2; a.lz_k = lz->k; a.lz_tab = lz->d_tab;
   } else {
-    a.lz_s = 0; a.lz_neg = a.lz_var_y = a.lz_p_n = a.lz_p_woff = a.lz_p_voff = a.lz_s_n = a.lz_s_woff = 0; a.lz_h2 = a.lz_m2 = 0; a.lz_k = 0; a.lz_tab = nullptr;
+    a.lz_s = 0; a.lz_neg = a.lz_var_y = a.lz_p_n = a.lz_p_woff = a.lz_p_voff = a.lz_s_n = a.lz_s_woff = a.lz_flush = 0; a.lz_h2 = a.lz_m2 = 0; a.lz_k = 0; a.lz_tab = nullptr;
   }
   a.n_slots = 15 * pl.R + 4 * pl.nb;
   a.out_mode = out_mode; a.w_int = w_int; a.out_simple = out_simple;

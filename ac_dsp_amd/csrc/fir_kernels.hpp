@@ -80,7 +80,8 @@ bool fir_gen_plan(const int64_t *h, int n_taps, int R, int first_mod16, FirGenPl
 // Class B on the ring kernel (lossy accumulator, AC_TRN / AC_RND into AC_WRAP; fir_gen.hip: LZ instantiations).  pl / d_frag are the
 // plan of the EFFECTIVE tap vector (the exact sum), this struct the per-tap residues.
 struct FirLossyPlan {
-  int32_t s;                           // F_in + F_c - F_acc, 1 .. 8
+  int32_t s;                           // F_in + F_c - F_acc, 1 .. 15
+  int32_t flush;                       // iterations after which the packed 16-bit sums are emptied into the 32-bit totals
   int32_t neg, var_y;                  // folded pairs: difference instead of sum (ac_fir_reg_share's anti-symmetric cores); even tap count
   int32_t p_n, p_woff, p_voff;         // pair loop: iterations (two pairs each), window offsets in samples relative to the output's own sample
   int32_t s_n, s_woff;                 // single-tap loop: iterations (two taps each), window offset
@@ -174,6 +175,7 @@ int set_error(int code, const char *msg);
 hipError_t launch_diag_copy(const void *src, void *dst, int64_t bytes, hipStream_t s);
 // d_frag: six Toeplitz fragments [4 low-plane blocks][2 high-plane blocks] x 64 lanes x 16 bytes; hipErrorInvalidValue: count not compiled
 bool diag_envelope_compiled(int mfma, int mfma_hi);
+hipError_t launch_diag_clock(float *d_mhz, int n_blocks, hipStream_t s);   // shader clock in MHz per block (diag.hip)
 hipError_t launch_diag_envelope(const uint32_t *d_frag, const void *x, void *y, int64_t bytes, int mfma, int mfma_hi, hipStream_t s);
 
 // Polyphase decimator, exact per-MAC order (polydec.hip); p.coeffs = STR_COEFF_TYPE array [ntaps*df], p.n = inputs used

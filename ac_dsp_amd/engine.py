@@ -81,6 +81,13 @@ def diag_copy_ms(src, dst, warmup=3, reps=10):
     return ms.value, nbytes
 
 
+def diag_shader_clock_mhz(device=0):
+    """Shader clock in MHz right behind the work torch's current stream of `device` ran last (acdsp_diag_shader_clock_mhz)."""
+    mhz = C.c_float()
+    check(lib.acdsp_diag_shader_clock_mhz(device, C.c_void_p(torch.cuda.current_stream(device).cuda_stream), C.byref(mhz)))
+    return mhz.value
+
+
 def diag_fir_envelope_ms(coeffs, mfma_per_step, mfma_hi_per_step, x, y, warmup=3, reps=10):
     """Average ms of the stream + issued-MFMA envelope of a FIR row over x -> y (acdsp_diag_fir_envelope_ms): roofline.envelope_ms."""
     assert x.is_cuda and y.is_cuda and x.is_contiguous() and y.is_contiguous()

@@ -524,6 +524,11 @@ def measure(w, steps, warmup, barrier, settle_s=0.0):
     barrier()
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1) / steps
+    try:    # shader clock right behind the timed steps (a 40 us spin kernel, outside the timed region): the clock state the row ran in
+        import ac_dsp_amd as A
+        w["clock_mhz_after"] = round(A.diag_shader_clock_mhz(torch.cuda.current_device()), 1)
+    except Exception:   # noqa: BLE001  (a diagnostic: never fails a bench line)
+        w["clock_mhz_after"] = None
     if hasattr(eng, "kernel_stats"):
         k_avg, k_min = eng.kernel_stats(min(steps, 64))   # HIP events around the dominant kernel, on the stream it is launched on
     else:                                                # handles without a kernel timer: events around the whole step
@@ -531,8 +536,8 @@ def measure(w, steps, warmup, barrier, settle_s=0.0):
     return dt, k_avg, k_min, ev_ms
 
 
-PROFILE_TAGS = {"fir255": "fir255", "fir255_dense": "fir255_dense", "fir255_wide": "fir255_wide", "fir1023": "fir1023", "cic_dec": "cic_dec",
-                "ddc": "ddc", "polydec": "polydec", "cic_intr": "cic_intr", "polyintr": "polyintr", "intgdump": "intgdump", "mvavg": "mvavg"}
+PROFILE_TAGS = {w_: w_ for w_ in ("fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "ddc", "polydec", "cic_intr", "polyintr", "intgdump", "mvavg",
+                                   "rtest_const_types", "rtest_load_types", "rtest_prog_types", "cic_dec_r7m2n4", "cic_intr_r7m2n5")}
 
 
 def roofline_of(w, k_avg, k_min, ev_ms):
@@ -700,6 +705,7 @@ def main():
                        "parallelism": "channel-slice x%d, no collectives" % world},
             "roofline": roofline_of(w, k_avg, k_min, ev_ms),
             "event_ms_per_step": ev_ms,
+            "clock_mhz_after": w.get("clock_mhz_after"),
             "clock_settle": {"seconds": args.settle, "steps": w["settle_steps"],
                              "note": "untimed pre-conditioning in front of the W warm-up steps (same step, same data): the shader clock needs "
                                      "20-40 ms of load to settle from idle; --settle 0 measures the cold-start transient instead"},
@@ -725,7 +731,8 @@ def main():
                 r2 = roofline_of(w2, ka2, km2, ev2)
                 sec[name] = {"workload": w2["name"], "kernel_path": w2["path"], "ms_per_step": dt2 / 10 * 1e3,
                              "Msamples_per_s": w2["samples_per_step"] * 10 / dt2 / 1e6, "kernel_ms_avg": ka2,
-                             "roofline_frac": r2["frac"], "roofline_frac_step": r2["frac_step"], "achieved_GBps": r2["achieved"]}
+                             "roofline_frac": r2["frac"], "roofline_frac_step": r2["frac_step"], "achieved_GBps": r2["achieved"],
+                             "traffic": r2.get("traffic"), "clock_mhz_after": w2.get("clock_mhz_after")}
                 if w2["macs_per_sample"]:
                     m2 = mfma_roofline_of(w2, ka2)
                     sec[name]["mfma_frac"] = m2["frac"]
@@ -866,7 +873,7 @@ def pmc_traffic(tag):
     (profiles/r<round>_<tag>_rocprof.txt, newest round first): FETCH_SIZE (KB, x2 on gfx950 for 16-byte streaming reads, see
     MI355X_MICROARCH.md) + WRITE_SIZE (KB).  A static value from the profile of the same binary, NOT measured in this run
     (the PMC passes are separate rocprofv3 invocations); (None, None) when no summary has been committed."""
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", "%s_%s_rocprof.txt" % (rnd, tag))
         try:
             vals = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}

@@ -184,6 +184,8 @@ int32_t acdsp_fill_stimulus(int32_t device, void *d_ptr, int32_t elem_bytes, int
  *              epilogue.  Compiled (per_step, hi): (0,0) (26,8) (36,18) (76,10) (132,66); anything else is ACDSP_EUNSUPPORTED. */
 int32_t acdsp_diag_copy_ms(int32_t device, const void *d_src, void *d_dst, uint64_t bytes, int32_t warmup, int32_t reps, void *stream,
                            float *ms_avg);
+/* shader clock (MHz) measured by a short spin kernel on `stream`, i.e. right behind whatever the stream ran last: the clock state of a bench row */
+int32_t acdsp_diag_shader_clock_mhz(int32_t device, void *stream, float *mhz);
 int32_t acdsp_diag_fir_envelope_ms(int32_t device, const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, int32_t mfma_hi_per_step,
                                    const void *d_x, void *d_y, uint64_t bytes, int32_t warmup, int32_t reps, void *stream, float *ms_avg);
 

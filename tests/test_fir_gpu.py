@@ -217,8 +217,11 @@ def test_lossy_wrapping_accumulators_on_16_bit_types(n_taps, ftype, fa):
     history across calls, a ragged last tile, per-channel coefficient sets.  Against the oracle's MAC loops in the reference's order."""
     fin, fc = A.Fmt(16, 2), A.Fmt(16, 2)
     fo = A.Fmt(16, 2, True, "RND", "SAT") if fa.S else A.Fmt(22, 5, True, "RND", "SAT")   # (signed containers: torch has no uint16)
-    n = 2048 + 600 + n_taps
-    check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=n, splits=[5, 1200], seed=n_taps + fa.W, expect_path="generic")
+    n = 2 * 4096 + 600 + n_taps
+    # (round 5: up to 15 dropped bits, a signed accumulator and <= ~130 taps of a shared set go to the matrix-core class-B kernel first -- whole
+    # 4096-sample chunks there, the rest on the exact-order kernel; everything else keeps fir_lossy_kernel.  Which one: tests/test_pathmap_gpu.py)
+    fir = check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=n, splits=[5, 4096 + 5], seed=n_taps + fa.W)
+    assert fir.kernel in ("lossy16", "mfma_lossy"), fir.kernel
     if ftype == "SHIFT_REG" and fa.F < 11 + 14:       # narrower sample / unsigned coefficient types: 25 fraction bits in a product
         check_case(n_taps, ftype, A.Fmt(12, 1), A.Fmt(15, 1, False), fa, fo, n_ch=4, n=n, per_channel=True, splits=[2047], seed=n_taps + fa.F,
                    expect_path="generic")
@@ -270,6 +273,9 @@ LOSSY_MFMA_TYPES = [
     (A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(48, 28)),                     # 16-bit samples, wide coefficients: s = 4
     (A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(48, 31, True, "RND", "WRAP")),  # s = 7
     (A.Fmt(15, 3, False), A.Fmt(24, 4), A.Fmt(46, 16)),               # unsigned 15-bit samples: s = 2
+    (A.Fmt(28, 6), A.Fmt(23, 7), A.Fmt(60, 34, True, "RND", "WRAP")),  # s = 12: the packed 16-bit sums are emptied every 8 iterations
+    (A.Fmt(32, 16), A.Fmt(24, 8), A.Fmt(48, 31)),                     # s = 15: ... every iteration
+    (A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(36, 14, True, "RND", "WRAP")),  # 16-bit types, s = 6 (ahead of fir_lossy_kernel since round 5)
 ]
 
 
@@ -299,10 +305,10 @@ def test_lossy_wrapping_accumulators_on_the_matrix_cores(ftype, types):
 
 
 def test_lossy_matrix_core_class_bounds():
-    """What the class refuses: more than 8 dropped bits, a 64-bit sum that could leave int64 while ACC_TYPE keeps its top bits, sign-dependent
+    """What the class refuses: more than 15 dropped bits, a 64-bit sum that could leave int64 while ACC_TYPE keeps its top bits, sign-dependent
     rounding, a saturating accumulator, a coefficient set per channel -- all of them bit-exact on the other kernels."""
     x28, c23 = A.Fmt(28, 6), A.Fmt(23, 7)
-    for fa, fc, want in ((A.Fmt(64, 40), c23, "generic"),                               # s = 14
+    for fa, fc, want in ((A.Fmt(64, 42), c23, "generic"),                               # s = 16
                          (A.Fmt(64, 32, True, "TRN_ZERO", "WRAP"), c23, "generic"),
                          (A.Fmt(64, 32, True, "TRN", "SAT"), c23, "generic"),
                          (A.Fmt(60, 28, False, "TRN", "WRAP"), c23, "generic"),
@@ -869,8 +875,8 @@ def test_reg_share_lossless_runs_on_the_matrix_cores(ftype):
 @pytest.mark.parametrize("q,o", [("TRN", "WRAP"), ("RND_CONV", "SAT"), ("TRN_ZERO", "SAT_SYM")])
 def test_reg_share_lossy_accumulator_keeps_the_ascending_mac_order(ftype, q, o):
     n_taps = 21 if "ODD" in ftype else 22
-    # (TRN into WRAP has no order: the folds run the matrix-core class-B kernel, SHIFT_REG the 16-bit VALU kernel; the others keep the exact order)
-    want = "mfma_lossy" if ((q, o) == ("TRN", "WRAP") and ftype != "SHIFT_REG") else "generic"
+    # (TRN into WRAP has no order: the matrix-core class-B kernel; the others keep the exact order)
+    want = "mfma_lossy" if (q, o) == ("TRN", "WRAP") else "generic"
     check_reg_share(n_taps, ftype, A.Fmt(14, 4), A.Fmt(12, 2), A.Fmt(20, 8, True, q, o), A.Fmt(10, 5, True, q, o), splits=[7, 300],
                     expect_path=want, seed=5)
 

@@ -45,6 +45,8 @@ CASES = [
     ("255 taps, OUT <16,2,RND_CONV,SAT_SYM>", 255, "SHIFT_REG", F(16, 2), F(16, 2), F(40, 12), F(16, 2, True, "RND_CONV", "SAT_SYM")),
     ("63 taps, lossy ACC <24,8,TRN,WRAP> (class B)", 63, "SHIFT_REG", F(16, 2), F(16, 2), F(24, 8), F(16, 2, True, "RND", "SAT")),
     ("63 taps, lossy ACC <24,8,RND,WRAP> (class B)", 63, "SHIFT_REG", F(16, 2), F(16, 2), F(24, 8, True, "RND", "WRAP"), F(16, 2, True, "RND", "SAT")),
+    ("63 taps, lossy ACC <32,12,TRN,WRAP>: 8 bits dropped (class B)", 63, "SHIFT_REG", F(16, 2), F(16, 2), F(32, 12), F(16, 2, True, "RND", "SAT")),
+    ("127 taps, lossy ACC <32,8,RND,WRAP>: 4 bits dropped (class B)", 127, "SHIFT_REG", F(16, 2), F(16, 2), F(32, 8, True, "RND", "WRAP"), F(16, 2, True, "RND", "SAT")),
     ("63 taps, saturating ACC <30,4,TRN,SAT> (class C)", 63, "SHIFT_REG", F(16, 2), F(16, 2), F(30, 4, True, "TRN", "SAT"), F(16, 2, True, "RND", "SAT")),
 ]
 only = sys.argv[1] if len(sys.argv) > 1 else None
