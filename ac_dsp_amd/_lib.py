@@ -134,6 +134,7 @@ SYMBOLS = {
     "acdsp_fir_reset": (_i32, [_vp]),
     "acdsp_fir_path": (_i32, [_vp]),
     "acdsp_fir_kernel_class": (_i32, [_vp]),
+    "acdsp_fir_mfma_epilogue": (_i32, [_vp]),
     "acdsp_fir_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "acdsp_fir_kernel_stats": (_i32, [_vp, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "acdsp_fir_mfma_issued": (_i32, [_vp, C.POINTER(C.c_int32)]),

@@ -177,6 +177,7 @@ struct acdsp_fir {
   int64_t *d_corr = nullptr;    // [n_sets] 128 * sum(c)
   FirMfmaPlan plan;             // worst case over the coefficient sets (bounds for the epilogue choice)
   bool mfma_ok = false;
+  int mfma_cshift = 0;          // the fragments hold the coefficients scaled by 2^mfma_cshift (narrow types: engine_fir.hip, set_coeffs)
   uint32_t *d_gfrag = nullptr;  // fragments of the generalised (wide-input) MFMA kernel
   FirGenPlan gplan;
   bool gen_ok = false;

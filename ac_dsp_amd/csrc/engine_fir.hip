@@ -14,7 +14,26 @@ __global__ void flip16_kernel(const uint16_t *x, int64_t xs, int64_t n, uint16_t
     else { dh[(int64_t)ch * hl + (j - ds)] = (uint16_t)(hist[(int64_t)ch * hl + (j - ds)] ^ 0x8000u); }
   }
 }
+// the same, 8 samples per lane: rows that are 16-byte aligned on both sides and a call of whole 8-sample groups (round 5: the element-wise
+// form above moved 2 bytes per lane and instruction and took twice the FIR kernel's own time on the 127-tap row of tools/fir_shapes.py)
+__global__ void __launch_bounds__(256) flip16_vec_kernel(const uint4 *x, int64_t xs8, int64_t n8, uint4 *dx, int64_t ds8, const uint4 *hist, uint4 *dh, int hl8) {
+  const int ch = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ds8 + hl8; j += (int64_t)gridDim.x * blockDim.x) {
+    uint4 v;
+    if (j < ds8) { v = j < n8 ? x[(int64_t)ch * xs8 + j] : make_uint4(0, 0, 0, 0); }
+    else { v = hist[(int64_t)ch * hl8 + (j - ds8)]; }
+    v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u;
+    if (j < ds8) { dx[(int64_t)ch * ds8 + j] = v; } else { dh[(int64_t)ch * hl8 + (j - ds8)] = v; }
+  }
+}
 hipError_t launch_flip16(const void *x, int64_t xs, int64_t n, void *dx, int64_t ds, const void *hist, void *dh, int hl, int n_ch, hipStream_t s) {
+  if (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)hist | (uintptr_t)dh) % 16 == 0 && xs % 8 == 0 && n % 8 == 0 && ds % 8 == 0 && hl % 8 == 0) {
+    int64_t blocks = ((ds + hl) / 8 + 255) / 256;
+    if (blocks > 2048) { blocks = 2048; }
+    hipLaunchKernelGGL(flip16_vec_kernel, dim3((unsigned)blocks, (unsigned)n_ch), dim3(256), 0, s, (const uint4 *)x, xs / 8, n / 8, (uint4 *)dx, ds / 8,
+                       (const uint4 *)hist, (uint4 *)dh, hl / 8);
+    return hipGetLastError();
+  }
   int64_t blocks = (ds + hl + 1023) / 1024;
   if (blocks > 4096) { blocks = 4096; }
   hipLaunchKernelGGL(flip16_kernel, dim3((unsigned)blocks, (unsigned)n_ch), dim3(256), 0, s, (const uint16_t *)x, xs, n, (uint16_t *)dx, ds,
@@ -257,35 +276,64 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
     std::vector<uint32_t> frag(n_sets * per_set, 0u);
     std::vector<int64_t> corr(n_sets, 0);
     FirMfmaPlan worst;
-    memset(&worst, 0, sizeof worst);
     bool ok = true;
-    for (size_t st = 0; st < n_sets && ok; st++) {
-      std::vector<int64_t> eff = effective_coeffs(coeffs + st * d.n_taps, d.n_taps, internal_ftype(d.kind, d.ftype));
-      FirMfmaPlan pl;
-      ok = fir_mfma_build_fragments(eff.data(), d.n_taps, &pl, frag.data() + st * per_set);
-      if (!ok) { break; }
-      if (flip) {   // + 32768 * sum(c): the samples go through the kernel as x - 32768
-        int64_t sc = 0;
-        for (int64_t v : eff) { sc += v; }
-        pl.corr += 32768 * sc;
-        // the kernel sees signed 16-bit samples (|x| <= 2^15) but the recombined sum is the UNSIGNED dot product, |y| <= 65535 * sum|c|:
-        // the no-wrap proof of the fast epilogues (fir_mfma_epilogue_class: sum_abs * x_max against ACC's range) must use that bound
-        pl.sum_abs *= 2;
+    // cshift: the sets go through the kernel scaled by 2^cshift (see below); one attempt with the shift the formats ask for, one without
+    auto build = [&](int cshift) {
+      std::fill(frag.begin(), frag.end(), 0u);
+      memset(&worst, 0, sizeof worst);
+      ok = true;
+      for (size_t st = 0; st < n_sets && ok; st++) {
+        std::vector<int64_t> eff = effective_coeffs(coeffs + st * d.n_taps, d.n_taps, internal_ftype(d.kind, d.ftype));
+        for (int64_t &v : eff) { v = (int64_t)((uint64_t)v << cshift); }
+        FirMfmaPlan pl;
+        ok = fir_mfma_build_fragments(eff.data(), d.n_taps, &pl, frag.data() + st * per_set);
+        if (!ok) { break; }
+        if (flip) {   // + 32768 * sum(c): the samples go through the kernel as x - 32768
+          int64_t sc = 0;
+          for (int64_t v : eff) { sc += v; }
+          pl.corr += 32768 * sc;
+          // the kernel sees signed 16-bit samples (|x| <= 2^15) but the recombined sum is the UNSIGNED dot product, |y| <= 65535 * sum|c|:
+          // the no-wrap proof of the fast epilogues (fir_mfma_epilogue_class: sum_abs * x_max against ACC's range) must use that bound
+          pl.sum_abs *= 2;
+        }
+        corr[st] = pl.corr;
+        worst.nb = pl.nb;
+        worst.hi_mask |= pl.hi_mask; worst.lo_mask |= pl.lo_mask;
+        if (pl.sum_abs > worst.sum_abs) { worst.sum_abs = pl.sum_abs; }
+        if (pl.sum_abs_hi > worst.sum_abs_hi) { worst.sum_abs_hi = pl.sum_abs_hi; }
+        if (pl.sum_abs_lo > worst.sum_abs_lo) { worst.sum_abs_lo = pl.sum_abs_lo; }
+        const int64_t ca = pl.corr < 0 ? -pl.corr : pl.corr, wa = worst.corr < 0 ? -worst.corr : worst.corr;
+        if (st == 0 || ca > wa) { worst.corr = pl.corr; }
       }
-      corr[st] = pl.corr;
-      worst.nb = pl.nb;
-      worst.hi_mask |= pl.hi_mask; worst.lo_mask |= pl.lo_mask;
-      if (pl.sum_abs > worst.sum_abs) { worst.sum_abs = pl.sum_abs; }
-      if (pl.sum_abs_hi > worst.sum_abs_hi) { worst.sum_abs_hi = pl.sum_abs_hi; }
-      if (pl.sum_abs_lo > worst.sum_abs_lo) { worst.sum_abs_lo = pl.sum_abs_lo; }
-      const int64_t ca = pl.corr < 0 ? -pl.corr : pl.corr, wa = worst.corr < 0 ? -worst.corr : worst.corr;
-      if (st == 0 || ca > wa) { worst.corr = pl.corr; }
+    };
+    // Narrow types (<8,1> samples and coefficients into an <8,1> output: 7 dropped bits) leave the 32-bit epilogue classes less than one bit
+    // to shift by once the 16 - W_out bits of the packed finish are taken off (fir_mfma_epilogue_class: rse >= 1), and ran the generic
+    // epilogue with element-wise stores (0.18 of the roofline).  The sum is linear in the set: the fragments are built from c << cshift and the
+    // kernel is told F_coeff + cshift -- every bound scales with it, and the classes are asked again with the scaled plan.
+    h->mfma_cshift = 0;
+    {
+      const int fi_ = d.in.W - d.in.I, fc_ = d.coeff.W - d.coeff.I, fo_ = d.out.W - d.out.I;
+      const int nar_d = (h->out_eb == 2 && d.out.W >= 2 && d.out.W < 16) ? 16 - d.out.W : 0, rse = fi_ + fc_ - fo_ - nar_d;
+      static const bool no_cshift = getenv("ACDSP_NO_CSHIFT") != nullptr;   // A/B knob
+      const int want = (h->out_eb == 2 && rse < 1 && rse > -14 && !no_cshift) ? 1 - rse : 0;
+      if (want > 0) {
+        build(want);
+        FirParams k;
+        memset(&k, 0, sizeof k);
+        k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+        k.cf.F += want;
+        k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
+        const int epi = ok ? fir_mfma_epilogue_class(k, worst) : 0;
+        if (epi == 1 || epi == 2) { h->mfma_cshift = want; }
+      }
+      if (!h->mfma_cshift) { build(0); }
     }
     if (ok && d.coeffs_per_channel && worst.nb > fir_mfma_max_reg_blocks()) {
       // a set per channel needs the register-resident kernels: beyond 9 K-blocks only band-limited sets with the fast int16 epilogue
       FirParams k;
       memset(&k, 0, sizeof k);
       k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+      k.cf.F += h->mfma_cshift;
       k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
       ok = fir_mfma_register_resident(k, worst);
     }
@@ -490,12 +538,16 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   // are launch-bound: no timing events, and the exact-order kernels write the next history themselves -- one launch per call.
   const bool small = h->small_call;
   const bool fuse_hist = small && !flipped && (!h->use_rt || hyb) && (path == ACDSP_PATH_LOSSLESS64 || path == ACDSP_PATH_GENERIC ||
-                                                (path == ACDSP_PATH_MFMA_I8 && fir_mfma_register_resident(k, h->plan)));   // single-wave workgroups
+                                                (path == ACDSP_PATH_MFMA_I8 && !h->mfma_cshift && fir_mfma_register_resident(k, h->plan)));   // single-wave workgroups
   const int nxt_fused = hist_next_index(h->cur, false);
   if (fuse_hist) { k.hist_next = h->d_hist[nxt_fused]; }
   if (!small && !flipped) { HIP_TRY(hipEventRecord(h->tm.start(), s)); }
   hipError_t e;
-  if (path == ACDSP_PATH_MFMA_I8) { e = launch_fir_mfma(k, h->plan, d.coeffs_per_channel, h->d_frag, h->d_corr, s); }
+  if (path == ACDSP_PATH_MFMA_I8) {
+    FirParams km = k;    // (the fragments hold c << mfma_cshift: the kernel's shifts follow; the state kernels below keep the handle's formats)
+    km.cf.F += h->mfma_cshift; km.lossless_shift -= h->mfma_cshift;
+    e = launch_fir_mfma(km, h->plan, d.coeffs_per_channel, h->d_frag, h->d_corr, s);
+  }
   else if (path == ACDSP_PATH_MFMA_GEN) { e = launch_fir_gen(k, h->gplan, h->d_gfrag, 0, 0, 0, n, s); }
   else if (path == ACDSP_PATH_MFMA_LOSSY) {
     // complete chunks on the matrix cores, the ragged rest (and calls shorter than a chunk) on the exact-order kernel
@@ -600,6 +652,17 @@ int32_t acdsp_fir_kernel_stats(acdsp_fir_t h, int32_t last_k, float *avg_ms, flo
   return h->tm.stats(last_k, avg_ms, min_ms);
 }
 
+int32_t acdsp_fir_mfma_epilogue(acdsp_fir_t h) {
+  if (!h || !h->coeffs_set || h->path != ACDSP_PATH_MFMA_I8) { return -1; }
+  const acdsp_fir_desc_t &d = h->d;
+  FirParams k;
+  memset(&k, 0, sizeof k);
+  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+  k.cf.F += h->mfma_cshift;
+  k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
+  return fir_mfma_epilogue_class(k, h->plan) | (h->mfma_cshift << 8) | (h->in_flip ? 1 << 16 : 0);
+}
+
 int32_t acdsp_fir_mfma_issued(acdsp_fir_t h, int32_t *per_1024_samples) {
   if (!h || !per_1024_samples) { return fail(ACDSP_EINVAL, "null argument"); }
   if (!h->coeffs_set) { return fail(ACDSP_ESTATE, "acdsp_fir_mfma_issued before acdsp_fir_set_coeffs"); }
@@ -609,6 +672,7 @@ int32_t acdsp_fir_mfma_issued(acdsp_fir_t h, int32_t *per_1024_samples) {
     FirParams k;
     memset(&k, 0, sizeof k);
     k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+    k.cf.F += h->mfma_cshift;
     k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
     *per_1024_samples = fir_mfma_issued_per_step(k, h->plan);
   }

@@ -57,6 +57,7 @@ int fir_mfma_max_reg_blocks();   // ... with the A fragments register-resident (
 // One wave = one channel x a time chunk; fragments and corr are per coefficient set:
 // d_frag[n_sets][2][nb][64][4], d_corr[n_sets]; `plan` carries the worst-case bounds over all sets.
 int fir_mfma_issued_per_step(const FirParams &p, const FirMfmaPlan &plan);
+int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan);   // 0 generic, 1 / 2 the 32-bit classes, 3 wide, 4 the 64-bit branch-free one
 bool fir_mfma_register_resident(const FirParams &p, const FirMfmaPlan &plan);   // fragments in registers: per-channel coefficient sets allowed
 hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag_per_channel, const uint32_t *d_frag,
                            const int64_t *d_corr, hipStream_t s);

@@ -128,6 +128,11 @@ class Fir:
         """path, with the VALU fast kernels inside "generic" told apart ("lossy16", "satacc16"): acdsp_fir_kernel_class"""
         return KCLASSES[lib.acdsp_fir_kernel_class(self._h)]
 
+    def mfma_epilogue(self):
+        """(epilogue class, coefficient pre-shift, samples sign-flipped) on the int8 matrix-core path, else None (acdsp_fir_mfma_epilogue)"""
+        v = lib.acdsp_fir_mfma_epilogue(self._h)
+        return None if v < 0 else (v & 255, (v >> 8) & 255, bool(v >> 16))
+
     def run(self, x, out=None):
         """x: [n_channels][n] device tensor of IN containers -> [n_channels][n] OUT containers."""
         assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1

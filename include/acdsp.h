@@ -209,6 +209,9 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
 int32_t acdsp_fir_run_host(acdsp_fir_t h, const void *h_in, int64_t n_samples, void *h_out);
 int32_t acdsp_fir_reset(acdsp_fir_t h);        /* back to the freshly constructed state (coefficients kept) */
 int32_t acdsp_fir_path(acdsp_fir_t h);         /* ACDSP_PATH_* chosen for the current coefficients */
+/* int8 matrix-core path only (else -1): epilogue class (0 generic, 1 / 2 the 32-bit classes, 3 wide, 4 64-bit branch-free) | coefficient pre-shift << 8 |
+ * sign-flipped unsigned samples << 16 -- diagnostic, recorded by tests/test_pathmap_gpu.py */
+int32_t acdsp_fir_mfma_epilogue(acdsp_fir_t h);
 int32_t acdsp_fir_kernel_class(acdsp_fir_t h); /* the same, with ACDSP_KCLASS_* inside ACDSP_PATH_GENERIC; -1 before set_coeffs */
 /* Duration of the main kernel of the most recent TIMED run(), from HIP events
  * recorded on the launch stream (blocks until that kernel has finished).  Small host-side

@@ -82,4 +82,5 @@ def resolve(args):
         fir.set_coeffs(np.stack([c, c]) if per_ch else c)
     except A.AcdspError:
         return "rejected_set"
-    return "%s/%d" % (fir.kernel, fir.mfma_issued())
+    e = fir.mfma_epilogue()
+    return "%s/%d" % (fir.kernel, fir.mfma_issued()) + ("" if e is None else "/e%d%s%s" % (e[0], "+c%d" % e[1] if e[1] else "", "+flip" if e[2] else ""))

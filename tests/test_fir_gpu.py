@@ -98,6 +98,26 @@ def test_all_q_o_modes_of_a_16_bit_output_on_the_matrix_core_epilogue(q, o):
         assert bad.size == 0, "%s %s case %d: %d mismatches, first at %s: got %d want %d" % (q, o, k, len(bad), bad[0], y[tuple(bad[0])], yo[tuple(bad[0])])
 
 
+@pytest.mark.parametrize("types", [(A.Fmt(8, 1), A.Fmt(8, 1), A.Fmt(30, 15), A.Fmt(8, 1, True, "RND", "SAT")),      # (accumulators that hold 255 full-range taps)
+                                   (A.Fmt(8, 1), A.Fmt(8, 1), A.Fmt(30, 15), A.Fmt(8, 1, True, "TRN", "WRAP")),
+                                   (A.Fmt(10, 2), A.Fmt(8, 2), A.Fmt(32, 16), A.Fmt(10, 2, True, "RND", "SAT")),
+                                   (A.Fmt(8, 4), A.Fmt(6, 1), A.Fmt(30, 18), A.Fmt(12, 4, True, "RND", "SAT")),
+                                   (A.Fmt(8, 1), A.Fmt(8, 1), A.Fmt(30, 16), A.Fmt(16, 2, True, "RND_CONV", "SAT"))])   # rs = 0 into 16 bits: every product bit kept
+@pytest.mark.parametrize("n_taps", [15, 63, 255])
+def test_narrow_types_run_the_fast_epilogue_on_pre_scaled_coefficients(types, n_taps):
+    """ADC-width filters end to end (<8,1> samples, coefficients and output: 7 dropped bits): less than one bit is left to shift by in the 32-bit
+    epilogue once the packed finish of a narrow OUT_TYPE has taken its 16 - W bits, so the coefficient set goes through the kernel scaled by a
+    power of two (engine_fir.hip: mfma_cshift).  Whole steps (pipelined body) and ragged calls, full-range sets, a set per channel."""
+    fin, fc, fa, fo = types
+    rng = np.random.default_rng(n_taps + fo.W)
+    c = rand_raw(rng, fc, (n_taps,))
+    fir = check_case(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_ch=3, n=5 * 1024 + 99, splits=[1024 + 8, 4096 + 8], seed=n_taps, coeffs=c, expect_path="mfma_i8")
+    epi, cshift, _ = fir.mfma_epilogue()
+    assert epi in (1, 2) and cshift >= 1, (epi, cshift)
+    check_case(n_taps, "FOLD_ODD" if n_taps % 2 else "FOLD_EVEN", fin, fc, fa, fo, n_ch=4, n=3 * 1024, per_channel=n_taps <= 63, seed=n_taps + 1,
+               coeffs=(rand_raw(rng, fc, (4, n_taps)) >> 1) if n_taps <= 63 else (c >> 1), expect_path="mfma_i8")
+
+
 def test_unsigned_types():
     check_case(8, "FOLD_EVEN", A.Fmt(10, 3, False), A.Fmt(9, 1, False), A.Fmt(24, 8, False), A.Fmt(12, 6, False, "RND", "SAT"))
     check_case(8, "SHIFT_REG", A.Fmt(10, 3, False), A.Fmt(9, 1, True), A.Fmt(24, 8, True), A.Fmt(12, 6, False, "RND", "SAT"))
