@@ -165,10 +165,9 @@ struct acdsp_fir {
   // of an EARLIER coefficient set are still in it -- for the n_taps - 1 samples behind a coefficient change (or a loaded state blob).  Those
   // samples run the exact-order kernel on reg_trans; everything else is the same dot product as SHIFT_REG and runs the matrix-core kernels
   // on the input history, which is kept up to date by every call.  reg_trans is rebuilt from the history (rt_from_hist) when it is asked for.
-  // unsigned 16-bit samples on the int8 MFMA kernel (round 4): x_u = (x_u ^ 0x8000 as int16) + 32768, so a flipped copy of the call's samples
-  // and of the history goes through the signed kernel and 32768 * sum(c) rides in the correction constant; the state stays raw
+  // unsigned 16-bit samples on the int8 MFMA kernel: x_u = (x_u ^ 0x8000 as int16) + 32768 -- the kernel flips the top bit as it splits
+  // the samples into byte planes (FirParams::in_flip) and 32768 * sum(c) rides in the correction constant; rows and state stay raw
   bool in_flip = false;
-  Staging st_u;
   bool rt_hybrid = false, rt_valid = true;
   int64_t rt_since = 0;         // samples since the last coefficient change / state load, saturating at n_taps - 1
   int cur_rt = 0;               // rt_hybrid: index of the current reg_trans buffer (the history has `cur`)

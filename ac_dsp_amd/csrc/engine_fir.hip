@@ -4,44 +4,6 @@
 using namespace acdsp;
 using namespace acdsp::eng;
 
-namespace {
-// dst[ch][j] = src[ch][j] ^ 0x8000 for the n samples of a call (row stride ds, multiple of 16: the tail up to ds is zero-filled in the
-// flipped domain's zero = 0x8000 ^ 0 ... it is never used by an output that exists) and for the hl history samples
-__global__ void flip16_kernel(const uint16_t *x, int64_t xs, int64_t n, uint16_t *dx, int64_t ds, const uint16_t *hist, uint16_t *dh, int hl) {
-  const int ch = blockIdx.y;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ds + hl; j += (int64_t)gridDim.x * blockDim.x) {
-    if (j < ds) { dx[(int64_t)ch * ds + j] = (uint16_t)((j < n ? x[(int64_t)ch * xs + j] : 0) ^ 0x8000u); }
-    else { dh[(int64_t)ch * hl + (j - ds)] = (uint16_t)(hist[(int64_t)ch * hl + (j - ds)] ^ 0x8000u); }
-  }
-}
-// the same, 8 samples per lane: rows that are 16-byte aligned on both sides and a call of whole 8-sample groups (round 5: the element-wise
-// form above moved 2 bytes per lane and instruction and took twice the FIR kernel's own time on the 127-tap row of tools/fir_shapes.py)
-__global__ void __launch_bounds__(256) flip16_vec_kernel(const uint4 *x, int64_t xs8, int64_t n8, uint4 *dx, int64_t ds8, const uint4 *hist, uint4 *dh, int hl8) {
-  const int ch = blockIdx.y;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ds8 + hl8; j += (int64_t)gridDim.x * blockDim.x) {
-    uint4 v;
-    if (j < ds8) { v = j < n8 ? x[(int64_t)ch * xs8 + j] : make_uint4(0, 0, 0, 0); }
-    else { v = hist[(int64_t)ch * hl8 + (j - ds8)]; }
-    v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u;
-    if (j < ds8) { dx[(int64_t)ch * ds8 + j] = v; } else { dh[(int64_t)ch * hl8 + (j - ds8)] = v; }
-  }
-}
-hipError_t launch_flip16(const void *x, int64_t xs, int64_t n, void *dx, int64_t ds, const void *hist, void *dh, int hl, int n_ch, hipStream_t s) {
-  if (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)hist | (uintptr_t)dh) % 16 == 0 && xs % 8 == 0 && n % 8 == 0 && ds % 8 == 0 && hl % 8 == 0) {
-    int64_t blocks = ((ds + hl) / 8 + 255) / 256;
-    if (blocks > 2048) { blocks = 2048; }
-    hipLaunchKernelGGL(flip16_vec_kernel, dim3((unsigned)blocks, (unsigned)n_ch), dim3(256), 0, s, (const uint4 *)x, xs / 8, n / 8, (uint4 *)dx, ds / 8,
-                       (const uint4 *)hist, (uint4 *)dh, hl / 8);
-    return hipGetLastError();
-  }
-  int64_t blocks = (ds + hl + 1023) / 1024;
-  if (blocks > 4096) { blocks = 4096; }
-  hipLaunchKernelGGL(flip16_kernel, dim3((unsigned)blocks, (unsigned)n_ch), dim3(256), 0, s, (const uint16_t *)x, xs, n, (uint16_t *)dx, ds,
-                     (const uint16_t *)hist, (uint16_t *)dh, hl);
-  return hipGetLastError();
-}
-}  // namespace
-
 // ---------------------------------------------------------------------------------------------
 // FIR
 // ---------------------------------------------------------------------------------------------
@@ -203,7 +165,6 @@ int32_t acdsp_fir_destroy(acdsp_fir_t h) {
   if (h->d_lzcl) { (void)hipFree(h->d_lzcl); }
   h->tm.destroy();
   h->st.destroy();
-  h->st_u.destroy();
   delete h;
   return ACDSP_OK;
 }
@@ -464,7 +425,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   if (rc) { return rc; }
   hipStream_t s = (hipStream_t)stream;
   FirParams k;
-  k.hist_next = nullptr; k.t_begin = 0;
+  k.hist_next = nullptr; k.t_begin = 0; k.in_flip = 0;
   k.n_taps = d.n_taps; k.ftype = internal_ftype(d.kind, d.ftype); k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
   k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff);
   if (h->wide) { memset(&k.acc, 0, sizeof k.acc); memset(&k.out, 0, sizeof k.out); k.acc.F = d.acc.W - d.acc.I; }
@@ -503,20 +464,13 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   FirParams kraw = k;   // the state kernels always see the caller's samples
   const bool flipped = h->in_flip && path == ACDSP_PATH_MFMA_I8;
   if (flipped) {
-    // unsigned 16-bit samples: a sign-flipped image of the call's rows and of the history (see acdsp_fir::in_flip)
-    const int64_t si = (n + 15) / 16 * 16;
-    const size_t ub_in = (size_t)d.n_channels * si * 2, ub_h = (size_t)d.n_channels * h->hl * 2;
-    if ((ub_in > h->st_u.cap_in || ub_h > h->st_u.cap_out) && stream_is_capturing(s)) {
-      return fail(ACDSP_ESTATE, "fir_run under graph capture: the staging image of unsigned 16-bit samples must grow (run one call of this length before capturing)");
-    }
-    if ((rc = h->st_u.ensure(ub_in, ub_h))) { return rc; }
-    if (!h->small_call) { HIP_TRY(hipEventRecord(h->tm.start(), s)); }   // the flip is part of this path's cost: inside the timed region
-    const hipError_t ef = launch_flip16(d_in, in_stride, n, h->st_u.d_in, si, h->d_hist[h->cur], h->st_u.d_out, h->hl, d.n_channels, s);
-    if (ef != hipSuccess) { return fail(ACDSP_EHIP, "FIR sample staging kernel launch failed: %s", hipGetErrorString(ef)); }
-    k.x = h->st_u.d_in; k.in_stride = si; k.hist = h->st_u.d_out;
+    // unsigned 16-bit samples: the kernel flips the top bit of every sample as it splits the rows and the history into byte planes
+    // (FirParams::in_flip; round 4 and the first half of round 5 wrote a flipped image of both first: a second pass over the call's input,
+    // 0.21 - 0.33 of the roofline where the signed types run at 0.55)
+    k.in_flip = 1;
     k.in.S = 1; k.in.lo = -32768; k.in.hi = 32767;
   }
-  if (!flipped && (path == ACDSP_PATH_MFMA_I8 || path == ACDSP_PATH_MFMA_GEN || path == ACDSP_PATH_MFMA_LOSSY)) {
+  if (path == ACDSP_PATH_MFMA_I8 || path == ACDSP_PATH_MFMA_GEN || path == ACDSP_PATH_MFMA_LOSSY) {
     // The matrix-core kernels read rows with 16-byte vector loads (fir_gen: in whole 16-sample slots).  gfx950 serves a vector
     // access at any ELEMENT-aligned address, so the int8 kernel takes unaligned rows as they are (round 3: a row stride of 2^20 + 3
     // samples costs +12 %, profiles/r3_unaligned.txt; the staging copy below -- hipMemcpy2DAsync of misaligned rows -- cost 6.4 ms
@@ -541,7 +495,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
                                                 (path == ACDSP_PATH_MFMA_I8 && !h->mfma_cshift && fir_mfma_register_resident(k, h->plan)));   // single-wave workgroups
   const int nxt_fused = hist_next_index(h->cur, false);
   if (fuse_hist) { k.hist_next = h->d_hist[nxt_fused]; }
-  if (!small && !flipped) { HIP_TRY(hipEventRecord(h->tm.start(), s)); }
+  if (!small) { HIP_TRY(hipEventRecord(h->tm.start(), s)); }
   hipError_t e;
   if (path == ACDSP_PATH_MFMA_I8) {
     FirParams km = k;    // (the fragments hold c << mfma_cshift: the kernel's shifts follow; the state kernels below keep the handle's formats)

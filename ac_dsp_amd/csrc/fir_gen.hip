@@ -620,21 +620,24 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   constexpr int LS = 8 / S;                                   // slots per 128-byte line
   constexpr int ADV = 16 * R, NSL = 15 * R + 4 * NBT;
   constexpr int H = (LS - 1 + NSL - ADV + LS - 1) / LS * LS;  // halo slots (line multiple): covers any delta
-  constexpr int M = (R * S >= 4) ? 1 : 2;                     // steps per load group: a plain (R = 1) FIR on int16 advances half a 1 KB load per step
+  constexpr int M = (R * S) % 4 == 0 ? 1 : 2;                 // steps per load group: a plain (R = 1) FIR on int16 advances half a 1 KB load per step, R = 5 two and a half
   constexpr int NLD = R * S * M / 4;                          // 1 KB loads per group of M steps
   constexpr int PPB = 16 / S;                                 // samples of a 16-byte piece = bytes of one of its planes
   constexpr int SPK = 64 / S;                                 // slots per 1 KB load
   static_assert(S == 2 || S == 4, "ring kernel: 2- and 4-byte samples");
-  static_assert((R % 2 == 0 || R == 1) && SPK % R == 0 && H <= ADV && S * H <= 64 && NLD * SPK == M * ADV && NLD >= 1 && SPW % M == 0, "ring geometry");
-  constexpr int KSTEP = (SPK + 2 * (SPK / R)) * 16;           // LDS bytes from a piece of load k to the same lane's piece of load k + 1
-  constexpr int PADV = (ADV + 2 * (ADV / R)) * 16;            // LDS bytes a step advances
+  // odd factors above 1 (R = 7: the reference's CIC testbench) keep the identity slot map -- gen_slot_map leaves them alone too: one or two
+  // extra LDS cycles per fragment read -- so a 1 KB load need not hold whole groups of R slots
+  constexpr bool HOLES = (R % 2 == 0) || R == 1;
+  static_assert((!HOLES || SPK % R == 0) && H <= ADV && S * H <= 64 && NLD * SPK == M * ADV && NLD >= 1 && SPW % M == 0, "ring geometry");
+  constexpr int KSTEP = HOLES ? (SPK + 2 * (SPK / R)) * 16 : SPK * 16;   // LDS bytes from a piece of load k to the same lane's piece of load k + 1
+  constexpr int PADV = HOLES ? (ADV + 2 * (ADV / R)) * 16 : ADV * 16;    // LDS bytes a step advances
   constexpr int RING = (SPW < 2 ? SPW : 2) * ADV + H;         // chunks of one or two steps never wrap
   // The two empty slots per R sit right in FRONT of ring slots H, H + R, ...: a staging store pass covers eight consecutive slots from
   // H + 8 j on, and must not straddle a hole (with the holes at multiples of R, as in gen_slot_map, every pass of this layout did: 2-way
   // conflicts on two of its eight slots, SQ_LDS_BANK_CONFLICT 31 % of SQ_LDS_IDX_ACTIVE in the first profile of this kernel).  The reads
   // only need one hole per R slots, wherever it sits (tools/lds_slot_map_check.py, and the replay in profiles/r4_ring_sweep.txt).
-  constexpr int PH = (R - H % R) % R;
-  constexpr int PLANE = (RING + 2 * ((RING + PH) / R) + 2) * 16;   // + one dump slot (mirror writes of the lanes that have none)
+  constexpr int PH = HOLES ? (R - H % R) % R : 0;
+  constexpr int PLANE = HOLES ? (RING + 2 * ((RING + PH) / R) + 2) * 16 : (RING + 2) * 16;   // + one dump slot (mirror writes of the lanes that have none)
   constexpr int DUMP = PLANE - 16;
   constexpr int TILE = 256 * OEB;
   static_assert(!LZ || R == 1, "class-B residues: plain FIR only");
@@ -651,7 +654,7 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
     for (int q = 0; q < kLossyTabWords / 64; q++) { ((uint32_t *)(lzr + LZP))[lane + 64 * q] = a.lz_tab[lane + 64 * q]; }
   }
   const int NB = a.pl.nb, PC = a.pl.pc;
-  auto phys = [](int s) { return s + 2 * ((s + PH) / R); };
+  auto phys = [](int s) { return HOLES ? s + 2 * ((s + PH) / R) : s; };
 
   v4i A[NBT][PCT];
 #pragma unroll
@@ -1113,17 +1116,17 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
 
   // Fast kernel: table of compiled shapes (BASELINE configs 3, 5a, 5b and the poly_dec row); nbt = K blocks compiled in.
   int nbt = 0;
-  const int in_eb = p.in_eb, oeb = p.out_eb, px = a.px, pc = pl.pc, nb = pl.nb;
+  const int in_eb = p.in_eb, oeb = p.out_eb, pc = pl.pc, nb = pl.nb;
   const int npc = (a.n_slots * in_eb + 63) / 64;   // 16-byte pieces per lane
-  if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 3 && spl == 3 && npc <= 9 && oeb == 8) { nbt = 3; }        // CIC R8 N5 on int32 -> int64
-  else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 6 && spl == 5 && npc <= 9 && oeb == 8) { nbt = 6; }   // CIC R16 N5 on int16 -> int64
-  else if (in_eb == 8 && px == 5 && pc <= 2 && nb <= 3 && spl == 1 && oeb == 4) { nbt = 3; }   // 127-tap FIR on 36-bit words -> int32
-  else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && spl == 3 && npc <= 5 && oeb == 2) { nbt = 4; }   // 128-tap decimate-by-8 on int16 -> int16
+  if (in_eb == 4 && a.px == 4 && pc <= 2 && nb <= 3 && spl == 3 && npc <= 9 && oeb == 8) { nbt = 3; }        // CIC R8 N5 on int32 -> int64
+  else if (in_eb == 2 && a.px == 2 && pc <= 3 && nb <= 6 && spl == 5 && npc <= 9 && oeb == 8) { nbt = 6; }   // CIC R16 N5 on int16 -> int64
+  else if (in_eb == 8 && a.px == 5 && pc <= 2 && nb <= 3 && spl == 1 && oeb == 4) { nbt = 3; }   // 127-tap FIR on 36-bit words -> int32
+  else if (in_eb == 2 && a.px == 2 && pc <= 2 && nb <= 4 && spl == 3 && npc <= 5 && oeb == 2) { nbt = 4; }   // 128-tap decimate-by-8 on int16 -> int16
   // ... and a conversion the branch-free form covers: signed wrapping accumulator, signed OUT, TRN/RND, WRAP/SAT
   const bool conv_ok = gen_conv_params(p, out_mode, w_int, &a, lz ? lz->acc_bits : 0);
   a.e_stages = ((a.e_ls != 0 || a.e_ka != 0) ? 1 : 0) | ((a.e_rnd != 0 || a.e_rs != 0 || a.e_ls2 != 0) ? 2 : 0) |
                ((a.e_lo != INT64_MIN || a.e_hi != INT64_MAX) ? 4 : 0) | (a.e_ko != 0 ? 8 : 0);
-  {
+  auto set_pairwise = [&]() {
     // plane accumulator w sums the products of (input plane pp, coefficient digit q), pp + q = w, |plane byte| <= 128
     int64_t bw[kGenMaxPX + kGenMaxPC] = {0};
     for (int w = 0; w < a.px + pl.pc - 1; w++) {
@@ -1133,7 +1136,8 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
     for (int w = 0; w + 1 < kGenMaxPX + kGenMaxPC; w += 2) { pw_ok = pw_ok && (bw[w + 1] * 256 + bw[w] < (int64_t(1) << 31)); }
     static const bool no_pw = getenv("ACDSP_GEN_NO_PW") != nullptr;   // A/B knob
     a.pw = (pw_ok && !no_pw) ? 1 : 0;
-  }
+  };
+  set_pairwise();
 
   // Ring variant (fir_gen_ring_kernel) for the decimating BASELINE shapes.  ACDSP_GEN_RING=0: the window-per-step kernel (A/B
   // reference); ACDSP_GEN_RING=spw,pf,nt,fb picks another compiled variant (steps per chunk, load distance, non-temporal loads,
@@ -1143,6 +1147,10 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
   // ones) and costs occupancy for 8-byte outputs.
   ACDSP_TUNE_ENV(ring_env, "ACDSP_GEN_RING");
   int r_spw = 2, r_pf = 2, r_nt = 1, r_fb = (oeb == 2) ? 1 : 0, ring_shape = 0;
+  // 17 .. 24-bit samples in int32 containers (three planes) take the four-plane ring shapes where one fits: the containers are sign-extended, the
+  // fourth plane is the sign -- 8 MFMAs more per step against the ring's better stream (CIC R8 M2 N3 on <24,8>: 0.71 on the window kernel)
+  const bool promote = !lz && in_eb == 4 && a.px == 3;
+  const int px = promote ? 4 : a.px;
   bool ring_on = true;
   if (ring_env) {
     int v[4];
@@ -1168,7 +1176,15 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
     else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 3 && (oeb == 8 || oeb == 4 || oeb == 2) && pl.R == 1 && !ring_env) { ring_shape = oeb == 8 ? 23 : (oeb == 4 ? 24 : 25); r_spw = 16; }
     // plain (R = 1) FIR on 32-bit samples, up to three coefficient digits and three K-blocks (~130 taps): one 1 KB load per 256-output step
     else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 3 && (oeb == 8 || oeb == 4) && pl.R == 1 && !ring_env) { ring_shape = oeb == 8 ? 20 : 21; r_spw = 8; }
+    else if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 4 && oeb == 8 && pl.R == 7 && !ring_env) { ring_shape = 7; r_spw = 2; }   // CIC R7 (M2 N4: the reference testbench) on int32: 7 KB per step
+    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 3 && (oeb == 4 || oeb == 8) && pl.R == 5 && !ring_env) { ring_shape = oeb == 4 ? 8 : 9; r_spw = 4; }   // CIC R5 on int16: 2.5 KB per step, one load group per two steps
     else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 6; if (!ring_env) { r_spw = 1; r_pf = 1; } }   // CIC R16 N5 on int32: 16 KB per step = one step per wave (LDS: 18 KB of planes per step)
+  }
+  if (promote && ring_shape) { a.px = 4; a.corr = gen_rebias_corr(a.px, pl.sum_h); set_pairwise(); }
+  static const bool trace = getenv("ACDSP_GEN_TRACE") != nullptr;   // diagnostic: which compiled shape a launch resolves to
+  if (trace) {
+    fprintf(stderr, "[acdsp] fir_gen: in_eb %d px %d pc %d nb %d oeb %d R %d conv_ok %d out_vec_ok %d -> ring shape %d, window shape nbt %d\n", in_eb, a.px, pc, nb, oeb,
+            pl.R, (int)conv_ok, (int)a.out_vec_ok, ring_shape, nbt);
   }
   if (ring_shape) {
     spw = r_spw; a.steps_per_wave = spw;
@@ -1205,6 +1221,9 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
     else if (ring_shape == 4) { e = launch_ring<int16_t, 2, 2, 3, 8, 4>(r_spw, r_pf, r_nt, r_fb, grid, s, p, fr, a); }
     else if (ring_shape == 5) { e = launch_ring1<int32_t, 4, 2, 2, 4, 8, 4, 4, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 6) { e = launch_ring1<int32_t, 4, 3, 6, 16, 8, 1, 1, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 7) { e = launch_ring1<int32_t, 4, 2, 4, 7, 8, 2, 2, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 8) { e = launch_ring1<int16_t, 2, 2, 3, 5, 4, 4, 2, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 9) { e = launch_ring1<int16_t, 2, 2, 3, 5, 8, 4, 2, true, false>(grid, s, p, fr, a); }
     // (plans of ONE K-block -- up to ~49 taps: the reference testbenches' 27 / 29 -- have their own instantiations: the three-block shapes
     // issue 3 x the MFMAs on zero fragments, 36 instead of 12 per 256 outputs on 32-bit samples -- the matrix pipe, not HBM, bounded them)
     else if (ring_shape == 23) { e = nb == 1 ? launch_ring1<int16_t, 2, 3, 1, 1, 8, 16, 8, true, false>(grid, s, p, fr, a) : launch_ring1<int16_t, 2, 3, 3, 1, 8, 16, 8, true, false>(grid, s, p, fr, a); }

@@ -22,6 +22,7 @@ struct FirParams {
   const int64_t *rt;           // [n_ch][n_taps] ACC raw words (use_rt)
   void *hist_next;             // small calls: the exact-order kernels write the next history themselves (one launch per call); else null
   int64_t t_begin;             // exact-order kernels: outputs [t_begin, n) only (the ragged rest behind a matrix-core launch); normally 0
+  int32_t in_flip;             // int8 matrix-core kernels: the rows hold UNSIGNED 16-bit samples, to be read as x - 32768 (MfmaArgs::hi_xor); else 0
 };
 
 // Exact per-tap emulation in the reference's loop order (any Q/O, any widths <= 64).

@@ -51,6 +51,14 @@
 
 namespace acdsp {
 
+// AC_RND and AC_RND_MIN_INF are "add a constant, then floor" (2^(rs-1) and 2^(rs-1) - 1): the constant rides in the preloaded low-plane
+// accumulator of every fast epilogue class, like AC_TRN's zero
+__host__ __device__ static inline bool q_const_mode(int q) { return q == ACDSP_TRN || q == ACDSP_RND || q == ACDSP_RND_MIN_INF; }
+__host__ __device__ static inline int64_t q_preload(int q, int rs) {
+  if (rs <= 0 || rs > 62) { return 0; }
+  return q == ACDSP_RND ? (int64_t(1) << (rs - 1)) : (q == ACDSP_RND_MIN_INF ? (int64_t(1) << (rs - 1)) - 1 : 0);
+}
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -152,9 +160,13 @@ struct MfmaArgs {
   int32_t nar_on, nar_d, nar_lo, nar_hi, nar_sh;
   // 16-bit OUT_TYPEs with a sign- / parity-dependent rounding mode or AC_SAT_SYM / AC_SAT_ZERO (round 5), also in the NAR instantiations
   // (nar_d = 0): the truncated quotient of the 32-bit epilogue plus the increment the dropped bits ask for (acdsp_dev.hpp: q_increment),
-  // then gq_o = 1: clamp to +-(2^15 - 1), 2: zero outside the int16 range.  gq_on = 0: AC_TRN / AC_RND, the rounding constant rides in ll.
-  // gq_q: mask word of the mode (epi32_gq).
-  int32_t gq_on, gq_q, gq_o;
+  // then a clamp to [gq_lo, gq_hi] (AC_SAT_SYM: +-(2^15 - 1)) or, gq_form = 2, zero outside the int16 range.  gq_on = 0: the constant modes
+  // (AC_TRN / AC_RND / AC_RND_MIN_INF) into AC_WRAP / AC_SAT, whose rounding constant rides in ll.
+  // gq_off / gq_c / gq_k: the mode's bit, increment and constant; gq_form: which copy of the loop (epi32_gq).
+  int32_t gq_on, gq_off, gq_c, gq_k, gq_form, gq_lo, gq_hi;
+  // unsigned 16-bit samples: 0x80808080 flips the top bit of every high byte as the planes are split (x - 32768 is a signed int16; the
+  // host adds 32768 sum(c) to corr); 0 for signed samples.  One v_xor per four samples, in every instantiation.
+  uint32_t hi_xor;
   // 4-byte containers in the wide class (W4 instantiations of the pipelined body): w4_sat = 1: AC_SAT bounds, 0: wrap to W_out bits in
   // 64 bits, 2: wrap in 32-bit arithmetic (2^8 mid + ll and, for rs > 16, hh + carry exact in int32: host-checked)
   int32_t w4_sat;
@@ -167,6 +179,17 @@ struct MfmaArgs {
 //   V >> rs = (hh << (16 - rs)) + (lo >> rs)            for rs <= 16   (2^16 hh is a multiple of 2^rs)
 //   V >> rs = (hh + (lo >> 16)) >> (rs - 16)            for rs  > 16
 // i.e. 3 (4) VALU ops per output; rs is wave-uniform.
+// high-byte plane of unsigned 16-bit samples (MfmaArgs::hi_xor): in place and from an SGPR.  The nine-block kernels sit at the
+// 256-register limit and the allocator's outcome there turns on details: written as `^` this spilled four VGPRs in the HS = 34 kernels of
+// classes 1 / 2 and 117 in the dense class-3 one; as a movable asm only the latter (118); as a fixed one (volatile) the class-3 kernel drops
+// to 2 spilled VGPRs (9 before the xor existed) but classes 1 / 2 spill 4 in their HS = 0 kernels -- so class 3 pins it, the others do not
+// (tests/test_abi.py: test_no_kernel_uses_scratch is the judge of any other arrangement).
+template <bool PINNED>
+__device__ __forceinline__ unsigned hi_flip(unsigned v, unsigned m) {
+  if constexpr (PINNED) { asm volatile("v_xor_b32 %0, %1, %0" : "+v"(v) : "s"(m)); }
+  else { asm("v_xor_b32 %0, %1, %0" : "+v"(v) : "s"(m)); }
+  return v;
+}
 template <bool WIDE>   // WIDE: rs > 16
 __device__ __forceinline__ void epi32_t(const v16i &hh, const v16i &mid, const v16i &ll, int rs, int (&o)[16]) {
 #pragma unroll
@@ -175,39 +198,62 @@ __device__ __forceinline__ void epi32_t(const v16i &hh, const v16i &mid, const v
     o[r] = WIDE ? (hh[r] + (lo >> 16)) >> (rs - 16) : (int)((unsigned)hh[r] << (16 - rs)) + (lo >> rs);
   }
 }
-// The same with the increment of a general rounding mode: the dropped bits of V >> rs are the low rs bits of lo (rs <= 16: 2^16 hh is a
-// multiple of 2^rs) or the low rs - 16 bits of hh + (lo >> 16) above the low half of lo.  ~10 VALU per output more than AC_TRN.
-// gq_q is a mask word, not the mode (one code path for all eight modes -- a switch over template instances of the mode multiplied the compile
-// time of every instantiation of this file by four): bit 0: the mode rounds on the half bit qb; bits 1 .. 5: what makes qb count beside the
-// other dropped bits r -- always (AC_RND), x < 0, x >= 0, an odd quotient, an even quotient; bit 6: AC_TRN_ZERO (x < 0 and any dropped bit).
-template <bool WIDE>
+// The same with the increment of a sign- or parity-dependent rounding mode (round 5, second form).  The dropped bits of V >> rs are the low
+// rs bits of lo (rs <= 16: 2^16 hh is a multiple of 2^rs), or the low rs - 16 bits of hh + (lo >> 16) above the low half of lo; with
+// rem = those bits, m = -1 where the floor quotient q0 is negative (gq_off = 31) or odd (gq_off = 0), every mode is
+//   q = q0 + ((rem + (m & C) + K) >> rs)
+// (acdsp_dev.hpp: q_increment, written as one carry): AC_TRN_ZERO C = 2^rs - 1, K = 0 on the sign; AC_RND_ZERO C = 1, K = half - 1 and
+// AC_RND_INF C = -1, K = half on the sign; AC_RND_CONV C = 1, K = half - 1 and AC_RND_CONV_ODD C = -1, K = half on the parity; the
+// constant modes (AC_TRN / AC_RND / AC_RND_MIN_INF: K rides in ll) come here only for AC_SAT_SYM / AC_SAT_ZERO, with C = K = 0.
+// Six (seven) VALU per output on top of epi32_t's three (four); the first form tested mask bits per condition, ~24.
+// For rs <= 16 the increment can go into lo BEFORE the shift -- (hh << (16 - rs)) + ((lo + (m & C) + K) >> rs), host-checked to stay inside
+// int32 -- which saves the separate carry: the parity of q0 is bit rs of lo for rs < 16 (three VALU more than epi32_t), its sign needs q0
+// first (five more, one less than the carry form: not worth a third copy of the loop in kernels that sit at the register limit -- with
+// it the six- and nine-block NAR kernels spilled five VGPRs).  One uniform branch per step picks the form; the sign modes, rs = 16 on the
+// parity and rs > 16 keep the carry form.
+// fence between groups of four outputs of epi32_gq: holds the VALU (register pressure) but lets MFMA, SALU, VMEM and DS instructions cross
+constexpr int kEpiFence = 0x0008 | 0x0004 | 0x0010 | 0x0080;
+// FORM is a compile-time copy of MfmaArgs::gq_form: 0 = increment before the shift on the parity (rs < 16), 1 = carry form, 2 = carry form
+// and AC_SAT_ZERO.  The pipelined loop must not branch: a uniform branch per emit splits its body into basic blocks, and the matrix
+// products of a group no longer overlap the epilogue next to them (0.29 ms where AC_RND runs 0.21, VALU count almost equal) -- the kernel
+// picks one of three copies of the loop instead (fir_mfma_kernel).  Forms 0 / 1 clamp to [gq_lo, gq_hi] (AC_SAT_SYM: +-(2^15 - 1); else the
+// whole int32 range) with one v_med3.
+template <bool WIDE, int FORM>
 __device__ __forceinline__ void epi32_gq(const v16i &hh, const v16i &mid, const v16i &ll, int rs, const MfmaArgs &a, int (&o)[16]) {
-  const int m = a.gq_q, om = a.gq_o;
-  const int m_half = m & 1, m_one = (m >> 1) & 1, m_neg = (m >> 2) & 1, m_pos = (m >> 3) & 1, m_odd = (m >> 4) & 1, m_even = (m >> 5) & 1, m_tz = (m >> 6) & 1;
+  const unsigned C = (unsigned)a.gq_c, K = (unsigned)a.gq_k, off = (unsigned)a.gq_off, mask = (rs >= 32 ? 0u : (1u << rs)) - 1u;
+  const int lo_b = a.gq_lo, hi_b = a.gq_hi;
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int lo = (int)(((unsigned)mid[r] << 8) + (unsigned)ll[r]);
-    int q, qb, rest;
-    if (!WIDE) {
-      q = (int)((unsigned)hh[r] << (16 - rs)) + (lo >> rs);
-      const unsigned rem = (unsigned)lo & ((1u << rs) - 1u);
-      qb = (int)(rem >> (rs - 1)) & 1;
-      rest = (rem & ((1u << (rs - 1)) - 1u)) != 0;
+    int q;
+    if constexpr (!WIDE && FORM == 0) {
+      const unsigned m = (unsigned)__builtin_amdgcn_sbfe(lo, (unsigned)rs, 1u);
+      q = (int)((unsigned)hh[r] << (16 - rs)) + ((int)((unsigned)lo + (m & C) + K) >> rs);
     } else {
-      const int t = hh[r] + (lo >> 16), s2 = rs - 16;
-      q = t >> s2;
-      const unsigned rem = (unsigned)t & ((1u << s2) - 1u);
-      qb = (int)(rem >> (s2 - 1)) & 1;
-      rest = ((rem & ((1u << (s2 - 1)) - 1u)) | ((unsigned)lo & 0xffffu)) != 0;
+      int q0;
+      unsigned rem;
+      if constexpr (!WIDE) {
+        q0 = (int)((unsigned)hh[r] << (16 - rs)) + (lo >> rs);
+        rem = (unsigned)lo & mask;
+      } else {
+        const int t = hh[r] + (lo >> 16);
+        q0 = t >> (rs - 16);
+        rem = __builtin_amdgcn_perm((unsigned)t, (unsigned)lo, 0x05040100u) & mask;   // t[15:0] : lo[15:0]
+      }
+      const unsigned m = (unsigned)__builtin_amdgcn_sbfe(q0, off, 1u);
+      q = q0 + (int)((rem + (m & C) + K) >> rs);
     }
-    const int neg = (int)((unsigned)q >> 31), odd = q & 1;      // V < 0 exactly when its floor quotient is
-    const int why = rest | m_one | (neg & m_neg) | ((neg ^ 1) & m_pos) | (odd & m_odd) | ((odd ^ 1) & m_even);
-    q += (qb & why & m_half) | (neg & (qb | rest) & m_tz);
-    if (om == 1) { q = q < -32767 ? -32767 : (q > 32767 ? 32767 : q); }
-    else if (om == 2) { q = (q < -32768 || q > 32767) ? 0 : q; }
-    o[r] = q;
-    if ((r & 3) == 3) { __builtin_amdgcn_sched_barrier(0); }   // four outputs at a time: interleaved, the temporaries of all sixteen spill at 256 registers
+    if constexpr (FORM == 2) { o[r] = (q < -32768 || q > 32767) ? 0 : q; }
+    else { o[r] = q < lo_b ? lo_b : (q > hi_b ? hi_b : q); }
+    if ((r & 3) == 3) { __builtin_amdgcn_sched_barrier(kEpiFence); }   // four outputs at a time: the kernels that carry this beside nine blocks of fragments have no registers to interleave sixteen
   }
+}
+// the same behind uniform branches, for the edge chunks (fir_mfma_body)
+template <bool WIDE>
+__device__ __forceinline__ void epi32_gq_rt(const v16i &hh, const v16i &mid, const v16i &ll, int rs, const MfmaArgs &a, int (&o)[16]) {
+  if (a.gq_form == 0 && !WIDE) { epi32_gq<WIDE, 0>(hh, mid, ll, rs, a, o); }
+  else if (a.gq_form == 2) { epi32_gq<WIDE, 2>(hh, mid, ll, rs, a, o); }
+  else { epi32_gq<WIDE, 1>(hh, mid, ll, rs, a, o); }
 }
 __device__ __forceinline__ void epi32_narrow(const MfmaArgs &a, int (&o)[16]) {
   if (a.nar_on) {
@@ -237,7 +283,7 @@ __device__ __forceinline__ v4i pk16_ashr(const v4i &v, int d) {
 template <bool GQ = true>   // GQ = false: the kernels of more than kMaxRegNB K-blocks, which the general-rounding class never reaches
 __device__ __forceinline__ void epi32(const v16i &hh, const v16i &mid, const v16i &ll, int rs, const MfmaArgs &a, int (&o)[16]) {
   if (GQ && a.gq_on) {
-    if (rs <= 16) { epi32_gq<false>(hh, mid, ll, rs, a, o); } else { epi32_gq<true>(hh, mid, ll, rs, a, o); }
+    if (rs <= 16) { epi32_gq_rt<false>(hh, mid, ll, rs, a, o); } else { epi32_gq_rt<true>(hh, mid, ll, rs, a, o); }
     return;
   }
   if (rs <= 16) { epi32_t<false>(hh, mid, ll, rs, o); }   // one uniform branch per step, not one per output
@@ -256,7 +302,7 @@ struct Epi64 { int64_t corr, rnd, lo, hi; int ls, ka, rs, ko; };
 __device__ __forceinline__ Epi64 make_epi64(const FirParams &p, int64_t corr) {
   Epi64 e;
   e.corr = corr; e.ls = p.lossless_shift; e.ka = 64 - p.acc.W; e.rs = p.acc.F - p.out.F;
-  e.rnd = (p.out.Q == ACDSP_RND && e.rs >= 1 && e.rs <= 62) ? (int64_t(1) << (e.rs - 1)) : 0;   // (EPI 4 guarantees the range; the other classes never read it)
+  e.rnd = q_preload(p.out.Q, e.rs);   // (EPI 4 guarantees the range; the other classes never read it)
   if (p.out.O == ACDSP_SAT) { e.lo = p.out.lo; e.hi = p.out.hi; e.ko = 0; }
   else { e.lo = INT64_MIN; e.hi = INT64_MAX; e.ko = 64 - p.out.W; }
   return e;
@@ -364,8 +410,8 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
       const int pc = lane + 64 * j;
       if (JN * 64 == NP || pc < NP) {
         const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
-        unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
-        unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
+        unsigned hi0 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u), a.hi_xor);
+        unsigned hi1 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u), a.hi_xor);
         unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
         unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -380,7 +426,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
   const int64_t corr = a.corr[set];
   // EPI 1/2: C = 128*sum(c) + rounding constant rides in as the initial value of the low-plane accumulator;
   // epi32() then needs 3 VALU ops per output and v_cvt_pk_i16_i32 packs (and clamps, for AC_SAT).
-  const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
+  const int64_t corr_t = corr + (EPI != 0 ? q_preload(p.out.Q, rs) : 0);
   const int c_ll = (EPI != 0) ? (int)corr_t : 0;   // preloaded into the low-plane accumulator (int32-safe, host-checked)
   const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
   int16_t *yrow = (int16_t *)p.y + (int64_t)ch * p.out_stride + 32 * n_col + 4 * h;  // EPI 1/2
@@ -541,7 +587,7 @@ __device__ __forceinline__ void fir_mfma_body(const FirParams &p, const v4i *__r
 // issue and the other work hides in their shadow (tools/mfma_probe.hip: 39 cycles/MFMA with the epilogue
 // interleaved vs 36 bare).  The loop is unrolled by two so the accumulator sets and the B-fragment
 // double buffer swap roles by renaming; it contains no branch.
-template <int NB, int EPI, int HS, int NAR = 0, bool W4 = false>   // NAR: 1 = OUT_TYPEs of fewer than 16 bits, 2 = general rounding / overflow modes of a 16-bit OUT_TYPE
+template <int NB, int EPI, int HS, int NAR = 0, bool W4 = false, int GQF = 1>   // NAR: 1 = OUT_TYPEs of fewer than 16 bits, 2 = general rounding / overflow modes of a 16-bit OUT_TYPE (GQF: epi32_gq's FORM)
 __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i *__restrict__ frag, const MfmaArgs &a,
                                                    unsigned char *lds) {
   static_assert(EPI >= 1 && EPI <= 3, "fast epilogue classes only");
@@ -622,8 +668,8 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
     for (int j = 0; j < 2; j++) {
       const int pc = lane + 64 * j;
       const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
-      const unsigned hi0 = __builtin_amdgcn_perm((unsigned)Q[j].y, (unsigned)Q[j].x, 0x07050301u);
-      const unsigned hi1 = __builtin_amdgcn_perm((unsigned)Q[j].w, (unsigned)Q[j].z, 0x07050301u);
+      const unsigned hi0 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)Q[j].y, (unsigned)Q[j].x, 0x07050301u), a.hi_xor);
+      const unsigned hi1 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)Q[j].w, (unsigned)Q[j].z, 0x07050301u), a.hi_xor);
       const unsigned lo0 = __builtin_amdgcn_perm((unsigned)Q[j].y, (unsigned)Q[j].x, 0x06040200u) ^ 0x80808080u;
       const unsigned lo1 = __builtin_amdgcn_perm((unsigned)Q[j].w, (unsigned)Q[j].z, 0x06040200u) ^ 0x80808080u;
       unsigned char *dh = lds + (0 * 2 + hh_) * ARR + (base + c) * 16 + sub * 8;
@@ -646,8 +692,8 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       const int pc = lane + 64 * j;
       const bool live = (64 * (j + 1) <= NP) || pc < NP;
       const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
-      unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
-      unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
+      unsigned hi0 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u), a.hi_xor);
+      unsigned hi1 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u), a.hi_xor);
       unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
       unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
       typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -664,7 +710,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   };
 
   const int rs = p.in.F + p.cf.F - p.out.F;
-  const int c_ll = (int)(a.corr[set] + ((p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0));
+  const int c_ll = (int)(a.corr[set] + q_preload(p.out.Q, rs));
   const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
 
   __builtin_amdgcn_sched_barrier(0);
@@ -742,7 +788,8 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       return;
     }
     int o[16];
-    if constexpr (NAR == 2) { epi32_gq<decltype(wide_c)::value>(hh, mid, ll, rs, a, o); }   // (general rounding modes: 16-bit OUT_TYPEs only)
+    if constexpr (NAR == 2 && GQF < 0) { epi32_gq_rt<decltype(wide_c)::value>(hh, mid, ll, rs, a, o); }
+    else if constexpr (NAR == 2) { epi32_gq<decltype(wide_c)::value, GQF>(hh, mid, ll, rs, a, o); }   // (general rounding modes: 16-bit OUT_TYPEs only)
     else { epi32_t<decltype(wide_c)::value>(hh, mid, ll, NAR == 1 ? rs - a.nar_d : rs, o); }
     // A lane holds rows 8 g + 4 h .. + 3 of column n: 8 bytes per g, and the 16 lanes of a ds_write_b64 group share h, so
     // they can reach only half of the 32 banks (2-way conflict on every store: the 16.6 % SQ_LDS_BANK_CONFLICT of round 1).
@@ -957,7 +1004,16 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   const bool interior = EPI != 0 && a.out_vec_ok && s1 * 1024 <= p.n && (s0 > 0 || s1 >= 2);
   const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (WAVES == 1 && EPI != 0) {
-    if (interior) { fir_mfma_pipe_body<NB, EPI, HS, NAR, W4>(p, frag, a, lds); }
+    if (interior) {
+      // one copy of the loop per form of the increment (epi32_gq); the eight- and nine-block kernels with most of their fragments live
+      // spill 6 - 18 VGPRs that way and keep one loop with the form behind uniform branches
+      if constexpr (NAR == 2 && NB >= 8 && HS != 3 + 16 * 3) { fir_mfma_pipe_body<NB, EPI, HS, NAR, W4, -1>(p, frag, a, lds); }
+      else if constexpr (NAR == 2) {
+        if (a.gq_form == 0) { fir_mfma_pipe_body<NB, EPI, HS, NAR, W4, 0>(p, frag, a, lds); }
+        else if (a.gq_form == 2) { fir_mfma_pipe_body<NB, EPI, HS, NAR, W4, 2>(p, frag, a, lds); }
+        else { fir_mfma_pipe_body<NB, EPI, HS, NAR, W4, 1>(p, frag, a, lds); }
+      } else { fir_mfma_pipe_body<NB, EPI, HS, NAR, W4>(p, frag, a, lds); }
+    }
     else if constexpr (EPI == 3) { fir_mfma_body<NB, 0, 0, WAVES, false>(p, frag, a, lds); }   // edges: generic epilogue
     else { fir_mfma_body<NB, EPI, HS, WAVES, false>(p, frag, a, lds); }
   } else {
@@ -986,12 +1042,14 @@ fir_mfma_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
 // NAR (OUT_TYPEs of fewer than 16 bits; no band skip) and W4 (4-byte containers) instantiations of up to kMaxRegNB K-blocks live in a
 // translation unit of their own (fir_mfma_alt.hip) for compile time
 hipError_t launch_fir_mfma_alt(const FirParams &p, int nb, int hs, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s);
+hipError_t launch_fir_mfma_alt2(const FirParams &p, int nb, int hs, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s);
 
 template <int NB, int HS, int WAVES>
 static hipError_t launch_nb_hs(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   const dim3 blk(64 * WAVES);
   if constexpr (WAVES == 1 && NB <= kMaxRegNB) {
     if ((HS == 0 && a.nar_on && (epi == 1 || epi == 2)) || (epi == 3 && p.out_eb == 4)) { return launch_fir_mfma_alt(p, NB, HS, d_frag, a, epi, grid, s); }
+    if (HS != 0 && a.nar_on && (epi == 1 || epi == 2)) { return launch_fir_mfma_alt2(p, NB, HS, d_frag, a, epi, grid, s); }
   }
   if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
   else if (epi == 2) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, HS, WAVES>), grid, blk, 0, s, p, (const v4i *)d_frag, a); }
@@ -1027,9 +1085,17 @@ static int pick_hs(int nb, uint64_t hi_mask) {
   return lo + 16 * hi;
 }
 
+// the NAR instantiations (narrow OUT_TYPEs, general rounding modes) exist for the widest and the narrowest skip only: 3 + 3 where the set
+// allows it, else 2 + 2 (fir_mfma_alt2.hip)
+static int pick_hs_nar(int nb, uint64_t hi_mask) {
+  const int hs = pick_hs(nb, hi_mask);
+  return hs == 3 + 16 * 3 ? hs : (hs ? 2 + 16 * 2 : 0);
+}
+
 template <int NB>
 static hipError_t launch_nb(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
-  const int hs = (epi && !a.nar_on) ? pick_hs(NB, a.hi_mask) : 0;
+  static const bool no_nar_hs = getenv("ACDSP_NO_NAR_SKIP") != nullptr;   // A/B knob: the round-4 NAR kernels (every high-plane product issued)
+  const int hs = !epi ? 0 : (a.nar_on ? (no_nar_hs ? 0 : pick_hs_nar(NB, a.hi_mask)) : pick_hs(NB, a.hi_mask));
   if (NB >= 7) {
     constexpr int H33 = NB >= 7 ? 3 + 16 * 3 : 0, H32 = NB >= 7 ? 3 + 16 * 2 : 0, H23 = NB >= 7 ? 2 + 16 * 3 : 0;
     if (hs == 3 + 16 * 3) { return launch_nb_hs<NB, H33, kSmallWaves>(p, d_frag, a, epi, grid, s); }
@@ -1111,8 +1177,8 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
       const int pc = lane + 64 * j;
       if (pc < NP) {
         const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
-        unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
-        unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
+        unsigned hi0 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u), a.hi_xor);
+        unsigned hi1 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u), a.hi_xor);
         unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
         unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -1124,7 +1190,7 @@ __device__ __forceinline__ void fir_mfma_big_body(const FirParams &p, const v4i 
 
   const int rs = p.in.F + p.cf.F - p.out.F;
   const int64_t corr = a.corr[0];
-  const int64_t corr_t = corr + ((EPI != 0 && p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0);
+  const int64_t corr_t = corr + (EPI != 0 ? q_preload(p.out.Q, rs) : 0);
   const int c_ll = (EPI == 1 || EPI == 2) ? (int)corr_t : 0;   // EPI 4 adds C in 64 bits: 128 sum(c) need not fit int32
   const Epi64 e64 = make_epi64(p, corr);
   const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
@@ -1275,8 +1341,8 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
       const int pc = lane + 64 * j;
       if (pc < NP) {
         const int c = pc >> 2, hh_ = (pc >> 1) & 1, sub = pc & 1;
-        unsigned hi0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u);
-        unsigned hi1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u);
+        unsigned hi0 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x07050301u), a.hi_xor);
+        unsigned hi1 = hi_flip<EPI == 3>(__builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x07050301u), a.hi_xor);
         unsigned lo0 = __builtin_amdgcn_perm((unsigned)R[j].y, (unsigned)R[j].x, 0x06040200u) ^ 0x80808080u;
         unsigned lo1 = __builtin_amdgcn_perm((unsigned)R[j].w, (unsigned)R[j].z, 0x06040200u) ^ 0x80808080u;
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -1287,7 +1353,7 @@ fir_mfma_big2_kernel(FirParams p, const v4i *__restrict__ frag, MfmaArgs a) {
   };
 
   const int rs = p.in.F + p.cf.F - p.out.F;
-  const int c_ll = EPI == 4 ? 0 : (int)(a.corr[0] + ((p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0));
+  const int c_ll = EPI == 4 ? 0 : (int)(a.corr[0] + q_preload(p.out.Q, rs));
   const Epi64 e64 = make_epi64(p, a.corr[0]);
   const v16i ll_init = {c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll};
   int16_t *yout = (int16_t *)p.y + (int64_t)ch * p.out_stride;
@@ -1444,6 +1510,35 @@ hipError_t launch_fir_mfma_alt(const FirParams &p, int nb, int hs, const uint32_
     default: return hipErrorInvalidValue;
   }
 }
+#elif ACDSP_FIR_TU_MID == 5
+// NAR instantiations with a band skip (round 5): band-limited sets into narrow OUT_TYPEs or through the general rounding modes ran every
+// high-plane product (36 instead of 24 MFMAs per step at nine blocks) -- that, not the epilogue, was most of their distance to the plain classes
+template <int NB, int HS>
+static hipError_t launch_alt2_hs(const FirParams &p, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  const v4i *f = (const v4i *)d_frag;
+  if (a.gq_on) {
+    if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, HS, 1, 2>), grid, dim3(64), 0, s, p, f, a); }
+    else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, HS, 1, 2>), grid, dim3(64), 0, s, p, f, a); }
+  }
+  else if (epi == 1) { hipLaunchKernelGGL((fir_mfma_kernel<NB, 1, HS, 1, 1>), grid, dim3(64), 0, s, p, f, a); }
+  else { hipLaunchKernelGGL((fir_mfma_kernel<NB, 2, HS, 1, 1>), grid, dim3(64), 0, s, p, f, a); }
+  return hipGetLastError();
+}
+template <int NB>
+static hipError_t launch_alt2_nb(const FirParams &p, int hs, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  if constexpr (NB >= 7) { if (hs == 3 + 16 * 3) { return launch_alt2_hs<NB, 3 + 16 * 3>(p, d_frag, a, epi, grid, s); } }
+  return hs == 2 + 16 * 2 ? launch_alt2_hs<NB, 2 + 16 * 2>(p, d_frag, a, epi, grid, s) : hipErrorInvalidValue;
+}
+hipError_t launch_fir_mfma_alt2(const FirParams &p, int nb, int hs, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
+  switch (nb) {
+    case 5: return launch_alt2_nb<5>(p, hs, d_frag, a, epi, grid, s);
+    case 6: return launch_alt2_nb<6>(p, hs, d_frag, a, epi, grid, s);
+    case 7: return launch_alt2_nb<7>(p, hs, d_frag, a, epi, grid, s);
+    case 8: return launch_alt2_nb<8>(p, hs, d_frag, a, epi, grid, s);
+    case 9: return launch_alt2_nb<9>(p, hs, d_frag, a, epi, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
 #else
 hipError_t launch_fir_mfma_mid3(const FirParams &p, int nb, const uint32_t *d_frag, const MfmaArgs &a, int epi, dim3 grid, hipStream_t s) {
   switch (nb) {
@@ -1516,7 +1611,7 @@ static hipError_t launch_big(const FirParams &p, const uint32_t *d_frag, MfmaArg
 // Can the all-32-bit epilogue be used for this plan / type combination?  0: no, 1: WRAP, 2: SAT
 // a rounding / overflow mode beyond the AC_TRN / AC_RND x AC_WRAP / AC_SAT of the plain fast classes
 static bool fir_mfma_general_q(const FirParams &p) {
-  return !((p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT));
+  return !(q_const_mode(p.out.Q) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT));
 }
 int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   // an unsigned AC_WRAP accumulator turns every negative sum into 2^W - |v| before OUT_TYPE sees it (the reference's
@@ -1529,7 +1624,8 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   const bool acc_wide = acc_bits >= 63 || plan.sum_abs * x_max < (int64_t(1) << (acc_bits > 0 ? acc_bits : 0));
   // ... hh*256 + mid + carry must fit int32, and so must the low plane with corr + rounding constant preloaded
   const int64_t hh_max = 128 * plan.sum_abs_hi, mid_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo), ll_max = 128 * plan.sum_abs_lo;
-  const int64_t rnd = (p.out.Q == ACDSP_RND && rs > 0 && rs <= 38) ? (int64_t(1) << (rs - 1)) : 0;
+  // (the sign- / parity-dependent modes add up to K + |C| <= 2^rs to lo before the shift: epi32_gq)
+  const int64_t rnd = q_const_mode(p.out.Q) ? (rs <= 38 ? q_preload(p.out.Q, rs) : 0) : (rs >= 1 && rs <= 31 ? (int64_t(1) << rs) : 0);
   const int64_t corr_abs = (plan.corr < 0 ? -plan.corr : plan.corr) + rnd;
   // lo = 2^8 mid + ll (with the preloaded constant) and the shifted sum must stay inside int32
   // (OUT_TYPEs of W < 16 bits shift by rse = rs - (16 - W) and finish on the packed words: MfmaArgs::nar_*)
@@ -1537,7 +1633,7 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   const bool small = mid_max * 256 + ll_max + corr_abs + 2 < (int64_t(1) << 31) &&
                      (rse <= 16 ? (hh_max << (16 - (rse < 16 ? (rse > 0 ? rse : 0) : 16))) + ((mid_max * 256 + ll_max + corr_abs) >> (rse > 0 ? rse : 0)) + 2
                                 : hh_max + ((mid_max * 256 + ll_max + corr_abs) >> 16) + 2) < (int64_t(1) << 31);
-  if (p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
+  if (p.out_eb == 2 && p.out.S && q_const_mode(p.out.Q) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) &&
       rse >= 1 && rs <= 31 && acc_wide && small && (p.out.W == 16 || (nar_d > 0 && plan.nb <= kMaxRegNB))) {
     return p.out.O == ACDSP_SAT ? 2 : 1;
   }
@@ -1550,18 +1646,18 @@ int fir_mfma_epilogue_class(const FirParams &p, const FirMfmaPlan &plan) {
   // EPI 4: int16 containers past the 32-bit bounds, on the LDS-resident kernels (more than kMaxRegNB K-blocks): exact 64-bit recombination,
   // ACC_TYPE wrap included, branch-free (epi64).  ACDSP_NO_EPI4: the generic class instead (A/B knob).
   static const bool no_epi4 = getenv("ACDSP_NO_EPI4") != nullptr;
-  if (!no_epi4 && plan.nb > kMaxRegNB && p.out_eb == 2 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) &&
+  if (!no_epi4 && plan.nb > kMaxRegNB && p.out_eb == 2 && p.out.S && q_const_mode(p.out.Q) &&
       (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && p.acc.W >= 2 && p.acc.W <= 62 && p.lossless_shift >= 0 && p.lossless_shift <= 32 &&
       p.acc.F - p.out.F >= 1 && p.acc.F - p.out.F <= 62 && p.out.W >= 2 && p.out.W <= 16) {
     return 4;
   }
   // 4-byte containers (W_out 17 .. 32): the wide class with an int32 tile; AC_WRAP or AC_SAT
-  if (p.out_eb == 4 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && acc_wide &&
+  if (p.out_eb == 4 && p.out.S && q_const_mode(p.out.Q) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && acc_wide &&
       rs >= 0 && rs <= 38 && p.out.W >= 2 && p.out.W <= 32 && ll_max + corr_abs + 2 < (int64_t(1) << 31) && plan.nb <= kMaxRegNB) {
     return 3;
   }
   // wide rows: 64-bit shift-and-wrap epilogue of the pipelined body (the low plane still carries C in 32 bits)
-  if (p.out_eb == 8 && p.out.S && (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && p.out.O == ACDSP_WRAP && acc_wide &&
+  if (p.out_eb == 8 && p.out.S && q_const_mode(p.out.Q) && p.out.O == ACDSP_WRAP && acc_wide &&
       rs >= -16 && rs <= 38 && p.out.W >= 2 && p.out.W <= 64 && (rs < 0 ? -rs : 0) + (64 - p.out.W) <= 63 && ll_max + corr_abs + 2 < (int64_t(1) << 31) && plan.nb <= kMaxRegNB) {
     return 3;
   }
@@ -1577,8 +1673,9 @@ int fir_mfma_issued_per_step(const FirParams &p, const FirMfmaPlan &plan) {
   const int epi = fir_mfma_epilogue_class(p, plan), nb = plan.nb;
   int band = nb;
   if (nb <= kMaxRegNB) {
-    const bool no_skip = (epi == 1 || epi == 2) && p.out_eb == 2 && (p.out.W < 16 || fir_mfma_general_q(p));   // NAR instantiations
-    const int hs = (epi && !no_skip) ? pick_hs(nb, plan.hi_mask) : 0;
+    const bool nar = (epi == 1 || epi == 2) && p.out_eb == 2 && (p.out.W < 16 || fir_mfma_general_q(p));   // NAR instantiations
+    static const bool no_nar_hs = getenv("ACDSP_NO_NAR_SKIP") != nullptr;
+    const int hs = !epi ? 0 : (nar ? (no_nar_hs ? 0 : pick_hs_nar(nb, plan.hi_mask)) : pick_hs(nb, plan.hi_mask));
     band = nb - (hs & 15) - (hs >> 4);
   } else if (epi) {
     int b0 = 0, b1 = nb - 1;
@@ -1608,17 +1705,27 @@ hipError_t launch_fir_mfma(const FirParams &p, const FirMfmaPlan &plan, int frag
   const int epi = fir_mfma_epilogue_class(p, plan);
   MfmaArgs a;
   a.nar_on = 0; a.nar_d = 0; a.nar_lo = INT32_MIN; a.nar_hi = INT32_MAX; a.nar_sh = 0;
-  a.gq_on = 0; a.gq_q = 0; a.gq_o = 0;
+  a.gq_on = 0; a.gq_off = 0; a.gq_c = 0; a.gq_k = 0; a.gq_form = 1; a.gq_lo = INT32_MIN; a.gq_hi = INT32_MAX;
+  a.hi_xor = p.in_flip ? 0x80808080u : 0u;
   if ((epi == 1 || epi == 2) && p.out_eb == 2 && fir_mfma_general_q(p)) {   // W_out = 16 (fir_mfma_epilogue_class)
-    // (AC_RND keeps its constant in ll like the plain classes: no increment on top of it)
-    static const int kMask[8] = {0 /* TRN */, 0 /* RND: preloaded */, 64 /* TRN_ZERO */, 1 | 4 /* RND_ZERO */, 1 | 8 /* RND_INF */, 1 /* RND_MIN_INF */,
-                                 1 | 16 /* RND_CONV */, 1 | 32 /* RND_CONV_ODD */};
-    a.nar_on = 1; a.gq_on = 1; a.gq_q = kMask[p.out.Q & 7]; a.gq_o = p.out.O == ACDSP_SAT_SYM ? 1 : (p.out.O == ACDSP_SAT_ZERO ? 2 : 0);
+    const int rsq = p.in.F + p.cf.F - p.out.F;                               // 1 .. 31 (fir_mfma_epilogue_class)
+    const int32_t half = (int32_t)(uint32_t(1) << (rsq - 1)), all = (int32_t)((uint32_t(1) << rsq) - 1u);
+    a.nar_on = 1; a.gq_on = 1;
+    if (p.out.O == ACDSP_SAT_SYM) { a.gq_lo = -32767; a.gq_hi = 32767; }
+    switch (p.out.Q) {   // (the constant modes keep their constant in ll like the plain classes: no increment on top of it)
+      case ACDSP_TRN_ZERO:     a.gq_off = 31; a.gq_c = all; a.gq_k = 0; break;
+      case ACDSP_RND_ZERO:     a.gq_off = 31; a.gq_c = 1;   a.gq_k = half - 1; break;
+      case ACDSP_RND_INF:      a.gq_off = 31; a.gq_c = -1;  a.gq_k = half; break;
+      case ACDSP_RND_CONV:     a.gq_off = 0;  a.gq_c = 1;   a.gq_k = half - 1; break;
+      case ACDSP_RND_CONV_ODD: a.gq_off = 0;  a.gq_c = -1;  a.gq_k = half; break;
+      default: break;
+    }
+    a.gq_form = p.out.O == ACDSP_SAT_ZERO ? 2 : ((a.gq_off == 0 && rsq < 16) ? 0 : 1);
   }
   a.w4_sat = (epi == 3 && p.out_eb == 4 && p.out.O == ACDSP_SAT) ? 1 : 0; a.w4_lo = p.out.lo; a.w4_hi = p.out.hi;
   if (epi == 3 && p.out_eb == 4 && p.out.O == ACDSP_WRAP) {
     const int rs4 = p.in.F + p.cf.F - p.out.F;
-    const int64_t rnd4 = (p.out.Q == ACDSP_RND && rs4 > 0) ? (int64_t(1) << (rs4 - 1)) : 0;
+    const int64_t rnd4 = q_preload(p.out.Q, rs4);
     const int64_t lo_max = 128 * (plan.sum_abs_hi + plan.sum_abs_lo) * 256 + 128 * plan.sum_abs_lo + (plan.corr < 0 ? -plan.corr : plan.corr) + rnd4 + 2;
     if (rs4 >= 1 && rs4 <= 31 && lo_max < (int64_t(1) << 31) && 128 * plan.sum_abs_hi + (lo_max >> 16) + 2 < (int64_t(1) << 31)) { a.w4_sat = 2; }
   }

@@ -222,20 +222,30 @@ def test_long_runs_take_the_branch_free_kernel(q, o):
     assert np.array_equal(y, run_oracle(False, 16, 1, 5, fin, fout, x))
 
 
-@pytest.mark.parametrize("R,N,fin,fout", [
-    (8, 4, A.Fmt(16, 1), None),                                   # int16 samples, INT_TYPE <28,13>: 4-byte containers
-    (8, 5, A.Fmt(16, 1), None),                                   # ... <31,16>
-    (8, 4, A.Fmt(16, 1), A.Fmt(24, 9, True, "RND", "SAT")),       # ... a narrowing conversion
-    (4, 3, A.Fmt(32, 16), None),                                  # R = 4 on int32: four steps of 4 KB per wave
-    (4, 5, A.Fmt(32, 16), None),
-    (16, 5, A.Fmt(32, 16), None),                                 # R = 16 on int32: three coefficient digits, one 16 KB step per wave
-    (16, 5, A.Fmt(32, 16), A.Fmt(40, 20, True, "TRN", "SAT")),
+@pytest.mark.parametrize("R,M,N,fin,fout", [
+    (8, 1, 4, A.Fmt(16, 1), None),                                # int16 samples, INT_TYPE <28,13>: 4-byte containers
+    (8, 1, 5, A.Fmt(16, 1), None),                                # ... <31,16>
+    (8, 1, 4, A.Fmt(16, 1), A.Fmt(24, 9, True, "RND", "SAT")),    # ... a narrowing conversion
+    (4, 1, 3, A.Fmt(32, 16), None),                               # R = 4 on int32: four steps of 4 KB per wave
+    (4, 1, 5, A.Fmt(32, 16), None),
+    (16, 1, 5, A.Fmt(32, 16), None),                              # R = 16 on int32: three coefficient digits, one 16 KB step per wave
+    (16, 1, 5, A.Fmt(32, 16), A.Fmt(40, 20, True, "TRN", "SAT")),
+    (7, 2, 4, A.Fmt(32, 16), None),                               # the reference testbench's parameters: odd factor, identity slot map, 7 KB steps
+    (7, 2, 4, A.Fmt(32, 16), A.Fmt(48, 32)),
+    (7, 2, 4, A.Fmt(32, 16), A.Fmt(40, 24, True, "RND", "SAT")),
+    (7, 1, 3, A.Fmt(32, 16), None),
+    (7, 2, 4, A.Fmt(30, 10, False), None),                        # unsigned samples: 31-bit signed planes
+    (8, 2, 3, A.Fmt(24, 8), None),                                # 24-bit samples in int32 containers: the sign plane rides along as a fourth plane
+    (4, 1, 4, A.Fmt(20, 3), A.Fmt(36, 19, True, "RND", "SAT")),
+    (5, 1, 6, A.Fmt(16, 1), None),                                # R = 5 on int16: two steps per load group (2.5 KB each), INT_TYPE <30,15>
+    (5, 1, 6, A.Fmt(16, 1), A.Fmt(40, 25)),                       # ... into 8-byte containers
+    (5, 2, 3, A.Fmt(16, 4), A.Fmt(24, 10, True, "RND", "SAT")),
 ])
-def test_decimator_ring_kernel_shapes_outside_the_baseline(R, N, fin, fout):
+def test_decimator_ring_kernel_shapes_outside_the_baseline(R, M, N, fin, fout):
     """The ring kernel (fir_gen_ring_kernel) serves more CIC decimator shapes than the BASELINE ones: whole chunks on it, the ragged
     tail and the continuation calls (history in front of the first window) on the general kernel; every output against the oracle."""
     rng = np.random.default_rng(7 * R + N)
-    probe = A.Cic(False, R, 1, N, fin, fin)
+    probe = A.Cic(False, R, M, N, fin, fin)
     it = probe.int_type
     fo = fout if fout is not None else A.Fmt(it.W, it.I)
     n = R * (256 * 4 * 3 + 16 * 5) + 16                           # three chunks of four steps + a ragged tail, whole 16-sample slots
@@ -243,10 +253,10 @@ def test_decimator_ring_kernel_shapes_outside_the_baseline(R, N, fin, fout):
     x[1, :R * 300] = (1 << (fin.W - 1)) - 1
     x[2, :R * 300] = -(1 << (fin.W - 1))
     for splits in (None, [R * 256 * 5 + 16 * R]):
-        cic = A.Cic(False, R, 1, N, fin, fo, n_channels=3)
+        cic = A.Cic(False, R, M, N, fin, fo, n_channels=3)
         y = run_engine(cic, x, splits)
         assert cic.path == "mfma_gen"
-        yo = run_oracle(False, R, 1, N, fin, fo, x, splits)
+        yo = run_oracle(False, R, M, N, fin, fo, x, splits)
         assert y.shape == yo.shape
         bad = np.argwhere(y != yo)
         assert bad.size == 0, "%d mismatches, first at %s" % (len(bad), bad[0])

@@ -18,7 +18,7 @@ for (W, I, R, M, Ns) in ((32, 16, 8, 1, 5), (32, 16, 7, 2, 4), (32, 16, 4, 1, 3)
     dt = A.torch_dtype_for(fin)
     x = torch.empty((NCH, N), dtype=dt, device=dev)
     A.fill_stimulus(x, 0xACD5, W if W <= 32 else 32, ch0=0)
-    y = torch.empty((NCH, N // R + 8), dtype=A.torch_dtype_for(fo), device=dev)
+    y = torch.empty((NCH, (N // R + 8 + 7) // 8 * 8), dtype=A.torch_dtype_for(fo), device=dev)
     for _ in range(10):
         eng.run(x, y)
     torch.cuda.synchronize()
