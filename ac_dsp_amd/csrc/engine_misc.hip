@@ -284,8 +284,24 @@ int32_t acdsp_mvavg_run(acdsp_mvavg_t h, const void *d_in, int64_t in_stride, in
   p.in = make_dfmt(d.in); p.cf = make_dfmt(d.coeff); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
   p.in_eb = h->in_eb; p.out_eb = h->out_eb;
   p.force_generic = (d.flags & ACDSP_FLAG_FORCE_GENERIC) != 0;
+  // order-free class: products (ACC_TYPE) w[j] * coeffs[j] inside 2^62.  The cast sample has at most min(W_acc, W_in + max(F_acc - F_in, 0))
+  // bits and the coefficients as many as the set on the handle needs (round 5: the bound by W_acc + W_coeff sent <32,16> samples into a
+  // <56,30> accumulator to the 128-bit per-tap kernel)
+  int cbits = d.coeff.W;
+  if (!h->h_coeffs.empty()) {
+    cbits = 1;
+    for (int64_t c : h->h_coeffs) {
+      const uint64_t m = (uint64_t)(c < 0 ? ~c : c);
+      int b = 1;
+      while (b < 64 && (m >> (b - 1)) != 0) { b++; }
+      if (b > cbits) { cbits = b; }
+    }
+    if (!d.coeff.S) { cbits++; }
+  }
+  const int dcast = p.acc.F - p.in.F, xbits_in = d.in.W + (d.in.S ? 0 : 1) + (dcast > 0 ? dcast : 0);
+  const int xbits = xbits_in < d.acc.W + (d.acc.S ? 0 : 1) ? xbits_in : d.acc.W + (d.acc.S ? 0 : 1);
   p.fast = !p.force_generic && d.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && p.cf.F >= 0 &&
-           p.cf.F < 62 && d.acc.W + d.coeff.W <= 62;
+           p.cf.F < 62 && xbits + cbits <= 62;
   p.n_sample = n_sample; p.n_frames = n_frames; p.out_per_frame = opf; p.in_stride = in_stride; p.out_stride = out_stride;
   p.x = d_in; p.y = d_out; p.coeffs = h->d_coeffs; p.h_coeffs = h->h_coeffs.data();
   hipError_t e = launch_mv_avg(p, (hipStream_t)stream, &h->last_path);

@@ -448,8 +448,15 @@ static bool make_conv(const IntgDumpParams &p, IdConv &cv) {
   cv.rnd = (p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0;
   if (p.out.O == ACDSP_SAT) { cv.lo = p.out.lo; cv.hi = p.out.hi; cv.ko = 0; cv.om = ~uint64_t(0); }
   else { cv.lo = INT64_MIN; cv.hi = INT64_MAX; cv.ko = 64 - p.out.W; cv.om = p.out.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.out.W)); }
-  cv.ok = (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (p.out.O == ACDSP_WRAP || p.out.O == ACDSP_SAT) && p.acc.W <= 61 && cv.rs <= 60 &&
-          p.acc.W + cv.ls2 <= 61 && p.out.W <= 62 &&              // neither the rounding add nor the left shift can leave int64
+  // 64-bit arithmetic of the conversion: the rounding add and (for AC_SAT) the left shift must not leave int64; an unsigned ACC_TYPE of 63 / 64
+  // bits is a negative int64 here, which only a pure bit copy (no right shift, AC_WRAP) survives; AC_SAT bounds of an unsigned OUT_TYPE must fit
+  // int64.  Round 5: the header's usage example (ac_intg_dump.h:47-51: <32,16> into ACC = OUT <64,32>) ran the tiled kernel at 0.30 of the
+  // roofline because this test asked for W_acc <= 61 whatever the shifts.
+  const bool wrap_o = p.out.O == ACDSP_WRAP;
+  cv.ok = (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (wrap_o || p.out.O == ACDSP_SAT) && cv.rs <= 60 &&
+          (cv.rnd == 0 || p.acc.W <= 61) && (cv.ls2 == 0 || p.acc.W + cv.ls2 <= 61 || wrap_o) &&
+          (p.acc.S || p.acc.W <= 62 || (rs == 0 && wrap_o)) && p.acc.W <= 64 &&
+          (wrap_o || p.out.S ? p.out.W <= 64 : p.out.W <= 62) &&
           cv.sh >= 0 && cv.sh + cv.ka < 64;                       // the IN -> ACC cast `<< (sh + ka)` stays a defined shift (else: tiled kernel)
   return cv.ok != 0;
 }

@@ -305,7 +305,147 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 32-bit samples (round 5; the header's usage example declares IN_TYPE ac_fixed<32,16>, ac_mv_avg.h:47): the order-free class on int32
+// containers whose cast to ACC_TYPE is exact -- xq = x << d, d = F_acc - F_in >= 0, enough integer bits -- and coefficients inside int32:
+//     acc = wrap( sum_j floor((x_j c_j 2^d + rnd) / 2^sh) ),  sh = F_coeff;  x_j c_j is ONE v_mad_i64_i32, host-checked to stay inside 2^62.
+// A 256-thread block takes a tile of 1024 outputs of one (object, frame): the 1024 + TAPS - 1 window samples go to LDS as int32 with
+// the boundary rule applied (coalesced loads), a thread owns four consecutive outputs and slides an eight-register window over the taps
+// -- one aligned 16-byte LDS read per four taps; coefficients are uniform reads -- then converts (requant64: any OUT_TYPE) and
+// stores its four outputs as one or two 16-byte vectors.  Before: 128-bit per-tap kernel, 0.034 of the roofline on <32,16> samples.
+struct MvW32Args {
+  int32_t d, sh, linear, ls, e; int64_t rnd_e; int32_t vec_ok;
+  // branch-free ACC -> OUT (CONV instantiations; IdConv's form in intg_dump.hip): wrap to ACC_TYPE, rounding shift, clamp, wrap to OUT_TYPE
+  int32_t ka, rs, ls2, ko; uint64_t am, om; int64_t rnd, lo, hi;
+};
+
+template <bool LINEAR, bool CONV>   // LINEAR: d >= sh, the products add up unshifted (one v_mad_i64_i32 per tap and output); CONV: TRN / RND into WRAP / SAT
+__global__ void __launch_bounds__(256) mv_avg_w32_kernel(MvAvgParams p, MvW32Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char w32_lds[];
+  const int h = p.taps / 2, tid = threadIdx.x;
+  const int nwin = (1024 + p.taps - 1 + 3 + 4) & ~3;            // window dwords, padded: the last 16-byte read of a thread may reach one group further
+  int32_t *win = (int32_t *)w32_lds;
+  int32_t *cf = win + nwin;                                       // [taps] coefficients (int32 by the host check)
+  for (int i = tid; i < p.taps; i += 256) { cf[i] = (int32_t)p.coeffs[i]; }
+  const int64_t pairs = (int64_t)p.n_obj * p.n_frames;
+  const int64_t first = p.win_mode == 0 ? h : 0;
+  for (int64_t pr = blockIdx.y; pr < pairs; pr += gridDim.y) {
+    const int64_t obj = pr / p.n_frames, fr = pr % p.n_frames;
+    const int32_t *xrow = (const int32_t *)p.x + obj * p.in_stride + fr * p.n_sample;
+    const int64_t ybase = obj * p.out_stride + fr * p.out_per_frame;
+    const int64_t m0 = first + (int64_t)blockIdx.x * 1024;
+    __syncthreads();
+    for (int j = tid; j < nwin; j += 256) {
+      int64_t pos = m0 - h + j;
+      if (p.win_mode != 0) { pos = fold_pos(pos, p.n_sample, p.win_mode); }
+      win[j] = (pos >= 0 && pos < p.n_sample) ? xrow[pos] : 0;
+    }
+    __syncthreads();
+    const int64_t k0 = (int64_t)blockIdx.x * 1024 + 4 * tid;    // first of this thread's four outputs within the frame
+    if (k0 < p.out_per_frame) {
+      typedef int v4i_ __attribute__((ext_vector_type(4)));
+      const v4i_ *wv = (const v4i_ *)(win + 4 * tid);
+      v4i_ cur = wv[0];
+      uint64_t s[4] = {0, 0, 0, 0};
+      for (int jg = 0; 4 * jg < p.taps; jg++) {
+        const v4i_ nxt = wv[jg + 1];
+        const int w8[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = 4 * jg + u;
+          if (j < p.taps) {
+            const int c = cf[j];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              if (LINEAR) { s[i] = (uint64_t)((int64_t)w8[u + i] * (int64_t)c + (int64_t)s[i]); }
+              else { s[i] += (uint64_t)(((int64_t)w8[u + i] * (int64_t)c + a.rnd_e) >> a.e); }
+            }
+          }
+        }
+        cur = nxt;
+      }
+      int64_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (CONV) {
+          const int64_t acc = (int64_t)(((uint64_t)((int64_t)(s[i] << (a.ls + a.ka)) >> a.ka)) & a.am);   // (sum << ls) wrapped to ACC_TYPE
+          int64_t qv = (int64_t)((uint64_t)((acc + a.rnd) >> a.rs) << a.ls2);
+          qv = qv < a.lo ? a.lo : (qv > a.hi ? a.hi : qv);
+          o[i] = (int64_t)(((uint64_t)((int64_t)((uint64_t)qv << a.ko) >> a.ko)) & a.om);
+        } else {
+          o[i] = requant64(wrap64((int64_t)(s[i] << a.ls), p.acc.W, p.acc.S), p.acc.F, p.out);
+        }
+      }
+      if (a.vec_ok && k0 + 4 <= p.out_per_frame) {
+        if (p.out_eb == 8) {
+          typedef long v2l_ __attribute__((ext_vector_type(2)));
+          v2l_ *yp = (v2l_ *)((int64_t *)p.y + ybase + k0);
+          yp[0] = (v2l_){o[0], o[1]}; yp[1] = (v2l_){o[2], o[3]};
+        } else if (p.out_eb == 4) {
+          *(v4i_ *)((int32_t *)p.y + ybase + k0) = (v4i_){(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+        } else {
+          typedef short v4s_ __attribute__((ext_vector_type(4)));
+          *(v4s_ *)((int16_t *)p.y + ybase + k0) = (v4s_){(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+        }
+      } else {
+        for (int i = 0; i < 4 && k0 + i < p.out_per_frame; i++) { store_raw(p.y, ybase + k0 + i, p.out_eb, o[i]); }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// true: launched (mv_avg_w32_kernel's class and shape conditions)
+static bool try_w32(const MvAvgParams &p, hipStream_t s) {
+  static const bool off = getenv("ACDSP_NO_MVAVG_W32") != nullptr;   // A/B knob
+  if (off || p.force_generic || !p.h_coeffs || p.in_eb != 4 || !(p.in.S || p.in.W <= 31) || p.taps > 1025) { return false; }
+  if (p.acc.O != ACDSP_WRAP || (p.acc.Q != ACDSP_TRN && p.acc.Q != ACDSP_RND) || p.cf.F >= 62) { return false; }   // order-free class
+  const int d = p.acc.F - p.in.F, sh = p.cf.F;
+  const int i_in = p.in.W - p.in.F, i_acc = p.acc.W - p.acc.F;
+  if (d < 0 || sh < 0) { return false; }
+  if (p.in.S ? (!p.acc.S || i_acc < i_in) : (i_acc < i_in + (p.acc.S ? 1 : 0))) { return false; }   // the cast (ACC_TYPE) w[j] is exact
+  int cbits = 1;
+  for (int i = 0; i < p.taps; i++) {
+    const int64_t c = p.h_coeffs[i];
+    if (c < INT32_MIN || c > INT32_MAX) { return false; }
+    const uint64_t m = (uint64_t)(c < 0 ? ~c : c);
+    int b = 1;
+    while (b < 64 && (m >> (b - 1)) != 0) { b++; }
+    if (b > cbits) { cbits = b; }
+  }
+  MvW32Args a;
+  memset(&a, 0, sizeof a);
+  a.d = d; a.sh = sh; a.linear = d >= sh; a.ls = a.linear ? d - sh : 0; a.e = a.linear ? 0 : sh - d;
+  // linear: the 32 x 32-bit products add up mod 2^64 and the shift comes once, after the sum; per tap: |x c| + rnd inside int64
+  if (a.ls > 62 || a.e > 62) { return false; }
+  a.rnd_e = (!a.linear && p.acc.Q == ACDSP_RND) ? (int64_t(1) << (a.e - 1)) : 0;
+  if (a.e > 0 && p.in.W + cbits > 61) { return false; }
+  a.vec_ok = p.out_per_frame % 4 == 0 && p.out_stride % 4 == 0 && ((uintptr_t)p.y % 16) == 0 && (p.out_eb == 2 || p.out_eb == 4 || p.out_eb == 8);
+  const int64_t pairs = (int64_t)p.n_obj * p.n_frames;
+  dim3 grid((unsigned)((p.out_per_frame + 1023) / 1024), (unsigned)(pairs < 65535 ? pairs : 65535));
+  const int nwin = (1024 + p.taps - 1 + 3 + 4) & ~3;
+  const size_t lds = (size_t)(nwin + p.taps) * sizeof(int32_t);
+  // ACC -> OUT without branches where the modes and the 64-bit arithmetic allow it (the conditions of intg_dump.hip: make_conv)
+  const int rs = p.acc.F - p.out.F;
+  const bool wrap_o = p.out.O == ACDSP_WRAP;
+  a.ka = 64 - p.acc.W; a.am = p.acc.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.acc.W));
+  a.rs = rs > 0 ? rs : 0; a.ls2 = rs < 0 ? -rs : 0;
+  a.rnd = (p.out.Q == ACDSP_RND && rs > 0) ? (int64_t(1) << (rs - 1)) : 0;
+  if (p.out.O == ACDSP_SAT) { a.lo = p.out.lo; a.hi = p.out.hi; a.ko = 0; a.om = ~uint64_t(0); }
+  else { a.lo = INT64_MIN; a.hi = INT64_MAX; a.ko = 64 - p.out.W; a.om = p.out.S ? ~uint64_t(0) : (~uint64_t(0) >> (64 - p.out.W)); }
+  const bool conv = (p.out.Q == ACDSP_TRN || p.out.Q == ACDSP_RND) && (wrap_o || p.out.O == ACDSP_SAT) && a.rs <= 60 && a.ls + a.ka < 64 &&
+                    (a.rnd == 0 || p.acc.W <= 61) && (a.ls2 == 0 || p.acc.W + a.ls2 <= 61 || wrap_o) &&
+                    (p.acc.S || p.acc.W <= 62 || (rs == 0 && wrap_o)) && (wrap_o || p.out.S ? p.out.W <= 64 : p.out.W <= 62);
+  if (a.linear) {
+    if (conv) { hipLaunchKernelGGL((mv_avg_w32_kernel<true, true>), grid, dim3(256), lds, s, p, a); }
+    else { hipLaunchKernelGGL((mv_avg_w32_kernel<true, false>), grid, dim3(256), lds, s, p, a); }
+  } else {
+    if (conv) { hipLaunchKernelGGL((mv_avg_w32_kernel<false, true>), grid, dim3(256), lds, s, p, a); }
+    else { hipLaunchKernelGGL((mv_avg_w32_kernel<false, false>), grid, dim3(256), lds, s, p, a); }
+  }
+  return true;
+}
 
 // true: launched.  Class and shape conditions of the streaming kernel (see above).
 static bool try_stream(const MvAvgParams &p, hipStream_t s) {
@@ -400,6 +540,7 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
 hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s, int *path) {
   if (p.out_per_frame <= 0 || p.n_frames <= 0) { return hipSuccess; }
   if (try_stream(p, s)) { *path = 2; return hipGetLastError(); }
+  if (try_w32(p, s)) { *path = 3; return hipGetLastError(); }
   *path = p.fast ? 1 : 0;
   const int64_t pairs = (int64_t)p.n_obj * p.n_frames;
   dim3 grid((unsigned)((p.out_per_frame + kTile - 1) / kTile), (unsigned)(pairs < 65535 ? pairs : 65535));

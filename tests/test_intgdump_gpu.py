@@ -72,6 +72,12 @@ def test_rejects_short_buffers():
     (36, 8, 36, 130, A.Fmt(12, 4), A.Fmt(24, 12), A.Fmt(24, 12)),                      # 36 lane-loads, eight channels
     (330, 2, 330, 51, A.Fmt(32, 16), A.Fmt(48, 32), A.Fmt(48, 32)),                    # int32 containers: 165 lane-loads
     (1000, 2, 1000, 9, A.Fmt(16, 2), A.Fmt(27, 13, True, "TRN", "WRAP"), A.Fmt(20, 6, True, "RND", "SAT")),   # 250 lane-loads, few blocks
+    (1024, 4, 1024, 8, A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(64, 32)),                   # the header's usage example (ac_intg_dump.h:47-51): 64-bit ACC = OUT, a bit copy
+    (64, 2, 64, 32, A.Fmt(32, 16, False), A.Fmt(63, 31, False), A.Fmt(63, 31, False)), # ... unsigned, 63 bits (the C ABI's widest unsigned format): a bit copy
+    (64, 4, 64, 32, A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(32, 16)),                      # 64-bit ACC, truncating right shift into a narrower OUT
+    (64, 4, 64, 32, A.Fmt(32, 16), A.Fmt(64, 40), A.Fmt(64, 32)),                      # ... left shift under AC_WRAP
+    (64, 4, 64, 32, A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(40, 20, True, "RND", "SAT")),  # rounding add on 64 bits: stays on the tiled kernel
+    (64, 4, 64, 32, A.Fmt(32, 16), A.Fmt(63, 31), A.Fmt(48, 31, True, "TRN", "SAT")),  # 63-bit ACC, clamp without a shift
 ])
 def test_streaming_kernel_shapes(ns, chn, rounds, n_blk, fin, fa, fo):
     check(ns, chn, fin, fa, fo, [[rounds] * n_blk, [rounds] * (n_blk // 2)], n_obj=5, seed=ns + chn)

@@ -145,3 +145,25 @@ def test_stream_kernel_fallbacks():
     check(9, "WIN", A.Fmt(16, 8, False), fc, fa, fo, 1024, 3, coeffs=c, seed=5, path="int64_sums")    # unsigned 16-bit samples
     check(9, "WIN", A.Fmt(15, 8, False), fc, fa, fo, 1024, 3, coeffs=c, seed=6, path="stream")        # unsigned 15-bit: fits int16
     check(5, "WIN", fin, fc, fa, fo, 1024, 3, coeffs=small_coeffs(rng, 5), seed=7, path="stream")      # 1020 outputs per frame: element stores
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_32_bit_samples_on_the_sliding_window_kernel(mode):
+    """int32 containers whose cast to ACC_TYPE is exact, coefficients inside int32, wrapping AC_TRN / AC_RND accumulator (mv_avg_w32_kernel):
+    whole tiles of 1024 outputs, ragged frames, frames shorter than a tile, windows longer than one 16-byte group, each OUT container."""
+    f32 = A.Fmt(32, 16)
+    check(9, mode, f32, A.Fmt(16, 2), A.Fmt(56, 30), A.Fmt(32, 16, True, "RND", "SAT"), 2048, 3, seed=1, path="stream32")     # linear: d = sh
+    check(9, mode, f32, A.Fmt(16, 2), A.Fmt(62, 22), A.Fmt(62, 22), 1024, 2, seed=2, path="stream32")                          # d = 24 > sh = 14: products shifted left by ten
+    check(9, mode, f32, A.Fmt(16, 2), A.Fmt(48, 22, True, "RND"), A.Fmt(16, 4, True, "RND", "SAT"), 1500, 3, seed=3, path="stream32")   # per-tap rounding, 2-byte OUT
+    check(33, mode, A.Fmt(24, 8), A.Fmt(24, 2), A.Fmt(40, 16), A.Fmt(40, 16), 1030, 2, seed=4, path="stream32")                # wrapping sums, ragged frame
+    check(65, mode, A.Fmt(20, 4, False), A.Fmt(18, 1), A.Fmt(44, 18), A.Fmt(30, 10, False), 300, 5, seed=5, path="stream32")   # unsigned samples, short frames
+    check(3, mode, f32, A.Fmt(16, 2), A.Fmt(56, 30), A.Fmt(64, 32), 4096, 2, seed=6, path="stream32")
+    check(1, mode, f32, A.Fmt(16, 2), A.Fmt(56, 30), A.Fmt(32, 16), 1024, 2, seed=7, path="stream32")
+    check(9, mode, f32, A.Fmt(16, 2), A.Fmt(56, 30, True, "TRN", "SAT"), A.Fmt(32, 16), 1024, 2, seed=8, path="exact_order")   # saturating accumulator: per-tap order
+    check(9, mode, f32, A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(64, 32), 1024, 2, seed=9)                                          # 64-bit products: not this class
+
+
+def test_usage_example_types():
+    """The header's usage example (ac_mv_avg.h:47-51): IN <32,16>, OUT <64,32>, ACC <16,2> (the cast of a sample drops bits and wraps), COEFF
+    <32,16> -- the order-free int64 kernel."""
+    check(9, "MIRROR", A.Fmt(32, 16), A.Fmt(32, 16), A.Fmt(16, 2), A.Fmt(64, 32), 1024, 3, seed=11, path="int64_sums")

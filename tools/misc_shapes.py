@@ -31,7 +31,8 @@ which = sys.argv[1] if len(sys.argv) > 1 else "both"
 if which in ("both", "intg"):
     for ns, chn, fin, fa, fo in ((64, 4, F(16, 8), F(32, 16), F(32, 16)), (8, 4, F(16, 8), F(32, 16), F(32, 16)), (1000, 4, F(16, 8), F(40, 24), F(40, 24)),
                                  (64, 1, F(16, 8), F(32, 16), F(32, 16)), (64, 7, F(16, 8), F(32, 16), F(32, 16)), (64, 16, F(16, 8), F(32, 16), F(16, 8, True, "RND", "SAT")),
-                                 (64, 4, F(32, 16), F(48, 32), F(48, 32)), (64, 4, F(12, 4), F(24, 12, True, "TRN", "SAT"), F(24, 12)), (256, 2, F(16, 8), F(32, 16), F(32, 16))):
+                                 (64, 4, F(32, 16), F(48, 32), F(48, 32)), (64, 4, F(12, 4), F(24, 12, True, "TRN", "SAT"), F(24, 12)), (256, 2, F(16, 8), F(32, 16), F(32, 16)),
+                                 (1024, 4, F(32, 16), F(64, 32), F(64, 32))):   # last: the types of the header's usage example (ac_intg_dump.h:47-51)
         try:
             eng = A.IntgDump(ns, chn, fin, fa, fo, n_objects=n_obj)
         except Exception as e:  # noqa: BLE001
@@ -54,14 +55,16 @@ if which in ("both", "mvavg"):
                                         (9, "MIRROR", 128, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")), (9, "MIRROR", 4096, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")),
                                         (9, "MIRROR", 1000, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")), (9, "MIRROR", 1024, F(16, 8), F(40, 18), F(32, 12)),
                                         (9, "MIRROR", 1024, F(16, 8), F(40, 18), F(40, 18)), (9, "MIRROR", 1024, F(12, 4), F(30, 10), F(12, 4, True, "RND", "SAT")),
-                                        (9, "MIRROR", 1024, F(32, 16), F(56, 30), F(32, 16, True, "RND", "SAT")), (9, "MIRROR", 1024, F(16, 8), F(24, 10), F(16, 8, True, "RND", "SAT"))):
+                                        (9, "MIRROR", 1024, F(32, 16), F(56, 30), F(32, 16, True, "RND", "SAT")), (9, "MIRROR", 1024, F(16, 8), F(24, 10), F(16, 8, True, "RND", "SAT")),
+                                        (9, "MIRROR", 1024, F(32, 16), F(16, 2), F(64, 32))):   # last: the types of the header's usage example (ac_mv_avg.h:47-51; COEFF <32,16> below)
         try:
-            eng = A.MvAvg(4096, taps, mode, fin, F(16, 2), fa, fo, n_objects=n_obj)
+            fcf = F(32, 16) if (fa.W == 16 and fin.W == 32) else F(16, 2)
+            eng = A.MvAvg(4096, taps, mode, fin, fcf, fa, fo, n_objects=n_obj)
         except Exception as e:  # noqa: BLE001
             print("mv_avg TAPS=%d %s rejected: %s" % (taps, mode, str(e)[:60]))
             continue
         w = np.hanning(taps + 2)[1:-1]
-        eng.set_coeffs(np.round(w / w.sum() * 2.0 ** 14).astype(np.int64))
+        eng.set_coeffs(np.round(w / w.sum() * 2.0 ** (fcf.W - fcf.I - (2 if fcf.W == 32 else 0))).astype(np.int64))
         frames = n // ns
         x = torch.empty((n_obj, frames * ns), dtype=A.torch_dtype_for(fin), device="cuda")
         A.fill_stimulus(x, 1, min(fin.W, 16))
