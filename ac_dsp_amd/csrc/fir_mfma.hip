@@ -335,6 +335,12 @@ __device__ __forceinline__ void epi64(const v16i &hh, const v16i &mid, const v16
 #ifndef ACDSP_FIR_PRIO
 #define ACDSP_FIR_PRIO 0
 #endif
+// B-fragment read-ahead group of the 33-block shape (one wave per SIMD, 512 registers to spend): same-box A/B on config 4, two passes
+// (round 5): 2: 2.067 / 2.068 ms, 3: 2.078, 4: 2.024 / 2.023, 6: 2.029 / 2.030, 8: 2.056 / 2.054.  The 12 + 12 band (nine high-plane blocks) keeps 2: at 4
+// the allocator moves eight VGPRs through AGPRs
+#ifndef ACDSP_GS_BIG
+#define ACDSP_GS_BIG 4
+#endif
 constexpr int kGroupSize = ACDSP_GS, kOccupancy = ACDSP_OCC;
 
 // EPI 0: any OUT_TYPE / ACC width through requant64.
@@ -602,7 +608,7 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
   constexpr int RING = 128 + HB, ARR = RINGED ? staged_array_bytes(RING) : staged_array_bytes(NC);
   // two accumulator sets + all Toeplitz fragments leave room for GS = 2 only when some high-byte blocks are skipped
   // (round 4: also NB = 7 dense and the wide-output class with at most two blocks skipped per side -- those spilled 1 - 9 VGPRs at GS = 2)
-  constexpr int GS = ((HS == 0 && NB >= 7) || (EPI == 3 && NB >= 9 && (HS == 0 || HS == 2 + 16 * 2))) ? 1 : 2, NG = (NB + GS - 1) / GS;
+  constexpr int GS = (NB == 33 && HS == 14 + 16 * 14) ? ACDSP_GS_BIG : (NB > kMaxRegNB ? 2 : (((HS == 0 && NB >= 7) || (EPI == 3 && NB >= 9 && (HS == 0 || HS == 2 + 16 * 2))) ? 1 : 2)), NG = (NB + GS - 1) / GS;
   const int lane = threadIdx.x & 63;
   const int n_col = lane & 31, h = lane >> 5;
   int ch = blockIdx.y;

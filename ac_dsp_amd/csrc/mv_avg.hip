@@ -126,7 +126,9 @@ template <int NR, bool LINEAR, bool CV32, bool EDGE>
 __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   constexpr int REGION = 512 + 8 * NR + 8;      // samples of one wave's LDS image (+ 8: the odd-offset window reads one dword further)
   constexpr int NQ = 4 * NR - 3;                // coefficient pairs covering 8 NR - 7 taps (+ a zero)
-  __shared__ __attribute__((aligned(16))) int16_t sm[4][REGION];
+  // (4- and 8-byte outputs turn their tile around in the same image -- 2 / 4 KB -- before it leaves: IMG)
+  constexpr int IMG = REGION > 2048 ? REGION : 2048;
+  __shared__ __attribute__((aligned(16))) int16_t sm[4][IMG];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int16_t *img = sm[wave];
   int bx, by_;
@@ -241,40 +243,15 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     const int64_t k0 = ti * 512 + 8 * lane;
     if (k0 < a.opf) {
       const int64_t yb = obj * a.out_stride + fr * a.opf + k0;
+      int64_t ov[8];                                  // OUT raw words (the low out_eb bytes are what leaves)
       if constexpr (CV32) {
-        int o[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           int q = S[i] >> a.s32;
           q = q < a.lo32 ? a.lo32 : (q > a.hi32 ? a.hi32 : q);
-          o[i] = q;
-          if (a.ko32) { o[i] = (int)((uint32_t)q << a.ko32) >> a.ko32; }
-          if (a.om != ~uint64_t(0)) { o[i] = (int)((uint32_t)o[i] & (uint32_t)a.om); }
-        }
-        if (a.vec_ok) {
-          if (a.out_eb == 2) {
-            uint4 v;
-            v.x = __builtin_amdgcn_perm((uint32_t)o[1], (uint32_t)o[0], 0x05040100u); v.y = __builtin_amdgcn_perm((uint32_t)o[3], (uint32_t)o[2], 0x05040100u);
-            v.z = __builtin_amdgcn_perm((uint32_t)o[5], (uint32_t)o[4], 0x05040100u); v.w = __builtin_amdgcn_perm((uint32_t)o[7], (uint32_t)o[6], 0x05040100u);
-            ACDSP_MV_ST(v, reinterpret_cast<uint4 *>((int16_t *)a.y + yb));
-          } else if (a.out_eb == 4) {
-            uint4 *d = reinterpret_cast<uint4 *>((int32_t *)a.y + yb);
-            d[0] = make_uint4(o[0], o[1], o[2], o[3]); d[1] = make_uint4(o[4], o[5], o[6], o[7]);
-          } else {
-            // unsigned OUT: the masked word zero-extends; signed: sign-extends
-            int64_t *d = (int64_t *)a.y + yb;
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-              const int64_t e0 = a.om != ~uint64_t(0) ? (int64_t)(uint32_t)o[i] : (int64_t)o[i];
-              const int64_t e1 = a.om != ~uint64_t(0) ? (int64_t)(uint32_t)o[i + 1] : (int64_t)o[i + 1];
-              *reinterpret_cast<ulonglong2 *>(d + i) = make_ulonglong2((uint64_t)e0, (uint64_t)e1);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            if (k0 + i < a.opf) { store_raw(a.y, yb + i, a.out_eb, a.om != ~uint64_t(0) ? (int64_t)(uint32_t)o[i] : (int64_t)o[i]); }
-          }
+          if (a.ko32) { q = (int)((uint32_t)q << a.ko32) >> a.ko32; }
+          if (a.om != ~uint64_t(0)) { q = (int)((uint32_t)q & (uint32_t)a.om); }
+          ov[i] = a.om != ~uint64_t(0) ? (int64_t)(uint32_t)q : (int64_t)q;   // unsigned OUT: the masked word zero-extends; signed: sign-extends
         }
       } else {
 #pragma unroll
@@ -282,9 +259,52 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
           const int64_t acc = (int64_t)(((uint64_t)((int64_t)((uint64_t)(int64_t)S[i] << (a.ls + a.ka)) >> a.ka)) & a.am);   // wrap to ACC_TYPE
           int64_t qv = (int64_t)((uint64_t)((acc + a.rnd) >> a.rs) << a.ls2);
           qv = qv < a.lo ? a.lo : (qv > a.hi ? a.hi : qv);
-          const int64_t o = (int64_t)(((uint64_t)((int64_t)((uint64_t)qv << a.ko) >> a.ko)) & a.om);
-          if (k0 + i < a.opf) { store_raw(a.y, yb + i, a.out_eb, o); }
+          ov[i] = (int64_t)(((uint64_t)((int64_t)((uint64_t)qv << a.ko) >> a.ko)) & a.om);
         }
+      }
+      if (a.vec_ok) {
+        if (a.out_eb == 2) {
+          uint4 v;
+          v.x = __builtin_amdgcn_perm((uint32_t)ov[1], (uint32_t)ov[0], 0x05040100u); v.y = __builtin_amdgcn_perm((uint32_t)ov[3], (uint32_t)ov[2], 0x05040100u);
+          v.z = __builtin_amdgcn_perm((uint32_t)ov[5], (uint32_t)ov[4], 0x05040100u); v.w = __builtin_amdgcn_perm((uint32_t)ov[7], (uint32_t)ov[6], 0x05040100u);
+          ACDSP_MV_ST(v, reinterpret_cast<uint4 *>((int16_t *)a.y + yb));
+        } else {
+          // 4- / 8-byte containers: a lane's eight outputs are 32 / 64 contiguous bytes, and stored from the registers every instruction
+          // covered its 2 / 4 KB with 16-byte pieces 32 / 64 bytes apart (0.48 / 0.38 of the roofline where the 2-byte row runs 0.69).
+          // The tile goes through the wave's LDS image once -- rows of 16 bytes per lane out -- and leaves in whole 1 KB runs.
+          unsigned char *ib = reinterpret_cast<unsigned char *>(img);
+          if (a.out_eb == 4) {
+            uint4 *w = reinterpret_cast<uint4 *>(ib + 32 * lane);
+            w[0] = make_uint4((uint32_t)ov[0], (uint32_t)ov[1], (uint32_t)ov[2], (uint32_t)ov[3]);
+            w[1] = make_uint4((uint32_t)ov[4], (uint32_t)ov[5], (uint32_t)ov[6], (uint32_t)ov[7]);
+          } else {
+            ulonglong2 *w = reinterpret_cast<ulonglong2 *>(ib + 64 * lane);
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) { w[i / 2] = make_ulonglong2((uint64_t)ov[i], (uint64_t)ov[i + 1]); }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (k0 + i < a.opf) { store_raw(a.y, yb + i, a.out_eb, ov[i]); }
+        }
+      }
+    }
+    {
+      if (a.vec_ok && a.out_eb != 2) {   // wave-uniform: the second half of the turn-around above
+        __builtin_amdgcn_wave_barrier();
+        const unsigned char *ib = reinterpret_cast<const unsigned char *>(img);
+        const int64_t rem_b = (a.opf - ti * 512) * a.out_eb;                 // bytes of this tile that exist (a multiple of 32)
+        unsigned char *yt = reinterpret_cast<unsigned char *>(a.y) + (obj * a.out_stride + fr * a.opf + ti * 512) * a.out_eb;
+        const int nk = a.out_eb == 4 ? 2 : 4;
+        for (int k = 0; k < nk; k++) {
+          const int off = 1024 * k + 16 * lane;
+          if (off < rem_b) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(ib + off);
+            ACDSP_MV_ST(v, reinterpret_cast<uint4 *>(yt + off));
+          }
+        }
+        __builtin_amdgcn_wave_barrier();   // read back before the next tile is staged over it
       }
     }
   };
