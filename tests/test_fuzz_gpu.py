@@ -144,10 +144,10 @@ def test_fir_long_band_limited_sets(seed):
 def test_cic_random_shapes(seed):
     rng = np.random.default_rng(2000 + seed)
     interp = bool(rng.integers(2))
-    R = int(rng.choice([2, 3, 7, 8, 16, 32]))
+    R = int(rng.choice([2, 3, 5, 7, 8, 16, 32]))
     M = int(rng.choice([1, 2, 3]))
     N = int(rng.choice([1, 2, 4, 5]))
-    fin = [A.Fmt(16, 1), A.Fmt(32, 16), A.Fmt(12, 12, False), A.Fmt(20, 4)][rng.integers(4)]
+    fin = [A.Fmt(16, 1), A.Fmt(32, 16), A.Fmt(12, 12, False), A.Fmt(20, 4), A.Fmt(24, 8)][rng.integers(5)]
     try:
         probe = A.Cic(interp, R, M, N, fin, fin, n_channels=1)
     except A.AcdspError:
@@ -157,7 +157,7 @@ def test_cic_random_shapes(seed):
     if fout.W > 64 or it.W > 64:
         pytest.skip("wider than 64 bits")
     n_ch = int(rng.choice([1, 3, 64, 65]))
-    n_total = int(rng.choice([1, 17, 256, 1000, 4096, 20000])) if not interp else int(rng.choice([1, 2, 17, 300, 2500]))
+    n_total = int(rng.choice([1, 17, 256, 1000, 4096, 20000, 16 * R * 256])) if not interp else int(rng.choice([1, 2, 17, 300, 2500]))
     x = rand_raw(rng, fin, (n_ch, n_total))
     cic = A.Cic(interp, R, M, N, fin, fout, n_channels=n_ch)
     orc = OracleCic(interp, R, M, N, ofmt(fin), ofmt(fout), n_ch=n_ch)
@@ -216,18 +216,20 @@ def test_intg_dump_random_block_sequences(seed):
     # mixes dumping blocks with n_sample = 0 / > NS blocks across calls: tiled kernel, general kernel and the carried sums
     from oracle import OracleIntgDump
     rng = np.random.default_rng(4000 + seed)
-    ns = int(rng.choice([4, 64, 100]))
+    ns = int(rng.choice([4, 64, 100, 1024]))
     chn = int(rng.choice([1, 2, 3, 4, 8]))
     fin = [A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(12, 12, False)][rng.integers(3)]
     fa, fo = [(A.Fmt(40, 20), A.Fmt(40, 20)), (A.Fmt(20, 10, True, "TRN", "SAT"), A.Fmt(12, 8, True, "RND", "SAT")),
-              (A.Fmt(48, 40, False), A.Fmt(48, 40, False))][rng.integers(3)]
+              (A.Fmt(48, 40, False), A.Fmt(48, 40, False)), (A.Fmt(64, 32), A.Fmt(64, 32)), (A.Fmt(64, 32), A.Fmt(32, 12, True, "TRN", "SAT"))][rng.integers(5)]
     n_obj = int(rng.choice([1, 5]))
     eng = A.IntgDump(ns, chn, fin, fa, fo, n_objects=n_obj)
     orc = OracleIntgDump(ns, chn, ofmt(fin), ofmt(fa), ofmt(fo), n_obj=n_obj)
     for _ in range(int(rng.integers(1, 5))):
-        nb = int(rng.integers(1, 200))
+        nb = int(rng.integers(1, 200)) if ns < 1024 else int(rng.integers(1, 24))
         n_sample = rng.integers(1, ns + 1, size=nb)
-        if rng.integers(2):
+        if rng.integers(4) == 0:                      # every block dumps after NS rounds: the streaming kernels' shape
+            n_sample[:] = ns
+        elif rng.integers(2):
             n_sample[rng.integers(0, nb, size=max(1, nb // 10))] = rng.choice([0, ns + 5])
         ni, no = eng.counts(n_sample)
         x = rand_raw(rng, fin, (n_obj, ni))
@@ -275,9 +277,9 @@ def test_poly_dec_and_intr_random_shapes(seed):
         assert y.shape == yo.shape and np.array_equal(y, yo), ("intr", seed, ftype, n_taps, ifac)
 
 
-MV_ACC = [A.Fmt(40, 18), A.Fmt(48, 20), A.Fmt(32, 16), A.Fmt(32, 16, True, "RND"), A.Fmt(30, 14, True, "RND"), A.Fmt(36, 14, False),
+MV_ACC = [A.Fmt(40, 18), A.Fmt(48, 20), A.Fmt(60, 30), A.Fmt(56, 36, True, "RND"), A.Fmt(32, 16), A.Fmt(32, 16, True, "RND"), A.Fmt(30, 14, True, "RND"), A.Fmt(36, 14, False),
           A.Fmt(24, 4), A.Fmt(40, 18, True, "RND_CONV", "SAT")]
-MV_OUT = [A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(24, 10, True, "TRN", "WRAP"), A.Fmt(40, 18), A.Fmt(12, 6, False, "RND", "SAT"),
+MV_OUT = [A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(64, 32), A.Fmt(32, 16, True, "RND", "SAT"), A.Fmt(24, 10, True, "TRN", "WRAP"), A.Fmt(40, 18), A.Fmt(12, 6, False, "RND", "SAT"),
           A.Fmt(33, 20, True, "RND", "SAT"), A.Fmt(16, 8, True, "RND_INF", "SAT_SYM"), A.Fmt(9, 3, False, "TRN", "WRAP")]
 
 
@@ -286,8 +288,8 @@ def test_mv_avg_random_shapes(seed):
     """ac_mv_avg: streaming kernel (aligned frames, small weights) and the general kernels, picked by the shapes / types drawn."""
     from oracle import OracleMvAvg
     rng = np.random.default_rng(6000 + seed)
-    fin = [A.Fmt(16, 8), A.Fmt(14, 3), A.Fmt(15, 8, False), A.Fmt(16, 8, False), A.Fmt(24, 12)][rng.integers(5)]
-    fc = [A.Fmt(16, 2), A.Fmt(12, 1), A.Fmt(16, 16), A.Fmt(10, 0, False)][rng.integers(4)]
+    fin = [A.Fmt(16, 8), A.Fmt(14, 3), A.Fmt(15, 8, False), A.Fmt(16, 8, False), A.Fmt(24, 12), A.Fmt(32, 16), A.Fmt(28, 9, False)][rng.integers(7)]
+    fc = [A.Fmt(16, 2), A.Fmt(12, 1), A.Fmt(16, 16), A.Fmt(10, 0, False), A.Fmt(24, 2)][rng.integers(5)]
     fa, fo = MV_ACC[rng.integers(len(MV_ACC))], MV_OUT[rng.integers(len(MV_OUT))]
     taps = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 17, 23, 25, 31, 33, 35]))
     mode = ["WIN", "MIRROR", "CLIP"][rng.integers(3)]
