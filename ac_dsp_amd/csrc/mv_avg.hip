@@ -107,6 +107,9 @@ struct MvStreamArgs {
   const int16_t *x;
   void *y;
   int32_t xcd_map;   // XCD-affine block order (acdsp_dev.hpp: xcd_remap)
+  // packed short frames (round 5, PK instantiations): pk_n = samples per frame (64 / 128 / 256; 0 = off), pk_pitch = image samples per frame
+  // (n + 2 hb); the tile loads then start at the tile, not hb samples in front of it: every halo is a patch
+  int32_t pk_n, pk_pitch, pk_sh;
 };
 
 typedef short v2s_t __attribute__((ext_vector_type(2)));
@@ -122,7 +125,7 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 #ifndef ACDSP_MV_AHEAD
 #define ACDSP_MV_AHEAD 2   // 4: -3 %, 8: -15 %, 16: -80 % on the bench row (profiles/r4_ab_up_store.txt, last block): more tiles in flight cost occupancy
 #endif
-template <int NR, bool LINEAR, bool CV32, bool EDGE>
+template <int NR, bool LINEAR, bool CV32, bool EDGE, bool PK = false>   // PK: packed short frames (MvStreamArgs::pk_*; as run-time branches they cost the bench row 1.4 %)
 __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   constexpr int REGION = 512 + 8 * NR + 8;      // samples of one wave's LDS image (+ 8: the odd-offset window reads one dword further)
   constexpr int NQ = 4 * NR - 3;                // coefficient pairs covering 8 NR - 7 taps (+ a zero)
@@ -148,13 +151,13 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   int f_left = n_my;   // tiles not fetched yet
   auto fetch = [&](Tile &T) {   // aligned 8-sample groups: whole groups lie inside or outside the frame
     const int16_t *row = a.x + f_obj * a.in_stride + f_fr * a.n_sample;
-    const int64_t n = a.n_sample, g = f_ti * 512 - a.hb + 8 * lane;
+    const int64_t n = a.n_sample, g = f_ti * 512 - (PK ? 0 : a.hb) + 8 * lane;
     T.ti = f_ti; T.fr = f_fr; T.obj = f_obj;
     // every load is unconditional (addresses clamped into the frame; what the clamped lanes fetch is never used), so
     // the loop body has no load under a branch and the waits stay counted
     const int64_t gc = g < 0 ? 0 : (g < n ? g : n - 8);
     { const v4u_t t_ = *reinterpret_cast<const v4u_t *>(row + gc); T.mv = make_uint4(t_.x, t_.y, t_.z, t_.w); }
-    const int64_t g2 = f_ti * 512 - a.hb + 512 + 8 * (lane < a.nxg ? lane : 0);
+    const int64_t g2 = f_ti * 512 - (PK ? 0 : a.hb) + 512 + 8 * (lane < a.nxg ? lane : 0);
     T.ev = *reinterpret_cast<const uint4 *>(row + (g2 < n ? g2 : n - 8));
     if constexpr (EDGE) {   // frame-edge patches of AC_CLIP / AC_MIRROR: the source samples of positions -1 - lane and n + lane
       const int l = lane < a.h ? lane : 0;
@@ -171,10 +174,25 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   };
   auto process = [&](Tile &T) {
     const int64_t ti = T.ti, fr = T.fr, obj = T.obj, p0 = ti * 512 - a.hb;
-    *reinterpret_cast<uint4 *>(img + 8 * lane) = T.mv;
+    // image position of this lane's eight samples: 8 lane, or -- packed short frames -- frame f' = 8 lane / n of the tile at hb + f' (n + 2 hb)
+    const int lb = PK ? a.hb + ((8 * lane) >> a.pk_sh) * a.pk_pitch + ((8 * lane) & (a.pk_n - 1)) : 8 * lane;
+    *reinterpret_cast<uint4 *>(img + lb) = T.mv;
     if (lane < a.nxg) { *reinterpret_cast<uint4 *>(img + 512 + 8 * lane) = T.ev; }
     if constexpr (EDGE) {   // positions outside [0, n) take the clipped / mirrored source sample
-      if (lane < a.h) {
+      if constexpr (PK) {
+        // every frame of the tile has both its halos inside the image: filled from the staged samples themselves
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n_patch = (512 >> a.pk_sh) * 2 * a.h;
+        for (int e = lane; e < n_patch; e += 64) {
+          const int fq = e / (2 * a.h), k2 = e - fq * 2 * a.h, right = k2 >= a.h, k = right ? k2 - a.h : k2;
+          const int base = a.hb + fq * a.pk_pitch;
+          const int dst = right ? base + a.pk_n + k : base - 1 - k;
+          const int src = a.mode == 2 ? (right ? base + a.pk_n - 1 : base) : (right ? base + a.pk_n - 2 - k : base + 1 + k);
+          img[dst] = img[src];
+        }
+      } else if (lane < a.h) {
         if (ti == 0) { img[a.hb - 1 - lane] = T.fxl; }
         const int64_t idx = a.n_sample + lane - p0;
         if (idx < REGION) { img[idx] = T.fxr; }
@@ -189,7 +207,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     // a 16-byte granule on the bench row), so the widest reads the offset is aligned for (the offset is wave-uniform: uniform branches).
     uint32_t R[4 * NR + 1];
     {
-      const unsigned char *wb = reinterpret_cast<const unsigned char *>(img + 8 * lane) + 2 * a.off;
+      const unsigned char *wb = reinterpret_cast<const unsigned char *>(img + (PK ? lb - a.hb : lb)) + 2 * a.off;
       const int bo = 2 * a.off;
       if ((bo & 15) == 0) {
 #pragma unroll
@@ -524,6 +542,17 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   a.n_sample = p.n_sample; a.n_frames = p.n_frames; a.opf = p.out_per_frame; a.in_stride = p.in_stride; a.out_stride = p.out_stride;
   a.tpf = (p.out_per_frame + 511) / 512;
   a.n_tiles = (int64_t)p.n_obj * p.n_frames * a.tpf;
+  // Frames shorter than a 512-output tile (round 5: 128-sample frames used 16 of a wave's 64 lanes, 0.21 of the roofline): with AC_CLIP /
+  // AC_MIRROR every output of a frame depends on that frame's samples only, frames lie back to back in the row, so a tile takes 512 / n whole
+  // frames -- each in its own slot of the LDS image, both halos patched from the staged samples -- and the row is walked as ONE frame.
+  a.pk_n = 0; a.pk_pitch = 0; a.pk_sh = 0;
+  static const bool no_pk = getenv("ACDSP_NO_MVAVG_PACK") != nullptr;   // A/B knob
+  if (!no_pk && p.win_mode != 0 && (p.n_sample == 64 || p.n_sample == 128 || p.n_sample == 256) && p.n_frames % (512 / p.n_sample) == 0) {
+    a.pk_n = (int32_t)p.n_sample; a.pk_pitch = a.pk_n + 2 * a.hb; a.pk_sh = p.n_sample == 64 ? 6 : (p.n_sample == 128 ? 7 : 8);
+    a.nxg = 0;
+    a.n_sample = p.n_sample * p.n_frames; a.n_frames = 1; a.opf = a.n_sample; a.tpf = a.opf / 512;
+    a.n_tiles = (int64_t)p.n_obj * a.tpf;
+  }
   a.tiles_per_wave = 16;   // 16 KB spans (8 / 16 tiles alike, 32: -5 %, 64: -9 %: profiles/r3_span_sweep.txt)
   while (a.tiles_per_wave > 1 && a.n_tiles / a.tiles_per_wave < 16384) { a.tiles_per_wave /= 2; }
   ACDSP_TUNE_ENV(tpw_env, "ACDSP_MVAVG_TPW");   // tuning knob: tiles per wave
@@ -536,7 +565,8 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   a.xcd_map = (xcd_map_wanted(false) && blocks % 8 == 0) ? 1 : 0;
   const int nr = p.taps <= 9 ? 2 : (p.taps <= 17 ? 3 : (p.taps <= 25 ? 4 : (p.taps <= 33 ? 5 : (p.taps <= 49 ? 7 : 9))));   // taps <= 8 NR - 7
 #define ACDSP_MV_LAUNCH2(NR_, LIN_, CV_)                                                                                           \
-  if (a.mode != 0) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true>), grid, dim3(256), 0, s, a); }                  \
+  if (a.pk_n) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true, true>), grid, dim3(256), 0, s, a); }               \
+  else if (a.mode != 0) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true>), grid, dim3(256), 0, s, a); }             \
   else { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, false>), grid, dim3(256), 0, s, a); }
 #define ACDSP_MV_LAUNCH(NR_)                                                                                                       \
   if (a.linear) {                                                                                                                   \

@@ -293,8 +293,8 @@ def test_mv_avg_random_shapes(seed):
     fa, fo = MV_ACC[rng.integers(len(MV_ACC))], MV_OUT[rng.integers(len(MV_OUT))]
     taps = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 17, 23, 25, 31, 33, 35]))
     mode = ["WIN", "MIRROR", "CLIP"][rng.integers(3)]
-    n_sample = int(rng.choice([8, 16, 24, 64, 200, 504, 512, 520, 1000, 1024, 1032, 2056]))
-    n_frames, n_obj = int(rng.choice([1, 2, 3, 17])), int(rng.choice([1, 2, 5]))
+    n_sample = int(rng.choice([8, 16, 24, 64, 128, 200, 256, 504, 512, 520, 1000, 1024, 1032, 2056]))
+    n_frames, n_obj = int(rng.choice([1, 2, 3, 8, 16, 17])), int(rng.choice([1, 2, 5]))
     x = rand_raw(rng, fin, (n_obj, n_sample * n_frames))
     c = rand_raw(rng, fc, (taps,))
     if rng.integers(3):                                   # mostly: weights small enough for the int32 class

@@ -167,3 +167,18 @@ def test_usage_example_types():
     """The header's usage example (ac_mv_avg.h:47-51): IN <32,16>, OUT <64,32>, ACC <16,2> (the cast of a sample drops bits and wraps), COEFF
     <32,16> -- the order-free int64 kernel."""
     check(9, "MIRROR", A.Fmt(32, 16), A.Fmt(32, 16), A.Fmt(16, 2), A.Fmt(64, 32), 1024, 3, seed=11, path="int64_sums")
+
+
+@pytest.mark.parametrize("mode", ["MIRROR", "CLIP"])
+@pytest.mark.parametrize("n_sample", [64, 128, 256])
+def test_short_frames_share_a_tile(mode, n_sample):
+    """Frames of 64 / 128 / 256 samples are packed 8 / 4 / 2 to a 512-output tile of the streaming kernel (own image slot and patched halos per
+    frame); frame counts that are no multiple of that, and AC_WIN, keep one frame per tile.  Every window length class, every OUT container."""
+    rng = np.random.default_rng(n_sample)
+    fin, fc, fa = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18)
+    per = 512 // n_sample
+    for taps, fo, nf in ((9, A.Fmt(16, 8, True, "RND", "SAT"), 8 * per), (33, A.Fmt(32, 12), 3 * per), (63 if n_sample > 64 else 31, A.Fmt(40, 18), 2 * per),
+                         (1, A.Fmt(16, 8, True, "RND", "SAT"), per), (17, A.Fmt(16, 8, True, "TRN", "WRAP"), 5 * per + 1), (5, A.Fmt(24, 10), 40 * per)):
+        check(taps, mode, fin, fc, fa, fo, n_sample, nf, n_obj=3, seed=taps + nf, coeffs=small_coeffs(rng, taps), path="stream")
+    check(9, "WIN", fin, fc, fa, A.Fmt(16, 8, True, "RND", "SAT"), n_sample, 4 * per, coeffs=small_coeffs(rng, 9), seed=3)
+    check(9, mode, A.Fmt(12, 4), fc, A.Fmt(24, 10), A.Fmt(12, 4, True, "RND", "SAT"), n_sample, 6 * per, coeffs=small_coeffs(rng, 9), seed=4, path="stream")   # per-tap class
