@@ -154,6 +154,10 @@ struct acdsp_fir {
   acdsp_fir_desc_t d;
   int in_eb, out_eb, hl;
   bool use_rt, lossless, coeffs_set;
+  // AC_SAT / AC_SAT_SYM / AC_SAT_ZERO accumulators (round 5): lossless_shape = the exact-sum conditions with the overflow mode left out (create);
+  // sat_free = no partial sum of the CURRENT coefficient set can reach the type's bounds, so the saturation is dead code and the handle
+  // runs the classes of a wrapping accumulator (set_coeffs; every FirParams of the handle then carries AC_WRAP: fir_acc_fmt)
+  bool lossless_shape = false, sat_free = false;
   bool wide = false;   // ACC_TYPE or OUT_TYPE wider than 64 bits: wide.hip (reg_trans words are then 16 bytes)
   bool small_call = false;   // set by run_host around a call that fits the pinned buffers (launch-bound: see acdsp_fir_run)
   int rt_eb = 8;

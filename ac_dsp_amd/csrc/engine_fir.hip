@@ -4,6 +4,13 @@
 using namespace acdsp;
 using namespace acdsp::eng;
 
+// ACC_TYPE as the kernels see it: a saturating accumulator that cannot saturate for the handle's coefficient set is a wrapping one
+static inline DFmt fir_acc_fmt(const acdsp_fir *h) {
+  DFmt a = make_dfmt(h->d.acc);
+  if (h->sat_free) { a.O = ACDSP_WRAP; }
+  return a;
+}
+
 // ---------------------------------------------------------------------------------------------
 // FIR
 // ---------------------------------------------------------------------------------------------
@@ -111,7 +118,7 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
   static const bool no_hybrid = getenv("ACDSP_NO_RT_HYBRID") != nullptr;   // A/B knob: reg_trans on the exact-order kernel for every sample
   h->rt_hybrid = h->use_rt && !no_hybrid && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) && (desc->in.S || desc->in.W <= 15) && desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && !h->wide;
   h->rt_since = desc->n_taps - 1;   // an all-zero state carries no coefficients
-  bool lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64 && (!h->use_rt || h->rt_hybrid) && !h->wide;
+  bool lossless = fa >= fi + fc && fa - fi - fc < 64 && (!h->use_rt || h->rt_hybrid) && !h->wide;   // (the overflow mode: below)
   const int ift = internal_ftype(desc->kind, desc->ftype);
   if (is_fold_odd(ift)) {
     // the ACC_TYPE `fold` must also keep every fraction bit of the pre-add (fc < 0 would let fa >= fi + fc pass with fa < fi)
@@ -120,7 +127,9 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
     int need_i = desc->in.I + 1 + ((desc->acc.S && !desc->in.S) ? 1 : 0);
     lossless = lossless && desc->acc.I >= need_i && (desc->acc.S || (!desc->in.S && ift != kRsFoldOddAnti));
   }
-  h->lossless = lossless;
+  h->lossless_shape = lossless;
+  h->sat_free = false;
+  h->lossless = lossless && desc->acc.O == ACDSP_WRAP;
   h->coeffs_set = false;
   h->path = ACDSP_PATH_GENERIC;
   const size_t hist_bytes = (size_t)desc->n_channels * h->hl * h->in_eb;
@@ -179,7 +188,7 @@ int32_t fir_rt_from_hist(acdsp_fir *h) {
   FirParams k;
   memset(&k, 0, sizeof k);
   k.n_taps = d.n_taps; k.ftype = internal_ftype(d.kind, d.ftype); k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
-  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = fir_acc_fmt(h); k.out = make_dfmt(d.out);
   k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl; k.use_rt = 1;
   k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
   k.x = h->d_hist[h->cur]; k.in_stride = h->hl; k.n = h->hl;
@@ -226,6 +235,39 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, n_sets * d.n_taps * sizeof(int64_t), hipMemcpyHostToDevice));
   h->mfma_ok = false;
   h->in_flip = false;
+  {
+    // Saturating accumulators: |every partial sum, in any order| <= sum|c| max|x| (the folds' pre-added pairs included: effective_coeffs lists
+    // both taps of a pair), plus one LSB per tap where a tap's product is quantised.  Inside the type's SYMMETRIC range the three saturating
+    // modes never act and equal AC_WRAP.  Signed accumulators, no carried partial sums (reg_trans), at most 64 bits.  ACDSP_NO_SAT_FREE: A/B knob.
+    static const bool no_sat_free = getenv("ACDSP_NO_SAT_FREE") != nullptr;
+    const int fi_ = d.in.W - d.in.I, fc_ = d.coeff.W - d.coeff.I, fa_ = d.acc.W - d.acc.I;
+    bool sf = !no_sat_free && d.acc.O != ACDSP_WRAP && d.acc.S && !h->wide && !h->use_rt && d.acc.W >= 2 && d.acc.W <= 64 &&
+              (fa_ >= fi_ + fc_ ? fa_ - fi_ - fc_ < 64 : ((d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && fi_ + fc_ - fa_ < 64));
+    const int ift_ = internal_ftype(d.kind, d.ftype);
+    if (sf && is_fold_odd(ift_)) {   // the `fold` pre-add variable is an ACC_TYPE too
+      const int need_i = d.in.I + 1 + (!d.in.S ? 1 : 0);
+      sf = fa_ >= fi_ && d.acc.I >= need_i;
+    }
+    const unsigned __int128 xmax = d.in.S ? ((unsigned __int128)1 << (d.in.W - 1)) : (((unsigned __int128)1 << d.in.W) - 1);
+    const unsigned __int128 top = ((unsigned __int128)1 << (d.acc.W - 1)) - 1;
+    for (size_t st = 0; st < n_sets && sf; st++) {
+      const std::vector<int64_t> eff = effective_coeffs(coeffs + st * d.n_taps, d.n_taps, ift_);
+      unsigned __int128 sa = 0;
+      for (int64_t v : eff) { sa += (unsigned __int128)(v < 0 ? -(__int128)v : (__int128)v); }
+      unsigned __int128 b = sa * xmax;                       // < 2^64 * 2^64 would overflow: W_in, W_coeff <= 64 but sums of 2^10 taps -- guard
+      if (sa != 0 && b / sa != xmax) { sf = false; break; }
+      if (fa_ >= fi_ + fc_) {
+        const int ls = fa_ - fi_ - fc_;
+        if (ls > 0 && (b >> (127 - ls)) != 0) { sf = false; break; }
+        b <<= ls;
+      } else {
+        b = (b >> (fi_ + fc_ - fa_)) + (unsigned __int128)eff.size() + 1;
+      }
+      sf = b <= top;
+    }
+    h->sat_free = sf;
+    h->lossless = h->lossless_shape && (d.acc.O == ACDSP_WRAP || sf);
+  }
   static const bool no_flip = getenv("ACDSP_NO_UNSIGNED16") != nullptr;   // A/B knob: unsigned 16-bit samples stay on the exact-sum VALU kernel
   const bool flip = !d.in.S && d.in.W == 16 && !no_flip && !h->use_rt;
   const bool i16_in = d.in.W <= 15 || (d.in.W == 16 && (d.in.S || flip));
@@ -281,7 +323,7 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
         build(want);
         FirParams k;
         memset(&k, 0, sizeof k);
-        k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+        k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = fir_acc_fmt(h); k.out = make_dfmt(d.out);
         k.cf.F += want;
         k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
         const int epi = ok ? fir_mfma_epilogue_class(k, worst) : 0;
@@ -293,7 +335,7 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
       // a set per channel needs the register-resident kernels: beyond 9 K-blocks only band-limited sets with the fast int16 epilogue
       FirParams k;
       memset(&k, 0, sizeof k);
-      k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+      k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = fir_acc_fmt(h); k.out = make_dfmt(d.out);
       k.cf.F += h->mfma_cshift;
       k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
       ok = fir_mfma_register_resident(k, worst);
@@ -327,7 +369,7 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
   memset(&kq, 0, sizeof kq);
   kq.n_taps = d.n_taps; kq.ftype = internal_ftype(d.kind, d.ftype); kq.n_ch = d.n_channels; kq.coeffs_per_channel = d.coeffs_per_channel;
   kq.in = make_dfmt(d.in); kq.cf = make_dfmt(d.coeff);
-  if (!h->wide) { kq.acc = make_dfmt(d.acc); kq.out = make_dfmt(d.out); }
+  if (!h->wide) { kq.acc = fir_acc_fmt(h); kq.out = make_dfmt(d.out); }
   kq.in_eb = h->in_eb; kq.out_eb = h->out_eb; kq.hl = h->hl; kq.use_rt = (h->use_rt && !h->rt_hybrid) ? 1 : 0;
   kq.lossless_shift = kq.acc.F - kq.in.F - kq.cf.F;
   static const bool no_lz = getenv("ACDSP_NO_MFMA_LOSSY") != nullptr;        // A/B knob: class B stays on the VALU kernels
@@ -340,7 +382,7 @@ int32_t acdsp_fir_set_coeffs(acdsp_fir_t h, const int64_t *coeffs) {
     const bool fold_odd = is_fold_odd(ift), fold_even = ift == ACDSP_FOLD_EVEN || ift == kRsFoldEven || ift == kRsFoldEvenAnti;
     const bool anti = ift == kRsFoldEvenAnti || ift == kRsFoldOddAnti;
     bool ok = !no_lz && !no_gen && !h->wide && !h->lossless && !h->use_rt && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && !d.coeffs_per_channel &&
-              d.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && d.acc.S && d.acc.W <= 64 && sbits >= 1 && sbits <= 15 &&
+              (d.acc.O == ACDSP_WRAP || h->sat_free) && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && d.acc.S && d.acc.W <= 64 && sbits >= 1 && sbits <= 15 &&
               (h->in_eb == 2 || h->in_eb == 4) && (d.in.W + (d.in.S ? 0 : 1) + 7) / 8 <= h->in_eb &&
               (lz_first || !fir_lossy_fast_ok(kq));
     if (ok && fold_odd) {
@@ -429,7 +471,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
   k.n_taps = d.n_taps; k.ftype = internal_ftype(d.kind, d.ftype); k.n_ch = d.n_channels; k.coeffs_per_channel = d.coeffs_per_channel;
   k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff);
   if (h->wide) { memset(&k.acc, 0, sizeof k.acc); memset(&k.out, 0, sizeof k.out); k.acc.F = d.acc.W - d.acc.I; }
-  else { k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out); }
+  else { k.acc = fir_acc_fmt(h); k.out = make_dfmt(d.out); }
   const bool hyb = h->rt_hybrid;
   k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl; k.use_rt = (h->use_rt && !hyb) ? 1 : 0;
   k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
@@ -611,7 +653,7 @@ int32_t acdsp_fir_mfma_epilogue(acdsp_fir_t h) {
   const acdsp_fir_desc_t &d = h->d;
   FirParams k;
   memset(&k, 0, sizeof k);
-  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+  k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = fir_acc_fmt(h); k.out = make_dfmt(d.out);
   k.cf.F += h->mfma_cshift;
   k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
   return fir_mfma_epilogue_class(k, h->plan) | (h->mfma_cshift << 8) | (h->in_flip ? 1 << 16 : 0);
@@ -625,7 +667,7 @@ int32_t acdsp_fir_mfma_issued(acdsp_fir_t h, int32_t *per_1024_samples) {
     const acdsp_fir_desc_t &d = h->d;
     FirParams k;
     memset(&k, 0, sizeof k);
-    k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+    k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = fir_acc_fmt(h); k.out = make_dfmt(d.out);
     k.cf.F += h->mfma_cshift;
     k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
     *per_1024_samples = fir_mfma_issued_per_step(k, h->plan);

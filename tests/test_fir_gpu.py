@@ -326,11 +326,12 @@ def test_lossy_wrapping_accumulators_on_the_matrix_cores(ftype, types):
 
 def test_lossy_matrix_core_class_bounds():
     """What the class refuses: more than 15 dropped bits, a 64-bit sum that could leave int64 while ACC_TYPE keeps its top bits, sign-dependent
-    rounding, a saturating accumulator, a coefficient set per channel -- all of them bit-exact on the other kernels."""
+    rounding, a saturating accumulator that could saturate, a coefficient set per channel -- all of them bit-exact on the other kernels."""
     x28, c23 = A.Fmt(28, 6), A.Fmt(23, 7)
     for fa, fc, want in ((A.Fmt(64, 42), c23, "generic"),                               # s = 16
                          (A.Fmt(64, 32, True, "TRN_ZERO", "WRAP"), c23, "generic"),
-                         (A.Fmt(64, 32, True, "TRN", "SAT"), c23, "generic"),
+                         (A.Fmt(64, 32, True, "TRN", "SAT"), c23, "mfma_lossy"),          # saturating, but 27 * 2^22 * 2^27 / 2^6 is far inside 63 bits: never fires
+                         (A.Fmt(46, 14, True, "TRN", "SAT"), c23, "generic"),             # ... 45 bits are not enough for this set: exact order
                          (A.Fmt(60, 28, False, "TRN", "WRAP"), c23, "generic"),
                          (A.Fmt(64, 32), A.Fmt(40, 7), "generic")):                     # 2^27 * 27 * 2^39 passes 2^62 and ACC keeps all 64 bits
         check_case(27, "FOLD_ODD", x28, fc, fa, A.Fmt(fa.W, fa.I, fa.S), n_ch=2, n=2048 + 100, kind="prog", splits=[2048], seed=fa.I, expect_path=want)
@@ -378,8 +379,19 @@ def test_saturating_accumulators_on_16_bit_types_keep_the_reference_tap_order(n_
     fin, fc = A.Fmt(16, 2), A.Fmt(16, 2)
     fo = A.Fmt(16, 2, True, "RND", "SAT") if fa.S else A.Fmt(22, 5, True, "RND", "SAT")
     n = 2048 + 600 + n_taps
-    check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=3, n=n, splits=[5, 1200], seed=n_taps + fa.W, expect_path="generic")
-    check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=4, n=n, per_channel=True, splits=[2047], seed=n_taps + fa.F, expect_path="generic")
+
+    def sat_free(c):   # engine_fir.hip: acdsp_fir::sat_free -- the set cannot drive a signed accumulator to its bounds (then it is a wrapping one)
+        if not fa.S:
+            return False
+        s = fin.F + fc.F - fa.F
+        worst = max(int(np.abs(row).sum()) for row in np.atleast_2d(c)) << 15
+        worst = (worst << -s) if s <= 0 else (worst >> s) + n_taps + 1
+        return worst <= (1 << (fa.W - 1)) - 1
+
+    for n_ch, per_channel, splits, seed in ((3, False, [5, 1200], n_taps + fa.W), (4, True, [2047], n_taps + fa.F)):
+        c = rand_raw(np.random.default_rng(1000 + seed), fc, (n_ch, n_taps) if per_channel else (n_taps,))
+        fir = check_case(n_taps, ftype, fin, fc, fa, fo, n_ch=n_ch, n=n, per_channel=per_channel, splits=splits, seed=seed, coeffs=c)
+        assert sat_free(c) or fir.path == "generic", fir.path      # (a set that cannot saturate may still land on the exact-order family: one tap, per-channel sets)
 
 
 @pytest.mark.parametrize("n_taps", [5, 29, 64, 127])
@@ -919,3 +931,35 @@ def test_reg_share_rejects_ftypes_without_a_branch():
     for ft in ("ROTATE_SHIFT", "C_BUFF", "TRANSPOSED"):
         with pytest.raises(A.AcdspError):
             A.Fir(8, ft, A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2), kind="reg_share")
+
+
+@pytest.mark.parametrize("o", ["SAT", "SAT_SYM", "SAT_ZERO"])
+def test_saturating_accumulators_that_cannot_saturate_run_the_wrapping_classes(o):
+    """AC_SAT* accumulators whose bounds no partial sum of the handle's coefficient set can reach are wrapping accumulators (set_coeffs decides per
+    set: acdsp_fir::sat_free).  At the bound exactly -- sum|c| * 2^15 = 2^(W - 1) - 1 is impossible, so one LSB inside and one outside -- with
+    full-scale inputs of the signs that reach it; the set that could saturate keeps the exact-order kernels and does saturate."""
+    fin, fc = A.Fmt(16, 2), A.Fmt(16, 2)
+    n_taps = 32
+    c_in = np.array([1023] * 31 + [1024], dtype=np.int64)              # sum|c| = 32737: 32737 * 2^15 <  2^30 - 1
+    c_out = np.array([1024] * 32, dtype=np.int64)                       # sum|c| = 32768: 32768 * 2^15 = 2^30  >  2^30 - 1
+    fa = A.Fmt(31, 3, True, "TRN", o)                                   # F = 28 = F_in + F_coeff: exact products
+    for c, want in ((c_in, "mfma_i8"), (c_out, "generic")):
+        for fo in (A.Fmt(16, 3, True, "RND", "SAT"), A.Fmt(31, 3)):
+            rng = np.random.default_rng(len(o))
+            x = rand_raw(rng, fin, (3, 4096 + 77))
+            x[0, :] = -32768                                            # every product at its largest magnitude, same sign
+            x[1, ::2] = 32767
+            fir = A.Fir(n_taps, "SHIFT_REG", fin, fc, fa, fo, n_channels=3, kind="load")
+            fir.set_coeffs(c)
+            assert fir.path == want, (fir.path, want)
+            y = run_engine(fir, x, [4096])
+            yo = OracleFir(n_taps, "SHIFT_REG", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_ch=3).run(c, x)
+            assert np.array_equal(y, yo), (o, want)
+    # the lossy class: two bits dropped per tap, one LSB of slack per tap in the bound
+    fa2 = A.Fmt(30, 4, True, "RND", o)
+    check_case(63, "SHIFT_REG", fin, fc, fa2, A.Fmt(16, 2, True, "RND", "SAT"), n=2 * 4096, splits=[4096], coeffs=np.round(np.hanning(65)[1:-1] * 1000).astype(np.int64),
+               expect_path="mfma_lossy")
+    check_case(63, "SHIFT_REG", fin, fc, fa2, A.Fmt(16, 2, True, "RND", "SAT"), n=4096 + 50, splits=[4096], seed=3, expect_path="generic")   # full-range weights: can saturate
+    # folds and a set per channel
+    check_case(31, "FOLD_ODD", fin, fc, A.Fmt(40, 12, True, "TRN", o), A.Fmt(16, 2, True, "RND", "SAT"), n=4096 + 9, splits=[4096],
+               coeffs=np.round(np.hanning(33)[1:-1] * 2000).astype(np.int64), expect_path="mfma_i8")
