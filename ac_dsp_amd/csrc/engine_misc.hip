@@ -20,7 +20,7 @@ struct acdsp_intgdump {
   // neither the table is rebuilt nor uploaded and run() stays asynchronous (no stream synchronisation)
   std::vector<int64_t> last_ns;
   void *last_stream = nullptr;
-  int64_t tbl_grp = 0, tbl_uni_rounds = 0;
+  int64_t tbl_grp = 0, tbl_uni_rounds = 0, tbl_max_rounds = 0;
   int32_t tbl_start = 0;
   Staging st;
 };
@@ -128,6 +128,8 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
     HIP_TRY(hipStreamSynchronize(s));   // blk / chain are stack vectors
     h->tbl_grp = grp; h->tbl_start = start;
     h->tbl_uni_rounds = blk[(size_t)n_blocks];
+    h->tbl_max_rounds = 0;
+    for (int64_t b = 0; b < n_blocks; b++) { if (blk[(size_t)(n_blocks + b)] > h->tbl_max_rounds) { h->tbl_max_rounds = blk[(size_t)(n_blocks + b)]; } }
     for (int64_t b = 1; b < n_blocks && h->tbl_uni_rounds > 0; b++) { if (blk[(size_t)(n_blocks + b)] != h->tbl_uni_rounds) { h->tbl_uni_rounds = 0; } }
     h->last_ns.assign(n_sample, n_sample + n_blocks);
     h->last_stream = stream;
@@ -139,7 +141,16 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
   p.chn = d.chn; p.n_obj = d.n_objects; p.n_blocks = (int32_t)n_blocks;
   p.in = make_dfmt(d.in); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
   p.in_eb = h->in_eb; p.out_eb = h->out_eb; p.in_stride = in_stride; p.out_stride = out_stride;
-  p.lossless = d.acc.O == ACDSP_WRAP && p.acc.F >= p.in.F && p.acc.F - p.in.F < 64 - d.in.W;
+  // A saturating ACC_TYPE whose bounds no block sum of this call can reach is a wrapping one (round 5; cf. acdsp_fir::sat_free): every block
+  // dumps and nothing is carried in, so a sum has at most max-rounds terms of at most max|x| each.
+  bool sat_free = false;
+  if (d.acc.O != ACDSP_WRAP && !h->pending && grp == n_blocks && p.acc.F >= p.in.F && p.acc.F - p.in.F < 64 - d.in.W && (d.acc.S || !d.in.S)) {
+    static const bool no_sat_free = getenv("ACDSP_NO_SAT_FREE") != nullptr;   // A/B knob
+    const unsigned __int128 xmax = d.in.S ? ((unsigned __int128)1 << (d.in.W - 1)) : (((unsigned __int128)1 << d.in.W) - 1);
+    const unsigned __int128 top = d.acc.S ? (((unsigned __int128)1 << (d.acc.W - 1)) - 1) : (((unsigned __int128)1 << d.acc.W) - 1);
+    sat_free = !no_sat_free && (((unsigned __int128)h->tbl_max_rounds * xmax) << (p.acc.F - p.in.F)) <= top;   // rounds < 2^63, xmax <= 2^64 - W .. : inside 128 bits
+  }
+  p.lossless = (d.acc.O == ACDSP_WRAP || sat_free) && p.acc.F >= p.in.F && p.acc.F - p.in.F < 64 - d.in.W;
   p.tile_ok = p.lossless && !h->pending && grp == n_blocks;
   if (p.tile_ok) { p.uni_rounds = h->tbl_uni_rounds; }
   p.x = d_in; p.y = d_out; p.temp = h->d_temp[h->cur];

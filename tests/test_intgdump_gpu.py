@@ -78,6 +78,10 @@ def test_rejects_short_buffers():
     (64, 4, 64, 32, A.Fmt(32, 16), A.Fmt(64, 40), A.Fmt(64, 32)),                      # ... left shift under AC_WRAP
     (64, 4, 64, 32, A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(40, 20, True, "RND", "SAT")),  # rounding add on 64 bits: stays on the tiled kernel
     (64, 4, 64, 32, A.Fmt(32, 16), A.Fmt(63, 31), A.Fmt(48, 31, True, "TRN", "SAT")),  # 63-bit ACC, clamp without a shift
+    (64, 4, 64, 96, A.Fmt(12, 4), A.Fmt(24, 12, True, "TRN", "SAT"), A.Fmt(24, 12)),   # saturating ACC that 64 x 2^11 x 2^4 cannot reach: a wrapping one
+    (64, 4, 64, 96, A.Fmt(12, 4), A.Fmt(22, 10, True, "TRN", "SAT_SYM"), A.Fmt(22, 10)),   # ... exactly one LSB inside (2^21 - 1 against 2^21): still saturating
+    (64, 4, 64, 96, A.Fmt(16, 8), A.Fmt(20, 12, True, "TRN", "SAT"), A.Fmt(20, 12)),   # ... that random full-scale samples do drive into the rails
+    (64, 2, 64, 96, A.Fmt(14, 6, False), A.Fmt(20, 12, False, "TRN", "SAT"), A.Fmt(20, 12, False)),   # unsigned: 64 x (2^14 - 1) < 2^20
 ])
 def test_streaming_kernel_shapes(ns, chn, rounds, n_blk, fin, fa, fo):
     check(ns, chn, fin, fa, fo, [[rounds] * n_blk, [rounds] * (n_blk // 2)], n_obj=5, seed=ns + chn)
