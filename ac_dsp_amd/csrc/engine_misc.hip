@@ -295,6 +295,25 @@ int32_t acdsp_mvavg_run(acdsp_mvavg_t h, const void *d_in, int64_t in_stride, in
   p.in = make_dfmt(d.in); p.cf = make_dfmt(d.coeff); p.acc = make_dfmt(d.acc); p.out = make_dfmt(d.out);
   p.in_eb = h->in_eb; p.out_eb = h->out_eb;
   p.force_generic = (d.flags & ACDSP_FLAG_FORCE_GENERIC) != 0;
+  // A saturating ACC_TYPE that cannot saturate is a wrapping one (cf. acdsp_fir::sat_free): the cast of a sample is exact, and every partial sum
+  // is bounded by sum|c| max|x| 2^d / 2^sh plus one LSB per tap, inside the type's symmetric range.  The kernels then see AC_WRAP.
+  if (d.acc.O != ACDSP_WRAP && d.acc.S && !h->h_coeffs.empty() && !p.force_generic && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && d.acc.W <= 64) {
+    static const bool no_sat_free = getenv("ACDSP_NO_SAT_FREE") != nullptr;   // A/B knob
+    const int dc = p.acc.F - p.in.F, sh = p.cf.F, i_in = d.in.I + (d.in.S ? 0 : 1);
+    if (!no_sat_free && dc >= 0 && dc < 40 && sh >= 0 && sh < 64 && d.acc.I >= i_in) {
+      unsigned __int128 sa = 0;
+      for (int64_t c : h->h_coeffs) { sa += (unsigned __int128)(c < 0 ? -(__int128)c : (__int128)c); }
+      const unsigned __int128 xmax = d.in.S ? ((unsigned __int128)1 << (d.in.W - 1)) : (((unsigned __int128)1 << d.in.W) - 1);
+      const unsigned __int128 top = ((unsigned __int128)1 << (d.acc.W - 1)) - 1;
+      unsigned __int128 b = sa * xmax;                     // sa < 2^74 (1025 taps of 64 bits), xmax <= 2^64: may leave 128 bits
+      if (sa == 0 || b / sa == xmax) {
+        if ((b >> (127 - dc)) == 0) {
+          b = ((b << dc) >> sh) + (unsigned __int128)h->h_coeffs.size() + 1;
+          if (b <= top) { p.acc.O = ACDSP_WRAP; }
+        }
+      }
+    }
+  }
   // order-free class: products (ACC_TYPE) w[j] * coeffs[j] inside 2^62.  The cast sample has at most min(W_acc, W_in + max(F_acc - F_in, 0))
   // bits and the coefficients as many as the set on the handle needs (round 5: the bound by W_acc + W_coeff sent <32,16> samples into a
   // <56,30> accumulator to the 128-bit per-tap kernel)
@@ -311,7 +330,7 @@ int32_t acdsp_mvavg_run(acdsp_mvavg_t h, const void *d_in, int64_t in_stride, in
   }
   const int dcast = p.acc.F - p.in.F, xbits_in = d.in.W + (d.in.S ? 0 : 1) + (dcast > 0 ? dcast : 0);
   const int xbits = xbits_in < d.acc.W + (d.acc.S ? 0 : 1) ? xbits_in : d.acc.W + (d.acc.S ? 0 : 1);
-  p.fast = !p.force_generic && d.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && p.cf.F >= 0 &&
+  p.fast = !p.force_generic && p.acc.O == ACDSP_WRAP && (d.acc.Q == ACDSP_TRN || d.acc.Q == ACDSP_RND) && p.cf.F >= 0 &&
            p.cf.F < 62 && xbits + cbits <= 62;
   p.n_sample = n_sample; p.n_frames = n_frames; p.out_per_frame = opf; p.in_stride = in_stride; p.out_stride = out_stride;
   p.x = d_in; p.y = d_out; p.coeffs = h->d_coeffs; p.h_coeffs = h->h_coeffs.data();

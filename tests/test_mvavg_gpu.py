@@ -140,7 +140,9 @@ def test_stream_kernel_fallbacks():
     c = small_coeffs(rng, 9)
     check(9, "MIRROR", fin, fc, fa, fo, 1020, 3, coeffs=c, seed=1, path="int64_sums")                 # frames not 16-byte aligned
     check(9, "MIRROR", fin, fc, fa, fo, 1024, 3, coeffs=[12000, -9000] * 4 + [30000], seed=2, path="int64_sums")             # sum |c| >= 2^15
-    check(9, "MIRROR", fin, fc, A.Fmt(40, 18, True, "TRN", "SAT"), fo, 1024, 3, coeffs=c, seed=3, path="exact_order")
+    check(9, "MIRROR", fin, fc, A.Fmt(40, 18, True, "TRN", "SAT"), fo, 1024, 3, coeffs=c, seed=3, path="stream")           # saturating, but sum|c| 2^15 is far inside 39 bits: a wrapping one
+    check(9, "MIRROR", fin, fc, A.Fmt(24, 9, True, "TRN", "SAT_SYM"), fo, 1024, 3, coeffs=c, seed=13, path="stream")        # ... 32767 * 2^15 * 2^7 / 2^14 + 10 = 8388362 <= 2^23 - 1: just inside
+    check(9, "MIRROR", fin, fc, A.Fmt(23, 8, True, "TRN", "SAT"), fo, 1024, 3, coeffs=[3600] * 9, seed=14, path="exact_order")   # 32400 * 2^15 > 2^22 * 2^7: can saturate
     check(9, "MIRROR", fin, fc, A.Fmt(20, 4), fo, 1024, 3, coeffs=c, seed=4, path="int64_sums")       # the cast to ACC wraps
     check(9, "WIN", A.Fmt(16, 8, False), fc, fa, fo, 1024, 3, coeffs=c, seed=5, path="int64_sums")    # unsigned 16-bit samples
     check(9, "WIN", A.Fmt(15, 8, False), fc, fa, fo, 1024, 3, coeffs=c, seed=6, path="stream")        # unsigned 15-bit: fits int16
@@ -159,7 +161,8 @@ def test_32_bit_samples_on_the_sliding_window_kernel(mode):
     check(65, mode, A.Fmt(20, 4, False), A.Fmt(18, 1), A.Fmt(44, 18), A.Fmt(30, 10, False), 300, 5, seed=5, path="stream32")   # unsigned samples, short frames
     check(3, mode, f32, A.Fmt(16, 2), A.Fmt(56, 30), A.Fmt(64, 32), 4096, 2, seed=6, path="stream32")
     check(1, mode, f32, A.Fmt(16, 2), A.Fmt(56, 30), A.Fmt(32, 16), 1024, 2, seed=7, path="stream32")
-    check(9, mode, f32, A.Fmt(16, 2), A.Fmt(56, 30, True, "TRN", "SAT"), A.Fmt(32, 16), 1024, 2, seed=8, path="exact_order")   # saturating accumulator: per-tap order
+    check(9, mode, f32, A.Fmt(16, 2), A.Fmt(56, 30, True, "TRN", "SAT"), A.Fmt(32, 16), 1024, 2, seed=8, path="stream32")      # saturating accumulator no sum can reach: a wrapping one
+    check(9, mode, f32, A.Fmt(16, 2), A.Fmt(40, 14, True, "TRN", "SAT"), A.Fmt(32, 14), 1024, 2, seed=18, path="exact_order")  # ... whose cast of a sample already saturates: per-tap order
     check(9, mode, f32, A.Fmt(32, 16), A.Fmt(64, 32), A.Fmt(64, 32), 1024, 2, seed=9)                                          # 64-bit products: not this class
 
 
