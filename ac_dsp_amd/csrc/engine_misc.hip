@@ -155,9 +155,10 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
   if (p.tile_ok) { p.uni_rounds = h->tbl_uni_rounds; }
   p.x = d_in; p.y = d_out; p.temp = h->d_temp[h->cur];
   p.blk_off = h->d_blk; p.blk_rounds = h->d_blk + n_blocks; p.blk_out = h->d_blk + 2 * n_blocks; p.blk_chain = h->d_chain;
-  hipError_t e = launch_intg_dump(p, h->d_temp[h->cur ^ 1], s);
+  bool temp_written = true;
+  hipError_t e = launch_intg_dump(p, h->d_temp[h->cur ^ 1], s, &temp_written);
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "intg_dump kernel launch failed: %s", hipGetErrorString(e)); }
-  h->cur ^= 1;
+  if (temp_written) { h->cur ^= 1; }   // (else: nothing carried in, every block dumped -- the all-zero temp[] of this side stays the state)
   h->pending = start != (int32_t)n_blocks;   // the call ended on blocks that did not dump: their sums sit in temp[]
   return ACDSP_OK;
 }

@@ -1,5 +1,6 @@
 // fir_kernels.hpp -- launch interface between the C-ABI layer (engine.hip) and the FIR kernels.
 #pragma once
+#include <cstdlib>
 #include <vector>
 
 #include "acdsp_dev.hpp"
@@ -106,6 +107,41 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
 // Fused decimator -> FIR cascade on the matrix cores (fir_gen.hip).  pa = stage A as for launch_fir_gen with
 // out_mode 1 (history of >= 256*R + off + 16 samples), pb = stage B formats + output buffer (int32 containers).
 // hipErrorNotSupported: shapes outside the compiled ones (run the two kernels instead).
+// A second stream of a handle (round 5) for the small kernels of a call that neither feed nor follow its main kernel -- the head / tail of an
+// ac_poly_intr call: a few thousand waves, latency-bound, and on the caller's stream they queued behind the main kernel (4.7 % of the bench row).
+// fork() makes the side stream wait for everything enqueued on the caller's stream so far, join() makes the caller's stream wait for the side
+// stream: an ordinary fork / join, legal under stream capture.  ACDSP_NO_SIDE_STREAM=1: everything on the caller's stream (A/B knob).
+// (Same-box A/B, two passes: poly_intr 0.870 -> 0.855 ms; the fused DDC's edge-chunk kernel, 143 us behind a 1.73 ms main kernel, gained nothing
+// from the same treatment -- 1.751 / 1.766 against 1.752 / 1.759 ms -- and stays on the caller's stream.)
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipError_t ensure() {
+    hipError_t e = hipSuccess;
+    if (!s) { e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+    if (e == hipSuccess && !ev_fork) { e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming); }
+    if (e == hipSuccess && !ev_join) { e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming); }
+    return e;
+  }
+  static bool enabled() { static const bool off = getenv("ACDSP_NO_SIDE_STREAM") != nullptr; return !off; }
+  hipError_t fork(hipStream_t main) {
+    hipError_t e = ensure();
+    if (e == hipSuccess) { e = hipEventRecord(ev_fork, main); }
+    if (e == hipSuccess) { e = hipStreamWaitEvent(s, ev_fork, 0); }
+    return e;
+  }
+  hipError_t join(hipStream_t main) {
+    hipError_t e = hipEventRecord(ev_join, s);
+    if (e == hipSuccess) { e = hipStreamWaitEvent(main, ev_join, 0); }
+    return e;
+  }
+  void destroy() {
+    if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+    if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
+    if (s) { (void)hipStreamDestroy(s); s = nullptr; }
+  }
+};
+
 hipError_t launch_cascade(const FirParams &pa, const FirGenPlan &pla, const uint32_t *d_fragA, int w_int, int64_t first,
                           const FirParams &pb, const FirGenPlan &plb, const uint32_t *d_fragB, int64_t n_out, hipStream_t s);
 
@@ -154,7 +190,9 @@ struct IntgDumpParams {
   const int64_t *blk_off, *blk_rounds, *blk_out;
   const int32_t *blk_chain;
 };
-hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStream_t s);
+// *temp_written = false: the call took a tile_ok kernel -- nothing carried in, every block dumped -- and left temp_next alone: the handle's
+// current temp[] is all zero and stays the state (round 5: a zeroing kernel per call was 1.4 % of the bench row)
+hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStream_t s, bool *temp_written);
 
 // Moving average (mv_avg.hip).  win_mode 0 AC_WIN, 1 AC_MIRROR, 2 AC_CLIP; rows = objects, frames of n_sample inputs back to back
 struct MvAvgParams {

@@ -537,18 +537,11 @@ static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
   }
 }
 
-__global__ void intg_dump_zero_kernel(int64_t *temp_next, int64_t n) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) { temp_next[t] = 0; }
-}
-
-hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStream_t s) {
+hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStream_t s, bool *temp_written) {
+  *temp_written = true;
   static const bool no_stream = getenv("ACDSP_NO_INTG_STREAM") != nullptr;   // A/B knob
   if (!no_stream && try_stream(p, s)) {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { return e; }
-    const int64_t nt = (int64_t)p.n_obj * p.chn;
-    hipLaunchKernelGGL(intg_dump_zero_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, temp_next, nt);   // every block dumped: temp[] = 0
+    *temp_written = false;   // every block dumped and nothing was carried in (tile_ok): temp[] was zero and is zero
     return hipGetLastError();
   }
   if (p.tile_ok && p.chn <= 256) {
@@ -560,10 +553,7 @@ hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStre
       case 4: hipLaunchKernelGGL(intg_dump_tile_kernel<int32_t>, grid, dim3(256), 48 * 1024, s, p, bpw, lds_elems); break;
       default: hipLaunchKernelGGL(intg_dump_tile_kernel<int64_t>, grid, dim3(256), 48 * 1024, s, p, bpw, lds_elems); break;
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { return e; }
-    const int64_t nt = (int64_t)p.n_obj * p.chn;
-    hipLaunchKernelGGL(intg_dump_zero_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, temp_next, nt);   // every block dumped: temp[] = 0
+    *temp_written = false;
     return hipGetLastError();
   }
   const int64_t n_work = (int64_t)(p.n_blocks + 1) * p.chn;
