@@ -469,16 +469,19 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
   } else {
     e = launch_polyintr(p, h->d_saved[h->cur ^ 1], s);
   }
+  hipError_t eh = hipSuccess;
+  if (e == hipSuccess) {
+    FirParams k;
+    memset(&k, 0, sizeof k);
+    k.n_ch = d.n_channels; k.in = p.in; k.in_eb = h->in_eb; k.hl = h->hl; k.in_stride = in_stride; k.n = n_in; k.x = d_in; k.hist = p.hist;
+    eh = launch_fir_hist_update(k, h->d_hist[h->cur ^ 1], vs);   // (always the other buffer: the saved sums flip with it -- so it may run beside the main kernel too)
+  }
   if (forked) {   // (always joined, used or not: an unjoined fork is an error under stream capture)
     const hipError_t ej = h->side.join(s);
     if (e == hipSuccess && ej != hipSuccess) { e = ej; }
   }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_intr kernel launch failed: %s", hipGetErrorString(e)); }
-  FirParams k;
-  memset(&k, 0, sizeof k);
-  k.n_ch = d.n_channels; k.in = p.in; k.in_eb = h->in_eb; k.hl = h->hl; k.in_stride = in_stride; k.n = n_in; k.x = d_in; k.hist = p.hist;
-  e = launch_fir_hist_update(k, h->d_hist[h->cur ^ 1], s);   // (always the other buffer: the saved sums flip with it)
-  if (e != hipSuccess) { return fail(ACDSP_EHIP, "poly_intr state kernel launch failed: %s", hipGetErrorString(e)); }
+  if (eh != hipSuccess) { return fail(ACDSP_EHIP, "poly_intr state kernel launch failed: %s", hipGetErrorString(eh)); }
   h->cur ^= 1;
   h->t_total += n_in;
   return ACDSP_OK;
