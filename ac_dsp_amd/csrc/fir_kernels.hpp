@@ -112,7 +112,8 @@ hipError_t launch_fir_gen(const FirParams &p, const FirGenPlan &pl, const uint32
 // fork() makes the side stream wait for everything enqueued on the caller's stream so far, join() makes the caller's stream wait for the side
 // stream: an ordinary fork / join, legal under stream capture.  ACDSP_NO_SIDE_STREAM=1: everything on the caller's stream (A/B knob).
 // (Same-box A/B, two passes: poly_intr 0.899 -> 0.846 ms with the state kernel on the side stream too; the fused DDC's edge-chunk kernel, 143 us behind a 1.73 ms main kernel, gained nothing
-// from the same treatment -- 1.751 / 1.766 against 1.752 / 1.759 ms -- and stays on the caller's stream.)
+// from the same treatment -- 1.751 / 1.766 against 1.752 / 1.759 ms -- and the head / tail of a CIC interpolator call (2 x 11 us beside
+// 3.2 ms) lost 0.3 - 0.8 %: both stay on the caller's stream.)
 struct SideStream {
   hipStream_t s = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
