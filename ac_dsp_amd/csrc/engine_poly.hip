@@ -11,6 +11,7 @@ struct acdsp_polydec {
   acdsp_polydec_desc_t d;
   int in_eb, out_eb, hl;
   bool lossless = false, coeffs_set = false, gen_ok = false;
+  bool lossless_shape = false, sat_free = false;   // a saturating ACC_TYPE no partial sum of the current set can reach is a wrapping one (cf. acdsp_fir::sat_free)
   void *d_hist[2] = {nullptr, nullptr};
   int cur = 0;
   int64_t *d_coeffs = nullptr;
@@ -45,7 +46,8 @@ int32_t acdsp_polydec_create(const acdsp_polydec_desc_t *desc, acdsp_polydec_t *
   h->in_eb = elem_bytes(desc->in.W);
   h->out_eb = elem_bytes(desc->out.W);
   h->hl = round_up(desc->n_taps * desc->df + 15, 32);
-  h->lossless = desc->acc.O == ACDSP_WRAP && fa >= fi + fc && fa - fi - fc < 64;
+  h->lossless_shape = fa >= fi + fc && fa - fi - fc < 64;
+  h->lossless = h->lossless_shape && desc->acc.O == ACDSP_WRAP;
   const size_t hb = (size_t)desc->n_channels * h->hl * h->in_eb;
   hipError_t e = hipSuccess;
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
@@ -86,6 +88,23 @@ int32_t acdsp_polydec_set_coeffs(acdsp_polydec_t h, const int64_t *coeffs) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
   h->gen_ok = false;
+  {
+    // |every partial sum of an output| <= sum|c| max|x| over all NTAPS * DF coefficients: inside the symmetric range of a signed saturating
+    // ACC_TYPE the saturation never acts (ACDSP_NO_SAT_FREE: A/B knob)
+    static const bool no_sat_free = getenv("ACDSP_NO_SAT_FREE") != nullptr;
+    bool sf = !no_sat_free && d.acc.O != ACDSP_WRAP && d.acc.S && h->lossless_shape && d.acc.W >= 2 && d.acc.W <= 64;
+    if (sf) {
+      const int ls = (d.acc.W - d.acc.I) - (d.in.W - d.in.I) - (d.coeff.W - d.coeff.I);
+      unsigned __int128 sa = 0;
+      for (int i = 0; i < n; i++) { sa += (unsigned __int128)(coeffs[i] < 0 ? -(__int128)coeffs[i] : (__int128)coeffs[i]); }
+      const unsigned __int128 xmax = d.in.S ? ((unsigned __int128)1 << (d.in.W - 1)) : (((unsigned __int128)1 << d.in.W) - 1);
+      const unsigned __int128 top = ((unsigned __int128)1 << (d.acc.W - 1)) - 1;
+      unsigned __int128 b = sa * xmax;
+      sf = (sa == 0 || b / sa == xmax) && (ls == 0 || (b >> (127 - ls)) == 0) && (b << ls) <= top;
+    }
+    h->sat_free = sf;
+    h->lossless = h->lossless_shape && (d.acc.O == ACDSP_WRAP || sf);
+  }
   static const bool no_gen = getenv("ACDSP_NO_GEN") != nullptr;
   if (h->lossless && !(d.flags & ACDSP_FLAG_FORCE_GENERIC) && !no_gen && (d.in.W + (d.in.S ? 0 : 1) + 7) / 8 <= h->in_eb) {
     // decimating FIR  y[g] = sum_k hh[k] x[g*DF + DF-1 - k],  hh[df + tp*DF] = c[tp + NTAPS*df]
@@ -119,6 +138,7 @@ int32_t acdsp_polydec_run(acdsp_polydec_t h, const void *d_in, int64_t in_stride
   memset(&k, 0, sizeof k);
   k.n_taps = d.n_taps * d.df; k.ftype = ACDSP_SHIFT_REG; k.n_ch = d.n_channels;
   k.in = make_dfmt(d.in); k.cf = make_dfmt(d.coeff); k.acc = make_dfmt(d.acc); k.out = make_dfmt(d.out);
+  if (h->sat_free) { k.acc.O = ACDSP_WRAP; }
   k.in_eb = h->in_eb; k.out_eb = h->out_eb; k.hl = h->hl;
   k.lossless_shift = k.acc.F - k.in.F - k.cf.F;
   k.in_stride = in_stride; k.out_stride = out_stride; k.n = n_in;

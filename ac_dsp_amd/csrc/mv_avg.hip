@@ -159,11 +159,13 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     { const v4u_t t_ = *reinterpret_cast<const v4u_t *>(row + gc); T.mv = make_uint4(t_.x, t_.y, t_.z, t_.w); }
     const int64_t g2 = f_ti * 512 - (PK ? 0 : a.hb) + 512 + 8 * (lane < a.nxg ? lane : 0);
     T.ev = *reinterpret_cast<const uint4 *>(row + (g2 < n ? g2 : n - 8));
+#ifndef ACDSP_MV_LDS_EDGE
     if constexpr (EDGE) {   // frame-edge patches of AC_CLIP / AC_MIRROR: the source samples of positions -1 - lane and n + lane
       const int l = lane < a.h ? lane : 0;
       T.fxl = row[a.mode == 2 ? 0 : 1 + l];
       T.fxr = row[a.mode == 2 ? n - 1 : n - 2 - l];
     }
+#endif
     if (f_left > 1) {
       f_left--;
       if (++f_ti == a.tpf) {
@@ -192,10 +194,27 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
           const int src = a.mode == 2 ? (right ? base + a.pk_n - 1 : base) : (right ? base + a.pk_n - 2 - k : base + 1 + k);
           img[dst] = img[src];
         }
-      } else if (lane < a.h) {
-        if (ti == 0) { img[a.hb - 1 - lane] = T.fxl; }
-        const int64_t idx = a.n_sample + lane - p0;
-        if (idx < REGION) { img[idx] = T.fxr; }
+      } else {
+#ifdef ACDSP_MV_LDS_EDGE
+        // the sources of a frame's out-of-frame positions lie inside the tile's own image (the first h + 1 / last h + 1 samples of the frame)
+        const bool left = ti == 0, right = a.n_sample - p0 < REGION;
+        if (left || right) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (lane < a.h) {
+            if (left) { img[a.hb - 1 - lane] = img[a.mode == 2 ? a.hb : a.hb + 1 + lane]; }
+            const int64_t idx = a.n_sample + lane - p0;
+            if (right && idx < REGION) { img[idx] = img[a.mode == 2 ? a.n_sample - 1 - p0 : a.n_sample - 2 - lane - p0]; }
+          }
+        }
+#else
+        if (lane < a.h) {
+          if (ti == 0) { img[a.hb - 1 - lane] = T.fxl; }
+          const int64_t idx = a.n_sample + lane - p0;
+          if (idx < REGION) { img[idx] = T.fxr; }
+        }
+#endif
       }
     }
     fetch(T);

@@ -127,3 +127,44 @@ def test_calls_whose_phase_would_be_baked_in_are_refused_under_capture():
                 errs.append(str(e))
     assert errs[0] and "graph capture" in errs[0], errs
     assert errs[1] and "graph capture" in errs[1], errs
+
+
+def test_poly_intr_calls_with_their_side_stream_replayed_from_a_graph():
+    """ac_poly_intr forks the head / tail / state kernels of a call onto a stream of its own beside the matrix-core kernel (fir_kernels.hpp:
+    SideStream): event record / wait pairs, which a capture turns into graph edges.  The handle flips its state buffers every call, so calls are
+    captured in pairs; replays continue the stream."""
+    nch, cs, nk, ifac, n_taps = 24, 4096, 2, 8, 16
+    fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
+    rng = np.random.default_rng(17)
+    csz = (n_taps // 2 - 1) + (ifac - 1) * n_taps // 2 + 1
+    c = rng.integers(-3000, 3000, size=csz, dtype=np.int64)
+    sign, corr = rng.integers(0, 2, size=ifac), np.arange(ifac)
+
+    def make():
+        e = A.PolyIntr(n_taps, csz, ifac, "FOLD_EVEN", fin, fc, fa, fo, n_channels=nch)
+        e.set_ctrl(c, sign, corr)
+        return e
+
+    x = torch.from_numpy(rng.integers(-32768, 32768, size=(nk, nch, cs), dtype=np.int16)).cuda()
+    n_replays = 3
+    ref_eng = make()
+    refs = [torch.stack([ref_eng.run(x[k]).clone() for k in range(nk)]) for _ in range(n_replays)]
+    assert ref_eng.path == "mfma_gen"
+    torch.cuda.synchronize()
+    eng = make()
+    y = torch.zeros_like(refs[0])
+    for k in range(nk):                # one-time work outside the capture
+        eng.run(x[k])
+    eng.reset()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+        for k in range(nk):
+            y[k].copy_(eng.run(x[k]))
+    eng.reset()
+    torch.cuda.synchronize()
+    for r in range(n_replays):
+        y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, refs[r]), "replay %d differs from the eager stream" % r

@@ -73,3 +73,12 @@ def test_ring_kernel_shapes_outside_the_bench_row(nt, df, fo):
     tail and the second call's head (history in front of its first window) on the general kernel; every output against the oracle."""
     groups = 256 * 8 * 3 + 200          # three chunks of the longest shape (eight 256-output steps) + a ragged tail
     check(nt, df, A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(44, 16), fo, n_groups=groups, expect="mfma_gen", splits=[256 * 9 + 16], seed=nt * df + fo.W)
+
+
+@pytest.mark.parametrize("o", ["SAT", "SAT_SYM", "SAT_ZERO"])
+def test_saturating_accumulator_that_cannot_saturate_runs_on_the_matrix_cores(o):
+    """A signed AC_SAT* ACC_TYPE whose bounds sum|c| * max|x| cannot reach is a wrapping one (acdsp_polydec_set_coeffs decides per set); a set that
+    could reach them keeps the exact-order kernel -- and does saturate with full-scale inputs."""
+    fin, fc, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(16, 2, True, "RND", "SAT")
+    check(16, 8, fin, fc, A.Fmt(60, 32, True, "TRN", o), fo, n_groups=704, expect="mfma_gen", splits=[32], seed=5)     # 128 * 2^15 * 2^15 << 2^59
+    check(16, 8, fin, fc, A.Fmt(34, 6, True, "TRN", o), fo, n_groups=704, expect="generic", splits=[32], seed=6)       # 2^37 > 2^33: exact order
