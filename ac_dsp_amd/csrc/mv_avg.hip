@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
         }
       } else {
 #ifdef ACDSP_MV_LDS_EDGE
-        // the sources of a frame's out-of-frame positions lie inside the tile's own image (the first h + 1 / last h + 1 samples of the frame)
+        // A/B variant, off: the sources of a frame's out-of-frame positions lie inside the tile's own image (the first h + 1 / last h + 1 samples of
+        // the frame), so the two scattered 2-byte loads per tile (fxl / fxr) could go.  Same box, three passes: 0.7625 ms with them, 0.7638 without.
         const bool left = ti == 0, right = a.n_sample - p0 < REGION;
         if (left || right) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
