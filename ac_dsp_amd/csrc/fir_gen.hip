@@ -625,9 +625,9 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   constexpr int PPB = 16 / S;                                 // samples of a 16-byte piece = bytes of one of its planes
   constexpr int SPK = 64 / S;                                 // slots per 1 KB load
   static_assert(S == 2 || S == 4, "ring kernel: 2- and 4-byte samples");
-  // odd factors above 1 (R = 7: the reference's CIC testbench) keep the identity slot map -- gen_slot_map leaves them alone too: one or two
-  // extra LDS cycles per fragment read -- so a 1 KB load need not hold whole groups of R slots
-  constexpr bool HOLES = (R % 2 == 0) || R == 1;
+  // odd factors above 1 (R = 7: the reference's CIC testbench) and even ones that do not divide the slots of a 1 KB load (R = 10) keep the identity
+  // slot map -- gen_slot_map leaves odd factors alone too: one or two extra LDS cycles per fragment read -- so a load need not hold whole groups of R slots
+  constexpr bool HOLES = (R % 2 == 0 && SPK % R == 0) || R == 1;   // (even factors that do not divide a 1 KB load -- R = 10: R = 2 mod 4 is conflict-free without holes anyway)
   static_assert((!HOLES || SPK % R == 0) && H <= ADV && S * H <= 64 && NLD * SPK == M * ADV && NLD >= 1 && SPW % M == 0, "ring geometry");
   constexpr int KSTEP = HOLES ? (SPK + 2 * (SPK / R)) * 16 : SPK * 16;   // LDS bytes from a piece of load k to the same lane's piece of load k + 1
   constexpr int PADV = HOLES ? (ADV + 2 * (ADV / R)) * 16 : ADV * 16;    // LDS bytes a step advances
@@ -1177,7 +1177,10 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
     // plain (R = 1) FIR on 32-bit samples, up to three coefficient digits and three K-blocks (~130 taps): one 1 KB load per 256-output step
     else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 3 && (oeb == 8 || oeb == 4) && pl.R == 1 && !ring_env) { ring_shape = oeb == 8 ? 20 : 21; r_spw = 8; }
     else if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 4 && oeb == 8 && pl.R == 7 && !ring_env) { ring_shape = 7; r_spw = 2; }   // CIC R7 (M2 N4: the reference testbench) on int32: 7 KB per step
-    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 3 && (oeb == 4 || oeb == 8) && pl.R == 5 && !ring_env) { ring_shape = oeb == 4 ? 8 : 9; r_spw = 4; }   // CIC R5 on int16: 2.5 KB per step, one load group per two steps
+    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 3 && (oeb == 4 || oeb == 8) && pl.R == 5 && !ring_env) { ring_shape = oeb == 4 ? 8 : 9; r_spw = 4; }
+    // decimal rates: R = 10 on int32 (10 KB per step, two steps per wave) and on int16 (5 KB per step, four steps)
+    else if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 4 && oeb == 8 && pl.R == 10 && !ring_env) { ring_shape = 30; r_spw = 2; }
+    else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 4 && (oeb == 4 || oeb == 8) && pl.R == 10 && !ring_env) { ring_shape = oeb == 4 ? 31 : 32; r_spw = 4; }   // CIC R5 on int16: 2.5 KB per step, one load group per two steps
     else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 6; if (!ring_env) { r_spw = 1; r_pf = 1; } }   // CIC R16 N5 on int32: 16 KB per step = one step per wave (LDS: 18 KB of planes per step)
   }
   if (promote && ring_shape) { a.px = 4; a.corr = gen_rebias_corr(a.px, pl.sum_h); set_pairwise(); }
@@ -1223,6 +1226,9 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
     else if (ring_shape == 6) { e = launch_ring1<int32_t, 4, 3, 6, 16, 8, 1, 1, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 7) { e = launch_ring1<int32_t, 4, 2, 4, 7, 8, 2, 2, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 8) { e = launch_ring1<int16_t, 2, 2, 3, 5, 4, 4, 2, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 30) { e = launch_ring1<int32_t, 4, 2, 4, 10, 8, 2, 2, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 31) { e = launch_ring1<int16_t, 2, 3, 4, 10, 4, 4, 2, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 32) { e = launch_ring1<int16_t, 2, 3, 4, 10, 8, 4, 2, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 9) { e = launch_ring1<int16_t, 2, 2, 3, 5, 8, 4, 2, true, false>(grid, s, p, fr, a); }
     // (plans of ONE K-block -- up to ~49 taps: the reference testbenches' 27 / 29 -- have their own instantiations: the three-block shapes
     // issue 3 x the MFMAs on zero fragments, 36 instead of 12 per 256 outputs on 32-bit samples -- the matrix pipe, not HBM, bounded them)

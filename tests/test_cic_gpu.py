@@ -237,6 +237,10 @@ def test_long_runs_take_the_branch_free_kernel(q, o):
     (7, 2, 4, A.Fmt(30, 10, False), None),                        # unsigned samples: 31-bit signed planes
     (8, 2, 3, A.Fmt(24, 8), None),                                # 24-bit samples in int32 containers: the sign plane rides along as a fourth plane
     (4, 1, 4, A.Fmt(20, 3), A.Fmt(36, 19, True, "RND", "SAT")),
+    (10, 1, 5, A.Fmt(32, 16), None),                              # R = 10 (even, does not divide a 1 KB load: identity slot map), two 10 KB steps per wave
+    (10, 1, 5, A.Fmt(32, 16), A.Fmt(44, 24, True, "RND", "SAT")),
+    (10, 1, 4, A.Fmt(16, 1), None),                               # ... on int16 into 4-byte containers (INT_TYPE <30,15>)
+    (10, 2, 3, A.Fmt(16, 1), A.Fmt(40, 25)),                      # ... into 8-byte containers, differential delay 2
     (5, 1, 6, A.Fmt(16, 1), None),                                # R = 5 on int16: two steps per load group (2.5 KB each), INT_TYPE <30,15>
     (5, 1, 6, A.Fmt(16, 1), A.Fmt(40, 25)),                       # ... into 8-byte containers
     (5, 2, 3, A.Fmt(16, 4), A.Fmt(24, 10, True, "RND", "SAT")),
