@@ -241,6 +241,16 @@ def test_long_runs_take_the_branch_free_kernel(q, o):
     (10, 1, 5, A.Fmt(32, 16), A.Fmt(44, 24, True, "RND", "SAT")),
     (10, 1, 4, A.Fmt(16, 1), None),                               # ... on int16 into 4-byte containers (INT_TYPE <30,15>)
     (10, 2, 3, A.Fmt(16, 1), A.Fmt(40, 25)),                      # ... into 8-byte containers, differential delay 2
+    (3, 1, 5, A.Fmt(16, 1), None),                                # small and decimal rates of multistage decimators: 3, 6, 12, 20
+    (3, 2, 4, A.Fmt(16, 1), A.Fmt(40, 25)),
+    (3, 1, 5, A.Fmt(32, 16), None),
+    (6, 1, 5, A.Fmt(16, 1), None),
+    (6, 1, 4, A.Fmt(16, 1), A.Fmt(34, 19)),
+    (6, 1, 5, A.Fmt(32, 16), A.Fmt(40, 24, True, "RND", "SAT")),
+    (12, 1, 4, A.Fmt(16, 1), None),
+    (12, 1, 5, A.Fmt(16, 1), None),
+    (20, 1, 3, A.Fmt(16, 1), None),
+    (20, 1, 5, A.Fmt(16, 1), None),
     (5, 1, 6, A.Fmt(16, 1), None),                                # R = 5 on int16: two steps per load group (2.5 KB each), INT_TYPE <30,15>
     (5, 1, 6, A.Fmt(16, 1), A.Fmt(40, 25)),                       # ... into 8-byte containers
     (5, 2, 3, A.Fmt(16, 4), A.Fmt(24, 10, True, "RND", "SAT")),

@@ -144,7 +144,7 @@ def test_fir_long_band_limited_sets(seed):
 def test_cic_random_shapes(seed):
     rng = np.random.default_rng(2000 + seed)
     interp = bool(rng.integers(2))
-    R = int(rng.choice([2, 3, 5, 7, 8, 10, 16, 32]))
+    R = int(rng.choice([2, 3, 5, 6, 7, 8, 10, 12, 16, 20, 32]))
     M = int(rng.choice([1, 2, 3]))
     N = int(rng.choice([1, 2, 4, 5]))
     fin = [A.Fmt(16, 1), A.Fmt(32, 16), A.Fmt(12, 12, False), A.Fmt(20, 4), A.Fmt(24, 8)][rng.integers(5)]
