@@ -1187,7 +1187,9 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 3 && (oeb == 4 || oeb == 8) && pl.R == 6 && !ring_env) { ring_shape = oeb == 4 ? 36 : 37; r_spw = 4; }
     else if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 3 && oeb == 8 && pl.R == 6 && !ring_env) { ring_shape = 38; r_spw = 2; }
     else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 5 && (oeb == 4 || oeb == 8) && pl.R == 12 && !ring_env) { ring_shape = oeb == 4 ? 39 : 40; r_spw = 2; }
-    else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 8 && (oeb == 4 || oeb == 8) && pl.R == 20 && !ring_env) { ring_shape = oeb == 4 ? 41 : 42; r_spw = 2; }   // CIC R5 on int16: 2.5 KB per step, one load group per two steps
+    else if (in_eb == 2 && px == 2 && pc <= 3 && nb <= 8 && (oeb == 4 || oeb == 8) && pl.R == 20 && !ring_env) { ring_shape = oeb == 4 ? 41 : 42; r_spw = 2; }
+    else if (in_eb == 4 && px == 4 && pc <= 2 && nb <= 3 && oeb == 8 && pl.R == 5 && !ring_env) { ring_shape = 43; r_spw = 2; }
+    else if (in_eb == 2 && px == 2 && pc <= 2 && nb <= 4 && (oeb == 4 || oeb == 8) && pl.R == 7 && !ring_env) { ring_shape = oeb == 4 ? 44 : 45; r_spw = 4; }   // CIC R5 on int16: 2.5 KB per step, one load group per two steps
     else if (in_eb == 4 && px == 4 && pc <= 3 && nb <= 6 && oeb == 8 && pl.R == 16) { ring_shape = 6; if (!ring_env) { r_spw = 1; r_pf = 1; } }   // CIC R16 N5 on int32: 16 KB per step = one step per wave (LDS: 18 KB of planes per step)
   }
   if (promote && ring_shape) { a.px = 4; a.corr = gen_rebias_corr(a.px, pl.sum_h); set_pairwise(); }
@@ -1246,6 +1248,9 @@ hipError_t launch_fir_gen(const FirParams &p_in, const FirGenPlan &pl, const uin
     else if (ring_shape == 40) { e = launch_ring1<int16_t, 2, 2, 5, 12, 8, 2, 2, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 41) { e = launch_ring1<int16_t, 2, 3, 8, 20, 4, 2, 2, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 42) { e = launch_ring1<int16_t, 2, 3, 8, 20, 8, 2, 2, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 43) { e = launch_ring1<int32_t, 4, 2, 3, 5, 8, 2, 2, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 44) { e = launch_ring1<int16_t, 2, 2, 4, 7, 4, 4, 2, true, false>(grid, s, p, fr, a); }
+    else if (ring_shape == 45) { e = launch_ring1<int16_t, 2, 2, 4, 7, 8, 4, 2, true, false>(grid, s, p, fr, a); }
     else if (ring_shape == 9) { e = launch_ring1<int16_t, 2, 2, 3, 5, 8, 4, 2, true, false>(grid, s, p, fr, a); }
     // (plans of ONE K-block -- up to ~49 taps: the reference testbenches' 27 / 29 -- have their own instantiations: the three-block shapes
     // issue 3 x the MFMAs on zero fragments, 36 instead of 12 per 256 outputs on 32-bit samples -- the matrix pipe, not HBM, bounded them)

@@ -251,6 +251,10 @@ def test_long_runs_take_the_branch_free_kernel(q, o):
     (12, 1, 5, A.Fmt(16, 1), None),
     (20, 1, 3, A.Fmt(16, 1), None),
     (20, 1, 5, A.Fmt(16, 1), None),
+    (5, 1, 5, A.Fmt(32, 16), None),
+    (7, 2, 4, A.Fmt(16, 1), None),                                # the reference testbench's factor on 16-bit samples: INT_TYPE <32,17>, 4-byte containers
+    (7, 1, 5, A.Fmt(16, 1), None),                                # ... 16 + 5 log2(7) -> 31 bits, 4-byte containers
+    (7, 2, 5, A.Fmt(16, 1), None),                                # ... 36 bits: 8-byte containers
     (5, 1, 6, A.Fmt(16, 1), None),                                # R = 5 on int16: two steps per load group (2.5 KB each), INT_TYPE <30,15>
     (5, 1, 6, A.Fmt(16, 1), A.Fmt(40, 25)),                       # ... into 8-byte containers
     (5, 2, 3, A.Fmt(16, 4), A.Fmt(24, 10, True, "RND", "SAT")),

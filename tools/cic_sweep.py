@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 NCH, N = 4096, 1 << 20
 for (W, I, R, M, Ns) in ((32, 16, 8, 1, 5), (32, 16, 7, 2, 4), (32, 16, 4, 1, 3), (32, 16, 16, 1, 5), (32, 16, 32, 1, 4), (32, 16, 10, 1, 5), (16, 1, 16, 1, 5),
                          (16, 1, 8, 1, 4), (16, 1, 64, 1, 3), (16, 1, 5, 1, 6), (24, 8, 8, 2, 3),
-                         (16, 1, 3, 1, 5), (32, 16, 3, 1, 5), (16, 1, 6, 1, 5), (32, 16, 6, 1, 5), (16, 1, 10, 1, 4), (16, 1, 12, 1, 5), (16, 1, 20, 1, 5)):
+                         (16, 1, 3, 1, 5), (32, 16, 3, 1, 5), (16, 1, 6, 1, 5), (32, 16, 6, 1, 5), (16, 1, 10, 1, 4), (16, 1, 12, 1, 5), (16, 1, 20, 1, 5), (32, 16, 5, 1, 5), (16, 1, 7, 2, 4)):
     fin = A.Fmt(W, I)
     it = A.Cic(False, R, M, Ns, fin, fin, n_channels=1, device=0).int_type
     fo = A.Fmt(it.W, it.I)
