@@ -46,7 +46,10 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
   // LDS tile [64 rows][64 samples] with a row pitch of 64*sizeof(TIN)+4 bytes (== 1 dword mod 32): the
   // per-sample column read of lane c (row c) is bank-conflict free for every container width
   constexpr int ROWB = kCicTile * (int)sizeof(TIN) + 4;
-  constexpr int OB = 16;                                // decimator: outputs staged per row before a flush (128-byte row segments; 8 and 32 measured slower)
+#ifndef ACDSP_CIC_OB
+#define ACDSP_CIC_OB 16
+#endif
+  constexpr int OB = ACDSP_CIC_OB;                      // decimator: outputs staged per row before a flush (128-byte row segments; 8 and 32 measured slower)
   constexpr int OPITCH = OB + 1;                        // int64 words per staged row (conflict-free ds_write_b64)
   __shared__ __attribute__((aligned(16))) unsigned char lds[64 * ROWB];
   __shared__ int64_t obuf[INTERP ? 1 : 64 * OPITCH];
