@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
 #ifndef ACDSP_CIC_OB
 #define ACDSP_CIC_OB 16
 #endif
-  constexpr int OB = ACDSP_CIC_OB;                      // decimator: outputs staged per row before a flush (128-byte row segments; 8 and 32 measured slower)
+  constexpr int OB = ACDSP_CIC_OB;                      // decimator: outputs staged per row before a flush (128-byte row segments; 8 and 32 measured slower -- again in round 5 at R = 32 / 64, where the smaller tile buys occupancy: 16 -> 8 -> 4: 3.57 / 3.94 / 4.09 ms and 2.38 / 2.52 / 2.69 ms)
   constexpr int OPITCH = OB + 1;                        // int64 words per staged row (conflict-free ds_write_b64)
   __shared__ __attribute__((aligned(16))) unsigned char lds[64 * ROWB];
   __shared__ int64_t obuf[INTERP ? 1 : 64 * OPITCH];
