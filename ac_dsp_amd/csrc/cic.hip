@@ -58,8 +58,9 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
   const int ch0 = blockIdx.y * 64;
   const int ch = ch0 + lane;
   const bool ch_ok = ch < p.n_ch;
-  const int64_t c_start = (int64_t)blockIdx.x * p.chunk;
+  const int64_t c_start = p.t_from + (int64_t)blockIdx.x * p.chunk;
   const int64_t c_end = (c_start + p.chunk < p.n_in) ? c_start + p.chunk : p.n_in;
+  const int64_t e_start = (!INTERP && p.emit_from > c_start) ? p.emit_from : c_start;   // first sample whose emission is stored
   const int64_t s0 = c_start - (int64_t)p.warm_tiles * kCicTile;  // >= -hl
   const int R = p.R;
 
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(64) cic_kernel(CicParams p) {
     // ---- every lane walks its own channel row ----
     // samples [0, nv) of the tile exist; emissions are stored from sample index e0 on (warm-up before)
     const int nv = (c_end - ts < kCicTile) ? (int)(c_end - ts) : kCicTile;
-    const int e0 = (c_start > ts) ? ((c_start - ts < kCicTile) ? (int)(c_start - ts) : kCicTile) : 0;
+    const int e0 = (e_start > ts) ? ((e_start - ts < kCicTile) ? (int)(e_start - ts) : kCicTile) : 0;
     if (!INTERP) {
       // The walk is split into runs that end at an emitting sample, so the integrator loop body is
       // branch-free: intStage (ac_cic_full_core.h:80-87) on every sample, comb + output only at run ends.
@@ -331,7 +332,8 @@ hipError_t launch_cic_intr_fir(const CicParams &p, const int64_t *d_taps, int n_
 
 hipError_t launch_cic(const CicParams &p, hipStream_t s) {
   if (p.n_in <= 0) { return hipSuccess; }
-  dim3 grid((unsigned)((p.n_in + p.chunk - 1) / p.chunk), (unsigned)((p.n_ch + 63) / 64));
+  if (p.n_in <= p.t_from) { return hipSuccess; }
+  dim3 grid((unsigned)((p.n_in - p.t_from + p.chunk - 1) / p.chunk), (unsigned)((p.n_ch + 63) / 64));
   switch (p.N) {
     case 1: return launch_n<1>(p, grid, s);
     case 2: return launch_n<2>(p, grid, s);

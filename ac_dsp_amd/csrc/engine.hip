@@ -372,13 +372,30 @@ int32_t acdsp_cic_state_set(acdsp_cic_t h, const void *buf, uint64_t bytes) {
   StateHdr s;
   if (bytes < sizeof s) { return fail(ACDSP_EINVAL, "cic_state_set: blob shorter than its header"); }
   memcpy(&s, buf, sizeof s);
-  if (!state_compatible(s, mine) || bytes != sizeof s + state_payload(mine) || s.t_total < 0) {
+  // A blob of another history LENGTH is still this filter's state as long as it covers the filter memory (N R M' - 1 inputs for the
+  // decimator): a handle that can take the two-stage kernel (cic2.hip) keeps a longer history than one that cannot (ACDSP_NO_CIC2, an
+  // older build), and the samples beyond the memory only ever feed warm-up values the combs cancel.  The newest min(blob, mine) samples
+  // are kept, older ones zero.
+  StateHdr same_len = s;
+  same_len.per_channel = mine.per_channel;
+  const uint64_t mem = h->d.interp ? (uint64_t)h->d.N * h->me + 1 : (uint64_t)h->d.N * h->d.R * h->me - 1;
+  const bool relen = s.per_channel != mine.per_channel && s.per_channel >= mem && s.per_channel <= (uint64_t(1) << 24) && state_compatible(same_len, mine) &&
+                     bytes == sizeof s + state_payload(s);
+  if ((!relen && (!state_compatible(s, mine) || bytes != sizeof s + state_payload(mine))) || s.t_total < 0) {
     return fail(ACDSP_EINVAL, "cic_state_set: blob does not belong to a CIC filter of these parameters / channel count");
   }
   int rc = check_device(h->d.device);
   if (rc) { return rc; }
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(h->d_hist[h->cur], (const char *)buf + sizeof s, state_payload(mine), hipMemcpyHostToDevice));
+  if (relen) {
+    const size_t eb = mine.elem_bytes, pm = (size_t)mine.per_channel, pb = (size_t)s.per_channel, keep = pm < pb ? pm : pb;
+    std::vector<unsigned char> img((size_t)mine.n_channels * pm * eb, 0);
+    const unsigned char *src = (const unsigned char *)buf + sizeof s;
+    for (size_t c = 0; c < mine.n_channels; c++) { memcpy(&img[(c * pm + (pm - keep)) * eb], src + (c * pb + (pb - keep)) * eb, keep * eb); }
+    HIP_TRY(hipMemcpy(h->d_hist[h->cur], img.data(), img.size(), hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMemcpy(h->d_hist[h->cur], (const char *)buf + sizeof s, state_payload(mine), hipMemcpyHostToDevice));
+  }
   h->t_total = s.t_total;
   return ACDSP_OK;
 }

@@ -69,6 +69,26 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
   h->wide = it.W > 64 || desc->out.W > 64;
   const int64_t mem = desc->interp ? (int64_t)desc->N * h->me + 1 : (int64_t)desc->N * desc->R * h->me - 1;
   h->hl = round_up((int)(mem > 1 ? mem : 1) + 16, kCicTile);   // + 16: the 16-aligned input windows of fir_gen
+  h->warm = h->hl;
+  {
+    // two-stage decimator (cic2.hip) where R = R1 R2 with a compiled stage-1 rate: its chunk 0 starts `wu` steps of 256 R1 inputs early,
+    // so the handle keeps that much input history (the samples beyond the filter memory only ever feed warm-up values the combs cancel)
+    static const bool no_c2 = getenv("ACDSP_NO_CIC2") != nullptr;         // A/B knob: recurrence kernel as before
+    static const bool c2_all = getenv("ACDSP_CIC2_ALL") != nullptr;       // A/B knob: also where the one-stage FIR identity fits (R < 32)
+    const int in_bits = desc->in.W + (desc->in.S ? 0 : 1);
+    if (!desc->interp && !h->wide && !no_c2 && (desc->R >= 32 || c2_all) && (in_bits + 7) / 8 <= h->in_eb && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) &&
+        cic2_factor(h->in_eb, desc->R, h->me, desc->N, &h->c2_R1, &h->c2_R2, &h->c2_wu)) {
+      cic2_stage1_taps(h->c2_R1, desc->N, &h->c2_taps);
+      FirGenPlan probe;
+      std::vector<uint32_t> fr;
+      h->c2_ok = fir_gen_plan(h->c2_taps.data(), (int)h->c2_taps.size(), h->c2_R1, 15, &probe, &fr) &&
+                 fir_gen_plan(h->c2_taps.data(), (int)h->c2_taps.size(), h->c2_R1, 0, &probe, &fr);
+      if (h->c2_ok) {
+        const int need = round_up(cic2_hist_len(h->in_eb, h->c2_R1, desc->N, h->c2_wu), kCicTile);
+        if (need > h->hl) { h->hl = need; }
+      }
+    }
+  }
   const size_t hb = (size_t)desc->n_channels * h->hl * h->in_eb;
   hipError_t e = hipSuccess;
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
@@ -114,19 +134,23 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
                 fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), desc->R, 15, &probe, &fr) &&   // worst-case window offset
                 fir_gen_plan(h->h_taps.data(), (int)h->h_taps.size(), desc->R, 0, &probe, &fr);
     if (h->gen_ok) { e = hipMalloc((void **)&h->d_gfrag, (size_t)16 * 3 * 8 * 64 * 4 * sizeof(uint32_t)); }
+    if (h->c2_ok && e == hipSuccess) { e = hipMalloc((void **)&h->d_c2frag, (size_t)16 * 3 * 8 * 64 * 4 * sizeof(uint32_t)); }
   }
   if (e != hipSuccess || h->tm.init() != ACDSP_OK) {
     acdsp_cic_destroy(h);
     return fail(ACDSP_EHIP, "CIC state allocation failed: %s", hipGetErrorString(e));
   }
   *out = h;
+  if (trace_handles()) { fprintf(stderr, "[acdsp] cic_create interp=%d R=%d M=%d N=%d n_channels=%d\n", desc->interp, desc->R, desc->M, desc->N, desc->n_channels); }
   return ACDSP_OK;
 }
 
 int32_t acdsp_cic_destroy(acdsp_cic_t h) {
   if (!h) { return ACDSP_OK; }
+  if (trace_handles()) { fprintf(stderr, "[acdsp] cic_destroy kernel_runs=%lld\n", (long long)h->tm.count); }
   (void)hipSetDevice(h->d.device);
   if (h->d_gfrag) { (void)hipFree(h->d_gfrag); }
+  if (h->d_c2frag) { (void)hipFree(h->d_c2frag); }
   if (h->d_taps) { (void)hipFree(h->d_taps); }
   if (h->d_upfrag) { (void)hipFree(h->d_upfrag); }
   if (h->d_upcorr) { (void)hipFree(h->d_upcorr); }
@@ -221,7 +245,8 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
   p.in = make_dfmt(d.in);
   if (h->wide) { memset(&p.out, 0, sizeof p.out); } else { p.out = make_dfmt(d.out); }
   p.in_eb = h->in_eb; p.out_eb = h->out_eb;
-  p.hl = h->hl; p.warm_tiles = h->hl / kCicTile;
+  p.hl = h->hl; p.warm_tiles = h->warm / kCicTile;
+  p.t_from = 0; p.emit_from = 0;
   p.vec_ok = ((uintptr_t)d_in % 16 == 0) && ((in_stride * h->in_eb) % 16 == 0);
   p.out_simple = (p.out.F == p.in.F && p.out.O == ACDSP_WRAP) ? ((p.out.S && p.out.W >= h->it.W) ? 2 : 1) : 0;
   p.in_stride = in_stride; p.out_stride = out_stride; p.n_in = n_in;
@@ -229,7 +254,7 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
   // chunking: aim at >= 4096 waves, keep the warm-up below ~6 % of a chunk
   const int64_t groups = (d.n_channels + 63) / 64;
   int64_t chunk = (n_in * groups + 4095) / 4096;
-  const int64_t floor_chunk = (int64_t)16 * h->hl > 1024 ? (int64_t)16 * h->hl : 1024;
+  const int64_t floor_chunk = (int64_t)16 * h->warm > 1024 ? (int64_t)16 * h->warm : 1024;
   if (chunk < floor_chunk) { chunk = floor_chunk; }
   p.chunk = (chunk + kCicTile - 1) / kCicTile * kCicTile;
   // decimator on the matrix cores when the FIR identity fits and the rows are slot-aligned
@@ -248,6 +273,22 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
       }
     }
     if (use_gen) { gfrag = h->d_gfrag + (size_t)fm * 3 * 8 * 64 * 4; gpl = h->gen_plan[fm]; }
+  }
+  // ... or in two stages (R = R1 R2, cic2.hip) where the one-stage window does not fit: complete chunks there, the ragged end on the recurrence kernel
+  bool use_c2 = h->c2_ok && !use_gen && p.vec_ok && in_stride >= (n_in + 15) / 16 * 16;
+  const uint32_t *c2frag = nullptr;
+  if (use_c2) {
+    const int fm = (int)(p.first % 16);
+    if (!h->c2_have[fm]) {
+      std::vector<uint32_t> fr;
+      if (!fir_gen_plan(h->c2_taps.data(), (int)h->c2_taps.size(), h->c2_R1, fm, &h->c2_plan[fm], &fr)) { use_c2 = false; }
+      else {
+        HIP_TRY(hipMemcpyAsync(h->d_c2frag + (size_t)fm * 3 * 8 * 64 * 4, fr.data(), fr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));   // fr is a stack vector
+        h->c2_have[fm] = true;
+      }
+    }
+    if (use_c2) { c2frag = h->d_c2frag + (size_t)fm * 3 * 8 * 64 * 4; }
   }
   const bool use_intr_fir = d.interp && h->d_taps != nullptr && !h->wide;
   h->last_path = h->wide ? ACDSP_PATH_WIDE : (use_gen ? ACDSP_PATH_MFMA_GEN : (use_intr_fir ? ACDSP_PATH_LOSSLESS64 : 0));
@@ -303,7 +344,19 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
       e = launch_cic_intr_fir(p, h->d_taps, (int)h->h_taps.size(), s);
     }
   } else {
-    e = launch_cic(p, s);
+    int64_t covered = 0;
+    e = hipSuccess;
+    if (use_c2) { e = launch_cic2(p, h->c2_plan[p.first % 16], c2frag, h->c2_R1, h->c2_R2, h->c2_wu, no, s, &covered); }
+    if (e == hipSuccess && covered < no) {
+      if (covered > 0) {            // the ragged end of the call: outputs from `covered` on, i.e. emitting samples from first + covered R on
+        p.emit_from = p.first + covered * d.R;
+        p.t_from = p.emit_from / kCicTile * kCicTile;
+        p.chunk = (floor_chunk + kCicTile - 1) / kCicTile * kCicTile;      // a short rest: many short chunks
+      }
+      e = launch_cic(p, s);
+      p.t_from = 0; p.emit_from = 0;
+    }
+    if (covered > 0) { h->last_path = ACDSP_PATH_CIC_2STAGE; }
   }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "CIC kernel launch failed: %s", hipGetErrorString(e)); }
   HIP_TRY(hipEventRecord(h->tm.stop(), s));

@@ -59,6 +59,13 @@ inline int check_fmt(const acdsp_fmt_t &f, const char *name, int max_w = 64) {
   return ACDSP_OK;
 }
 
+// ACDSP_TRACE=1: one stderr line per handle created and destroyed (with the number of run() calls it launched kernels for) -- how
+// tests/test_cpp_gpu.py tells a testbench that reached the HIP kernels from one the header's host loop served (include/ac_dsp/acdsp_engine.h)
+inline bool trace_handles() {
+  static const bool t = getenv("ACDSP_TRACE") != nullptr;
+  return t;
+}
+
 inline int elem_bytes(int W) { return W <= 16 ? 2 : (W <= 32 ? 4 : (W <= 64 ? 8 : 16)); }
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -188,6 +195,7 @@ struct acdsp_fir {
   bool lz_ok = false;
   FirLossyPlan lzp;
   uint32_t *d_lzcl = nullptr;
+  int64_t n_runs = 0;             // run() calls that launched kernels (ACDSP_TRACE)
   int kclass = 0;                 // acdsp_fir_kernel_class
   std::vector<int64_t> h_coeffs;  // last coefficient set (for clone)
   Timer tm;
@@ -204,6 +212,14 @@ struct acdsp_cic {
   bool gen_have[16] = {false};
   FirGenPlan gen_plan[16];
   uint32_t *d_gfrag = nullptr;   // [16][3*8*64*4]
+  // decimator in two stages (cic2.hip): R = c2_R1 * c2_R2, stage-1 taps z^-(N-1) boxcar(R1)^N with their per (first mod 16) plans / fragments
+  bool c2_ok = false;
+  int c2_R1 = 0, c2_R2 = 0, c2_wu = 0;
+  std::vector<int64_t> c2_taps;
+  bool c2_have[16] = {false};
+  FirGenPlan c2_plan[16];
+  uint32_t *d_c2frag = nullptr;  // [16][3*8*64*4]
+  int warm = 0;                  // inputs the recurrence kernel simulates in front of a chunk (the filter memory; hl may be longer: cic2.hip)
   int64_t *d_taps = nullptr;     // interpolator: the identity's taps for the polyphase kernel
   // interpolator on the matrix cores (fir_up.hip): per-phase taps E_r[k] = h[r + R k]
   bool up_ok = false;

@@ -157,11 +157,13 @@ int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out) {
     return fail(ACDSP_EHIP, "FIR state allocation failed: %s", hipGetErrorString(e));
   }
   *out = h;
+  if (trace_handles()) { fprintf(stderr, "[acdsp] fir_create kind=%d ftype=%d n_taps=%d n_channels=%d\n", desc->kind, desc->ftype, desc->n_taps, desc->n_channels); }
   return ACDSP_OK;
 }
 
 int32_t acdsp_fir_destroy(acdsp_fir_t h) {
   if (!h) { return ACDSP_OK; }
+  if (trace_handles()) { fprintf(stderr, "[acdsp] fir_destroy kernel_runs=%lld\n", (long long)h->n_runs); }
   (void)hipSetDevice(h->d.device);
   for (int i = 0; i < 2; i++) {
     if (h->d_hist[i]) { (void)hipFree(h->d_hist[i]); }
@@ -557,6 +559,7 @@ int32_t acdsp_fir_run(acdsp_fir_t h, const void *d_in, int64_t in_stride, int64_
     e = (!no_lossy && fir_lossy_fast_ok(k)) ? launch_fir_lossy(k, s) : ((!no_lossy && fir_satacc_fast_ok(k)) ? launch_fir_satacc(k, s) : launch_fir_generic(k, s));
   }
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "FIR kernel launch failed: %s", hipGetErrorString(e)); }
+  h->n_runs++;
   if (!small) {
     HIP_TRY(hipEventRecord(h->tm.stop(), s));
     h->tm.commit();

@@ -193,10 +193,10 @@ class Fir:
 class Cic:
     """n_channels independent ac_cic_dec_full (interp=False) / ac_cic_intr_full (interp=True) objects."""
 
-    def __init__(self, interp, R, M, N, fin, fout, n_channels=1, device=0):
+    def __init__(self, interp, R, M, N, fin, fout, n_channels=1, device=0, force_generic=False):
         self.interp, self.R, self.M, self.N = bool(interp), R, M, N
         self.fin, self.fout, self.n_channels, self.device = fin, fout, n_channels, device
-        self._d = CicDesc(int(self.interp), R, M, N, n_channels, fin, fout, device, 0)
+        self._d = CicDesc(int(self.interp), R, M, N, n_channels, fin, fout, device, _lib.FLAG_FORCE_GENERIC if force_generic else 0)
         self._h = C.c_void_p()
         check(lib.acdsp_cic_create(C.byref(self._d), C.byref(self._h)))
 
@@ -211,7 +211,7 @@ class Cic:
 
     @property
     def path(self):
-        return {0: "recurrence", 1: "fir_identity", 3: "mfma_gen", 4: "wide"}[lib.acdsp_cic_path(self._h)]
+        return {0: "recurrence", 1: "fir_identity", 3: "mfma_gen", 4: "wide", 6: "two_stage"}[lib.acdsp_cic_path(self._h)]
 
     def run(self, x, out=None):
         assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_channels and x.stride(1) == 1

@@ -157,6 +157,31 @@ def build_workload(workload, args, world, rank, local_rank):
             eng.run(x, y)
         path = eng.kernel
         samples_per_step = (hi - lo) * n
+    elif workload == "cic_dec_r64":
+        # round 6: ac_cic_dec_full at a rate it is deployed at -- R = 64, N = 4 on 16-bit samples (two-stage kernel, ac_dsp_amd/csrc/cic2.hip).
+        # ACDSP_BENCH_CIC="W,I,R,M,N" swaps the parameter set (tools/knob_sweep.py: same-process A/B on other rates / widths)
+        W, I, R, M, N = (int(v) for v in os.environ.get("ACDSP_BENCH_CIC", "16,1,64,1,4").split(","))
+        fin = A.Fmt(W, I)
+        ch_per_gpu = args.channels or 4096
+        n = args.samples or (1 << 20)
+        lo, hi = shard(ch_per_gpu * world, world, rank)
+        it = A.Cic(False, R, M, N, fin, fin, n_channels=1, device=local_rank).int_type
+        fo = A.Fmt(it.W, it.I)                   # OUT_TYPE = the reference's lossless INT_TYPE
+        eng = A.Cic(False, R, M, N, fin, fo, n_channels=hi - lo, device=local_rank)
+        x = torch.empty((hi - lo, n), dtype=A.torch_dtype_for(fin), device=dev)
+        A.fill_stimulus(x, seed, W, ch0=lo)
+        y = torch.empty((hi - lo, (n // R + 8 + 7) // 8 * 8), dtype=A.torch_dtype_for(fo), device=dev)
+        bytes_per_sample = float(x.element_size()) + float(y.element_size()) / R
+        macs_per_sample = 0.0
+        name = "ac_cic_dec_full N=%d R=%d M=%d ac_fixed<%d,%d> -> <%d,%d>, %d ch x %d samples per GPU" % (N, R, M, W, I, it.W, it.I, ch_per_gpu, n)
+        dtype = "int64 (wrap arithmetic mod 2^%d)" % it.W
+        coeffs = None
+
+        def step():
+            eng.run(x, y)
+        samples_per_step = (hi - lo) * n
+        step()
+        path = "cic_dec_" + eng.path
     elif workload in ("cic_dec_r7m2n4", "cic_intr_r7m2n5"):
         # the reference's CIC testbench parameters (tests/ac_cic_dec_full_param.h:33-47, ac_cic_intr_full_param.h:33-47) at batch scale
         interp = workload.startswith("cic_intr")
@@ -385,21 +410,21 @@ def build_node_workload(workload, args, n_shards, one_gpu):
         xs, ys = node.alloc(fin, n, fill(fin.W)), node.alloc(fo, n)
         bps = xs[0].element_size() + 8.0
         name = "ac_fir_%s_coeffs %d-tap FOLD_ODD, the types and coefficients of tests/rtest_ac_fir_%s_coeffs.cpp, %d ch x %d samples per GPU" % (which, n_taps, which, ch, n)
-    elif workload in ("cic_dec", "cic_intr", "cic_dec_r7m2n4", "cic_intr_r7m2n5"):
+    elif workload in ("cic_dec", "cic_intr", "cic_dec_r7m2n4", "cic_intr_r7m2n5", "cic_dec_r64"):
         interp = "intr" in workload
-        R, M, N = (7, 2, 5 if interp else 4) if "r7" in workload else (8, 1, 5)
-        fin = A.Fmt(32, 16)
+        R, M, N = (7, 2, 5 if interp else 4) if "r7" in workload else ((64, 1, 4) if "r64" in workload else (8, 1, 5))
+        fin = A.Fmt(16, 1) if "r64" in workload else A.Fmt(32, 16)
         ch = args.channels or (1024 if interp else 4096)
-        n = args.samples or ((1 << 18) if interp else (7 * (1 << 17) if R == 7 else (1 << 22)))
+        n = args.samples or ((1 << 18) if interp else (7 * (1 << 17) if R == 7 else ((1 << 20) if R == 64 else (1 << 22))))
         it = A.Cic(interp, R, M, N, fin, fin, n_channels=1).int_type
         fo = A.Fmt(it.W, it.I)
         node = A.NodeCic(interp, R, M, N, fin, fo, ch * n_shards, devices)
-        xs = node.alloc(fin, n, fill(32))
+        xs = node.alloc(fin, n, fill(fin.W))
         ys = node.alloc(fo, (n * R + 64) if interp else (n // R + 8))
         if interp:
             node.run([x[:, :64] for x in xs], ys)      # steady state: later calls emit R outputs per input
-        bps = 4.0 + (8.0 * R if interp else 8.0 / R)
-        name = "ac_cic_%s_full N=%d R=%d M=%d ac_fixed<32,16> -> <%d,%d>, %d ch x %d input samples per GPU" % ("intr" if interp else "dec", N, R, M, it.W, it.I, ch, n)
+        bps = xs[0].element_size() + (8.0 * R if interp else 8.0 / R)
+        name = "ac_cic_%s_full N=%d R=%d M=%d ac_fixed<%d,%d> -> <%d,%d>, %d ch x %d input samples per GPU" % ("intr" if interp else "dec", N, R, M, fin.W, fin.I, it.W, it.I, ch, n)
     elif workload == "ddc":
         ch, n = args.channels or 4096, args.samples or (1 << 20)
         cin, fc, fa, fo = A.Fmt(16, 1), A.Fmt(16, 1), A.Fmt(60, 30), A.Fmt(24, 9, True, "RND", "SAT")
@@ -537,7 +562,7 @@ def measure(w, steps, warmup, barrier, settle_s=0.0):
 
 
 PROFILE_TAGS = {w_: w_ for w_ in ("fir255", "fir255_dense", "fir255_wide", "fir1023", "cic_dec", "ddc", "polydec", "cic_intr", "polyintr", "intgdump", "mvavg",
-                                   "rtest_const_types", "rtest_load_types", "rtest_prog_types", "cic_dec_r7m2n4", "cic_intr_r7m2n5")}
+                                   "rtest_const_types", "rtest_load_types", "rtest_prog_types", "cic_dec_r7m2n4", "cic_intr_r7m2n5", "cic_dec_r64")}
 
 
 def roofline_of(w, k_avg, k_min, ev_ms):
@@ -614,7 +639,9 @@ def mfma_roofline_of(w, k_avg):
 # first, then the SURVEY 8 (f) rows
 SECONDARY = ["fir255_dense", "fir255_wide", "fir1023", "cic_dec", "ddc", "cic_intr", "polydec", "polyintr", "intgdump", "mvavg",
              # round 5: the reference's own shipped testbench parameterisations at batch scale
-             "rtest_const_types", "rtest_load_types", "rtest_prog_types", "cic_dec_r7m2n4", "cic_intr_r7m2n5"]
+             "rtest_const_types", "rtest_load_types", "rtest_prog_types", "cic_dec_r7m2n4", "cic_intr_r7m2n5",
+             # round 6: CIC decimation at R >= 32 (two-stage kernel)
+             "cic_dec_r64"]
 ALL_WORKLOADS = ["fir255"] + SECONDARY
 
 

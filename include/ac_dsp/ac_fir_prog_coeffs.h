@@ -4,8 +4,12 @@
 // (include/ac_dsp/ac_fir_prog_coeffs.h:261-277): N_TAPS is an `int` here, ftype
 // defaults to SHIFT_REG, and run() consumes at most ONE sample per call
 // (`if (data_in.available(1))`, :281) with the coefficient array passed on that
-// call.  Each call is therefore one (tiny) GPU launch; streams that can be
-// batched should use acdsp::fir_engine directly (include/ac_dsp/acdsp_engine.h).
+// call.  A call of one sample is far below what a GPU launch is worth: calls of
+// fewer than ACDSP_HOST_SMALL_MACS samples x taps (default 8192) run in the
+// header's own ac_fixed loop (acdsp::fir_engine::run_values_c, the filter state
+// moving between host and device as a state blob); with ACDSP_HOST_SMALL_MACS=0
+// every call is one (tiny) GPU launch.  Streams that can be batched should use
+// acdsp::fir_engine directly (include/ac_dsp/acdsp_engine.h).
 #ifndef _INCLUDED_AC_FIR_PROG_COEFFS_H_
 #define _INCLUDED_AC_FIR_PROG_COEFFS_H_
 

@@ -65,7 +65,8 @@ enum {
 /* which kernel family a FIR handle resolved to (acdsp_fir_path) */
 enum { ACDSP_PATH_GENERIC = 0, ACDSP_PATH_LOSSLESS64 = 1, ACDSP_PATH_MFMA_I8 = 2, ACDSP_PATH_MFMA_GEN = 3,
        ACDSP_PATH_WIDE = 4 /* a format wider than 64 bits: exact-order kernels on 128-bit words, 256-bit intermediates */,
-       ACDSP_PATH_MFMA_LOSSY = 5 /* lossy wrapping accumulator (per-tap AC_TRN / AC_RND): exact sum on the matrix cores minus the dropped bits */ };
+       ACDSP_PATH_MFMA_LOSSY = 5 /* lossy wrapping accumulator (per-tap AC_TRN / AC_RND): exact sum on the matrix cores minus the dropped bits */,
+       ACDSP_PATH_CIC_2STAGE = 6 /* ac_cic_dec_full with R = R1 R2: FIR identity of rate R1 on the matrix cores, integrators / combs of rate R2 behind it, one launch */ };
 /* finer: the kernel family inside ACDSP_PATH_GENERIC (acdsp_fir_kernel_class; the other values equal the path) */
 enum { ACDSP_KCLASS_LOSSY16 = 6 /* fir_lossy_kernel: class B on 16-bit types, int32 VALU */,
        ACDSP_KCLASS_SATACC16 = 7 /* fir_satacc_kernel: saturating accumulator of <= 32 bits on 16-bit types, reference tap order */ };
@@ -236,7 +237,8 @@ int32_t acdsp_cic_run(acdsp_cic_t h, const void *d_in, int64_t in_stride, int64_
                       int64_t *n_out, void *stream);
 int32_t acdsp_cic_run_host(acdsp_cic_t h, const void *h_in, int64_t n_in, void *h_out, int64_t out_cap, int64_t *n_out);
 int32_t acdsp_cic_reset(acdsp_cic_t h);
-int32_t acdsp_cic_path(acdsp_cic_t h);         /* 0: recurrence kernel, 3: FIR-identity MFMA kernel (ACDSP_PATH_MFMA_GEN) */
+int32_t acdsp_cic_path(acdsp_cic_t h);         /* last run(): 0 recurrence kernel, 3 FIR-identity MFMA kernel (ACDSP_PATH_MFMA_GEN), 6 two-stage kernel (ACDSP_PATH_CIC_2STAGE; decimation
+                                                  factors from 32 on that a compiled stage-1 rate divides -- others keep the recurrence kernel), 4 wide */
 int32_t acdsp_cic_last_kernel_ms(acdsp_cic_t h, float *ms);
 int32_t acdsp_cic_kernel_stats(acdsp_cic_t h, int32_t last_k, float *avg_ms, float *min_ms);
 

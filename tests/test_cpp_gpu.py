@@ -5,6 +5,7 @@ tests/rtest_*.cpp).  rtest_* are the reference's testbenches themselves, compile
 headers by __graft_entry__.build() in the build container (binaries only travel; the reference sources
 never enter the repo); they are run when present."""
 import os
+import re
 import subprocess
 
 import pytest
@@ -16,9 +17,19 @@ BIN = os.path.join(ROOT, "tests", "_bin")
 VEC = os.path.join(ROOT, "tests", "golden", "ref_txt")   # the testbenches open their vectors by bare name
 
 
-def run(exe):
-    p = subprocess.run([exe], cwd=VEC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+def run(exe, env=None):
+    e = dict(os.environ)
+    e.pop("ACDSP_HOST_SMALL_MACS", None)
+    e.update(env or {})
+    p = subprocess.run([exe], cwd=VEC, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     return p.returncode, p.stdout.decode(errors="replace")
+
+
+def kernel_runs(out):
+    """ACDSP_TRACE=1 lines of the C-ABI layer: (handles created, run() calls that launched kernels, summed over the destroyed handles)"""
+    created = len(re.findall(r"^\[acdsp\] (?:fir|cic)_create ", out, flags=re.M))
+    runs = sum(int(v) for v in re.findall(r"^\[acdsp\] (?:fir|cic)_destroy kernel_runs=(\d+)", out, flags=re.M))
+    return created, runs
 
 
 TBS = ("tb_tiny", "tb_fir", "tb_cic", "tb_batched", "tb_polydec", "tb_reg_share", "tb_poly_intr", "tb_intg_dump", "tb_mv_avg", "tb_wide", "tb_node")
@@ -39,12 +50,39 @@ def test_own_cpp_testbench(tb):
     assert rc == 0 and "Test PASSED." in out, out
 
 
+# The drop-in FIR classes keep one-channel calls of fewer than ACDSP_HOST_SMALL_MACS samples x taps (default 8192) in the header's own
+# ac_fixed loop (include/ac_dsp/acdsp_engine.h: run_values_c) -- with the reference's testbench sizes that is every call of
+# rtest_ac_fir_prog_coeffs (one sample x 27 taps per call).  Each testbench therefore runs twice: as shipped, and with the host path
+# switched off, where it must have created a device handle and launched kernels for its run() calls (ACDSP_TRACE lines).
+HOST_LEGS = [pytest.param(None, id="default"), pytest.param("0", id="host_small_macs_0")]
+
+
+@pytest.mark.parametrize("small_macs", HOST_LEGS)
 @pytest.mark.parametrize("name", ["ac_fir_const_coeffs", "ac_fir_load_coeffs", "ac_fir_prog_coeffs", "ac_cic_dec_full",
                                   "ac_cic_intr_full"])
-def test_reference_rtest_binary_unchanged(name):
+def test_reference_rtest_binary_unchanged(name, small_macs):
     exe = os.path.join(BIN, "rtest_" + name)
     if not os.path.exists(exe):
         assert not PREBUILT, "tests/_bin holds prebuilt testbenches but %s is missing: __graft_entry__.build() did not run with /root/reference" % exe
         pytest.skip("rtest binary not prebuilt (needs /root/reference at build time)")
-    rc, out = run(exe)
+    env = {"ACDSP_TRACE": "1"}
+    if small_macs is not None:
+        env["ACDSP_HOST_SMALL_MACS"] = small_macs
+    rc, out = run(exe, env)
     assert rc == 0 and "PASSED" in out, out
+    created, runs = kernel_runs(out)
+    if small_macs == "0" or "cic" in name:
+        # every run() of the testbench went through the C ABI into HIP kernels
+        assert created >= 1 and runs >= 1, (created, runs, out[-2000:])
+
+
+@pytest.mark.parametrize("small_macs", HOST_LEGS)
+def test_own_fir_testbench_on_both_sides_of_the_host_threshold(small_macs):
+    env = {"ACDSP_TRACE": "1"}
+    if small_macs is not None:
+        env["ACDSP_HOST_SMALL_MACS"] = small_macs
+    rc, out = run(os.path.join(BIN, "tb_fir"), env)
+    assert rc == 0 and "Test PASSED." in out, out
+    created, runs = kernel_runs(out)
+    if small_macs == "0":
+        assert created >= 1 and runs >= 1, (created, runs)
