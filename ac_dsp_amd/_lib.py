@@ -170,6 +170,7 @@ SYMBOLS = {
     "acdsp_intgdump_run": (_i32, [_vp, _vp, _i64, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64), _vp]),
     "acdsp_intgdump_run_host": (_i32, [_vp, _vp, C.POINTER(_i64), _i64, _vp, _i64, C.POINTER(_i64)]),
     "acdsp_intgdump_reset": (_i32, [_vp]),
+    "acdsp_intgdump_path": (_i32, [_vp]),
     "acdsp_mvavg_create": (_i32, [C.POINTER(MvAvgDesc), C.POINTER(_vp)]),
     "acdsp_mvavg_destroy": (_i32, [_vp]),
     "acdsp_mvavg_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),

@@ -16,6 +16,7 @@ struct acdsp_intgdump {
   int32_t *d_chain = nullptr;   // [cap]
   int64_t blk_cap = 0;
   bool pending = false;         // the last call ended on a block that did not dump: temp[] is non-zero
+  int last_path = 0;            // acdsp_intgdump_path
   // block table of the last call: a stream that dumps on a fixed schedule passes the same n_sample[] every call, and then
   // neither the table is rebuilt nor uploaded and run() stays asynchronous (no stream synchronisation)
   std::vector<int64_t> last_ns;
@@ -156,12 +157,14 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
   p.x = d_in; p.y = d_out; p.temp = h->d_temp[h->cur];
   p.blk_off = h->d_blk; p.blk_rounds = h->d_blk + n_blocks; p.blk_out = h->d_blk + 2 * n_blocks; p.blk_chain = h->d_chain;
   bool temp_written = true;
-  hipError_t e = launch_intg_dump(p, h->d_temp[h->cur ^ 1], s, &temp_written);
+  hipError_t e = launch_intg_dump(p, h->d_temp[h->cur ^ 1], s, &temp_written, &h->last_path);
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "intg_dump kernel launch failed: %s", hipGetErrorString(e)); }
   if (temp_written) { h->cur ^= 1; }   // (else: nothing carried in, every block dumped -- the all-zero temp[] of this side stays the state)
   h->pending = start != (int32_t)n_blocks;   // the call ended on blocks that did not dump: their sums sit in temp[]
   return ACDSP_OK;
 }
+
+int32_t acdsp_intgdump_path(acdsp_intgdump_t h) { return h ? h->last_path : -1; }
 
 int32_t acdsp_intgdump_run_host(acdsp_intgdump_t h, const void *h_in, const int64_t *n_sample, int64_t n_blocks, void *h_out,
                                 int64_t out_cap, int64_t *n_out) {

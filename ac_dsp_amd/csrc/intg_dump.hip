@@ -537,10 +537,12 @@ static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
   }
 }
 
-hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStream_t s, bool *temp_written) {
+hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStream_t s, bool *temp_written, int *path) {
   *temp_written = true;
+  *path = 0;
   static const bool no_stream = getenv("ACDSP_NO_INTG_STREAM") != nullptr;   // A/B knob
   if (!no_stream && try_stream(p, s)) {
+    *path = 2;
     *temp_written = false;   // every block dumped and nothing was carried in (tile_ok): temp[] was zero and is zero
     return hipGetLastError();
   }
@@ -554,6 +556,7 @@ hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStre
       default: hipLaunchKernelGGL(intg_dump_tile_kernel<int64_t>, grid, dim3(256), 48 * 1024, s, p, bpw, lds_elems); break;
     }
     *temp_written = false;
+    *path = 1;
     return hipGetLastError();
   }
   const int64_t n_work = (int64_t)(p.n_blocks + 1) * p.chn;

@@ -454,6 +454,11 @@ class IntgDump:
                                      C.c_void_p(out.data_ptr()), out.stride(0), C.byref(n_out), _stream_ptr(x)))
         return out[:, :n_out.value]
 
+    @property
+    def path(self):
+        """kernel family of the last run() (acdsp_intgdump_path)"""
+        return {0: "exact_order", 1: "tile", 2: "stream"}[lib.acdsp_intgdump_path(self._h)]
+
     def reset(self):
         check(lib.acdsp_intgdump_reset(self._h))
 

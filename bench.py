@@ -38,7 +38,8 @@ def shard(n_total, world, rank):
 def windowed_sinc_raw(n_taps, cutoff, frac_bits):
     m = (n_taps - 1) / 2.0
     k = np.arange(n_taps) - m
-    h = np.sinc(2 * cutoff * k) * 2 * cutoff * (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(n_taps) / (n_taps - 1)))
+    win = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(n_taps) / (n_taps - 1)) if n_taps > 1 else np.ones(1)   # (one tap: unity gain)
+    h = np.sinc(2 * cutoff * k) * 2 * cutoff * win
     h = h / h.sum()
     raw = np.round(h * 2.0 ** frac_bits).astype(np.int64)
     return (raw + raw[::-1]) // 2
