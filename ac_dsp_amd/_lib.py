@@ -125,6 +125,7 @@ SYMBOLS = {
     "acdsp_diag_copy_ms": (_i32, [_i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_diag_shader_clock_mhz": (_i32, [_i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_diag_fir_envelope_ms": (_i32, [_i32, C.POINTER(_i64), _i32, _i32, _i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
+    "acdsp_diag_fir_envelope_copygeom_ms": (_i32, [_i32, C.POINTER(_i64), _i32, _i32, _i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_fir_create": (_i32, [C.POINTER(FirDesc), C.POINTER(_vp)]),
     "acdsp_fir_destroy": (_i32, [_vp]),
     "acdsp_fir_clone": (_i32, [_vp, C.POINTER(_vp)]),

@@ -69,6 +69,79 @@ __global__ void __launch_bounds__(256, 2) diag_envelope_kernel(const v4i *__rest
   }
 }
 
+// The same envelope in the COPY kernel's geometry (round 6: the stream-only leg above runs 0.76 ms on the 4.3 GB of config 2 where the plain copy
+// runs 0.69): one 16-byte element per thread, 256-thread workgroups in memory order, every wave lives for ONE 1 KB load, MK MFMAs and one store.
+// Such a wave cannot keep Toeplitz fragments resident (six fragment loads per data load would be an L1-bound kernel), so the A operands are
+// stand-ins made of the loaded bytes themselves: full-range bytes for the low-plane products, bytes masked to +-3 for the HI high-plane ones.
+template <int MK, int HI>
+__global__ void __launch_bounds__(256) diag_envelope_copygeom_kernel(const v4i *__restrict__ x, v4i *__restrict__ y, int64_t n_vec) {
+  const int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n_vec) { return; }
+  const v4i v = x[i];
+  v16i acc[4] = {{0}, {0}, {0}, {0}};
+  const v4i al = (v4i){v.y, v.z, v.w, v.x}, ah = (v4i){v.z & 0x03030303, v.w & 0x03030303, v.x & 0x03030303, v.y & 0x03030303};
+#pragma unroll
+  for (int m = 0; m < MK; m++) { acc[m & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(m < HI ? ah : al, v, acc[m & 3], 0, 0, 0); }
+  v4i o = v;
+  if (MK > 0) { o = (v4i){acc[0][0], acc[1][5], acc[2][10], acc[3][15]}; }
+  y[i] = o;
+}
+
+// ... and with the REAL Toeplitz fragments: four elements per thread (a 256-thread workgroup copies 16 KB, still in memory order, all four loads
+// issued before the first product), the six fragments loaded once per wave (L1 hits: 6 KB per 4 KB of samples)
+template <int MK, int HI>
+__global__ void __launch_bounds__(256) diag_envelope_copygeom4_kernel(const v4i *__restrict__ frag, const v4i *__restrict__ x, v4i *__restrict__ y, int64_t n_vec) {
+  const int64_t i0 = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 1024 + threadIdx.x;
+  if (i0 + 768 >= n_vec) { return; }
+  v4i v[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { v[u] = x[i0 + 256 * u]; }
+  const int lane = threadIdx.x & 63;
+  v4i Al[4], Ah[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { Al[i] = frag[i * 64 + lane]; }
+#pragma unroll
+  for (int i = 0; i < 2; i++) { Ah[i] = frag[(4 + i) * 64 + lane]; }
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    v16i acc[4] = {{0}, {0}, {0}, {0}};
+#pragma unroll
+    for (int m = 0; m < MK; m++) { acc[m & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(m < HI ? Ah[m & 1] : Al[m & 3], v[u], acc[m & 3], 0, 0, 0); }
+    v4i o = v[u];
+    if (MK > 0) { o = (v4i){acc[0][0], acc[1][5], acc[2][10], acc[3][15]}; }
+    y[i0 + 256 * u] = o;
+  }
+}
+
+hipError_t launch_diag_envelope_copygeom(const uint32_t *d_frag, const void *x, void *y, int64_t bytes, int mfma, int mfma_hi, hipStream_t s) {
+  if (d_frag) {
+    const int64_t n_vec = bytes / 16, blocks = n_vec / 1024;
+    if (blocks <= 0) { return hipSuccess; }
+    const int64_t gx = blocks < (1 << 20) ? blocks : (1 << 20), gy = (blocks + gx - 1) / gx;
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+#define ACDSP_ENVC4_CASE(NM, NH)                                                                                                 \
+    if (mfma == NM && mfma_hi == NH) {                                                                                           \
+      hipLaunchKernelGGL((diag_envelope_copygeom4_kernel<NM / 2, NH / 2>), grid, dim3(256), 0, s, (const v4i *)d_frag, (const v4i *)x, (v4i *)y, n_vec); \
+      return hipGetLastError();                                                                                                  \
+    }
+    ACDSP_ENVC4_CASE(0, 0) ACDSP_ENVC4_CASE(26, 8) ACDSP_ENVC4_CASE(36, 18) ACDSP_ENVC4_CASE(76, 10) ACDSP_ENVC4_CASE(132, 66)
+#undef ACDSP_ENVC4_CASE
+    return hipErrorInvalidValue;
+  }
+  const int64_t n_vec = bytes / 16;
+  if (n_vec <= 0) { return hipSuccess; }
+  const int64_t blocks = (n_vec + 255) / 256, gx = blocks < (1 << 20) ? blocks : (1 << 20), gy = (blocks + gx - 1) / gx;
+  const dim3 grid((unsigned)gx, (unsigned)gy);
+#define ACDSP_ENVC_CASE(NM, NH)                                                                                                  \
+  if (mfma == NM && mfma_hi == NH) {                                                                                             \
+    hipLaunchKernelGGL((diag_envelope_copygeom_kernel<NM / 2, NH / 2>), grid, dim3(256), 0, s, (const v4i *)x, (v4i *)y, n_vec); \
+    return hipGetLastError();                                                                                                    \
+  }
+  ACDSP_ENVC_CASE(0, 0) ACDSP_ENVC_CASE(26, 8) ACDSP_ENVC_CASE(36, 18) ACDSP_ENVC_CASE(76, 10) ACDSP_ENVC_CASE(132, 66)
+#undef ACDSP_ENVC_CASE
+  return hipErrorInvalidValue;
+}
+
 bool diag_envelope_compiled(int mfma, int mfma_hi) {
   return (mfma == 0 && mfma_hi == 0) || (mfma == 26 && mfma_hi == 8) || (mfma == 36 && mfma_hi == 18) || (mfma == 76 && mfma_hi == 10) ||
          (mfma == 132 && mfma_hi == 66);

@@ -194,21 +194,11 @@ extern "C" int32_t acdsp_diag_shader_clock_mhz(int32_t device, void *stream, flo
   return ACDSP_OK;
 }
 
-extern "C" int32_t acdsp_diag_fir_envelope_ms(int32_t device, const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, int32_t mfma_hi_per_step,
-                                              const void *d_x, void *d_y, uint64_t bytes, int32_t warmup, int32_t reps, void *stream, float *ms_avg) {
-  if (!d_x || !d_y || bytes < 16 || bytes % 16 || ((uintptr_t)d_x | (uintptr_t)d_y) % 16) { return fail(ACDSP_EINVAL, "diag_fir_envelope: 16-byte aligned buffers of a multiple of 16 bytes"); }
-  if (mfma_per_step < 0 || mfma_hi_per_step < 0 || mfma_hi_per_step > mfma_per_step || (mfma_per_step > 0 && (!coeffs || n_taps < 1 || n_taps > 1025))) {
-    return fail(ACDSP_EINVAL, "diag_fir_envelope: bad coefficient set or MFMA counts");
-  }
-  if (!diag_envelope_compiled(mfma_per_step, mfma_hi_per_step)) {
-    return fail(ACDSP_EUNSUPPORTED, "diag_fir_envelope: (%d, %d) MFMAs per step is not a compiled count", mfma_per_step, mfma_hi_per_step);
-  }
-  int rc = check_device(device);
-  if (rc) { return rc; }
-  hipStream_t s = (hipStream_t)stream;
-  // A operands with the statistics of the product's: Toeplitz fragments of the caller's set (fir_mfma_build_fragments: [2 planes][nb][64][4]
-  // dwords), four blocks of the low-byte plane spread over the taps and two non-zero blocks of the high-byte plane (the centre of the band)
-  std::vector<uint32_t> six((size_t)6 * 64 * 4, 0u);
+// A operands with the statistics of the product's: Toeplitz fragments of the caller's set (fir_mfma_build_fragments: [2 planes][nb][64][4]
+// dwords), four blocks of the low-byte plane spread over the taps and two non-zero blocks of the high-byte plane (the centre of the band)
+static int envelope_fragments(const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, std::vector<uint32_t> *six_out) {
+  std::vector<uint32_t> &six = *six_out;
+  six.assign((size_t)6 * 64 * 4, 0u);
   if (mfma_per_step > 0) {
     for (int i = 0; i < n_taps; i++) {
       if (coeffs[i] < -32768 || coeffs[i] > 32767) { return fail(ACDSP_EINVAL, "diag_fir_envelope: coefficient %d is not a 16-bit word", i); }
@@ -232,12 +222,54 @@ extern "C" int32_t acdsp_diag_fir_envelope_ms(int32_t device, const int64_t *coe
     if (h1 < 0) { h1 = h0; }
     take(4, 0, h0); take(5, 0, h1);
   }
+  return ACDSP_OK;
+}
+
+extern "C" int32_t acdsp_diag_fir_envelope_ms(int32_t device, const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, int32_t mfma_hi_per_step,
+                                              const void *d_x, void *d_y, uint64_t bytes, int32_t warmup, int32_t reps, void *stream, float *ms_avg) {
+  if (!d_x || !d_y || bytes < 16 || bytes % 16 || ((uintptr_t)d_x | (uintptr_t)d_y) % 16) { return fail(ACDSP_EINVAL, "diag_fir_envelope: 16-byte aligned buffers of a multiple of 16 bytes"); }
+  if (mfma_per_step < 0 || mfma_hi_per_step < 0 || mfma_hi_per_step > mfma_per_step || (mfma_per_step > 0 && (!coeffs || n_taps < 1 || n_taps > 1025))) {
+    return fail(ACDSP_EINVAL, "diag_fir_envelope: bad coefficient set or MFMA counts");
+  }
+  if (!diag_envelope_compiled(mfma_per_step, mfma_hi_per_step)) {
+    return fail(ACDSP_EUNSUPPORTED, "diag_fir_envelope: (%d, %d) MFMAs per step is not a compiled count", mfma_per_step, mfma_hi_per_step);
+  }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<uint32_t> six;
+  if ((rc = envelope_fragments(coeffs, n_taps, mfma_per_step, &six))) { return rc; }
   uint32_t *d_frag = nullptr;
   HIP_TRY(hipMalloc((void **)&d_frag, six.size() * sizeof(uint32_t)));
   hipError_t ce = hipMemcpy(d_frag, six.data(), six.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
   if (ce != hipSuccess) { (void)hipFree(d_frag); return fail(ACDSP_EHIP, "diag_fir_envelope: upload failed: %s", hipGetErrorString(ce)); }
   int out = time_launches([&] { return launch_diag_envelope(d_frag, d_x, d_y, (int64_t)bytes, mfma_per_step, mfma_hi_per_step, s); }, warmup, reps, s, ms_avg);
   (void)hipFree(d_frag);
+  return out;
+}
+
+extern "C" int32_t acdsp_diag_fir_envelope_copygeom_ms(int32_t device, const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, int32_t mfma_hi_per_step,
+                                                       const void *d_x, void *d_y, uint64_t bytes, int32_t warmup, int32_t reps, void *stream, float *ms_avg) {
+  if (!d_x || !d_y || bytes < 16 || bytes % 16 || ((uintptr_t)d_x | (uintptr_t)d_y) % 16) { return fail(ACDSP_EINVAL, "diag_fir_envelope_copygeom: 16-byte aligned buffers of a multiple of 16 bytes"); }
+  if (mfma_per_step < 0 || mfma_hi_per_step < 0 || mfma_hi_per_step > mfma_per_step || (coeffs && (n_taps < 1 || n_taps > 1025))) {
+    return fail(ACDSP_EINVAL, "diag_fir_envelope_copygeom: bad coefficient set or MFMA counts");
+  }
+  if (!diag_envelope_compiled(mfma_per_step, mfma_hi_per_step)) {
+    return fail(ACDSP_EUNSUPPORTED, "diag_fir_envelope_copygeom: (%d, %d) MFMAs per step is not a compiled count", mfma_per_step, mfma_hi_per_step);
+  }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t *d_frag = nullptr;
+  if (coeffs) {     // the real fragments, four elements per thread
+    std::vector<uint32_t> six;
+    if ((rc = envelope_fragments(coeffs, n_taps, mfma_per_step, &six))) { return rc; }
+    HIP_TRY(hipMalloc((void **)&d_frag, six.size() * sizeof(uint32_t)));
+    hipError_t ce = hipMemcpy(d_frag, six.data(), six.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (ce != hipSuccess) { (void)hipFree(d_frag); return fail(ACDSP_EHIP, "diag_fir_envelope_copygeom: upload failed: %s", hipGetErrorString(ce)); }
+  }
+  int out = time_launches([&] { return launch_diag_envelope_copygeom(d_frag, d_x, d_y, (int64_t)bytes, mfma_per_step, mfma_hi_per_step, s); }, warmup, reps, s, ms_avg);
+  if (d_frag) { (void)hipFree(d_frag); }
   return out;
 }
 

@@ -219,6 +219,9 @@ hipError_t launch_diag_copy(const void *src, void *dst, int64_t bytes, hipStream
 bool diag_envelope_compiled(int mfma, int mfma_hi);
 hipError_t launch_diag_clock(float *d_mhz, int n_blocks, hipStream_t s);   // shader clock in MHz per block (diag.hip)
 hipError_t launch_diag_envelope(const uint32_t *d_frag, const void *x, void *y, int64_t bytes, int mfma, int mfma_hi, hipStream_t s);
+// ... in the copy kernel's geometry (one 16-byte element per thread; stand-in A operands made of the loaded bytes)
+// d_frag != nullptr: four elements per thread and the real fragments (loaded once per wave)
+hipError_t launch_diag_envelope_copygeom(const uint32_t *d_frag, const void *x, void *y, int64_t bytes, int mfma, int mfma_hi, hipStream_t s);
 
 // Polyphase decimator, exact per-MAC order (polydec.hip); p.coeffs = STR_COEFF_TYPE array [ntaps*df], p.n = inputs used
 hipError_t launch_polydec_generic(const FirParams &p, int ntaps, int df, int64_t n_out, hipStream_t s);

@@ -99,6 +99,19 @@ def diag_fir_envelope_ms(coeffs, mfma_per_step, mfma_hi_per_step, x, y, warmup=3
     return ms.value, nbytes
 
 
+def diag_fir_envelope_copygeom_ms(coeffs, mfma_per_step, mfma_hi_per_step, x, y, warmup=3, reps=10):
+    """The same MFMA counts in the plain copy's launch geometry (acdsp_diag_fir_envelope_copygeom_ms): roofline.envelope_copy_geometry_ms.
+    coeffs None: one element per thread, stand-in A operands; else four elements per thread and the set's real Toeplitz fragments."""
+    assert x.is_cuda and y.is_cuda and x.is_contiguous() and y.is_contiguous()
+    nbytes = min(x.numel() * x.element_size(), y.numel() * y.element_size()) // 16 * 16
+    ms = C.c_float()
+    c = None if coeffs is None else np.ascontiguousarray(coeffs, dtype=np.int64)
+    check(lib.acdsp_diag_fir_envelope_copygeom_ms(_dev_index(x.device), None if c is None else c.ctypes.data_as(C.POINTER(C.c_int64)), 0 if c is None else len(c),
+                                                  mfma_per_step, mfma_hi_per_step, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                  nbytes, warmup, reps, _stream_ptr(x), C.byref(ms)))
+    return ms.value, nbytes
+
+
 class Fir:
     """n_channels independent reference FIR objects (ac_fir_{const,load,prog}_coeffs) behind one handle."""
 

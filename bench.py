@@ -612,6 +612,24 @@ def diag_of(w, k_avg, roof):
             roof["envelope_stream_only_ms"] = sms
             roof["envelope_mfma_per_1024_samples"] = {"issued": issued, "high_plane": hi}
             roof["frac_of_envelope"] = ems / k_avg
+            # round 6: the same MFMA counts in the plain copy's geometry (one 16-byte element per thread): is the 32 KB-span stream leg the best one?
+            gms, _ = A.diag_fir_envelope_copygeom_ms(w["coeffs"], issued, hi, x, scratch, warmup=20, reps=20)     # four elements per thread, the set's fragments
+            gs1, _ = A.diag_fir_envelope_copygeom_ms(None, issued, hi, x, scratch, warmup=20, reps=20)           # one element per thread, stand-in A operands
+            g0, _ = A.diag_fir_envelope_copygeom_ms(None, 0, 0, x, scratch, warmup=10, reps=20)
+            # ... the same kernel and MFMA count on the fragments of a set with ONE non-zero tap (all-zero operands but one row), and without MFMAs
+            zc = np.zeros(len(w["coeffs"]), dtype=np.int64)
+            zc[len(zc) // 2] = 1
+            gz, _ = A.diag_fir_envelope_copygeom_ms(zc, issued, hi, x, scratch, warmup=20, reps=20)
+            g4, _ = A.diag_fir_envelope_copygeom_ms(zc, 0, 0, x, scratch, warmup=10, reps=20)
+            roof["envelope_copy_geometry_ms"] = gms
+            roof["envelope_copy_geometry_zero_fragments_ms"] = gz
+            roof["envelope_copy_geometry_4_per_thread_stream_only_ms"] = g4
+            roof["envelope_copy_geometry_standin_ms"] = gs1
+            roof["envelope_copy_geometry_stream_only_ms"] = g0
+            roof["envelope_copy_geometry_note"] = ("the envelope's MFMA count in the plain copy's geometry (256-thread workgroups in memory order, four 16-byte elements per thread, "
+                                                   "the set's Toeplitz fragments loaded once per wave); _zero_fragments: the same instructions on the fragments of a one-tap set; "
+                                                   "_standin: one element per thread, A operand = the loaded bytes rotated (every MFMA of a wave repeats the same operands); the "
+                                                   "MFMAs cost time only where their operands toggle: the package power cap, not issue or geometry (DESIGN 5.2)")
             roof["envelope_note"] = ("stream (2 B in + 2 B out per sample, 32 KB spans, 8-load / 8-store non-temporal bursts) + the product's MFMA count on "
                                      "Toeplitz fragments of the same coefficient set, nothing else in the loop; timed in this process after the workload "
                                      "(ac_dsp_amd/csrc/diag.hip)")
@@ -767,7 +785,9 @@ def main():
                     sec[name]["mfma_per_1024_samples"] = m2["mfma_per_1024_samples"]
                     if name in ("fir255_dense", "fir1023"):      # int16 in / int16 out rows: the envelope moves the same bytes
                         diag_of(w2, ka2, r2)
-                        for k in ("copy_GBps", "envelope_ms", "envelope_stream_only_ms", "frac_of_envelope", "envelope_mfma_per_1024_samples", "envelope_error"):
+                        for k in ("copy_GBps", "envelope_ms", "envelope_stream_only_ms", "frac_of_envelope", "envelope_mfma_per_1024_samples", "envelope_error",
+                                  "envelope_copy_geometry_ms", "envelope_copy_geometry_zero_fragments_ms", "envelope_copy_geometry_4_per_thread_stream_only_ms",
+                                  "envelope_copy_geometry_standin_ms", "envelope_copy_geometry_stream_only_ms"):
                             if k in r2:
                                 sec[name][k] = r2[k]
                 del w2

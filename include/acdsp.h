@@ -190,6 +190,12 @@ int32_t acdsp_diag_shader_clock_mhz(int32_t device, void *stream, float *mhz);
 int32_t acdsp_diag_fir_envelope_ms(int32_t device, const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, int32_t mfma_hi_per_step,
                                    const void *d_x, void *d_y, uint64_t bytes, int32_t warmup, int32_t reps, void *stream, float *ms_avg);
 
+/* the same MFMA counts in the COPY kernel's geometry (256-thread workgroups in memory order, every wave lives for its loads, their MFMAs and
+ * stores).  coeffs == NULL: one 16-byte element per thread, A operands are stand-ins made of the loaded bytes (such a wave cannot keep
+ * fragments resident); coeffs != NULL: four elements per thread, the real Toeplitz fragments of the set loaded once per wave */
+int32_t acdsp_diag_fir_envelope_copygeom_ms(int32_t device, const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, int32_t mfma_hi_per_step,
+                                            const void *d_x, void *d_y, uint64_t bytes, int32_t warmup, int32_t reps, void *stream, float *ms_avg);
+
 /* ---- FIR ---- */
 int32_t acdsp_fir_create(const acdsp_fir_desc_t *desc, acdsp_fir_t *out);
 int32_t acdsp_fir_destroy(acdsp_fir_t h);
