@@ -89,7 +89,9 @@ __global__ void __launch_bounds__(256) diag_envelope_copygeom_kernel(const v4i *
 
 // ... and with the REAL Toeplitz fragments: four elements per thread (a 256-thread workgroup copies 16 KB, still in memory order, all four loads
 // issued before the first product), the six fragments loaded once per wave (L1 hits: 6 KB per 4 KB of samples)
-template <int MK, int HI>
+// ORD (ACDSP_DIAG_ENV_ORDER, an experiment on what the MFMA power follows): 0 = element by element, the A fragment changes with every product and B stays;
+// 1 = fragment by fragment, A stays for four products and B changes; 2 = both operands change with every product
+template <int MK, int HI, int ORD>
 __global__ void __launch_bounds__(256) diag_envelope_copygeom4_kernel(const v4i *__restrict__ frag, const v4i *__restrict__ x, v4i *__restrict__ y, int64_t n_vec) {
   const int64_t i0 = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 1024 + threadIdx.x;
   if (i0 + 768 >= n_vec) { return; }
@@ -102,14 +104,32 @@ __global__ void __launch_bounds__(256) diag_envelope_copygeom4_kernel(const v4i 
   for (int i = 0; i < 4; i++) { Al[i] = frag[i * 64 + lane]; }
 #pragma unroll
   for (int i = 0; i < 2; i++) { Ah[i] = frag[(4 + i) * 64 + lane]; }
+  if constexpr (ORD == 0) {
 #pragma unroll
-  for (int u = 0; u < 4; u++) {
-    v16i acc[4] = {{0}, {0}, {0}, {0}};
+    for (int u = 0; u < 4; u++) {
+      v16i acc[4] = {{0}, {0}, {0}, {0}};
 #pragma unroll
-    for (int m = 0; m < MK; m++) { acc[m & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(m < HI ? Ah[m & 1] : Al[m & 3], v[u], acc[m & 3], 0, 0, 0); }
-    v4i o = v[u];
-    if (MK > 0) { o = (v4i){acc[0][0], acc[1][5], acc[2][10], acc[3][15]}; }
-    y[i0 + 256 * u] = o;
+      for (int m = 0; m < MK; m++) { acc[m & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(m < HI ? Ah[m & 1] : Al[m & 3], v[u], acc[m & 3], 0, 0, 0); }
+      v4i o = v[u];
+      if (MK > 0) { o = (v4i){acc[0][0], acc[1][5], acc[2][10], acc[3][15]}; }
+      y[i0 + 256 * u] = o;
+    }
+  } else {
+    v16i acc[4] = {{0}, {0}, {0}, {0}};     // one accumulator per element
+#pragma unroll
+    for (int m = 0; m < MK; m++) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int mm = ORD == 1 ? m : (m + u) % (MK > 0 ? MK : 1);
+        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(mm < HI ? Ah[mm & 1] : Al[mm & 3], v[u], acc[u], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      v4i o = v[u];
+      if (MK > 0) { o = (v4i){acc[u][0], acc[u][5], acc[u][10], acc[u][15]}; }
+      y[i0 + 256 * u] = o;
+    }
   }
 }
 
@@ -119,9 +139,13 @@ hipError_t launch_diag_envelope_copygeom(const uint32_t *d_frag, const void *x, 
     if (blocks <= 0) { return hipSuccess; }
     const int64_t gx = blocks < (1 << 20) ? blocks : (1 << 20), gy = (blocks + gx - 1) / gx;
     const dim3 grid((unsigned)gx, (unsigned)gy);
+    ACDSP_TUNE_ENV(ord_env, "ACDSP_DIAG_ENV_ORDER");
+    const int ord = ord_env ? atoi(ord_env) : 0;
 #define ACDSP_ENVC4_CASE(NM, NH)                                                                                                 \
     if (mfma == NM && mfma_hi == NH) {                                                                                           \
-      hipLaunchKernelGGL((diag_envelope_copygeom4_kernel<NM / 2, NH / 2>), grid, dim3(256), 0, s, (const v4i *)d_frag, (const v4i *)x, (v4i *)y, n_vec); \
+      if (ord == 1) { hipLaunchKernelGGL((diag_envelope_copygeom4_kernel<NM / 2, NH / 2, 1>), grid, dim3(256), 0, s, (const v4i *)d_frag, (const v4i *)x, (v4i *)y, n_vec); } \
+      else if (ord == 2) { hipLaunchKernelGGL((diag_envelope_copygeom4_kernel<NM / 2, NH / 2, 2>), grid, dim3(256), 0, s, (const v4i *)d_frag, (const v4i *)x, (v4i *)y, n_vec); } \
+      else { hipLaunchKernelGGL((diag_envelope_copygeom4_kernel<NM / 2, NH / 2, 0>), grid, dim3(256), 0, s, (const v4i *)d_frag, (const v4i *)x, (v4i *)y, n_vec); } \
       return hipGetLastError();                                                                                                  \
     }
     ACDSP_ENVC4_CASE(0, 0) ACDSP_ENVC4_CASE(26, 8) ACDSP_ENVC4_CASE(36, 18) ACDSP_ENVC4_CASE(76, 10) ACDSP_ENVC4_CASE(132, 66)

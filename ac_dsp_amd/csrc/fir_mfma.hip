@@ -922,12 +922,25 @@ __device__ __forceinline__ void fir_mfma_pipe_body(const FirParams &p, const v4i
       for (int i = 0; i < GS; i++) {
         const int b = g * GS + i;
         if (b < NB) {
+#if ACDSP_FIR_BORDER
+          // (round 6 A/B) the sample operand stays for two consecutive products of a band block: Bh, Bh, Bl, Bl instead of Bh, Bl, Bl, Bh
+          if (HS == 0 || (b >= (HS & 15) && b <= NB - 1 - (HS >> 4))) {
+            hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bh[cb][i], hh, 0, 0, 0);
+            mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[cb][i], mid, 0, 0, 0);
+            ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bl[cb][i], ll, 0, 0, 0);
+            mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[cb][i], mid, 0, 0, 0);
+          } else {
+            ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bl[cb][i], ll, 0, 0, 0);
+            mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[cb][i], mid, 0, 0, 0);
+          }
+#else
           if (HS == 0 || (b >= (HS & 15) && b <= NB - 1 - (HS >> 4))) {
             hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bh[cb][i], hh, 0, 0, 0);
             mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah[b], Bl[cb][i], mid, 0, 0, 0);
           }
           ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bl[cb][i], ll, 0, 0, 0);
           mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al[b], Bh[cb][i], mid, 0, 0, 0);
+#endif
         }
       }
 #if ACDSP_FIR_PRIO
