@@ -11,7 +11,7 @@ O_MODES = {"WRAP": 0, "SAT": 1, "SAT_ZERO": 2, "SAT_SYM": 3}
 FTYPES = {"SHIFT_REG": 0, "ROTATE_SHIFT": 1, "C_BUFF": 2, "FOLD_EVEN": 3, "FOLD_ODD": 4, "TRANSPOSED": 5,
           "FOLD_EVEN_ANTI": 6, "FOLD_ODD_ANTI": 7}
 KINDS = {"const": 0, "load": 1, "prog": 2, "reg_share": 3}
-PATHS = {0: "generic", 1: "lossless64", 2: "mfma_i8", 3: "mfma_gen", 4: "wide", 5: "mfma_lossy"}
+PATHS = {0: "generic", 1: "lossless64", 2: "mfma_i8", 3: "mfma_gen", 4: "wide", 5: "mfma_lossy"}   # (6 = ACDSP_PATH_CIC_2STAGE: Cic.path only)
 KCLASSES = {**PATHS, 6: "lossy16", 7: "satacc16"}
 FLAG_FORCE_GENERIC = 1
 

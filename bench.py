@@ -760,6 +760,14 @@ def main():
             diag_of(w, k_avg, out["roofline"])
         if cold is not None:
             out["cold_start"] = cold
+        if world == 1 and args.workload == "fir255" and not args.no_secondary:
+            # what a fresh process pays before its first output (one code object with every kernel): tools/load_cost.py as a child process
+            try:
+                import subprocess
+                lc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "load_cost.py")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+                out.setdefault("cold_start", {})["load_ms"] = json.loads(lc.stdout.decode().strip().splitlines()[-1])
+            except Exception as e:  # noqa: BLE001
+                out.setdefault("cold_start", {})["load_ms_error"] = str(e)[:200]
         if w["macs_per_sample"]:
             out["mfma_roofline"] = mfma_roofline_of(w, k_avg)
         fin, fc, fa, fo = w["fmts"]

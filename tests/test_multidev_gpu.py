@@ -142,3 +142,47 @@ def test_bench_refuses_a_world_size_mismatch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def _one_json_line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout must hold exactly ONE JSON line:\n" + p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _env8():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if A.device_count() < 8:
+        env["ACDSP_BENCH_ONE_GPU"] = "1"      # every rank / shard on device 0: the 8-rank code path on a one-GPU box
+    return env
+
+
+def test_bench_eight_ranks_the_drivers_launch_line():
+    """The driver's own 8-GPU command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...` -- at reduced channels: ONE JSON line on stdout (no gloo chatter, no `secondary` rows), n_gpus 8,
+    value = the SUM of the ranks' samples over the MAX of their times."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ch, n, steps = 32, 65536, 3
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(steps), "--warmup", "1", "--channels", str(ch), "--samples", str(n),
+                        "--settle", "0", "--no-cpu-baseline"], env=_env8(), capture_output=True, text=True, timeout=900)
+    d = _one_json_line(p)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == steps and "secondary" not in d
+    assert abs(d["value"] - 8 * ch * n * steps / (d["ms_per_step"] * steps * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert d["config"]["workload"] and d["metric"]
+
+
+def test_bench_eight_shards_in_one_process():
+    """`bench.py --gpus 8 --inproc`: eight channel slices behind one acdsp_node_* handle (one host thread + stream per shard), same contract."""
+    ch, n, steps = 32, 65536, 3
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--inproc", "--steps", str(steps), "--warmup", "1", "--channels", str(ch),
+                        "--samples", str(n), "--settle", "0", "--no-cpu-baseline"], env=_env8(), capture_output=True, text=True, timeout=900)
+    d = _one_json_line(p)
+    assert d["n_gpus"] == 8 and d["steps"] == steps and "secondary" not in d
+    assert abs(d["value"] - 8 * ch * n * steps / (d["ms_per_step"] * steps * 1e-3) / 1e6) < 1e-6 * d["value"]
