@@ -180,8 +180,12 @@ extern "C" int32_t acdsp_diag_shader_clock_mhz(int32_t device, void *stream, flo
   if (!mhz) { return fail(ACDSP_EINVAL, "diag_shader_clock: null output"); }
   int rc = check_device(device);
   if (rc) { return rc; }
-  static thread_local float *d_buf = nullptr;
-  if (!d_buf) { HIP_TRY(hipMalloc((void **)&d_buf, 8 * sizeof(float))); }
+  // one 32-byte result buffer per device and calling thread (a buffer of another device would fault without peer access: advisor, round 5);
+  // they live as long as the process -- a measurement helper, 16 devices at most
+  static thread_local float *d_bufs[16] = {nullptr};
+  if (device < 0 || device >= 16) { return fail(ACDSP_EINVAL, "diag_shader_clock: device %d outside 0..15", device); }
+  if (!d_bufs[device]) { HIP_TRY(hipMalloc((void **)&d_bufs[device], 8 * sizeof(float))); }
+  float *d_buf = d_bufs[device];
   hipStream_t s = (hipStream_t)stream;
   const hipError_t e = launch_diag_clock(d_buf, 8, s);
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "diag clock launch failed: %s", hipGetErrorString(e)); }

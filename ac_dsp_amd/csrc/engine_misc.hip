@@ -16,6 +16,8 @@ struct acdsp_intgdump {
   int32_t *d_chain = nullptr;   // [cap]
   int64_t blk_cap = 0;
   bool pending = false;         // the last call ended on a block that did not dump: temp[] is non-zero
+  bool temp_zero = true;        // d_temp[cur] is known to be all zero (create / reset / zeroed behind a general-kernel call that dumped everything):
+                                // what the tile / stream kernels rely on when they leave temp[] alone (advisor, round 5)
   int last_path = 0;            // acdsp_intgdump_path
   // block table of the last call: a stream that dumps on a fixed schedule passes the same n_sample[] every call, and then
   // neither the table is rebuilt nor uploaded and run() stays asynchronous (no stream synchronisation)
@@ -152,7 +154,7 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
     sat_free = !no_sat_free && (((unsigned __int128)h->tbl_max_rounds * xmax) << (p.acc.F - p.in.F)) <= top;   // rounds < 2^63, xmax <= 2^64 - W .. : inside 128 bits
   }
   p.lossless = (d.acc.O == ACDSP_WRAP || sat_free) && p.acc.F >= p.in.F && p.acc.F - p.in.F < 64 - d.in.W;
-  p.tile_ok = p.lossless && !h->pending && grp == n_blocks;
+  p.tile_ok = p.lossless && !h->pending && h->temp_zero && grp == n_blocks;
   if (p.tile_ok) { p.uni_rounds = h->tbl_uni_rounds; }
   p.x = d_in; p.y = d_out; p.temp = h->d_temp[h->cur];
   p.blk_off = h->d_blk; p.blk_rounds = h->d_blk + n_blocks; p.blk_out = h->d_blk + 2 * n_blocks; p.blk_chain = h->d_chain;
@@ -161,6 +163,14 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "intg_dump kernel launch failed: %s", hipGetErrorString(e)); }
   if (temp_written) { h->cur ^= 1; }   // (else: nothing carried in, every block dumped -- the all-zero temp[] of this side stays the state)
   h->pending = start != (int32_t)n_blocks;   // the call ended on blocks that did not dump: their sums sit in temp[]
+  if (temp_written) {
+    // the general kernel wrote the next temp[]: non-zero while sums are pending; when every chain dumped it is zeroed HERE rather than trusted
+    h->temp_zero = false;
+    if (!h->pending) {
+      HIP_TRY(hipMemsetAsync(h->d_temp[h->cur], 0, (size_t)d.n_objects * d.chn * sizeof(int64_t), s));
+      h->temp_zero = true;
+    }
+  }
   return ACDSP_OK;
 }
 
@@ -198,6 +208,7 @@ int32_t acdsp_intgdump_reset(acdsp_intgdump_t h) {
   HIP_TRY(hipDeviceSynchronize());
   for (int i = 0; i < 2; i++) { HIP_TRY(hipMemset(h->d_temp[i], 0, (size_t)h->d.n_objects * h->d.chn * sizeof(int64_t))); }
   h->pending = false;
+  h->temp_zero = true;
   return ACDSP_OK;
 }
 

@@ -477,6 +477,7 @@ int32_t acdsp_polyintr_run(acdsp_polyintr_t h, const void *d_in, int64_t in_stri
         o_a = 16 * slot_a * L + out_off; o_b = 16 * (slot_a + 32 * n_steps) * L + out_off;
         h->last_path = ACDSP_PATH_MFMA_GEN;
       } else if (e != hipErrorNotSupported) {
+        if (forked) { (void)h->side.join(s); }   // (an unjoined fork invalidates a stream capture and leaves the side stream waiting: advisor, round 5)
         return fail(ACDSP_EHIP, "poly_intr matrix-core kernel launch failed: %s", hipGetErrorString(e));
       }
     }

@@ -226,8 +226,9 @@ public:
     // Compare by integer part first (no overflow), then by aligned fraction.
     i128 ai = v >> F, bi = o.raw128() >> F2;  // floor of each value (F,F2 < 128 given W<=128 in practice)
     if (ai != bi) { return ai < bi ? -1 : 1; }
-    ac_private::u128 af = (ac_private::u128)(v - (ai << F)) << (FM - F);
-    ac_private::u128 bf = (ac_private::u128)(o.raw128() - (bi << F2)) << (FM - F2);
+    // (shifts on the unsigned image: `ai << F` of a negative ai is undefined before C++20 -- found by the UBSan build of tb_tiny)
+    ac_private::u128 af = ((ac_private::u128)v - ((ac_private::u128)ai << F)) << (FM - F);
+    ac_private::u128 bf = ((ac_private::u128)o.raw128() - ((ac_private::u128)bi << F2)) << (FM - F2);
     return af < bf ? -1 : (af > bf ? 1 : 0);
   }
   template <int W2, int I2, bool S2, ac_q_mode Q2, ac_o_mode O2> bool operator==(const ac_fixed<W2, I2, S2, Q2, O2> &o) const { return cmp(o) == 0; }

@@ -105,7 +105,7 @@ int any_below(const W256 &a, int k) {
 }
 
 /* ---- ac_fixed conversion rules (AC Datatypes semantics, restated as in acdsp_oracle.c) ---- */
-i128 fmt_min(const orc_fmt_t *f) { return f->S ? -(i128)((u128)1 << (f->W - 1)) : (i128)0; }
+i128 fmt_min(const orc_fmt_t *f) { return f->S ? (i128)(~(u128)0 << (f->W - 1)) : (i128)0; }   /* (not -(1 << (W-1)): W = 128 negates INT128_MIN -- found by the UBSan build) */
 i128 fmt_max(const orc_fmt_t *f) { return f->S ? (i128)(((u128)1 << (f->W - 1)) - 1) : (i128)(((u128)1 << f->W) - 1); }
 
 i128 wrap_w(const W256 &q, int W, int S) {

@@ -7,6 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libacdsp_oracle.so")
+_SAN = os.environ.get("ACDSP_ORACLE_LIB")   # the sanitizer build (oracle/Makefile: sanitize), tests/test_sanitizers.py
 
 Q_MODES = {"TRN": 0, "RND": 1, "TRN_ZERO": 2, "RND_ZERO": 3, "RND_INF": 4, "RND_MIN_INF": 5, "RND_CONV": 6,
            "RND_CONV_ODD": 7}
@@ -38,7 +39,7 @@ def _build():
 
 
 _build()
-lib = C.CDLL(_SO)
+lib = C.CDLL(_SAN if _SAN else _SO)
 _i64p = C.POINTER(C.c_int64)
 lib.orc_requant.restype = C.c_int64
 lib.orc_requant.argtypes = [C.c_int64, C.c_int32, C.POINTER(Fmt)]

@@ -86,3 +86,16 @@ def test_own_fir_testbench_on_both_sides_of_the_host_threshold(small_macs):
     created, runs = kernel_runs(out)
     if small_macs == "0":
         assert created >= 1 and runs >= 1, (created, runs)
+
+
+@pytest.mark.parametrize("tb,asan", [("tb_tiny_san", False), ("tb_tiny_asan", True)])
+def test_host_loop_of_the_drop_in_classes_under_sanitizers(tb, asan):
+    """tb_tiny (72 configurations: the header's host loop against the kernels, state blobs moving both ways) built with UBSan + checked std::vector
+    indexing, and with AddressSanitizer as well: acdsp_engine.h's host_step indexes its rings with % on every tap."""
+    env = {"UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"}
+    if asan:
+        env["ASAN_OPTIONS"] = "detect_leaks=0:protect_shadow_gap=0"      # (the HIP runtime maps the shadow gap)
+    rc, out = run(os.path.join(BIN, tb), env)
+    if asan and rc != 0 and "Test PASSED." not in out and ("Shadow memory" in out or "ReserveShadowMemoryRange" in out or "failed to" in out.lower() and "shadow" in out.lower()):
+        pytest.skip("AddressSanitizer cannot start beside the HIP runtime on this box")
+    assert rc == 0 and "Test PASSED." in out and "runtime error" not in out and "AddressSanitizer" not in out, out[-3000:]

@@ -139,3 +139,28 @@ def test_block_table_is_cached_across_calls_and_streams():
                 y = eng.run(xd, n_sample)
         torch.cuda.synchronize()
         assert np.array_equal(y.cpu().numpy().astype(np.int64), orc.run(x, n_sample))
+
+
+def test_pending_sums_and_uniform_calls_alternate_on_every_kernel_family():
+    """Calls that leave an undumped sum behind (general kernel, temp[] non-zero), calls that dump it and everything after (general kernel again:
+    a sum is carried in), then uniform calls (tile / streaming kernels, which leave temp[] alone and rely on it being zero) -- several times
+    round, with full-scale samples so that a stale temp[] would show.  acdsp_intgdump_path tells which family ran."""
+    ns, chn, n_obj = 64, 4, 5
+    fin, fa, fo = A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)
+    rng = np.random.default_rng(21)
+    eng = A.IntgDump(ns, chn, fin, fa, fo, n_objects=n_obj)
+    orc = OracleIntgDump(ns, chn, ofmt(fin), ofmt(fa), ofmt(fo), n_obj=n_obj)
+    uniform, leaves_pending, dumps_pending, ragged_clean = [ns] * 64, [ns, ns, 7, 100], [ns, ns], [5, ns, 9, ns]   # (a block of n_sample > NS runs NS rounds and does not dump)
+    seen = []
+    for n_sample in [uniform, leaves_pending, dumps_pending, uniform, uniform, leaves_pending, leaves_pending, dumps_pending, ragged_clean, uniform,
+                     [ns] * 3, leaves_pending, uniform]:
+        ni, no = eng.counts(n_sample)
+        x = rand_raw(rng, fin, (n_obj, ni))
+        x[0] = 32767
+        x[1] = -32768
+        y = eng.run(torch.from_numpy(x).to(torch.int16).cuda(), n_sample).cpu().numpy().astype(np.int64)
+        seen.append(eng.path)
+        assert np.array_equal(y, orc.run(x, n_sample)), (n_sample[:6], eng.path)
+    assert seen[0] == "stream" and seen[1] == "exact_order" and seen[2] == "exact_order" and seen[3] == "stream" and seen[9] == "stream", seen
+    # (the last call starts with a pending sum: it must NOT take a kernel that ignores temp[])
+    assert seen[-1] == "exact_order", seen
