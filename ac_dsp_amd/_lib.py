@@ -122,6 +122,9 @@ SYMBOLS = {
     "acdsp_node_mvavg_create": (_i32, [C.POINTER(MvAvgDesc), _i32, C.POINTER(_i32), C.POINTER(_vp)]),
     "acdsp_node_mvavg_set_coeffs": (_i32, [_vp, C.POINTER(_i64)]),
     "acdsp_node_mvavg_run": (_i32, [_vp, C.POINTER(_vp), _i64, _i64, _i64, C.POINTER(_vp), _i64, C.POINTER(_i64)]),
+    "acdsp_diag_mix_ms": (_i32, [_i32, _vp, C.c_uint64, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
+    "acdsp_dev_alloc_shop": (_i32, [_i32, C.c_uint64, _i32, _vp, _vp, _i32, C.POINTER(_vp), C.POINTER(C.c_float)]),
+    "acdsp_dev_alloc_paired": (_i32, [_i32, C.c_uint64, _vp, C.c_uint64, _i32, _i32, C.POINTER(_vp), C.POINTER(C.c_float)]),
     "acdsp_diag_copy_ms": (_i32, [_i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_diag_shader_clock_mhz": (_i32, [_i32, _vp, C.POINTER(C.c_float)]),
     "acdsp_diag_fir_envelope_ms": (_i32, [_i32, C.POINTER(_i64), _i32, _i32, _i32, _vp, _vp, C.c_uint64, _i32, _i32, _vp, C.POINTER(C.c_float)]),

@@ -166,6 +166,46 @@ hipError_t launch_diag_envelope_copygeom(const uint32_t *d_frag, const void *x, 
   return hipErrorInvalidValue;
 }
 
+// Placement probe (acdsp_diag_mix_ms, acdsp_dev_alloc_paired): a bare stream that READS one block and WRITES another at the byte ratio of the two
+// blocks, in the product kernels' geometry -- one wave per span in memory order, up to eight 1 KB non-temporal loads in flight, 1 KB non-temporal
+// stores.  The HBM-bound rows run 3 - 8 % apart on different (input, output) allocation pairs (profiles/r3_placement_modes.txt: same bytes, same
+// TLB and L2 counters, more DRAM credit stalls on the slow pair); this kernel ranks candidate allocations the same way at a fraction of a row's time.
+//   rd_per_wr >= 1: every wave reads rd_per_wr KB and writes 1 KB;  rd_per_wr < 0: reads 1 KB and writes -rd_per_wr KB
+__global__ void __launch_bounds__(64) diag_mix_kernel(const v4i *__restrict__ src, v4i *__restrict__ dst, int64_t n_waves, int rd_per_wr) {
+  const int64_t w = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (w >= n_waves) { return; }
+  const int lane = threadIdx.x;
+  if (rd_per_wr >= 1) {
+    const v4i *s = src + w * rd_per_wr * 64 + lane;
+    v4i acc = {0, 0, 0, 0};
+    for (int r0 = 0; r0 < rd_per_wr; r0 += 8) {
+      v4i v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { v[u] = __builtin_nontemporal_load(s + (r0 + u < rd_per_wr ? r0 + u : r0) * 64); }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { acc ^= v[u]; }
+    }
+    __builtin_nontemporal_store(acc, dst + w * 64 + lane);
+  } else {
+    const int k = -rd_per_wr;
+    v4i v = __builtin_nontemporal_load(src + w * 64 + lane);
+    for (int r = 0; r < k; r++) { v.x += r; __builtin_nontemporal_store(v, dst + (w * k + r) * 64 + lane); }
+  }
+}
+
+// reads [src, src + src_bytes), writes [dst, dst + dst_bytes); the ratio is rounded to a whole number of KB per wave
+hipError_t launch_diag_mix(const void *src, int64_t src_bytes, void *dst, int64_t dst_bytes, hipStream_t s) {
+  if (src_bytes < 1024 || dst_bytes < 1024) { return hipSuccess; }
+  int ratio;
+  int64_t n_waves;
+  if (src_bytes >= dst_bytes) { int64_t r = src_bytes / dst_bytes; if (r > 256) { r = 256; } ratio = (int)r; n_waves = dst_bytes / 1024; if (n_waves * ratio * 1024 > src_bytes) { n_waves = src_bytes / (1024 * ratio); } }
+  else { int64_t r = dst_bytes / src_bytes; if (r > 256) { r = 256; } ratio = -(int)r; n_waves = src_bytes / 1024; if (n_waves * r * 1024 > dst_bytes) { n_waves = dst_bytes / (1024 * r); } }
+  if (n_waves <= 0) { return hipSuccess; }
+  const int64_t gx = n_waves < (1 << 20) ? n_waves : (1 << 20), gy = (n_waves + gx - 1) / gx;
+  hipLaunchKernelGGL(diag_mix_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(64), 0, s, (const v4i *)src, (v4i *)dst, n_waves, ratio);
+  return hipGetLastError();
+}
+
 bool diag_envelope_compiled(int mfma, int mfma_hi) {
   return (mfma == 0 && mfma_hi == 0) || (mfma == 26 && mfma_hi == 8) || (mfma == 36 && mfma_hi == 18) || (mfma == 76 && mfma_hi == 10) ||
          (mfma == 132 && mfma_hi == 66);

@@ -198,6 +198,104 @@ extern "C" int32_t acdsp_diag_shader_clock_mhz(int32_t device, void *stream, flo
   return ACDSP_OK;
 }
 
+extern "C" int32_t acdsp_diag_mix_ms(int32_t device, const void *d_src, uint64_t src_bytes, void *d_dst, uint64_t dst_bytes, int32_t warmup, int32_t reps, void *stream,
+                                     float *ms_avg) {
+  if (!d_src || !d_dst || src_bytes < 1024 || dst_bytes < 1024 || ((uintptr_t)d_src | (uintptr_t)d_dst) % 16) { return fail(ACDSP_EINVAL, "diag_mix: 16-byte aligned blocks of at least 1 KB"); }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  return time_launches([&] { return launch_diag_mix(d_src, (int64_t)src_bytes, d_dst, (int64_t)dst_bytes, s); }, warmup, reps, s, ms_avg);
+}
+
+// Allocation with a placement probe.  The HBM-bound operators run 3 - 8 % apart (config 3: 14.4 / 15.3 ms) on different (input, output)
+// allocation pairs -- same bytes, same TLB and L2 behaviour, more DRAM credit stalls on the slow pair (profiles/r3_placement_modes.txt) -- and
+// the level belongs to the pair of allocations, not to an offset inside one.  A caller that allocates its output AFTER its input can shop:
+// n_candidates blocks are allocated, each is timed with the bare mixed stream of acdsp_diag_mix_ms against the partner block (partner_reads != 0:
+// the partner is the stream that is read, the new block the one written; 0: the other way round), the fastest is kept and the others freed.
+extern "C" int32_t acdsp_dev_alloc_paired(int32_t device, uint64_t bytes, const void *d_partner, uint64_t partner_bytes, int32_t partner_reads,
+                                          int32_t n_candidates, void **d_ptr, float *probe_ms) {
+  if (!d_ptr || bytes == 0) { return fail(ACDSP_EINVAL, "dev_alloc_paired: null output or zero size"); }
+  if (n_candidates < 1) { n_candidates = 1; }
+  if (n_candidates > 16) { n_candidates = 16; }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  const bool probe = d_partner && partner_bytes >= (1u << 20) && bytes >= (1u << 20) && n_candidates > 1 && (uintptr_t)d_partner % 16 == 0;
+  if (!probe) {
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    if (probe_ms) { probe_ms[0] = 0.f; }
+    return ACDSP_OK;
+  }
+  void *cand[16] = {nullptr};
+  float ms[16];
+  int n = 0, best = 0;
+  for (; n < n_candidates; n++) {
+    if (hipMalloc(&cand[n], bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }   // out of memory: shop among what fitted
+  }
+  if (n == 0) { return fail(ACDSP_EHIP, "dev_alloc_paired: hipMalloc of %llu bytes failed", (unsigned long long)bytes); }
+  // the probe walks BOTH blocks end to end (a 4 GB prefix does not show the level: profiles/r6_placement.txt)
+  const uint64_t pb = partner_bytes / 1024 * 1024, nb = bytes / 1024 * 1024;
+  for (int pass = 0; pass < 2; pass++) {          // two passes: a candidate's time does not depend on its turn
+    for (int i = 0; i < n; i++) {
+      float t = 0;
+      rc = partner_reads ? acdsp_diag_mix_ms(device, d_partner, pb, cand[i], nb, 2, 5, nullptr, &t) : acdsp_diag_mix_ms(device, cand[i], nb, const_cast<void *>(d_partner), pb, 2, 5, nullptr, &t);
+      if (rc) { for (int k = 0; k < n; k++) { (void)hipFree(cand[k]); } return rc; }
+      ms[i] = pass == 0 ? t : (t < ms[i] ? t : ms[i]);
+    }
+  }
+  for (int i = 1; i < n; i++) { if (ms[i] < ms[best]) { best = i; } }
+  for (int i = 0; i < n; i++) { if (i != best) { (void)hipFree(cand[i]); } }
+  if (probe_ms) { for (int i = 0; i < n_candidates; i++) { probe_ms[i] = i < n ? ms[i] : 0.f; } }
+  *d_ptr = cand[best];
+  return ACDSP_OK;
+}
+
+// ... and with the caller's OWN call as the probe: the bare stream ranks candidate blocks like the operator only where the thin stream is
+// thin enough (16 : 1 and beyond: a 12 % level on a <16,1> R = 64 decimator found by both; config 3's 4 : 1 pairs, 6 % apart, are invisible to
+// it: profiles/r6_placement.txt).  trial(ctx, candidate) enqueues one call of the operator with the candidate as its output (or input) on the
+// NULL stream and returns 0; every candidate is timed over `reps` calls behind one untimed call, twice round; the fastest is kept.
+extern "C" int32_t acdsp_dev_alloc_shop(int32_t device, uint64_t bytes, int32_t n_candidates, int32_t (*trial)(void *ctx, void *d_candidate), void *ctx, int32_t reps,
+                                        void **d_ptr, float *trial_ms) {
+  if (!d_ptr || bytes == 0) { return fail(ACDSP_EINVAL, "dev_alloc_shop: null output or zero size"); }
+  if (n_candidates < 1) { n_candidates = 1; }
+  if (n_candidates > 16) { n_candidates = 16; }
+  if (reps < 1) { reps = 1; }
+  int rc = check_device(device);
+  if (rc) { return rc; }
+  if (!trial || n_candidates == 1) {
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    if (trial_ms) { trial_ms[0] = 0.f; }
+    return ACDSP_OK;
+  }
+  void *cand[16] = {nullptr};
+  float ms[16];
+  int n = 0, best = 0;
+  for (; n < n_candidates; n++) {
+    if (hipMalloc(&cand[n], bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
+  }
+  if (n == 0) { return fail(ACDSP_EHIP, "dev_alloc_shop: hipMalloc of %llu bytes failed", (unsigned long long)bytes); }
+  auto free_all = [&](int keep) { for (int k = 0; k < n; k++) { if (k != keep) { (void)hipFree(cand[k]); } } };
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { free_all(-1); return fail(ACDSP_EHIP, "dev_alloc_shop: event creation failed"); }
+  for (int pass = 0; pass < 2 && rc == 0; pass++) {
+    for (int i = 0; i < n && rc == 0; i++) {
+      rc = trial(ctx, cand[i]);
+      if (rc == 0) { (void)hipEventRecord(e0, nullptr); }
+      for (int r = 0; r < reps && rc == 0; r++) { rc = trial(ctx, cand[i]); }
+      float t = 0;
+      if (rc == 0 && (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess)) { rc = ACDSP_EHIP; }
+      t /= (float)reps;
+      ms[i] = pass == 0 ? t : (t < ms[i] ? t : ms[i]);
+    }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc) { free_all(-1); return rc == ACDSP_EHIP ? fail(ACDSP_EHIP, "dev_alloc_shop: timing a trial failed") : rc; }
+  for (int i = 1; i < n; i++) { if (ms[i] < ms[best]) { best = i; } }
+  free_all(best);
+  if (trial_ms) { for (int i = 0; i < n_candidates; i++) { trial_ms[i] = i < n ? ms[i] : 0.f; } }
+  *d_ptr = cand[best];
+  return ACDSP_OK;
+}
+
 // A operands with the statistics of the product's: Toeplitz fragments of the caller's set (fir_mfma_build_fragments: [2 planes][nb][64][4]
 // dwords), four blocks of the low-byte plane spread over the taps and two non-zero blocks of the high-byte plane (the centre of the band)
 static int envelope_fragments(const int64_t *coeffs, int32_t n_taps, int32_t mfma_per_step, std::vector<uint32_t> *six_out) {

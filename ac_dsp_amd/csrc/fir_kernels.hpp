@@ -215,6 +215,8 @@ int set_error(int code, const char *msg);
 
 // Measurement kernels of acdsp_diag_* (diag.hip): a plain 16-byte-per-thread copy, and the stream + issued-MFMA envelope of a FIR row.
 hipError_t launch_diag_copy(const void *src, void *dst, int64_t bytes, hipStream_t s);
+// placement probe: a bare stream reading one block and writing the other at their byte ratio (diag.hip)
+hipError_t launch_diag_mix(const void *src, int64_t src_bytes, void *dst, int64_t dst_bytes, hipStream_t s);
 // d_frag: six Toeplitz fragments [4 low-plane blocks][2 high-plane blocks] x 64 lanes x 16 bytes; hipErrorInvalidValue: count not compiled
 bool diag_envelope_compiled(int mfma, int mfma_hi);
 hipError_t launch_diag_clock(float *d_mhz, int n_blocks, hipStream_t s);   // shader clock in MHz per block (diag.hip)

@@ -88,6 +88,67 @@ def diag_shader_clock_mhz(device=0):
     return mhz.value
 
 
+def diag_mix_ms(src, dst, warmup=2, reps=5):
+    """Average ms of the bare mixed stream src (read) -> dst (written) at the byte ratio of the two blocks (acdsp_diag_mix_ms): the placement probe."""
+    assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()
+    ms = C.c_float()
+    check(lib.acdsp_diag_mix_ms(_dev_index(src.device), C.c_void_p(src.data_ptr()), src.numel() * src.element_size() // 1024 * 1024,
+                                C.c_void_p(dst.data_ptr()), dst.numel() * dst.element_size() // 1024 * 1024, warmup, reps, _stream_ptr(src), C.byref(ms)))
+    return ms.value
+
+
+def empty_paired(shape, dtype, partner, candidates=4, partner_reads=True, cap_bytes=1 << 50):
+    """torch.empty(shape, dtype) on the partner's device with a placement probe (the torch-side twin of acdsp_dev_alloc_paired): `candidates` blocks are
+    allocated, each timed with diag_mix_ms against `partner` (read when partner_reads, else written), the fastest kept.  Returns (tensor, probe ms list)."""
+    import torch
+    cands = [torch.empty(shape, dtype=dtype, device=partner.device) for _ in range(max(1, candidates))]
+    if len(cands) == 1 or not partner.is_contiguous() or cands[0].numel() * cands[0].element_size() < (1 << 20):
+        return cands[0], [0.0]
+    pf, big = partner.view(-1), max(partner.numel() * partner.element_size(), cands[0].numel() * cands[0].element_size())
+    f = min(1.0, cap_bytes / big)
+    pn = int(pf.numel() * f)
+    best, times = None, []
+    for pas in range(2):
+        for i, c in enumerate(cands):
+            cf = c.view(-1)
+            cn = int(cf.numel() * f)
+            t = diag_mix_ms(pf[:pn], cf[:cn]) if partner_reads else diag_mix_ms(cf[:cn], pf[:pn])
+            if pas == 0:
+                times.append(t)
+            else:
+                times[i] = min(times[i], t)
+    best = min(range(len(cands)), key=lambda i: times[i])
+    keep = cands[best]
+    del cands
+    return keep, times
+
+
+def shop_output(trial, shape, dtype, device, candidates=4, reps=3):
+    """torch.empty(shape, dtype) chosen among `candidates` separately allocated blocks by timing the caller's own call -- trial(y) runs the operator
+    with y as its output -- `reps` times behind one untimed call, twice round (the torch-side twin of acdsp_dev_alloc_shop).  The HBM-bound operators
+    run up to 12 % apart on different (input, output) allocation pairs (profiles/r6_placement.txt).  Returns (tensor, ms per candidate)."""
+    import torch
+    cands = [torch.empty(shape, dtype=dtype, device=device) for _ in range(max(1, candidates))]
+    if len(cands) == 1:
+        return cands[0], [0.0]
+    times = [0.0] * len(cands)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for pas in range(2):
+        for i, y in enumerate(cands):
+            trial(y)
+            e0.record()
+            for _ in range(reps):
+                trial(y)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps
+            times[i] = t if pas == 0 else min(times[i], t)
+    best = min(range(len(cands)), key=lambda i: times[i])
+    keep = cands[best]
+    del cands
+    return keep, times
+
+
 def diag_fir_envelope_ms(coeffs, mfma_per_step, mfma_hi_per_step, x, y, warmup=3, reps=10):
     """Average ms of the stream + issued-MFMA envelope of a FIR row over x -> y (acdsp_diag_fir_envelope_ms): roofline.envelope_ms."""
     assert x.is_cuda and y.is_cuda and x.is_contiguous() and y.is_contiguous()

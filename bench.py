@@ -87,6 +87,17 @@ def build_workload(workload, args, world, rank, local_rank):
     step() = one pass of the hot path over the resident [channels][samples] block."""
     import ac_dsp_amd as A
     dev = torch.device("cuda", local_rank)
+    placement = {}
+
+    def shop(shape, dtype, trial):
+        """the output buffer of an HBM-bound row: one of --placement K separately allocated candidates, chosen by timing the row's own call on each
+        (A.shop_output; INTEGRATION.md 7: the same operator runs up to 12 % apart on different input / output allocation pairs)"""
+        kcand = int(getattr(args, "placement", 0) or 0)
+        if kcand <= 1:
+            return torch.empty(shape, dtype=dtype, device=dev)
+        yb, ms = A.shop_output(trial, shape, dtype, dev, candidates=kcand, reps=2)
+        placement.update({"candidates": kcand, "trial_ms": [round(t, 4) for t in ms]})
+        return yb
     seed = 0xACD5
     coeffs = n_taps = fin = fc = fa = fo = None
     if workload in ("fir255", "fir255_dense", "fir255_wide", "fir1023"):
@@ -171,7 +182,7 @@ def build_workload(workload, args, world, rank, local_rank):
         eng = A.Cic(False, R, M, N, fin, fo, n_channels=hi - lo, device=local_rank)
         x = torch.empty((hi - lo, n), dtype=A.torch_dtype_for(fin), device=dev)
         A.fill_stimulus(x, seed, W, ch0=lo)
-        y = torch.empty((hi - lo, (n // R + 8 + 7) // 8 * 8), dtype=A.torch_dtype_for(fo), device=dev)
+        y = shop((hi - lo, (n // R + 8 + 7) // 8 * 8), A.torch_dtype_for(fo), lambda yy: eng.run(x, yy))
         bytes_per_sample = float(x.element_size()) + float(y.element_size()) / R
         macs_per_sample = 0.0
         name = "ac_cic_dec_full N=%d R=%d M=%d ac_fixed<%d,%d> -> <%d,%d>, %d ch x %d samples per GPU" % (N, R, M, W, I, it.W, it.I, ch_per_gpu, n)
@@ -196,7 +207,7 @@ def build_workload(workload, args, world, rank, local_rank):
         eng = A.Cic(interp, 7, 2, N, fin, fo, n_channels=hi - lo, device=local_rank)
         x = torch.empty((hi - lo, n), dtype=torch.int32, device=dev)
         A.fill_stimulus(x, seed, 32, ch0=lo)
-        y = torch.empty((hi - lo, (n * 7 + 64) if interp else (n // 7 + 8)), dtype=torch.int64, device=dev)
+        y = shop((hi - lo, (n * 7 + 64) if interp else (n // 7 + 8)), torch.int64, (lambda yy: eng.run(x, yy)) if not interp else (lambda yy: None))
         if interp:
             eng.run(x[:, :64], y)                # steady state: later calls emit R outputs per input
         bytes_per_sample = 4.0 + (8.0 * 7 if interp else 8.0 / 7)
@@ -223,7 +234,7 @@ def build_workload(workload, args, world, rank, local_rank):
         eng.set_coeffs(np.array([hh[df + tp * 8] for df in range(8) for tp in range(16)], dtype=np.int64))
         x = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
         A.fill_stimulus(x, seed, 16, ch0=lo)
-        y = torch.empty((hi - lo, n // 8 + 8), dtype=torch.int16, device=dev)
+        y = shop((hi - lo, n // 8 + 8), torch.int16, lambda yy: eng.run(x, yy))
         bytes_per_sample = 2.0 + 2.0 / 8
         macs_per_sample = 0.0
         name = "ac_poly_dec NTAPS=16 DF=8 ac_fixed<16,2> -> <16,2,RND,SAT>, %d ch x %d samples per GPU (SURVEY 8 f2)" % (ch_per_gpu, n)
@@ -338,7 +349,7 @@ def build_workload(workload, args, world, rank, local_rank):
         eng.set_coeffs(coeffs)
         x = torch.empty((hi - lo, n + args.pad), dtype=torch.int16, device=dev)[:, :n]
         A.fill_stimulus(x, seed, 16, ch0=lo)
-        y = torch.empty((hi - lo, n // 16 + 8), dtype=torch.int32, device=dev)
+        y = shop((hi - lo, n // 16 + 8), torch.int32, lambda yy: eng.run(x, yy))
         bytes_per_sample = 2.0 + 4.0 / 16      # 2 B read per real input sample + 4 B written per 16 (intermediate stays on chip ideally)
         macs_per_sample = 0.0
         name = "DDC: ac_cic_dec_full R=16 N=5 <16,1> -> 127-tap ac_fir_const_coeffs IN <36,21>, %d real streams x %d samples per GPU " \
@@ -358,7 +369,7 @@ def build_workload(workload, args, world, rank, local_rank):
         eng = A.Cic(False, 8, 1, 5, fin, fo, n_channels=hi - lo, device=local_rank)
         x = torch.empty((hi - lo, n + args.pad), dtype=torch.int32, device=dev)[:, :n]
         A.fill_stimulus(x, seed, 32, ch0=lo)
-        y = torch.empty((hi - lo, n // 8 + 8 + args.pad), dtype=torch.int64, device=dev)
+        y = shop((hi - lo, n // 8 + 8 + args.pad), torch.int64, lambda yy: eng.run(x, yy))
         bytes_per_sample = 5.0                   # 4 B read + 8 B / 8 written
         macs_per_sample = 0.0
         name = "ac_cic_dec_full N=5 R=8 M=1 ac_fixed<32,16> -> <47,31>, %d ch x %d samples per GPU (BASELINE configs[2])" % (ch_per_gpu, n)
@@ -372,7 +383,7 @@ def build_workload(workload, args, world, rank, local_rank):
 
     if not macs_per_sample:
         issued_macs_per_sample = 0.0
-    return {"workload": workload, "name": name, "dtype": dtype, "step": step, "path": path, "samples_per_step": samples_per_step,
+    return {"workload": workload, "name": name, "dtype": dtype, "step": step, "path": path, "samples_per_step": samples_per_step, "placement": placement,
             "bytes_per_sample": bytes_per_sample, "macs_per_sample": macs_per_sample, "issued_macs_per_sample": issued_macs_per_sample, "coeffs": coeffs, "eng": eng, "x": x, "n": n,
             "ch_per_gpu": ch_per_gpu, "n_taps": n_taps, "fmts": (fin, fc, fa, fo), "seed": seed}
 
@@ -675,6 +686,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs after the headline workload")
     ap.add_argument("--pad", type=int, default=0, help="extra elements per row (row stride = samples + pad)")
+    ap.add_argument("--placement", type=int, default=6, help="output buffers of the HBM-bound decimator rows: candidates to allocate and time the row's own call on "
+                    "(the fastest is kept, outside the timed region; 0 / 1: plain allocation).  INTEGRATION.md 7")
     ap.add_argument("--stim-bits", type=int, default=0, help="diagnostic: amplitude of the FIR stimulus in bits (default: full 16)")
     ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed pre-conditioning steps in front of the warm-up "
                     "(shader-clock ramp from idle; 0 = cold start, the K timed steps then include the DVFS transient)")
@@ -758,6 +771,8 @@ def main():
         }
         if world == 1:
             diag_of(w, k_avg, out["roofline"])
+        if w.get("placement"):
+            out["config"]["placement"] = w["placement"]
         if cold is not None:
             out["cold_start"] = cold
         if world == 1 and args.workload == "fir255" and not args.no_secondary:
@@ -787,6 +802,8 @@ def main():
                              "Msamples_per_s": w2["samples_per_step"] * 10 / dt2 / 1e6, "kernel_ms_avg": ka2,
                              "roofline_frac": r2["frac"], "roofline_frac_step": r2["frac_step"], "achieved_GBps": r2["achieved"],
                              "traffic": r2.get("traffic"), "clock_mhz_after": w2.get("clock_mhz_after")}
+                if w2.get("placement"):
+                    sec[name]["placement"] = w2["placement"]
                 if w2["macs_per_sample"]:
                     m2 = mfma_roofline_of(w2, ka2)
                     sec[name]["mfma_frac"] = m2["frac"]

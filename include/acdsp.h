@@ -165,6 +165,21 @@ int32_t acdsp_elem_bytes(int32_t W);           /* 2, 4 or 8 */
 /* device-memory helpers so that pure C/C++ callers need no HIP headers */
 int32_t acdsp_dev_alloc(int32_t device, uint64_t bytes, void **d_ptr);
 int32_t acdsp_dev_free(int32_t device, void *d_ptr);
+/* Allocation with a placement probe: the HBM-bound operators run 3 - 8 % apart on different (input, output) allocation pairs
+ * (profiles/r3_placement_modes.txt).  n_candidates blocks of `bytes` are allocated, each is timed with a bare mixed stream against the partner block
+ * (partner_reads != 0: the partner is read and the new block written -- an output allocated beside its input; 0: the other way round), the
+ * fastest is kept, the others freed.  probe_ms: optional [n_candidates] probe times.  Without a partner (or n_candidates <= 1): plain allocation. */
+int32_t acdsp_dev_alloc_paired(int32_t device, uint64_t bytes, const void *d_partner, uint64_t partner_bytes, int32_t partner_reads,
+                               int32_t n_candidates, void **d_ptr, float *probe_ms);
+/* ... with the caller's own call as the probe (the bare stream ranks pairs like the operator only for thin streams: 16 : 1 and beyond):
+ * trial(ctx, d_candidate) enqueues ONE call of the operator on the NULL stream with the candidate as its output (or input) and returns 0.  Every
+ * candidate is timed over `reps` calls behind one untimed call, twice round; the fastest is kept, the others freed.  The trial runs the
+ * operator for real: point it at a clone of the handle (acdsp_*_clone) when the stream's state must not advance.  trial_ms: optional [n_candidates]. */
+int32_t acdsp_dev_alloc_shop(int32_t device, uint64_t bytes, int32_t n_candidates, int32_t (*trial)(void *ctx, void *d_candidate), void *ctx, int32_t reps,
+                             void **d_ptr, float *trial_ms);
+/* the probe itself: average ms of a bare stream reading [d_src, +src_bytes) and writing [d_dst, +dst_bytes) at their byte ratio */
+int32_t acdsp_diag_mix_ms(int32_t device, const void *d_src, uint64_t src_bytes, void *d_dst, uint64_t dst_bytes, int32_t warmup, int32_t reps, void *stream,
+                          float *ms_avg);
 int32_t acdsp_copy_h2d(int32_t device, void *d_dst, const void *h_src, uint64_t bytes);
 int32_t acdsp_copy_d2h(int32_t device, void *h_dst, const void *d_src, uint64_t bytes);
 int32_t acdsp_sync(int32_t device, void *stream);
