@@ -410,12 +410,13 @@ hipError_t launch_n(int n, dim3 grid, hipStream_t s, const Cic2Args &a, const v4
     default: return hipErrorInvalidValue;
   }
 }
-// G = steps per stage-2 batch (ACDSP_CIC2_G: tuning knob)
+// G = steps per stage-2 batch: two where a load group is one step (G = 4 measured equal -- 2.144 / 2.125 ms, profiles/r6_cic2_ablation.txt -- and its
+// tile is LDS the occupancy pays for), four where a group is two steps
 template <typename TIN, int PCT, int NBT, int R1>
 hipError_t launch_g(int g, int n, dim3 grid, hipStream_t s, const Cic2Args &a, const v4i *frag) {
-  if (g == 4) { return launch_n<TIN, PCT, NBT, R1, 4>(n, grid, s, a, frag); }
-  if constexpr (Cic2Geom<TIN, PCT, NBT, R1>::M == 1) { if (g == 2) { return launch_n<TIN, PCT, NBT, R1, 2>(n, grid, s, a, frag); } }
-  return hipErrorInvalidValue;
+  constexpr int G = Cic2Geom<TIN, PCT, NBT, R1>::M == 1 ? 2 : 4;
+  if (g != G) { return hipErrorInvalidValue; }
+  return launch_n<TIN, PCT, NBT, R1, G>(n, grid, s, a, frag);
 }
 
 }  // namespace
@@ -516,13 +517,7 @@ int cic2_hist_len(int in_eb, int R1, int N, int wu) {
   return wu * 256 * R1 + (N * R1 + 15) + 16 * ls + 64;
 }
 
-static int cic2_batch(const Shape *sh) {
-  ACDSP_TUNE_ENV(env, "ACDSP_CIC2_G");     // tuning knob: steps per stage-2 batch (2 or 4)
-  int g = env && atoi(env) > 0 ? atoi(env) : 2;     // two steps per batch measured best where a load group is one step (the tile is LDS the occupancy pays for)
-  if (g != 2 && g != 4) { g = 2; }
-  if (sh && sh->m == 2) { g = 4; }
-  return g;
-}
+static int cic2_batch(const Shape *sh) { return (sh && sh->m == 2) ? 4 : 2; }
 
 // Steps per chunk, warm-up included.  A chunk pays `wu` steps of re-read and re-computed input and one pipeline start (fragments, halo,
 // two load groups before the first product): 48 steps where a row holds at least two such chunks, 24 where it holds two of those, else 12
