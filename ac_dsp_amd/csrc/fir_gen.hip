@@ -628,33 +628,53 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   // odd factors above 1 (R = 7: the reference's CIC testbench) and even ones that do not divide the slots of a 1 KB load (R = 10) keep the identity
   // slot map -- gen_slot_map leaves odd factors alone too: one or two extra LDS cycles per fragment read -- so a load need not hold whole groups of R slots
   constexpr bool HOLES = (R % 2 == 0 && SPK % R == 0) || R == 1;   // (even factors that do not divide a 1 KB load -- R = 10: R = 2 mod 4 is conflict-free without holes anyway)
+  // -DACDSP_GEN_ODDPAD (round 6 A/B, profiles/r6_lds_ab.txt): odd factors get (2 - R) mod 4 empty slots per R, i.e. a column stride of 2 mod 4 slots like the
+  // conflict-free even shapes (tools/lds_slot_map_check.py: R = 7 with three empty slots per seven reads 0 / 2 / 0 / 0 extra cycles per K block, the identity
+  // map 4 / 4 / 4 / 4).  A 1 KB load then no longer holds whole groups of R slots, so the staging offsets of a lane's pieces are per-load registers, not immediates.
+#ifdef ACDSP_GEN_ODDPAD
+  constexpr int PADK = HOLES ? 2 : ((R % 2 == 1 && R > 1 && M == 1) ? (2 - R % 4 + 4) % 4 : 0);
+#else
+  constexpr int PADK = HOLES ? 2 : 0;
+#endif
+  constexpr bool GENPAD = !HOLES && PADK > 0;
   static_assert((!HOLES || SPK % R == 0) && H <= ADV && S * H <= 64 && NLD * SPK == M * ADV && NLD >= 1 && SPW % M == 0, "ring geometry");
   constexpr int KSTEP = HOLES ? (SPK + 2 * (SPK / R)) * 16 : SPK * 16;   // LDS bytes from a piece of load k to the same lane's piece of load k + 1
-  constexpr int PADV = HOLES ? (ADV + 2 * (ADV / R)) * 16 : ADV * 16;    // LDS bytes a step advances
+  constexpr int PADV = (ADV + PADK * (ADV / R)) * 16;                   // LDS bytes a step advances
   constexpr int RING = (SPW < 2 ? SPW : 2) * ADV + H;         // chunks of one or two steps never wrap
   // The two empty slots per R sit right in FRONT of ring slots H, H + R, ...: a staging store pass covers eight consecutive slots from
   // H + 8 j on, and must not straddle a hole (with the holes at multiples of R, as in gen_slot_map, every pass of this layout did: 2-way
   // conflicts on two of its eight slots, SQ_LDS_BANK_CONFLICT 31 % of SQ_LDS_IDX_ACTIVE in the first profile of this kernel).  The reads
   // only need one hole per R slots, wherever it sits (tools/lds_slot_map_check.py, and the replay in profiles/r4_ring_sweep.txt).
-  constexpr int PH = HOLES ? (R - H % R) % R : 0;
-  constexpr int PLANE = HOLES ? (RING + 2 * ((RING + PH) / R) + 2) * 16 : (RING + 2) * 16;   // + one dump slot (mirror writes of the lanes that have none)
+  constexpr int PH = PADK ? (R - H % R) % R : 0;
+  constexpr int PLANE = (RING + PADK * ((RING + PH) / R) + 2) * 16;   // + one dump slot (mirror writes of the lanes that have none)
   constexpr int DUMP = PLANE - 16;
   constexpr int TILE = 256 * OEB;
   static_assert(!LZ || R == 1, "class-B residues: plain FIR only");
   constexpr int LZP = LZ ? (RING + 1) * 32 : 0;               // low-bit ring: 16 samples x 2 bytes per slot, + one dump slot
   constexpr int LZ_DUMP = RING * 32, KSTEP_L = SPK * 32, PADV_L = ADV * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[PX * PLANE + (FB ? SPW : 1) * TILE + LZP + (LZ ? 4 * kLossyTabWords : 0)];
+  // (round 6 A/B, -DACDSP_LZ_TWO_COPY, NOT the default) a SECOND copy of the low-bit ring, one dword further on, for the columns 8 .. 15.  The residue loops
+  // read aligned dwords at byte 32 n_col + 8 kg + ...: even dword banks only, so the 64 lanes of a read share 32 banks -- columns n and n + 8 collide, the
+  // 52 % SQ_LDS_BANK_CONFLICT of the class-B row (LDS 66 % busy beside a VALU at 0.82 of its issue rate).  With the upper columns on the shifted copy (staged
+  // with dword writes: it sits off the 16-byte grid) the conflicts halve -- 2.64e8 -> 0.98e8 of 5.1e8 -> 3.6e8 active cycles -- and the kernel is 8 % SLOWER
+  // (1.395 -> 1.505 ms, same box, alternating processes): the two base pointers cost 9.5 % more VALU instructions in a VALU-bound loop.  profiles/r6_lds_ab.txt
+#ifdef ACDSP_LZ_TWO_COPY
+  constexpr int LZB = LZ ? LZP + 16 : 0;                     // byte distance of the second copy's origin (the +4 of the shift is added where it is used)
+#else
+  constexpr int LZB = 0;
+#endif
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PX * PLANE + (FB ? SPW : 1) * TILE + LZP + (LZ ? 4 * kLossyTabWords : 0) + (LZB ? LZP + 32 : 0)];
   const int lane = threadIdx.x;
   const int n_col = lane & 15, kg = lane >> 4;
   int bx, ch;
   xcd_remap(a.xcd_map, bx, ch);
   unsigned char *const lzr = lds + PX * PLANE + (FB ? SPW : 1) * TILE;   // low-bit ring, then the 128 coefficient words
+  unsigned char *const lzr2 = lzr + LZP + (LZ ? 4 * kLossyTabWords : 0) + 4;   // the second copy: LZB + 4 bytes behind the first once the table is skipped
   if constexpr (LZ) {
 #pragma unroll
     for (int q = 0; q < kLossyTabWords / 64; q++) { ((uint32_t *)(lzr + LZP))[lane + 64 * q] = a.lz_tab[lane + 64 * q]; }
   }
   const int NB = a.pl.nb, PC = a.pl.pc;
-  auto phys = [](int s) { return HOLES ? s + 2 * ((s + PH) / R) : s; };
+  auto phys = [](int s) { return PADK ? s + PADK * ((s + PH) / R) : s; };
 
   v4i A[NBT][PCT];
 #pragma unroll
@@ -672,7 +692,11 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   const int pl_lane = lane < S * H ? lane : S * H - 1;          // prime: S H pieces; the other lanes repeat the last one
   const int pr_off = phys(pl_lane / S) * 16 + (pl_lane % S) * PPB;
   const int st_base = phys(H + lane / S) * 16 + (lane % S) * PPB;
-  const int mir_off = lane >= 64 - S * H ? st_base - KSTEP : DUMP;
+  const int mir_off = lane >= 64 - S * H ? (GENPAD ? phys(H + lane / S - SPK) * 16 + (lane % S) * PPB : st_base - KSTEP) : DUMP;
+  int st_q[GENPAD ? NLD : 1];     // GENPAD: LDS byte offset of this lane's piece of load q (no constant stride between the loads)
+#pragma unroll
+  for (int q = 0; q < (GENPAD ? NLD : 1); q++) { st_q[q] = phys(H + lane / S + q * SPK) * 16 + (lane % S) * PPB; }
+  auto st_of = [&](int q) { if constexpr (GENPAD) { return st_q[q]; } else { return st_base + q * KSTEP; } };
   // the same three places in the low-bit ring (linear slots of 32 bytes)
   const int pr_lin = (pl_lane / S) * 32 + (pl_lane % S) * PPB * 2;
   const int st_lin = (H + lane / S) * 32 + (lane % S) * PPB * 2;
@@ -698,11 +722,21 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
   auto stage_piece = [&](const v4i &v, int off, int loff) {
     if constexpr (LZ) {
       if constexpr (S == 2) {     // 8 samples: the dwords already hold two 16-bit fields
-        *(v4i *)(lzr + loff) = (v4i){(int)((unsigned)v.x & a.lz_m2), (int)((unsigned)v.y & a.lz_m2), (int)((unsigned)v.z & a.lz_m2), (int)((unsigned)v.w & a.lz_m2)};
+        const v4i lw = (v4i){(int)((unsigned)v.x & a.lz_m2), (int)((unsigned)v.y & a.lz_m2), (int)((unsigned)v.z & a.lz_m2), (int)((unsigned)v.w & a.lz_m2)};
+        *(v4i *)(lzr + loff) = lw;
+        if constexpr (LZB != 0) {
+          int *c2 = (int *)(lzr2 + loff);
+          c2[0] = lw.x; c2[1] = lw.y; c2[2] = lw.z; c2[3] = lw.w;
+        }
       } else {                    // 4 samples: low halves of two dwords side by side
         typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
-        *(v2u_ *)(lzr + loff) = (v2u_){__builtin_amdgcn_perm((unsigned)v.y, (unsigned)v.x, 0x05040100u) & a.lz_m2,
-                                       __builtin_amdgcn_perm((unsigned)v.w, (unsigned)v.z, 0x05040100u) & a.lz_m2};
+        const v2u_ lw2 = (v2u_){__builtin_amdgcn_perm((unsigned)v.y, (unsigned)v.x, 0x05040100u) & a.lz_m2,
+                                __builtin_amdgcn_perm((unsigned)v.w, (unsigned)v.z, 0x05040100u) & a.lz_m2};
+        *(v2u_ *)(lzr + loff) = lw2;
+        if constexpr (LZB != 0) {
+          unsigned *c2 = (unsigned *)(lzr2 + loff);
+          c2[0] = lw2.x; c2[1] = lw2.y;
+        }
       }
     }
 #pragma unroll
@@ -766,7 +800,7 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
       const int g = k / dummy_m;
       if (k % M == 0) {   // (M = 2: one load covers the even step's region and the odd one's behind it)
 #pragma unroll
-        for (int q = 0; q < NLD; q++) { stage_piece(pre[g % PF][q], st_base + q * KSTEP + par, st_lin + q * KSTEP_L + par_l); }
+        for (int q = 0; q < NLD; q++) { stage_piece(pre[g % PF][q], st_of(q) + par, st_lin + q * KSTEP_L + par_l); }
       }
       if ((k & 1) && k + 1 < SPW) { stage_piece(pre[g % PF][NLD - 1], mir_off, mir_lin); }   // the mirror is read by step k + 1
       if (!FB && k > 0) { flush(s0 + k - 1, 0); }
@@ -800,7 +834,7 @@ __global__ void __launch_bounds__(64, 2) fir_gen_ring_kernel(FirParams p, const 
         typedef unsigned short v2us_ __attribute__((ext_vector_type(2)));
         typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
         // byte address of the sample of output r = 0, tap 0: ring position 16 (delta + n_col) + off + 4 kg  (+ the step's parity)
-        const unsigned char *p0 = lzr + 2 * (16 * (a.ring_delta + n_col) + a.pl.off + 4 * kg) + par_l;
+        const unsigned char *p0 = ((LZB != 0 && n_col >= 8) ? lzr2 : lzr) + 2 * (16 * (a.ring_delta + n_col) + a.pl.off + 4 * kg) + par_l;
         const v2u_ *ctab = (const v2u_ *)(lzr + LZP);
         const v2us_ h2 = __builtin_bit_cast(v2us_, a.lz_h2);
         auto ld32 = [&](const unsigned char *q) -> unsigned { return *(const unsigned *)q; };
