@@ -193,7 +193,7 @@ struct IntgDumpParams {
 };
 // *temp_written = false: the call took a tile_ok kernel -- nothing carried in, every block dumped -- and left temp_next alone: the handle's
 // current temp[] is all zero and stays the state (round 5: a zeroing kernel per call was 1.4 % of the bench row)
-// *path: 0 exact-order kernel, 1 LDS-tiled kernel, 2 streaming kernels
+// *path: 0 exact-order kernel, 1 LDS-tiled kernel, 2 streaming kernels, 3 matrix-core kernel (channel counts that do not divide a 16-byte load)
 hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStream_t s, bool *temp_written, int *path);
 
 // Moving average (mv_avg.hip).  win_mode 0 AC_WIN, 1 AC_MIRROR, 2 AC_CLIP; rows = objects, frames of n_sample inputs back to back

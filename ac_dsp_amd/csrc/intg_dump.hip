@@ -477,6 +477,139 @@ static bool launch_stream(const IntgDumpParams &p, int gs, int lpr, int64_t rpw,
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Channel counts that do not divide a 16-byte load (round 6: CHN = 3, 5, 6, 7, 9 ... 16 -- ac_intg_dump.h:127-151 loops any CHN; the LDS-tiled
+// kernel ran them at 0.30 of the roofline).  The column sums of a block, out[c] = sum_r x[r CHN + c], are a matrix product with a 0 / 1 selection
+// matrix, and the matrix cores take it at no cost beside the stream (v_mfma_i32_16x16x64_i8):
+//   column n  = block blk0 + n of the tile (16 blocks per wave tile),   K = 64 consecutive samples of that block (segment j),
+//   A[c][k]   = 1 where sample 64 j + k of a block belongs to channel c, i.e. (64 j + k) mod CHN == c (a block starts on a channel-0 sample),
+//               and 64 j + k lies inside the block;  the pattern repeats with period P = CHN / gcd(64, CHN) segments: P fragments in registers,
+//   B         = the samples' byte planes (the low planes re-biased to signed bytes, 128 x rounds added back at the end),
+//   D[c][n]  += A_j B_j over the segments of the block: lane (n, kg) ends up with channels 4 kg .. 4 kg + 3 of block n in int32 per plane.
+// Every lane loads 16 consecutive samples (32 / 64 bytes) per segment: the wave reads 16 x 128 (256) contiguous bytes, each byte once.
+// Conditions (launch_intg_dump): wrapping / sat-free accumulator, every block dumps the same number of rounds, nothing carried in, a block is a
+// multiple of 16 samples, 16-byte aligned rows, CHN <= 16, fewer than 2^23 rounds (int32 plane sums).
+template <typename TIN, int CHN>
+__global__ void __launch_bounds__(64) intg_dump_mfma_kernel(IntgDumpParams p, int tiles_per_wave, int n_tiles) {
+  constexpr int S = (int)sizeof(TIN), PX = S;
+  constexpr int G64 = (CHN % 16 == 0) ? 16 : ((CHN % 8 == 0) ? 8 : ((CHN % 4 == 0) ? 4 : ((CHN % 2 == 0) ? 2 : 1)));   // gcd(64, CHN), CHN <= 16
+  constexpr int P = CHN / G64;
+  const int lane = threadIdx.x, n = lane & 15, kg = lane >> 4, obj = blockIdx.y;
+  const int64_t B = p.uni_rounds * CHN;                 // samples per block (a multiple of 16)
+  const int nseg = (int)((B + 63) / 64), rem = (int)(B - 64 * (int64_t)(nseg - 1));
+  // selection fragments: lane (row c = lane & 15, kg) holds A[c][16 kg .. 16 kg + 15] of phase ph = (64 j) mod CHN, j mod P = q
+  v4i_t A[P];
+#pragma unroll
+  for (int q = 0; q < P; q++) {
+    const int ph = (64 * q) % CHN;
+    unsigned w[4];
+#pragma unroll
+    for (int dw = 0; dw < 4; dw++) {
+      w[dw] = 0;
+#pragma unroll
+      for (int bj = 0; bj < 4; bj++) {
+        const int k = 16 * kg + 4 * dw + bj;
+        w[dw] |= (unsigned)(((k + ph) % CHN == n && n < CHN) ? 1u : 0u) << (8 * bj);
+      }
+    }
+    A[q] = (v4i_t){(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+  }
+  const v4i_t zero4 = {0, 0, 0, 0};
+  const TIN *row = (const TIN *)p.x + (int64_t)obj * p.in_stride;
+  const int sh = p.acc.F - p.in.F;
+  const int nbias = p.in.S ? PX - 1 : PX;               // planes that hold unsigned bytes
+  const int t0 = blockIdx.x * tiles_per_wave, t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
+  auto fetch = [&](int64_t e, v4i_t (&d)[S]) {
+#pragma unroll
+    for (int q = 0; q < S; q++) { d[q] = ((const v4i_t *)(row + e))[q]; }
+  };
+  for (int t = t0; t < t1; t++) {
+    const int b = 16 * t + n, bc = b < p.n_blocks ? b : p.n_blocks - 1;
+    const int64_t eb = (int64_t)bc * B;
+    v4i_t acc[PX];
+#pragma unroll
+    for (int pp = 0; pp < PX; pp++) { acc[pp] = zero4; }
+    v4i_t cur[S], nxt[S];
+    fetch(eb + (16 * kg < B ? 16 * kg : 0), cur);
+    auto segment = [&](int j, v4i_t a) __attribute__((always_inline)) {
+      const int64_t on = 64 * (int64_t)(j + 1) + 16 * kg;
+      fetch(eb + (on < B ? on : 0), nxt);               // beyond the block: any sample of it (the fragment is zero there)
+      // byte planes of the lane's 16 samples (fir_gen.hip: stage_slot)
+      union { v4i_t v[S]; unsigned d[4 * S]; } u;
+#pragma unroll
+      for (int q = 0; q < S; q++) { u.v[q] = cur[q]; }
+      if (j == nseg - 1 && 16 * kg >= rem) { a = zero4; }
+#pragma unroll
+      for (int pp = 0; pp < PX; pp++) {
+        v4i_t o;
+        if constexpr (S == 2) {
+          const unsigned sel = pp == 0 ? 0x06040200u : 0x07050301u;
+          o.x = (int)__builtin_amdgcn_perm(u.d[1], u.d[0], sel); o.y = (int)__builtin_amdgcn_perm(u.d[3], u.d[2], sel);
+          o.z = (int)__builtin_amdgcn_perm(u.d[5], u.d[4], sel); o.w = (int)__builtin_amdgcn_perm(u.d[7], u.d[6], sel);
+        } else {
+          auto g4 = [](unsigned d0, unsigned d1, unsigned d2, unsigned d3, int bp) {
+            const unsigned sel = 0x0c0c0400u + 0x0101u * (unsigned)bp;
+            return __builtin_amdgcn_perm(__builtin_amdgcn_perm(d3, d2, sel), __builtin_amdgcn_perm(d1, d0, sel), 0x05040100u);
+          };
+          o.x = (int)g4(u.d[0], u.d[1], u.d[2], u.d[3], pp); o.y = (int)g4(u.d[4], u.d[5], u.d[6], u.d[7], pp);
+          o.z = (int)g4(u.d[8], u.d[9], u.d[10], u.d[11], pp); o.w = (int)g4(u.d[12], u.d[13], u.d[14], u.d[15], pp);
+        }
+        if (pp < nbias) { o ^= (v4i_t){(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u}; }
+        acc[pp] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, o, acc[pp], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < S; q++) { cur[q] = nxt[q]; }
+    };
+    for (int j0 = 0; j0 < nseg; j0 += P) {              // the fragment of segment j is A[j mod P]: P segments per trip, static register choice
+#pragma unroll
+      for (int q = 0; q < P; q++) {
+        if (j0 + q < nseg) { segment(j0 + q, A[q]); }
+      }
+    }
+    // lane (n, kg) holds channels 4 kg + r of block b: recombine the planes, ACC_TYPE wrap, OUT_TYPE conversion
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = 4 * kg + r;
+      if (c < CHN && b < p.n_blocks) {
+        uint64_t sum = 0;
+#pragma unroll
+        for (int pp = 0; pp < PX; pp++) {
+          const int64_t v = (int64_t)acc[pp][r] + (pp < nbias ? 128 * p.uni_rounds : 0);
+          sum += (uint64_t)v << (8 * pp);
+        }
+        const int64_t accv = wrap64((int64_t)(sum << sh), p.acc.W, p.acc.S);
+        store_raw(p.y, (int64_t)obj * p.out_stride + (int64_t)b * CHN + c, p.out_eb, requant64(accv, p.acc.F, p.out));
+      }
+    }
+  }
+}
+
+template <typename TIN>
+static bool launch_mfma_t(const IntgDumpParams &p, int tpw, int n_tiles, dim3 grid, hipStream_t s) {
+#define ACDSP_ID_CASE(C) case C: hipLaunchKernelGGL((intg_dump_mfma_kernel<TIN, C>), grid, dim3(64), 0, s, p, tpw, n_tiles); return true;
+  switch (p.chn) {
+    ACDSP_ID_CASE(1) ACDSP_ID_CASE(2) ACDSP_ID_CASE(3) ACDSP_ID_CASE(4) ACDSP_ID_CASE(5) ACDSP_ID_CASE(6) ACDSP_ID_CASE(7) ACDSP_ID_CASE(8)
+    ACDSP_ID_CASE(9) ACDSP_ID_CASE(10) ACDSP_ID_CASE(11) ACDSP_ID_CASE(12) ACDSP_ID_CASE(13) ACDSP_ID_CASE(14) ACDSP_ID_CASE(15) ACDSP_ID_CASE(16)
+    default: return false;
+  }
+#undef ACDSP_ID_CASE
+}
+
+// true: launched
+static bool try_mfma(const IntgDumpParams &p, hipStream_t s) {
+  static const bool off = getenv("ACDSP_NO_INTG_MFMA") != nullptr;   // A/B knob: the LDS-tiled kernel
+  if (off || !p.tile_ok || p.uni_rounds <= 0 || p.uni_rounds >= (1 << 23) || (p.in_eb != 2 && p.in_eb != 4) || p.chn < 1 || p.chn > 16) { return false; }
+  const int64_t B = p.uni_rounds * p.chn;
+  if (B % 16 != 0 || ((uintptr_t)p.x % 16) != 0 || (p.in_stride * p.in_eb) % 16 != 0 || p.acc.F < p.in.F || p.acc.F - p.in.F >= 32) { return false; }
+  const int n_tiles = (p.n_blocks + 15) / 16;
+  // ~32 KB per wave, at least ~16 K waves when the problem allows it
+  int64_t tpw = (32768 + 16 * B * p.in_eb - 1) / (16 * B * p.in_eb);
+  if (tpw < 1) { tpw = 1; }
+  while (tpw > 1 && ((n_tiles + tpw - 1) / tpw) * (int64_t)p.n_obj < 16384) { tpw /= 2; }
+  dim3 grid((unsigned)((n_tiles + tpw - 1) / tpw), (unsigned)p.n_obj);
+  return p.in_eb == 2 ? launch_mfma_t<int16_t>(p, (int)tpw, n_tiles, grid, s) : launch_mfma_t<int32_t>(p, (int)tpw, n_tiles, grid, s);
+}
+
 // true: launched.  Shape conditions of the streaming kernel (see above); rows must start on 16-byte boundaries.
 static bool try_stream(const IntgDumpParams &p, hipStream_t s) {
   if (!p.tile_ok || p.uni_rounds <= 0 || p.uni_rounds >= 32768 || (p.in_eb != 2 && p.in_eb != 4)) { return false; }
@@ -544,6 +677,11 @@ hipError_t launch_intg_dump(const IntgDumpParams &p, int64_t *temp_next, hipStre
   if (!no_stream && try_stream(p, s)) {
     *path = 2;
     *temp_written = false;   // every block dumped and nothing was carried in (tile_ok): temp[] was zero and is zero
+    return hipGetLastError();
+  }
+  if (try_mfma(p, s)) {
+    *path = 3;
+    *temp_written = false;
     return hipGetLastError();
   }
   if (p.tile_ok && p.chn <= 256) {

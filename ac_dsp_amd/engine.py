@@ -531,7 +531,7 @@ class IntgDump:
     @property
     def path(self):
         """kernel family of the last run() (acdsp_intgdump_path)"""
-        return {0: "exact_order", 1: "tile", 2: "stream"}[lib.acdsp_intgdump_path(self._h)]
+        return {0: "exact_order", 1: "tile", 2: "stream", 3: "mfma"}[lib.acdsp_intgdump_path(self._h)]
 
     def reset(self):
         check(lib.acdsp_intgdump_reset(self._h))

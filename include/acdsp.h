@@ -318,7 +318,7 @@ int32_t acdsp_intgdump_run(acdsp_intgdump_t h, const void *d_in, int64_t in_stri
 int32_t acdsp_intgdump_run_host(acdsp_intgdump_t h, const void *h_in, const int64_t *n_sample, int64_t n_blocks, void *h_out,
                                 int64_t out_cap, int64_t *n_out);
 int32_t acdsp_intgdump_reset(acdsp_intgdump_t h);
-int32_t acdsp_intgdump_path(acdsp_intgdump_t h);   /* kernel family of the last run(): 0 exact order (ragged blocks / carried sums / saturating ACC), 1 LDS-tiled, 2 streaming */
+int32_t acdsp_intgdump_path(acdsp_intgdump_t h);   /* kernel family of the last run(): 0 exact order (ragged blocks / carried sums / saturating ACC), 1 LDS-tiled, 2 streaming, 3 matrix cores (selection-matrix product: CHN that does not divide a 16-byte load) */
 
 /* ---- moving average (reference ac_mv_avg.h:93-196) ----
  * One run() = one run() call of every object: n_frames frames of n_sample input samples each, back to back in the row (the

@@ -111,7 +111,7 @@ ID_TYPES = {"i16": (F(16, 8), F(32, 16), F(32, 16)), "i16_o16": (F(16, 8), F(32,
 def intgdump_grid():
     for tname, (fin, fa, fo) in ID_TYPES.items():
         for chn in (1, 2, 3, 4, 7, 8, 16):
-            for ns in (8, 64, 1000):
+            for ns in (7, 8, 64, 1000):      # 7: blocks of 7 CHN samples are no multiple of 16 for odd CHN -- the tiled kernel
                 yield "intgdump|%s|CHN%d|NS%d" % (tname, chn, ns), (fin, fa, fo, chn, ns)
 
 

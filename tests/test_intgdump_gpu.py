@@ -164,3 +164,54 @@ def test_pending_sums_and_uniform_calls_alternate_on_every_kernel_family():
     assert seen[0] == "stream" and seen[1] == "exact_order" and seen[2] == "exact_order" and seen[3] == "stream" and seen[9] == "stream", seen
     # (the last call starts with a pending sum: it must NOT take a kernel that ignores temp[])
     assert seen[-1] == "exact_order", seen
+
+
+# ---- matrix-core kernel (round 6): channel counts that do not divide a 16-byte load; every block the same rounds, a multiple of 16 samples ----
+
+@pytest.mark.parametrize("ns,chn,rounds,n_blk,fin,fa,fo", [
+    (64, 7, 64, 40, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)),                       # tools/misc_shapes.py: CHN = 7 (0.30 on the tiled kernel)
+    (64, 16, 64, 33, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(16, 8, True, "RND", "SAT")),   # CHN = 16, narrow saturating output
+    (64, 3, 64, 50, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)),
+    (32, 5, 32, 17, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)),                       # a partial tile of blocks (17 = 16 + 1)
+    (48, 6, 48, 64, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)),                       # 288 samples per block: the last segment holds 32
+    (16, 9, 16, 100, A.Fmt(12, 4, False), A.Fmt(24, 12, False), A.Fmt(24, 12, False)), # unsigned samples: every plane re-biased
+    (80, 11, 80, 31, A.Fmt(16, 1), A.Fmt(40, 20), A.Fmt(40, 20)),                      # F_acc > F_in
+    (64, 13, 64, 20, A.Fmt(32, 16), A.Fmt(48, 32), A.Fmt(48, 32)),                     # 32-bit samples: four planes
+    (64, 15, 64, 16, A.Fmt(24, 8), A.Fmt(40, 24), A.Fmt(20, 10, True, "RND_CONV", "SAT_SYM")),
+    (1024, 7, 1024, 19, A.Fmt(16, 8), A.Fmt(40, 24), A.Fmt(40, 24)),                   # long blocks: 112 segments each
+    (64, 12, 64, 48, A.Fmt(16, 8), A.Fmt(31, 15, True, "TRN", "SAT"), A.Fmt(31, 15)),  # a saturating accumulator that cannot saturate (64 x 2^23 < 2^30)
+    (16, 10, 16, 64, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)),
+    (8, 14, 8, 64, A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)),                        # 112 samples per block
+])
+def test_matrix_core_kernel_for_channel_counts_that_do_not_divide_a_vector(ns, chn, rounds, n_blk, fin, fa, fo):
+    n_obj = 5
+    rng = np.random.default_rng(ns * 100 + chn)
+    eng = A.IntgDump(ns, chn, fin, fa, fo, n_objects=n_obj)
+    orc = OracleIntgDump(ns, chn, ofmt(fin), ofmt(fa), ofmt(fo), n_obj=n_obj)
+    for call in range(2):                                   # two calls: nothing is carried, the second call takes the same kernel
+        n_sample = [rounds] * n_blk
+        ni, no = eng.counts(n_sample)
+        x = rand_raw(rng, fin, (n_obj, ni))
+        lo, hi = (-(1 << (fin.W - 1)), (1 << (fin.W - 1)) - 1) if fin.S else (0, (1 << fin.W) - 1)
+        x[0], x[1] = hi, lo                                  # full-scale rows
+        stride = (ni + 63) // 64 * 64                        # 16-byte aligned rows
+        xd = torch.zeros((n_obj, stride), dtype=A.torch_dtype_for(fin), device="cuda")
+        xd[:, :ni] = torch.from_numpy(x).to(A.torch_dtype_for(fin)).cuda()
+        y = eng.run(xd[:, :ni], n_sample).cpu().numpy().astype(np.int64)
+        assert eng.path == "mfma", eng.path
+        yo = orc.run(x, n_sample)
+        assert y.shape == yo.shape == (n_obj, no)
+        assert np.array_equal(y, yo), np.argwhere(y != yo)[:5]
+
+
+def test_matrix_core_kernel_declines_what_it_cannot_take():
+    # blocks that are no multiple of 16 samples (7 x 9 = 63), ragged blocks, a carried sum: the tiled / exact-order kernels, same results
+    fin, fa, fo = A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(32, 16)
+    for ns, chn, n_sample in ((9, 7, [9] * 32), (64, 7, [64, 64, 3, 64]), (64, 7, [64, 100, 64, 64])):
+        eng = A.IntgDump(ns, chn, fin, fa, fo, n_objects=2)
+        orc = OracleIntgDump(ns, chn, ofmt(fin), ofmt(fa), ofmt(fo), n_obj=2)
+        ni, no = eng.counts(n_sample)
+        x = rand_raw(np.random.default_rng(ns + len(n_sample)), fin, (2, ni))
+        y = eng.run(torch.from_numpy(x).to(torch.int16).cuda(), n_sample).cpu().numpy().astype(np.int64)
+        assert eng.path != "mfma"
+        assert np.array_equal(y, orc.run(x, n_sample))

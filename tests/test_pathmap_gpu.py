@@ -47,4 +47,4 @@ def test_the_ops_grid_reaches_every_cic_family():
         t = json.load(f)
     assert {"recurrence", "mfma_gen", "two_stage", "wide"} <= {v for k, v in t.items() if k.startswith("cic|dec")}
     assert {"mfma_gen", "fir_identity", "wide"} <= {v for k, v in t.items() if k.startswith("cic|intr")}
-    assert {"stream", "tile"} <= {v for k, v in t.items() if k.startswith("intgdump")}
+    assert {"stream", "tile", "mfma"} <= {v for k, v in t.items() if k.startswith("intgdump")}
