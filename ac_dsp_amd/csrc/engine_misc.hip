@@ -223,6 +223,9 @@ struct acdsp_mvavg {
   bool coeffs_set = false;
   int64_t *d_coeffs = nullptr;
   std::vector<int64_t> h_coeffs;
+  uint32_t *d_frag = nullptr;   // matrix-core form of the streaming kernel: fragments of the coefficient set (mv_avg_build_frags)
+  int frag_nb = 0;
+  int64_t frag_csum = 0;
   int last_path = 0;
   Staging st;
 };
@@ -249,7 +252,9 @@ int32_t acdsp_mvavg_create(const acdsp_mvavg_desc_t *desc, acdsp_mvavg_t *out) {
   h->d = *desc;
   h->in_eb = elem_bytes(desc->in.W);
   h->out_eb = elem_bytes(desc->out.W);
-  if (hipMalloc((void **)&h->d_coeffs, (size_t)desc->taps * sizeof(int64_t)) != hipSuccess) {
+  if (hipMalloc((void **)&h->d_coeffs, (size_t)desc->taps * sizeof(int64_t)) != hipSuccess ||
+      hipMalloc((void **)&h->d_frag, (size_t)kMvAvgFragWords * sizeof(uint32_t)) != hipSuccess) {
+    if (h->d_coeffs) { (void)hipFree(h->d_coeffs); }
     delete h;
     return fail(ACDSP_EHIP, "mv_avg: coefficient allocation failed");
   }
@@ -261,6 +266,7 @@ int32_t acdsp_mvavg_destroy(acdsp_mvavg_t h) {
   if (!h) { return ACDSP_OK; }
   (void)hipSetDevice(h->d.device);
   if (h->d_coeffs) { (void)hipFree(h->d_coeffs); }
+  if (h->d_frag) { (void)hipFree(h->d_frag); }
   h->st.destroy();
   delete h;
   return ACDSP_OK;
@@ -277,6 +283,11 @@ int32_t acdsp_mvavg_set_coeffs(acdsp_mvavg_t h, const int64_t *coeffs) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h->d_coeffs, coeffs, (size_t)h->d.taps * sizeof(int64_t), hipMemcpyHostToDevice));
   h->h_coeffs.assign(coeffs, coeffs + h->d.taps);
+  {
+    std::vector<uint32_t> fr((size_t)kMvAvgFragWords, 0u);
+    h->frag_nb = mv_avg_build_frags(coeffs, h->d.taps, h->d.win_mode, fr.data(), &h->frag_csum);
+    if (h->frag_nb > 0) { HIP_TRY(hipMemcpy(h->d_frag, fr.data(), fr.size() * sizeof(uint32_t), hipMemcpyHostToDevice)); }
+  }
   h->coeffs_set = true;
   return ACDSP_OK;
 }
@@ -349,6 +360,7 @@ int32_t acdsp_mvavg_run(acdsp_mvavg_t h, const void *d_in, int64_t in_stride, in
            p.cf.F < 62 && xbits + cbits <= 62;
   p.n_sample = n_sample; p.n_frames = n_frames; p.out_per_frame = opf; p.in_stride = in_stride; p.out_stride = out_stride;
   p.x = d_in; p.y = d_out; p.coeffs = h->d_coeffs; p.h_coeffs = h->h_coeffs.data();
+  p.frag = h->frag_nb > 0 ? h->d_frag : nullptr; p.frag_nb = h->frag_nb; p.frag_csum = h->frag_csum;
   hipError_t e = launch_mv_avg(p, (hipStream_t)stream, &h->last_path);
   if (e != hipSuccess) { return fail(ACDSP_EHIP, "mv_avg kernel launch failed: %s", hipGetErrorString(e)); }
   return ACDSP_OK;

@@ -207,8 +207,13 @@ struct MvAvgParams {
   const void *x; void *y;
   const int64_t *coeffs;      // [taps]
   const int64_t *h_coeffs;    // host copy (the streaming kernel takes its coefficients as kernel arguments)
+  const uint32_t *frag;       // device: Toeplitz fragments of the matrix-core form (mv_avg_build_frags), frag_nb K blocks (0: none), frag_csum = sum of the coefficients
+  int32_t frag_nb;
+  int64_t frag_csum;
 };
-hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s, int *path);   // *path: 0 exact order, 1 int64 sums, 2 streaming kernel
+hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s, int *path);   // *path: 0 exact order, 1 int64 sums, 2 streaming kernel, 3 32-bit samples, 4 streaming kernel on the matrix cores
+constexpr int kMvAvgFragWords = 2 * 2 * 2 * 64 * 4;   // [m][b][plane][lane][4]
+int mv_avg_build_frags(const int64_t *c, int taps, int win_mode, uint32_t *out, int64_t *csum);
 
 // Sets the calling thread's acdsp_last_error() message and returns `code` (engine.hip); for the layers above the engine (node.hip).
 int set_error(int code, const char *msg);

@@ -102,7 +102,7 @@ struct MvStreamArgs {
   int32_t ka, rs, ls2, ko;    // 64-bit epilogue (see IdConv in intg_dump.hip)
   uint64_t am, om;
   int64_t rnd, lo, hi;
-  int32_t out_eb, vec_ok;
+  int32_t out_eb, vec_ok, run_ok;   // vec_ok: every lane's eight outputs are an aligned 16 / 32 / 64 bytes; else run_ok: tiles leave through the image as aligned pieces
   int64_t n_sample, n_frames, opf, in_stride, out_stride, tpf, n_tiles, tiles_per_wave;
   const int16_t *x;
   void *y;
@@ -110,10 +110,15 @@ struct MvStreamArgs {
   // packed short frames (round 5, PK instantiations): pk_n = samples per frame (64 / 128 / 256; 0 = off), pk_pitch = image samples per frame
   // (n + 2 hb); the tile loads then start at the tile, not hb samples in front of it: every halo is a patch
   int32_t pk_n, pk_pitch, pk_sh;
+  // matrix-core instantiations (MF = K blocks of 64 samples): Toeplitz fragments [m][b][plane][lane] x 16 bytes (mv_avg_build_frags), and
+  // 128 sum(c), what the re-biased low sample plane leaves out
+  const uint32_t *frag;
+  int32_t kbias;
 };
 
 typedef short v2s_t __attribute__((ext_vector_type(2)));
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef int v4i_mv __attribute__((ext_vector_type(4)));
 // (tile loads keep the plain policy: non-temporal +3 % in time, profiles/r2_copy_probe_ldsdma.txt / DESIGN 5.1)
 // 2-byte outputs (the bench row: one 16-byte store per lane) leave with the non-temporal policy; -DACDSP_MV_ST_PLAIN: plain (A/B)
 #ifdef ACDSP_MV_ST_PLAIN
@@ -125,13 +130,21 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 #ifndef ACDSP_MV_AHEAD
 #define ACDSP_MV_AHEAD 2   // 4: -3 %, 8: -15 %, 16: -80 % on the bench row (profiles/r4_ab_up_store.txt, last block): more tiles in flight cost occupancy
 #endif
-template <int NR, bool LINEAR, bool CV32, bool EDGE, bool PK = false>   // PK: packed short frames (MvStreamArgs::pk_*; as run-time branches they cost the bench row 1.4 %)
+// MF > 0 (round 6; windows of 17 taps and more, where the v_dot2 form is bound by VALU issue: 0.46 / 0.29 of the roofline at 33 / 65 taps): the
+// window sums of a tile on the matrix cores.  The wave's image is the B operand as it lies -- column j' of v_mfma_i32_16x16x64_i8 is the 64 samples
+// from image position 32 j' (+ 64 per further K block), a lane reads 32 aligned bytes and splits them into a low (re-biased by -128) and a high
+// byte plane with v_perm_b32 -- and A is the Toeplitz matrix of the coefficients (balanced signed byte digits, built on the host), in TWO row
+// orders: row i of fragment set m is output 32 j' + 8 (i >> 2) + (i & 3) + 4 m.  A lane's accumulator rows are then outputs 8 v .. 8 v + 7 of
+// the tile, v = 4 (lane & 15) + (lane >> 4): eight consecutive outputs, the same epilogue and 16-byte stores as the v_dot2 form, a whole KB
+// per store instruction.  8 MF MFMAs per 512 outputs (4 plane products x 2 row orders), 2 MF 16-byte LDS reads per lane instead of NR.
+template <int NR, bool LINEAR, bool CV32, bool EDGE, bool PK = false, int MF = 0>   // PK: packed short frames (MvStreamArgs::pk_*; as run-time branches they cost the bench row 1.4 %)
 __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
+  static_assert(MF == 0 || (LINEAR && !PK), "matrix-core form: linear class, whole-frame tiles");
   constexpr int REGION = 512 + 8 * NR + 8;      // samples of one wave's LDS image (+ 8: the odd-offset window reads one dword further)
   constexpr int NQ = 4 * NR - 3;                // coefficient pairs covering 8 NR - 7 taps (+ a zero)
   // (4- and 8-byte outputs turn their tile around in the same image -- 2 / 4 KB -- before it leaves: IMG)
   constexpr int IMG = REGION > 2048 ? REGION : 2048;
-  __shared__ __attribute__((aligned(16))) int16_t sm[4][IMG];
+  __shared__ __attribute__((aligned(16))) int16_t sm[4][IMG + 8];   // + 16 bytes: a tile of 8-byte outputs behind its misalignment (run_ok)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int16_t *img = sm[wave];
   int bx, by_;
@@ -141,6 +154,12 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   if (t0 >= t_end) { return; }
   const int n_my = (int)(t_end - t0);
   const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.c16), *cpo = reinterpret_cast<const uint32_t *>(a.c16o);
+  const int vlane = MF > 0 ? 4 * (lane & 15) + (lane >> 4) : lane;   // whose eight outputs this lane converts and stores
+  v4i_mv A[MF > 0 ? 4 * MF : 1];                                        // [m][b][plane]
+  if constexpr (MF > 0) {
+#pragma unroll
+    for (int f = 0; f < 4 * MF; f++) { A[f] = reinterpret_cast<const v4i_mv *>(a.frag)[f * 64 + lane]; }
+  }
 
   // Tiles are fetched two ahead into alternating register sets.  (object, frame, tile) of the tile being fetched: one
   // division per wave, then counted up; past the wave's last tile the fetch repeats that tile (branch-free loop body, so
@@ -225,6 +244,38 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     // The window starts a.off samples into the image: any even byte offset.  A DS read off its natural alignment is replayed lane by lane
     // (~85 instead of ~8 cycles per wave read, profiles/r5_lds_align.txt; rounds 2 - 4 read 16 bytes at 2-byte alignment here -- 8 bytes into
     // a 16-byte granule on the bench row), so the widest reads the offset is aligned for (the offset is wave-uniform: uniform branches).
+    int S[8];
+    const int s_init = CV32 ? a.r32 : 0;   // the 32-bit epilogue's rounding constant rides in the sum (|sum| < 2^30, r32 <= 2^29)
+    if constexpr (MF > 0) {
+      const unsigned char *ib = reinterpret_cast<const unsigned char *>(img) + 64 * (lane & 15) + 32 * (lane >> 4);
+      const v4i_mv z4 = {0, 0, 0, 0};
+      v4i_mv acc[2][3] = {{z4, z4, z4}, {z4, z4, z4}};   // [row order m][weight 1, 2^8, 2^16]
+#pragma unroll
+      for (int b = 0; b < MF; b++) {
+        const uint4 d0 = *reinterpret_cast<const uint4 *>(ib + 128 * b), d1 = *reinterpret_cast<const uint4 *>(ib + 128 * b + 16);
+        v4i_mv lo, hi;
+        lo.x = (int)(__builtin_amdgcn_perm(d0.y, d0.x, 0x06040200u) ^ 0x80808080u); lo.y = (int)(__builtin_amdgcn_perm(d0.w, d0.z, 0x06040200u) ^ 0x80808080u);
+        lo.z = (int)(__builtin_amdgcn_perm(d1.y, d1.x, 0x06040200u) ^ 0x80808080u); lo.w = (int)(__builtin_amdgcn_perm(d1.w, d1.z, 0x06040200u) ^ 0x80808080u);
+        hi.x = (int)__builtin_amdgcn_perm(d0.y, d0.x, 0x07050301u); hi.y = (int)__builtin_amdgcn_perm(d0.w, d0.z, 0x07050301u);
+        hi.z = (int)__builtin_amdgcn_perm(d1.y, d1.x, 0x07050301u); hi.w = (int)__builtin_amdgcn_perm(d1.w, d1.z, 0x07050301u);
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          const v4i_mv cl = A[(m * MF + b) * 2], ch = A[(m * MF + b) * 2 + 1];
+          acc[m][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cl, lo, acc[m][0], 0, 0, 0);
+          acc[m][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cl, hi, acc[m][1], 0, 0, 0);
+          acc[m][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ch, lo, acc[m][1], 0, 0, 0);
+          acc[m][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ch, hi, acc[m][2], 0, 0, 0);
+        }
+      }
+      // every partial stays far inside int32; the recombination is modular and the sum itself is inside 2^30 (host-checked)
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          S[4 * m + r] = (int)((uint32_t)acc[m][0][r] + ((uint32_t)acc[m][1][r] << 8) + ((uint32_t)acc[m][2][r] << 16) + (uint32_t)(s_init + a.kbias));
+        }
+      }
+    } else {
     uint32_t R[4 * NR + 1];
     {
       const unsigned char *wb = reinterpret_cast<const unsigned char *>(img + (PK ? lb - a.hb : lb)) + 2 * a.off;
@@ -249,8 +300,6 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
       }
     }
     R[4 * NR] = 0;
-    int S[8];
-    const int s_init = CV32 ? a.r32 : 0;   // the 32-bit epilogue's rounding constant rides in the sum (|sum| < 2^30, r32 <= 2^29)
     if constexpr (LINEAR) {
       // output i of the lane starts at sample i of its dwords: even outputs pair (x[i+2q], x[i+2q+1]) = dword i/2 + q with
       // (c[2q], c[2q+1]); odd outputs pair the same aligned dwords with the coefficient pairs shifted by one tap,
@@ -277,8 +326,9 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
         S[i] = sum;
       }
     }
+    }
     __builtin_amdgcn_wave_barrier();   // every lane has its window: the image may be overwritten
-    const int64_t k0 = ti * 512 + 8 * lane;
+    const int64_t k0 = ti * 512 + 8 * vlane;
     if (k0 < a.opf) {
       const int64_t yb = obj * a.out_stride + fr * a.opf + k0;
       int64_t ov[8];                                  // OUT raw words (the low out_eb bytes are what leaves)
@@ -312,14 +362,40 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
           // The tile goes through the wave's LDS image once -- rows of 16 bytes per lane out -- and leaves in whole 1 KB runs.
           unsigned char *ib = reinterpret_cast<unsigned char *>(img);
           if (a.out_eb == 4) {
-            uint4 *w = reinterpret_cast<uint4 *>(ib + 32 * lane);
+            uint4 *w = reinterpret_cast<uint4 *>(ib + 32 * vlane);
             w[0] = make_uint4((uint32_t)ov[0], (uint32_t)ov[1], (uint32_t)ov[2], (uint32_t)ov[3]);
             w[1] = make_uint4((uint32_t)ov[4], (uint32_t)ov[5], (uint32_t)ov[6], (uint32_t)ov[7]);
           } else {
-            ulonglong2 *w = reinterpret_cast<ulonglong2 *>(ib + 64 * lane);
+            ulonglong2 *w = reinterpret_cast<ulonglong2 *>(ib + 64 * vlane);
 #pragma unroll
             for (int i = 0; i < 8; i += 2) { w[i / 2] = make_ulonglong2((uint64_t)ov[i], (uint64_t)ov[i + 1]); }
           }
+        }
+      } else if (a.run_ok) {
+        // output frames that start off a 16-byte boundary (round 6: AC_WIN with TAPS - 1 no multiple of 8 -- 1012 outputs per frame -- ran eight
+        // element stores per lane, 0.25 - 0.30 of the roofline): the tile's outputs go to the image at the byte offset their first one has
+        // inside its 16-byte granule, and leave below as aligned 16-byte pieces
+        // (no guards: what a lane writes past the tile's last output stays in the image)
+        const int mis = (int)(((uintptr_t)a.y + (uint64_t)(yb - 8 * vlane) * a.out_eb) & 15);
+        unsigned char *ib = reinterpret_cast<unsigned char *>(img) + mis + 8 * vlane * a.out_eb;
+        if (a.out_eb == 2) {
+          const uint32_t p0_ = __builtin_amdgcn_perm((uint32_t)ov[1], (uint32_t)ov[0], 0x05040100u), p1_ = __builtin_amdgcn_perm((uint32_t)ov[3], (uint32_t)ov[2], 0x05040100u);
+          const uint32_t p2_ = __builtin_amdgcn_perm((uint32_t)ov[5], (uint32_t)ov[4], 0x05040100u), p3_ = __builtin_amdgcn_perm((uint32_t)ov[7], (uint32_t)ov[6], 0x05040100u);
+          if (!(mis & 2)) {         // wave-uniform: dword-aligned pairs
+            uint32_t *w = reinterpret_cast<uint32_t *>(ib);
+            w[0] = p0_; w[1] = p1_; w[2] = p2_; w[3] = p3_;
+          } else {                  // one element, three straddling pairs, one element
+            reinterpret_cast<int16_t *>(ib)[0] = (int16_t)ov[0];
+            uint32_t *w = reinterpret_cast<uint32_t *>(ib + 2);
+            w[0] = __builtin_amdgcn_alignbit(p1_, p0_, 16); w[1] = __builtin_amdgcn_alignbit(p2_, p1_, 16); w[2] = __builtin_amdgcn_alignbit(p3_, p2_, 16);
+            reinterpret_cast<int16_t *>(ib)[7] = (int16_t)ov[7];
+          }
+        } else if (a.out_eb == 4) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) { reinterpret_cast<int32_t *>(ib)[i] = (int32_t)ov[i]; }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) { reinterpret_cast<int64_t *>(ib)[i] = ov[i]; }
         }
       } else {
 #pragma unroll
@@ -327,6 +403,33 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
           if (k0 + i < a.opf) { store_raw(a.y, yb + i, a.out_eb, ov[i]); }
         }
       }
+    }
+    if (!a.vec_ok && a.run_ok) {   // wave-uniform: second half of the unaligned turn-around
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned char *ib = reinterpret_cast<const unsigned char *>(img);
+      const uintptr_t b0 = (uintptr_t)a.y + (uint64_t)(obj * a.out_stride + fr * a.opf + ti * 512) * a.out_eb;
+      const int mis = (int)(b0 & 15);
+      const int64_t left = a.opf - ti * 512;
+      const int total = mis + (int)(left < 512 ? left : 512) * a.out_eb;      // image bytes [mis, total) are this tile's outputs
+      unsigned char *g = reinterpret_cast<unsigned char *>(b0 - mis);
+#pragma unroll
+      for (int k = 0; k < 5; k++) {                                             // 512 x 8 bytes + 15 = 257 pieces at most
+        const int o = 16 * (lane + 64 * k);
+        if (o >= mis && o + 16 <= total) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(ib + o);
+          ACDSP_MV_ST(v, reinterpret_cast<uint4 *>(g + o));
+        }
+      }
+      {
+        // the first and the last piece of the run hold up to seven 2-byte units each: ONE store instruction for both, a unit per lane (lanes 0 - 7
+        // the head, 8 - 15 the tail; as 2-byte stores per piece they were 16 more memory instructions per tile than the aligned form's one)
+        const int hf = (mis + 15) & ~15, tf = total & ~15, t0b = tf > hf ? tf : hf;
+        const int bb = (lane < 8 ? mis : t0b) + 2 * (lane & 7);
+        if (lane < 16 && bb < total && (lane >= 8 || bb < hf)) { *reinterpret_cast<int16_t *>(g + bb) = *reinterpret_cast<const int16_t *>(ib + bb); }
+      }
+      __builtin_amdgcn_wave_barrier();   // read back before the next tile is staged over it
     }
     {
       if (a.vec_ok && a.out_eb != 2) {   // wave-uniform: the second half of the turn-around above
@@ -506,7 +609,8 @@ static bool try_w32(const MvAvgParams &p, hipStream_t s) {
 }
 
 // true: launched.  Class and shape conditions of the streaming kernel (see above).
-static bool try_stream(const MvAvgParams &p, hipStream_t s) {
+static bool try_stream(const MvAvgParams &p, hipStream_t s, bool *mfma) {
+  *mfma = false;
   static const bool off = getenv("ACDSP_NO_MVAVG_STREAM") != nullptr;   // A/B knob
   if (off || p.force_generic || !p.h_coeffs || p.taps > 65 || p.in_eb != 2 || !(p.in.S || p.in.W <= 15)) { return false; }
   if (p.n_sample < p.taps || p.n_sample % 8 != 0 || p.in_stride % 8 != 0 || ((uintptr_t)p.x % 16) != 0) { return false; }
@@ -559,6 +663,8 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   }
   a.out_eb = p.out_eb;
   a.vec_ok = p.out_per_frame % 8 == 0 && p.out_stride % 8 == 0 && ((uintptr_t)p.y % 16) == 0;
+  static const bool no_run = getenv("ACDSP_NO_MVAVG_RUN") != nullptr;   // A/B knob: element stores for unaligned output frames
+  a.run_ok = !a.vec_ok && !no_run && ((uintptr_t)p.y % p.out_eb) == 0;
   a.n_sample = p.n_sample; a.n_frames = p.n_frames; a.opf = p.out_per_frame; a.in_stride = p.in_stride; a.out_stride = p.out_stride;
   a.tpf = (p.out_per_frame + 511) / 512;
   a.n_tiles = (int64_t)p.n_obj * p.n_frames * a.tpf;
@@ -583,6 +689,27 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   if (blocks > 0x7FFFFFFF) { return false; }
   dim3 grid((unsigned)blocks);
   a.xcd_map = (xcd_map_wanted(false) && blocks % 8 == 0) ? 1 : 0;
+  // windows of 17 taps and more: the sums on the matrix cores (fragments built by the handle at set_coeffs: mv_avg_build_frags)
+  ACDSP_TUNE_ENV(mf_env, "ACDSP_MVAVG_MFMA_MIN");   // A/B knob: the smallest window that takes them (0: never)
+  // (same box, 512 objects x 2^20, frames of 1024: v_dot2 0.68 / MFMA 0.62 of the roofline at 9 taps, 0.57 / 0.62 at 11, 0.46 / 0.61 at 33, 0.29 / 0.53 at
+  // 65; AC_WIN 0.54 / 0.58 at 9 taps -- profiles/r6_mvavg_mfma.txt)
+  const int mf_min = mf_env ? atoi(mf_env) : (p.win_mode == 0 ? 9 : 11);
+  if (p.frag && p.frag_nb > 0 && a.linear && !a.pk_n && mf_min > 0 && p.taps >= mf_min) {
+    a.frag = p.frag;
+    a.kbias = (int32_t)(128 * p.frag_csum);
+// (NR = 9: only REGION -- how far the right-edge patches reach into the image -- depends on it here)
+#define ACDSP_MV_MF(CV_, EDGE_, MF_) hipLaunchKernelGGL((mv_avg_stream_kernel<9, true, CV_, EDGE_, false, MF_>), grid, dim3(256), 0, s, a)
+    if (p.frag_nb == 1) {
+      if (a.cv32) { if (a.mode != 0) { ACDSP_MV_MF(true, true, 1); } else { ACDSP_MV_MF(true, false, 1); } }
+      else { if (a.mode != 0) { ACDSP_MV_MF(false, true, 1); } else { ACDSP_MV_MF(false, false, 1); } }
+    } else {
+      if (a.cv32) { if (a.mode != 0) { ACDSP_MV_MF(true, true, 2); } else { ACDSP_MV_MF(true, false, 2); } }
+      else { if (a.mode != 0) { ACDSP_MV_MF(false, true, 2); } else { ACDSP_MV_MF(false, false, 2); } }
+    }
+#undef ACDSP_MV_MF
+    *mfma = true;
+    return true;
+  }
   const int nr = p.taps <= 9 ? 2 : (p.taps <= 17 ? 3 : (p.taps <= 25 ? 4 : (p.taps <= 33 ? 5 : (p.taps <= 49 ? 7 : 9))));   // taps <= 8 NR - 7
 #define ACDSP_MV_LAUNCH2(NR_, LIN_, CV_)                                                                                           \
   if (a.pk_n) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true, true>), grid, dim3(256), 0, s, a); }               \
@@ -607,9 +734,46 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s) {
   return true;
 }
 
+// Toeplitz fragments of the matrix-core form (mv_avg_stream_kernel, MF instantiations).  Returns the K blocks (1 / 2; 0: the coefficient set
+// or the window does not fit) and fills out[((m nb + b) 2 + plane) 64 + lane][4 dwords]: lane (row i = lane & 15, kg = lane >> 4) holds
+// A[i][16 kg .. 16 kg + 15] of K block b, A[i][kk] = digit_plane(c[64 b + kk - sigma_m(i) - off]), sigma_m(i) = 8 (i >> 2) + (i & 3) + 4 m;
+// c = 256 ch + cl with both digits signed bytes (balanced: cl = int8(c & 255)), so that every product is a signed i8 x i8 one.
+int mv_avg_build_frags(const int64_t *c, int taps, int win_mode, uint32_t *out, int64_t *csum) {
+  const int h = taps / 2, hb = win_mode == 0 ? 0 : 8 * ((h + 7) / 8), off = win_mode == 0 ? 0 : hb - h;
+  if (taps > 65 || 31 + off + taps - 1 >= 128) { return 0; }
+  const int nb = (31 + off + taps - 1 < 64) ? 1 : 2;
+  int64_t sum = 0;
+  for (int t = 0; t < taps; t++) {
+    if (c[t] < -32768 || c[t] > 32639) { return 0; }   // the balanced high digit of 32640 .. 32767 is 128
+    sum += c[t];
+  }
+  *csum = sum;
+  for (int m = 0; m < 2; m++) {
+    for (int b = 0; b < nb; b++) {
+      for (int lane = 0; lane < 64; lane++) {
+        const int i = lane & 15, kg = lane >> 4, sig = 8 * (i >> 2) + (i & 3) + 4 * m;
+        for (int dw = 0; dw < 4; dw++) {
+          uint32_t wl = 0, wh = 0;
+          for (int bj = 0; bj < 4; bj++) {
+            const int t = 64 * b + 16 * kg + 4 * dw + bj - sig - off;
+            const int64_t cv = (t >= 0 && t < taps) ? c[t] : 0;
+            const int cl = (int)(int8_t)(uint8_t)(cv & 0xFF), ch = (int)((cv - cl) >> 8);
+            wl |= (uint32_t)(uint8_t)cl << (8 * bj);
+            wh |= (uint32_t)(uint8_t)ch << (8 * bj);
+          }
+          out[(((size_t)(m * nb + b) * 2 + 0) * 64 + lane) * 4 + dw] = wl;
+          out[(((size_t)(m * nb + b) * 2 + 1) * 64 + lane) * 4 + dw] = wh;
+        }
+      }
+    }
+  }
+  return nb;
+}
+
 hipError_t launch_mv_avg(const MvAvgParams &p, hipStream_t s, int *path) {
   if (p.out_per_frame <= 0 || p.n_frames <= 0) { return hipSuccess; }
-  if (try_stream(p, s)) { *path = 2; return hipGetLastError(); }
+  bool mfma = false;
+  if (try_stream(p, s, &mfma)) { *path = mfma ? 4 : 2; return hipGetLastError(); }
   if (try_w32(p, s)) { *path = 3; return hipGetLastError(); }
   *path = p.fast ? 1 : 0;
   const int64_t pairs = (int64_t)p.n_obj * p.n_frames;

@@ -570,7 +570,7 @@ class MvAvg:
     @property
     def path(self):
         """kernel family of the last run()"""
-        return {0: "exact_order", 1: "int64_sums", 2: "stream", 3: "stream32"}[lib.acdsp_mvavg_path(self._h)]
+        return {0: "exact_order", 1: "int64_sums", 2: "stream", 3: "stream32", 4: "stream_mfma"}[lib.acdsp_mvavg_path(self._h)]
 
     def run(self, x, n_sample, out=None):
         assert x.is_cuda and x.dim() == 2 and x.shape[0] == self.n_objects and x.stride(1) == 1 and x.shape[1] % n_sample == 0

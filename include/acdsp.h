@@ -330,7 +330,7 @@ int32_t acdsp_mvavg_create(const acdsp_mvavg_desc_t *desc, acdsp_mvavg_t *out);
 int32_t acdsp_mvavg_destroy(acdsp_mvavg_t h);
 int32_t acdsp_mvavg_set_coeffs(acdsp_mvavg_t h, const int64_t *coeffs);   /* raw COEFF_TYPE words [TAPS] */
 int64_t acdsp_mvavg_out_per_frame(acdsp_mvavg_t h, int64_t n_sample);     /* -1: n_sample outside 1..MAX_SAMPLE */
-int32_t acdsp_mvavg_path(acdsp_mvavg_t h);   /* kernel family of the last run(): 0 exact per-tap order, 1 order-free int64 sums, 2 streaming (16-bit samples, int32 sums), 3 sliding window on 32-bit samples (int64 sums) */
+int32_t acdsp_mvavg_path(acdsp_mvavg_t h);   /* kernel family of the last run(): 0 exact per-tap order, 1 order-free int64 sums, 2 streaming (16-bit samples, int32 sums), 3 sliding window on 32-bit samples (int64 sums), 4 streaming with the window sums on the matrix cores (17 taps and more) */
 int32_t acdsp_mvavg_run(acdsp_mvavg_t h, const void *d_in, int64_t in_stride, int64_t n_sample, int64_t n_frames, void *d_out,
                         int64_t out_stride, int64_t *n_out, void *stream);
 int32_t acdsp_mvavg_run_host(acdsp_mvavg_t h, const void *h_in, int64_t n_sample, int64_t n_frames, void *h_out, int64_t out_cap,

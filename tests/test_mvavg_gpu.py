@@ -28,7 +28,10 @@ def check(taps, mode, fin, fc, fa, fo, n_sample, n_frames, n_obj=3, seed=0, forc
     bad = np.argwhere(y != yo)
     assert bad.size == 0, "%d mismatches, first at %s" % (len(bad), bad[0])
     if path is not None:
-        assert eng.path == path, eng.path
+        # "stream": the streaming kernel in either form (v_dot2 / matrix cores -- the split is by window length, tested in
+        # test_stream_kernel_classes); "stream_dot2" / "stream_mfma": that form
+        allowed = {"stream": ("stream", "stream_mfma"), "stream_dot2": ("stream",)}.get(path, (path,))
+        assert eng.path in allowed, (eng.path, path)
 
 
 MODES = ["WIN", "MIRROR", "CLIP"]
@@ -100,7 +103,79 @@ def test_stream_kernel_classes(mode, taps):
     fin, fc = A.Fmt(16, 8), A.Fmt(16, 2)
     for k, (fa, _) in enumerate(STREAM_ACC):
         for fo in (A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(24, 10, True, "TRN", "WRAP"), A.Fmt(40, 18), A.Fmt(12, 6, False, "RND", "SAT")):
-            check(taps, mode, fin, fc, fa, fo, 1024, 3, n_obj=2, seed=200 + k, coeffs=small_coeffs(rng, taps), path="stream")
+            # windows of 11 taps and more (9 with AC_WIN) in the linear class: the same kernel with its sums on the matrix cores (round 6)
+            want = "stream_mfma" if (taps >= (9 if mode == "WIN" else 11) and k < 2) else "stream_dot2"
+            check(taps, mode, fin, fc, fa, fo, 1024, 3, n_obj=2, seed=200 + k, coeffs=small_coeffs(rng, taps), path=want)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("taps", [11, 13, 15, 17, 19, 21, 23, 27, 31, 33, 35, 41, 47, 49, 57, 63, 65])
+def test_window_sums_on_the_matrix_cores(mode, taps):
+    """Round 6: 11 taps and more, linear class.  Every odd window offset into the image (TAPS / 2 mod 8), one and two K blocks, frame lengths around
+    the 512-output tile, full-scale samples against extreme weights, both epilogues, all container widths of the output."""
+    rng = np.random.default_rng(300 + taps)
+    fin, fc = A.Fmt(16, 8), A.Fmt(16, 2)
+    for fa, fo in ((A.Fmt(40, 18), A.Fmt(16, 8, True, "RND", "SAT")), (A.Fmt(48, 20), A.Fmt(24, 10, True, "TRN", "WRAP")), (A.Fmt(40, 18), A.Fmt(40, 18)),
+                   (A.Fmt(30, 8), A.Fmt(12, 6, False, "RND", "SAT"))):       # last: W_acc = 30 may wrap -- the 64-bit epilogue
+        for n in (72, 504, 512, 520, 1024, 1032, 4096 + 8):
+            if n >= taps:
+                check(taps, mode, fin, fc, fa, fo, n, 3, n_obj=2, seed=n + fa.W, coeffs=small_coeffs(rng, taps), path="stream_mfma", max_sample=8192)
+    fa, fo = A.Fmt(40, 18), A.Fmt(40, 18)
+    # extreme weights and samples: one weight of 32639 (the largest whose balanced high digit is a signed byte), alternating +-, a negative giant
+    for k, c in enumerate(([0] * (taps // 2) + [32639] + [0] * (taps // 2), [(-1) ** j * (32767 // taps) for j in range(taps)],
+                           [-32767] + [0] * (taps - 1), [0] * (taps - 1) + [-32640], [127] * taps, [-128] * taps, [128] * taps, [-129] * taps)):
+        rs = np.random.default_rng(k)
+        n_sample, n_frames = 1024, 4
+        x = rs.choice(np.array([-32768, 32767, -1, 0, 255, 256, -256, 127, 128, -129], dtype=np.int64), size=(2, n_sample * n_frames))
+        eng = A.MvAvg(n_sample, taps, mode, fin, fc, fa, fo, n_objects=2)
+        eng.set_coeffs(np.asarray(c, dtype=np.int64))
+        y = eng.run(torch.from_numpy(x).to(torch.int16).cuda(), n_sample).cpu().numpy().astype(np.int64)
+        assert eng.path == "stream_mfma", (k, eng.path)
+        yo = OracleMvAvg(taps, mode, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_obj=2).run(np.asarray(c, dtype=np.int64), x, n_sample)
+        assert np.array_equal(y, yo), (k, np.argwhere(y != yo)[:4])
+    # a weight above 32639 keeps the v_dot2 form
+    check(taps, mode, fin, fc, fa, fo, 1024, 2, coeffs=[0] * (taps - 1) + [32700], seed=5, path="stream_dot2")
+
+
+@pytest.mark.parametrize("taps", [3, 5, 7, 11, 13, 21, 35, 63])
+def test_output_frames_off_a_16_byte_boundary_leave_as_aligned_runs(taps):
+    """AC_WIN with TAPS - 1 no multiple of 8: N - TAPS + 1 outputs per frame, so every frame of the output row starts at another offset inside a
+    16-byte granule (round 6: the tile goes through the wave's image and leaves in aligned pieces; first / last piece by elements).  2-, 4- and
+    8-byte output containers, frames around the tile size, an output row that itself starts off the boundary."""
+    rng = np.random.default_rng(taps)
+    fin, fc, fa = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18)
+    for fo in (A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(32, 12), A.Fmt(40, 18)):
+        for n in (72, 512, 520, 1024, 1032, 2048 + 8):
+            if n >= taps:
+                check(taps, "WIN", fin, fc, fa, fo, n, 7, n_obj=3, seed=n, coeffs=small_coeffs(rng, taps), path="stream", max_sample=4096)
+    # the output row starts 2 / 6 / 14 bytes into a granule (a view into a larger buffer), rows of an odd stride
+    fo = A.Fmt(16, 8, True, "RND", "SAT")
+    c = small_coeffs(rng, taps)
+    for mode, shift in (("WIN", 1), ("MIRROR", 3), ("CLIP", 7)):
+        n, nf, n_obj = 1024, 5, 3
+        x = rand_raw(rng, fin, (n_obj, n * nf))
+        eng = A.MvAvg(n, taps, mode, fin, fc, fa, fo, n_objects=n_obj)
+        eng.set_coeffs(c)
+        opf = eng.out_per_frame(n)
+        buf = torch.full((n_obj, opf * nf + 21), -7, dtype=torch.int16, device="cuda")
+        out = buf[:, shift:shift + opf * nf]
+        y = eng.run(torch.from_numpy(x).to(torch.int16).cuda(), n, out=out)
+        assert y.data_ptr() == out.data_ptr()
+        yo = OracleMvAvg(taps, mode, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_obj=n_obj).run(c, x, n)
+        assert np.array_equal(y.cpu().numpy().astype(np.int64), yo), (mode, shift)
+        full = buf.cpu().numpy()
+        assert (full[:, :shift] == -7).all() and (full[:, shift + opf * nf:] == -7).all(), "stores outside the output row"
+        assert eng.path in ("stream", "stream_mfma")
+
+
+def test_matrix_core_window_sums_many_frames_and_objects():
+    """Runs of tiles that cross frames and objects, a partial last run, unsigned 15-bit samples."""
+    rng = np.random.default_rng(77)
+    fc, fa, fo = A.Fmt(16, 2), A.Fmt(40, 18), A.Fmt(16, 8, True, "RND", "SAT")
+    check(33, "MIRROR", A.Fmt(16, 8), fc, fa, fo, 1024, 37, n_obj=7, seed=1, coeffs=small_coeffs(rng, 33), path="stream_mfma")
+    check(65, "CLIP", A.Fmt(16, 8), fc, fa, fo, 520, 61, n_obj=3, seed=2, coeffs=small_coeffs(rng, 65), path="stream_mfma")
+    check(25, "WIN", A.Fmt(15, 8, False), fc, fa, A.Fmt(15, 7, False, "RND", "SAT"), 2048, 9, n_obj=5, seed=3, coeffs=small_coeffs(rng, 25), path="stream_mfma")
+    check(33, "MIRROR", A.Fmt(12, 4), fc, A.Fmt(32, 10), A.Fmt(12, 4, True, "RND", "SAT"), 1024, 9, n_obj=5, seed=4, coeffs=small_coeffs(rng, 33), path="stream_mfma")
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -113,7 +188,7 @@ def test_stream_kernel_shapes(mode):
             if n >= taps:
                 check(taps, mode, fin, fc, fa, fo, n, 5, n_obj=3, seed=n, coeffs=small_coeffs(rng, taps), path="stream", max_sample=8192)
     check(9, mode, fin, fc, fa, fo, 64, 700, n_obj=5, seed=1, coeffs=small_coeffs(rng, 9), path="stream")       # runs of tiles cross frames and objects
-    check(33, mode, fin, fc, fa, A.Fmt(40, 18), 256, 9, n_obj=2, seed=2, coeffs=small_coeffs(rng, 33), path="stream")
+    check(33, mode, fin, fc, fa, A.Fmt(40, 18), 256, 9, n_obj=2, seed=2, coeffs=small_coeffs(rng, 33), path="stream")   # packed short frames keep v_dot2
     # extreme samples and weights: the int32 bound is tight
     c = np.zeros(9, dtype=np.int64)
     c[4] = 32767
@@ -181,7 +256,7 @@ def test_short_frames_share_a_tile(mode, n_sample):
     fin, fc, fa = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18)
     per = 512 // n_sample
     for taps, fo, nf in ((9, A.Fmt(16, 8, True, "RND", "SAT"), 8 * per), (33, A.Fmt(32, 12), 3 * per), (63 if n_sample > 64 else 31, A.Fmt(40, 18), 2 * per),
-                         (1, A.Fmt(16, 8, True, "RND", "SAT"), per), (17, A.Fmt(16, 8, True, "TRN", "WRAP"), 5 * per + 1), (5, A.Fmt(24, 10), 40 * per)):
+                         (1, A.Fmt(16, 8, True, "RND", "SAT"), per), (17, A.Fmt(16, 8, True, "TRN", "WRAP"), 5 * per + 1), (5, A.Fmt(24, 10), 40 * per)):   # 5 per + 1 frames: not packed, one frame per tile
         check(taps, mode, fin, fc, fa, fo, n_sample, nf, n_obj=3, seed=taps + nf, coeffs=small_coeffs(rng, taps), path="stream")
     check(9, "WIN", fin, fc, fa, A.Fmt(16, 8, True, "RND", "SAT"), n_sample, 4 * per, coeffs=small_coeffs(rng, 9), seed=3)
     check(9, mode, A.Fmt(12, 4), fc, A.Fmt(24, 10), A.Fmt(12, 4, True, "RND", "SAT"), n_sample, 6 * per, coeffs=small_coeffs(rng, 9), seed=4, path="stream")   # per-tap class
