@@ -79,6 +79,25 @@ if not os.path.exists(LIB_PATH):
         "ac_dsp_amd: %s is missing -- build it with `make` (or __graft_entry__.build()); there is no CPU "
         "fallback for the HIP engine" % LIB_PATH)
 
+
+
+def _torch_runtime_first():
+    """This package hands torch tensors to the library, and torch carries its own copy of the HIP runtime: in one process torch's copy has to open
+    the device BEFORE the library's does ("No HIP GPUs are available" from torch otherwise, seen when a process created an engine handle before its
+    first CUDA tensor).  Importing the package therefore initialises torch's runtime when a GPU is there; a C / C++ caller of libacdsp.so has no
+    torch and nothing to order.  ACDSP_NO_TORCH_INIT=1 skips it."""
+    if os.environ.get("ACDSP_NO_TORCH_INIT"):
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.empty(1, device="cuda")
+    except Exception:   # noqa: BLE001 -- no torch / no GPU: the library reports its own errors at the first call
+        pass
+
+
+_torch_runtime_first()
 lib = C.CDLL(LIB_PATH)
 _vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 
