@@ -427,10 +427,13 @@ hipError_t launch_g(int g, int n, dim3 grid, hipStream_t s, const Cic2Args &a, c
 // step first (a step's fixed work -- fragment reads, recombination, the prefix-sum levels -- is per 256 u, whatever R1).
 // Translation units (Makefile): cic2.hip = unit 0 + the host side; cic2_b / _c / _d.hip re-include this file with ACDSP_CIC2_PART set.
 #define ACDSP_CIC2_SHAPES(X)                                                                                       \
-  X(0, int16_t, s16_r16, 2, 16, 3, 6) X(1, int16_t, s16_r10, 2, 10, 3, 4) X(1, int16_t, s16_r8, 2, 8, 2, 3)        \
-  X(3, int16_t, s16_r15, 2, 15, 2, 5) X(3, int16_t, s16_r5, 2, 5, 2, 2)                                            \
-  X(2, int32_t, s32_r10, 4, 10, 3, 4) X(2, int32_t, s32_r8, 4, 8, 2, 3) X(3, int32_t, s32_r5, 4, 5, 2, 2)          \
-  X(3, int32_t, s32_r4, 4, 4, 2, 2) X(3, int32_t, s32_r3, 4, 3, 2, 2)
+  X(0, int16_t, s16_r16, 2, 16, 3, 6) X(4, int16_t, s16_r12, 2, 12, 3, 4) X(1, int16_t, s16_r10, 2, 10, 3, 4)        \
+  X(1, int16_t, s16_r8, 2, 8, 2, 3) X(4, int16_t, s16_r6, 2, 6, 2, 2) X(5, int16_t, s16_r4, 2, 4, 2, 2)              \
+  X(3, int16_t, s16_r15, 2, 15, 2, 5) X(4, int16_t, s16_r7, 2, 7, 2, 3) X(3, int16_t, s16_r5, 2, 5, 2, 2)            \
+  X(5, int16_t, s16_r3, 2, 3, 2, 2)                                                                                  \
+  X(2, int32_t, s32_r10, 4, 10, 3, 4) X(2, int32_t, s32_r8, 4, 8, 2, 3) X(5, int32_t, s32_r7, 4, 7, 2, 3)            \
+  X(5, int32_t, s32_r6, 4, 6, 2, 2) X(3, int32_t, s32_r5, 4, 5, 2, 2) X(3, int32_t, s32_r4, 4, 4, 2, 2)              \
+  X(3, int32_t, s32_r3, 4, 3, 2, 2)
 #ifndef ACDSP_CIC2_PART
 #define ACDSP_CIC2_PART 0
 #endif
@@ -464,6 +467,16 @@ ACDSP_CIC2_SHAPES(ACDSP_CIC2_DECL)
 #else
 #define ACDSP_CIC2_IF_3 ACDSP_CIC2_DROP
 #endif
+#if ACDSP_CIC2_PART == 4
+#define ACDSP_CIC2_IF_4 ACDSP_CIC2_KEEP
+#else
+#define ACDSP_CIC2_IF_4 ACDSP_CIC2_DROP
+#endif
+#if ACDSP_CIC2_PART == 5
+#define ACDSP_CIC2_IF_5 ACDSP_CIC2_KEEP
+#else
+#define ACDSP_CIC2_IF_5 ACDSP_CIC2_DROP
+#endif
 ACDSP_CIC2_SHAPES(ACDSP_CIC2_DEF)
 #undef ACDSP_CIC2_DEF
 
@@ -493,6 +506,17 @@ bool cic2_factor(int in_eb, int R, int me, int N, int *R1_out, int *R2_out, int 
     const int R2 = R / s.R1;
     const int wu = (N * (R2 * me - 1) + 255) / 256;
     if (wu < 1 || wu > 2) { continue; }
+    // the stage-1 taps of this rate must fit the digit planes / K blocks the shape was compiled with, at both extreme phases of a call start
+    // (R1 = 15 at N = 6 needs a third plane: R = 45 then goes to R1 = 5, not to the recurrence kernel)
+    std::vector<int64_t> taps;
+    cic2_stage1_taps(s.R1, N, &taps);
+    bool fits = true;
+    for (int ph : {0, 15}) {
+      FirGenPlan probe;
+      std::vector<uint32_t> fr;
+      if (!fir_gen_plan(taps.data(), (int)taps.size(), s.R1, ph, &probe, &fr) || probe.pc > s.pct || probe.nb > s.nbt) { fits = false; }
+    }
+    if (!fits) { continue; }
     *R1_out = s.R1; *R2_out = R2; *wu_out = wu;
     return true;
   }

@@ -137,14 +137,14 @@ typedef int v4i_mv __attribute__((ext_vector_type(4)));
 // orders: row i of fragment set m is output 32 j' + 8 (i >> 2) + (i & 3) + 4 m.  A lane's accumulator rows are then outputs 8 v .. 8 v + 7 of
 // the tile, v = 4 (lane & 15) + (lane >> 4): eight consecutive outputs, the same epilogue and 16-byte stores as the v_dot2 form, a whole KB
 // per store instruction.  8 MF MFMAs per 512 outputs (4 plane products x 2 row orders), 2 MF 16-byte LDS reads per lane instead of NR.
-template <int NR, bool LINEAR, bool CV32, bool EDGE, bool PK = false, int MF = 0>   // PK: packed short frames (MvStreamArgs::pk_*; as run-time branches they cost the bench row 1.4 %)
+template <int NR, bool LINEAR, bool CV32, bool EDGE, bool PK = false, int MF = 0, bool RUN = false>   // RUN: output tiles that start off a 16-byte boundary leave as aligned runs (a.run_ok; as a run-time branch it cost the bench row 12 VGPRs and two waves per SIMD: -8 %); PK: packed short frames (MvStreamArgs::pk_*; as run-time branches they cost the bench row 1.4 %)
 __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   static_assert(MF == 0 || (LINEAR && !PK), "matrix-core form: linear class, whole-frame tiles");
   constexpr int REGION = 512 + 8 * NR + 8;      // samples of one wave's LDS image (+ 8: the odd-offset window reads one dword further)
   constexpr int NQ = 4 * NR - 3;                // coefficient pairs covering 8 NR - 7 taps (+ a zero)
   // (4- and 8-byte outputs turn their tile around in the same image -- 2 / 4 KB -- before it leaves: IMG)
   constexpr int IMG = REGION > 2048 ? REGION : 2048;
-  __shared__ __attribute__((aligned(16))) int16_t sm[4][IMG + 8];   // + 16 bytes: a tile of 8-byte outputs behind its misalignment (run_ok)
+  __shared__ __attribute__((aligned(16))) int16_t sm[4][IMG];   // (exactly 16 KB per workgroup: 16 bytes more -- tried for run_ok tiles of 8-byte outputs -- cost the bench row 9 %, one workgroup per CU less)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int16_t *img = sm[wave];
   int bx, by_;
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
             for (int i = 0; i < 8; i += 2) { w[i / 2] = make_ulonglong2((uint64_t)ov[i], (uint64_t)ov[i + 1]); }
           }
         }
-      } else if (a.run_ok) {
+      } else if (RUN) {
         // output frames that start off a 16-byte boundary (round 6: AC_WIN with TAPS - 1 no multiple of 8 -- 1012 outputs per frame -- ran eight
         // element stores per lane, 0.25 - 0.30 of the roofline): the tile's outputs go to the image at the byte offset their first one has
         // inside its 16-byte granule, and leave below as aligned 16-byte pieces
@@ -390,12 +390,9 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
             w[0] = __builtin_amdgcn_alignbit(p1_, p0_, 16); w[1] = __builtin_amdgcn_alignbit(p2_, p1_, 16); w[2] = __builtin_amdgcn_alignbit(p3_, p2_, 16);
             reinterpret_cast<int16_t *>(ib)[7] = (int16_t)ov[7];
           }
-        } else if (a.out_eb == 4) {
-#pragma unroll
-          for (int i = 0; i < 8; i++) { reinterpret_cast<int32_t *>(ib)[i] = (int32_t)ov[i]; }
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; i++) { reinterpret_cast<int64_t *>(ib)[i] = ov[i]; }
+          for (int i = 0; i < 8; i++) { reinterpret_cast<int32_t *>(ib)[i] = (int32_t)ov[i]; }
         }
       } else {
 #pragma unroll
@@ -404,7 +401,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
         }
       }
     }
-    if (!a.vec_ok && a.run_ok) {   // wave-uniform: second half of the unaligned turn-around
+    if (RUN && !a.vec_ok) {   // wave-uniform: second half of the unaligned turn-around
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -415,7 +412,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
       const int total = mis + (int)(left < 512 ? left : 512) * a.out_eb;      // image bytes [mis, total) are this tile's outputs
       unsigned char *g = reinterpret_cast<unsigned char *>(b0 - mis);
 #pragma unroll
-      for (int k = 0; k < 5; k++) {                                             // 512 x 8 bytes + 15 = 257 pieces at most
+      for (int k = 0; k < 3; k++) {                                             // 512 x 4 bytes + 15 = 129 pieces at most
         const int o = 16 * (lane + 64 * k);
         if (o >= mis && o + 16 <= total) {
           const uint4 v = *reinterpret_cast<const uint4 *>(ib + o);
@@ -664,7 +661,7 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s, bool *mfma) {
   a.out_eb = p.out_eb;
   a.vec_ok = p.out_per_frame % 8 == 0 && p.out_stride % 8 == 0 && ((uintptr_t)p.y % 16) == 0;
   static const bool no_run = getenv("ACDSP_NO_MVAVG_RUN") != nullptr;   // A/B knob: element stores for unaligned output frames
-  a.run_ok = !a.vec_ok && !no_run && ((uintptr_t)p.y % p.out_eb) == 0;
+  a.run_ok = !a.vec_ok && !no_run && ((uintptr_t)p.y % p.out_eb) == 0 && p.out_eb <= 4;   // (8-byte outputs: 4 KB + the offset would not fit the image; they keep element stores, 64 contiguous bytes per lane)
   a.n_sample = p.n_sample; a.n_frames = p.n_frames; a.opf = p.out_per_frame; a.in_stride = p.in_stride; a.out_stride = p.out_stride;
   a.tpf = (p.out_per_frame + 511) / 512;
   a.n_tiles = (int64_t)p.n_obj * p.n_frames * a.tpf;
@@ -678,6 +675,7 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s, bool *mfma) {
     a.nxg = 0;
     a.n_sample = p.n_sample * p.n_frames; a.n_frames = 1; a.opf = a.n_sample; a.tpf = a.opf / 512;
     a.n_tiles = (int64_t)p.n_obj * a.tpf;
+    a.run_ok = 0;   // (packed tiles keep element stores when the output row is off the boundary)
   }
   a.tiles_per_wave = 16;   // 16 KB spans (8 / 16 tiles alike, 32: -5 %, 64: -9 %: profiles/r3_span_sweep.txt)
   while (a.tiles_per_wave > 1 && a.n_tiles / a.tiles_per_wave < 16384) { a.tiles_per_wave /= 2; }
@@ -698,7 +696,11 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s, bool *mfma) {
     a.frag = p.frag;
     a.kbias = (int32_t)(128 * p.frag_csum);
 // (NR = 9: only REGION -- how far the right-edge patches reach into the image -- depends on it here)
-#define ACDSP_MV_MF(CV_, EDGE_, MF_) hipLaunchKernelGGL((mv_avg_stream_kernel<9, true, CV_, EDGE_, false, MF_>), grid, dim3(256), 0, s, a)
+#define ACDSP_MV_MF(CV_, EDGE_, MF_)                                                                                      \
+  do {                                                                                                                      \
+    if (a.run_ok) { hipLaunchKernelGGL((mv_avg_stream_kernel<9, true, CV_, EDGE_, false, MF_, true>), grid, dim3(256), 0, s, a); } \
+    else { hipLaunchKernelGGL((mv_avg_stream_kernel<9, true, CV_, EDGE_, false, MF_, false>), grid, dim3(256), 0, s, a); }   \
+  } while (0)
     if (p.frag_nb == 1) {
       if (a.cv32) { if (a.mode != 0) { ACDSP_MV_MF(true, true, 1); } else { ACDSP_MV_MF(true, false, 1); } }
       else { if (a.mode != 0) { ACDSP_MV_MF(false, true, 1); } else { ACDSP_MV_MF(false, false, 1); } }
@@ -713,6 +715,10 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s, bool *mfma) {
   const int nr = p.taps <= 9 ? 2 : (p.taps <= 17 ? 3 : (p.taps <= 25 ? 4 : (p.taps <= 33 ? 5 : (p.taps <= 49 ? 7 : 9))));   // taps <= 8 NR - 7
 #define ACDSP_MV_LAUNCH2(NR_, LIN_, CV_)                                                                                           \
   if (a.pk_n) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true, true>), grid, dim3(256), 0, s, a); }               \
+  else if (a.run_ok) {                                                                                                             \
+    if (a.mode != 0) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true, false, 0, true>), grid, dim3(256), 0, s, a); } \
+    else { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, false, false, 0, true>), grid, dim3(256), 0, s, a); }          \
+  }                                                                                                                                \
   else if (a.mode != 0) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true>), grid, dim3(256), 0, s, a); }             \
   else { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, false>), grid, dim3(256), 0, s, a); }
 #define ACDSP_MV_LAUNCH(NR_)                                                                                                       \

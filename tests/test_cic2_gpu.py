@@ -49,12 +49,15 @@ def int_fmt(R, M, N, fin):
 
 
 CASES = [
-    # W, I, R, M, N      (stage-1 rates compiled: 16 / 10 / 8 / 15 / 5 on 16-bit samples, 10 / 8 / 5 / 4 / 3 on 32-bit samples: cic2.hip ACDSP_CIC2_SHAPES)
+    # W, I, R, M, N      (stage-1 rates compiled: 16 / 10 / 8 / 15 / 5 / 12 / 6 / 7 / 4 / 3 on 16-bit samples, 10 / 8 / 5 / 4 / 3 / 6 / 7 on 32-bit samples: cic2.hip ACDSP_CIC2_SHAPES)
     (16, 1, 32, 1, 4), (16, 1, 64, 1, 3), (16, 1, 128, 2, 3), (16, 1, 256, 1, 3), (16, 1, 32, 1, 6), (16, 1, 48, 2, 3), (16, 1, 40, 1, 5),
     (16, 1, 64, 1, 5), (12, 4, 96, 1, 3), (16, 1, 100, 1, 3), (16, 1, 250, 1, 3), (16, 1, 255, 2, 3), (16, 1, 35, 1, 4), (16, 1, 45, 1, 5),
     (16, 1, 56, 1, 2), (16, 1, 200, 1, 1),
     (32, 16, 32, 1, 4), (32, 16, 64, 2, 3), (32, 16, 128, 1, 3), (32, 16, 72, 1, 3), (32, 16, 32, 2, 5), (24, 8, 64, 1, 4), (32, 16, 200, 1, 3),
     (32, 16, 100, 1, 4), (32, 16, 255, 2, 3), (32, 16, 250, 1, 3), (32, 16, 36, 1, 5), (32, 16, 33, 1, 4), (20, 3, 35, 2, 3),
+    # second set of stage-1 rates (12 / 6 / 7 / 4 / 3 on 16-bit samples, 6 / 7 on 32-bit samples)
+    (16, 1, 36, 1, 4), (16, 1, 42, 1, 3), (16, 1, 49, 2, 3), (16, 1, 44, 1, 4), (16, 1, 33, 1, 5), (16, 1, 252, 1, 3), (12, 4, 84, 2, 3), (16, 1, 63, 1, 4),
+    (16, 1, 39, 2, 2), (32, 16, 42, 1, 4), (32, 16, 49, 1, 3), (32, 16, 66, 2, 3), (24, 8, 77, 1, 3),
 ]
 
 

@@ -144,7 +144,7 @@ def test_fir_long_band_limited_sets(seed):
 def test_cic_random_shapes(seed):
     rng = np.random.default_rng(2000 + seed)
     interp = bool(rng.integers(2))
-    R = int(rng.choice([2, 3, 5, 6, 7, 8, 10, 12, 16, 20, 32]))
+    R = int(rng.choice([2, 3, 5, 6, 7, 8, 10, 12, 16, 20, 32, 36, 40, 42, 48, 49, 64, 100]))   # from 32: the two-stage decimator where a compiled rate divides
     M = int(rng.choice([1, 2, 3]))
     N = int(rng.choice([1, 2, 4, 5]))
     fin = [A.Fmt(16, 1), A.Fmt(32, 16), A.Fmt(12, 12, False), A.Fmt(20, 4), A.Fmt(24, 8)][rng.integers(5)]
@@ -217,7 +217,7 @@ def test_intg_dump_random_block_sequences(seed):
     from oracle import OracleIntgDump
     rng = np.random.default_rng(4000 + seed)
     ns = int(rng.choice([4, 64, 100, 1024]))
-    chn = int(rng.choice([1, 2, 3, 4, 8]))
+    chn = int(rng.choice([1, 2, 3, 4, 8, 5, 6, 7, 12, 16]))   # 3, 5, 6, 7, 12, 16: the matrix-core de-interleave when every block dumps after NS rounds
     fin = [A.Fmt(16, 8), A.Fmt(32, 16), A.Fmt(12, 12, False)][rng.integers(3)]
     fa, fo = [(A.Fmt(40, 20), A.Fmt(40, 20)), (A.Fmt(20, 10, True, "TRN", "SAT"), A.Fmt(12, 8, True, "RND", "SAT")),
               (A.Fmt(48, 40, False), A.Fmt(48, 40, False)), (A.Fmt(64, 32), A.Fmt(64, 32)), (A.Fmt(64, 32), A.Fmt(32, 12, True, "TRN", "SAT"))][rng.integers(5)]
@@ -227,7 +227,7 @@ def test_intg_dump_random_block_sequences(seed):
     for _ in range(int(rng.integers(1, 5))):
         nb = int(rng.integers(1, 200)) if ns < 1024 else int(rng.integers(1, 24))
         n_sample = rng.integers(1, ns + 1, size=nb)
-        if rng.integers(4) == 0:                      # every block dumps after NS rounds: the streaming kernels' shape
+        if rng.integers(3) == 0:                      # every block dumps after NS rounds: the streaming / matrix-core kernels' shape
             n_sample[:] = ns
         elif rng.integers(2):
             n_sample[rng.integers(0, nb, size=max(1, nb // 10))] = rng.choice([0, ns + 5])
@@ -291,7 +291,7 @@ def test_mv_avg_random_shapes(seed):
     fin = [A.Fmt(16, 8), A.Fmt(14, 3), A.Fmt(15, 8, False), A.Fmt(16, 8, False), A.Fmt(24, 12), A.Fmt(32, 16), A.Fmt(28, 9, False)][rng.integers(7)]
     fc = [A.Fmt(16, 2), A.Fmt(12, 1), A.Fmt(16, 16), A.Fmt(10, 0, False), A.Fmt(24, 2)][rng.integers(5)]
     fa, fo = MV_ACC[rng.integers(len(MV_ACC))], MV_OUT[rng.integers(len(MV_OUT))]
-    taps = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 17, 23, 25, 31, 33, 35]))
+    taps = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 17, 23, 25, 31, 33, 35, 41, 49, 65]))
     mode = ["WIN", "MIRROR", "CLIP"][rng.integers(3)]
     n_sample = int(rng.choice([8, 16, 24, 64, 128, 200, 256, 504, 512, 520, 1000, 1024, 1032, 2056]))
     n_frames, n_obj = int(rng.choice([1, 2, 3, 8, 16, 17])), int(rng.choice([1, 2, 5]))

@@ -129,11 +129,13 @@ def test_calls_whose_phase_would_be_baked_in_are_refused_under_capture():
     assert errs[1] and "graph capture" in errs[1], errs
 
 
-def test_poly_intr_calls_with_their_side_stream_replayed_from_a_graph():
+@pytest.mark.parametrize("ifac,n_taps", [(8, 16), (2, 16), (3, 12), (6, 8)])
+def test_poly_intr_calls_with_their_side_stream_replayed_from_a_graph(ifac, n_taps):
     """ac_poly_intr forks the head / tail / state kernels of a call onto a stream of its own beside the matrix-core kernel (fir_kernels.hpp:
     SideStream): event record / wait pairs, which a capture turns into graph edges.  The handle flips its state buffers every call, so calls are
-    captured in pairs; replays continue the stream."""
-    nch, cs, nk, ifac, n_taps = 24, 4096, 2, 8, 16
+    captured in pairs; replays continue the stream.  Factors 2 / 3 / 6 with 2-byte outputs: the head / tail kernels write [0, o_a) and [o_b, n_out)
+    of the same rows the matrix-core kernel fills between them, concurrently -- ranges that are closest to sharing a 4-byte word where IF is small."""
+    nch, cs, nk = 24, 4096, 2
     fin, fc, fa, fo = A.Fmt(16, 2), A.Fmt(16, 2), A.Fmt(40, 12), A.Fmt(16, 2, True, "RND", "SAT")
     rng = np.random.default_rng(17)
     csz = (n_taps // 2 - 1) + (ifac - 1) * n_taps // 2 + 1
@@ -153,7 +155,7 @@ def test_poly_intr_calls_with_their_side_stream_replayed_from_a_graph():
     for k in range(nk):
         ref_eng.run(x[k])
     refs = [torch.stack([ref_eng.run(x[k]).clone() for k in range(nk)]) for _ in range(n_replays)]
-    assert ref_eng.path == "mfma_gen"
+    assert ref_eng.path == "mfma_gen", ref_eng.path
     torch.cuda.synchronize()
     eng = make()
     for k in range(nk):
