@@ -946,7 +946,7 @@ def pmc_traffic(tag):
     (profiles/r<round>_<tag>_rocprof.txt, newest round first): FETCH_SIZE (KB, x2 on gfx950 for 16-byte streaming reads, see
     MI355X_MICROARCH.md) + WRITE_SIZE (KB).  A static value from the profile of the same binary, NOT measured in this run
     (the PMC passes are separate rocprofv3 invocations); (None, None) when no summary has been committed."""
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", "%s_%s_rocprof.txt" % (rnd, tag))
         try:
             vals = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}

@@ -12,8 +12,8 @@ NCH, N = 4096, 1 << 20
 SMALL = ((32, 16, 8, 1, 5), (32, 16, 7, 2, 4), (32, 16, 4, 1, 3), (32, 16, 16, 1, 5), (32, 16, 32, 1, 4), (32, 16, 10, 1, 5), (16, 1, 16, 1, 5),
          (16, 1, 8, 1, 4), (16, 1, 64, 1, 3), (16, 1, 5, 1, 6), (24, 8, 8, 2, 3),
          (16, 1, 3, 1, 5), (32, 16, 3, 1, 5), (16, 1, 6, 1, 5), (32, 16, 6, 1, 5), (16, 1, 10, 1, 4), (16, 1, 12, 1, 5), (16, 1, 20, 1, 5), (32, 16, 5, 1, 5), (16, 1, 7, 2, 4))
-# `large`: the rates a CIC is deployed at, every (R, N) the reference's int power<> admits ((R M)^N < 2^31), 16- and 32-bit samples
-LARGE = tuple((W, I, R, M, Ns) for (W, I) in ((16, 1), (32, 16)) for R in (32, 64, 100, 128, 250, 255) for (M, Ns) in ((1, 3), (1, 4), (1, 5), (2, 3))
+# `large`: the rates a CIC is deployed at (36 / 42 / 44 / 49 / 252: the second set of stage-1 rates; 37: a prime, recurrence kernel), every (R, N) the reference's int power<> admits ((R M)^N < 2^31), 16- and 32-bit samples
+LARGE = tuple((W, I, R, M, Ns) for (W, I) in ((16, 1), (32, 16)) for R in (32, 36, 42, 44, 49, 64, 100, 128, 250, 252, 255, 37) for (M, Ns) in ((1, 3), (1, 4), (1, 5), (2, 3))
               if (R * M) ** Ns < 2 ** 31)
 QUICK = ((16, 1, 32, 1, 3), (16, 1, 32, 1, 5), (16, 1, 64, 1, 4), (16, 1, 128, 2, 3), (32, 16, 32, 1, 5), (32, 16, 64, 1, 3), (32, 16, 128, 1, 4))
 SETS = LARGE if "large" in sys.argv[1:] else (QUICK if "quick" in sys.argv[1:] else SMALL)

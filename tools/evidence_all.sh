@@ -1,4 +1,4 @@
-# tools/evidence_all.sh -- on the GPU box: the whole evidence set of a round (tests, per-workload bench lines + rocprofv3, shape sweeps, default bench)
+# tools/evidence_all.sh -- on the GPU box (about 12 minutes of box time): the whole evidence set of a round (tests, per-workload bench lines + rocprofv3, shape sweeps, default bench)
 export ACDSP_ROUND=${ACDSP_ROUND:-r6}
 bash tools/profile_all.sh fir255 fir255_dense fir255_wide fir1023 cic_dec cic_intr ddc polydec polyintr intgdump mvavg rtest_const_types rtest_load_types rtest_prog_types cic_dec_r7m2n4 cic_intr_r7m2n5 cic_dec_r64 > gpurun_out/profile_all.log 2>&1
 {
