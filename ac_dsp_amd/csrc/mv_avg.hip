@@ -110,6 +110,7 @@ struct MvStreamArgs {
   // packed short frames (round 5, PK instantiations): pk_n = samples per frame (64 / 128 / 256; 0 = off), pk_pitch = image samples per frame
   // (n + 2 hb); the tile loads then start at the tile, not hb samples in front of it: every halo is a patch
   int32_t pk_n, pk_pitch, pk_sh;
+  int32_t row_n, row_opf;   // ROW instantiations: samples / outputs per frame (the kernel's n_sample / opf are then the ROW's lengths, n_frames = 1); row_n 0: off
   // matrix-core instantiations (MF = K blocks of 64 samples): Toeplitz fragments [m][b][plane][lane] x 16 bytes (mv_avg_build_frags), and
   // 128 sum(c), what the re-biased low sample plane leaves out
   const uint32_t *frag;
@@ -137,9 +138,10 @@ typedef int v4i_mv __attribute__((ext_vector_type(4)));
 // orders: row i of fragment set m is output 32 j' + 8 (i >> 2) + (i & 3) + 4 m.  A lane's accumulator rows are then outputs 8 v .. 8 v + 7 of
 // the tile, v = 4 (lane & 15) + (lane >> 4): eight consecutive outputs, the same epilogue and 16-byte stores as the v_dot2 form, a whole KB
 // per store instruction.  8 MF MFMAs per 512 outputs (4 plane products x 2 row orders), 2 MF 16-byte LDS reads per lane instead of NR.
-template <int NR, bool LINEAR, bool CV32, bool EDGE, bool PK = false, int MF = 0, bool RUN = false>   // RUN: output tiles that start off a 16-byte boundary leave as aligned runs (a.run_ok; as a run-time branch it cost the bench row 12 VGPRs and two waves per SIMD: -8 %); PK: packed short frames (MvStreamArgs::pk_*; as run-time branches they cost the bench row 1.4 %)
+template <int NR, bool LINEAR, bool CV32, bool EDGE, bool PK = false, int MF = 0, bool RUN = false, int ROW = 0>   // ROW: tiles walk the ROW, frame edges fall inside them (a.row_n; 1: AC_CLIP / AC_MIRROR, 2: AC_WIN; see try_stream); RUN: output tiles that start off a 16-byte boundary leave as aligned runs (a.run_ok; as a run-time branch it cost the bench row 12 VGPRs and two waves per SIMD: -8 %); PK: packed short frames (MvStreamArgs::pk_*; as run-time branches they cost the bench row 1.4 %)
 __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   static_assert(MF == 0 || (LINEAR && !PK), "matrix-core form: linear class, whole-frame tiles");
+  static_assert(ROW == 0 || (!PK && MF == 0 && !RUN && EDGE == (ROW == 1)), "row walk: v_dot2 form, aligned outputs");
   constexpr int REGION = 512 + 8 * NR + 8;      // samples of one wave's LDS image (+ 8: the odd-offset window reads one dword further)
   constexpr int NQ = 4 * NR - 3;                // coefficient pairs covering 8 NR - 7 taps (+ a zero)
   // (4- and 8-byte outputs turn their tile around in the same image -- 2 / 4 KB -- before it leaves: IMG)
@@ -164,22 +166,43 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   // Tiles are fetched two ahead into alternating register sets.  (object, frame, tile) of the tile being fetched: one
   // division per wave, then counted up; past the wave's last tile the fetch repeats that tile (branch-free loop body, so
   // the waits in front of the LDS writes are counted vmcnt's on the older set only).
-  struct Tile { uint4 mv, ev; int16_t fxl, fxr; int64_t ti, fr, obj; };
+  struct Tile { uint4 mv, ev; int16_t fxl, fxr; int64_t ti, fr, obj; int bnd; };   // bnd (ROW): image position of the frame edge inside this tile's image, 2^20: none
   const int64_t pair0 = t0 / a.tpf;
   int64_t f_ti = t0 - pair0 * a.tpf, f_obj = pair0 / a.n_frames, f_fr = pair0 - f_obj * a.n_frames;
   int f_left = n_my;   // tiles not fetched yet
   auto fetch = [&](Tile &T) {   // aligned 8-sample groups: whole groups lie inside or outside the frame
     const int16_t *row = a.x + f_obj * a.in_stride + f_fr * a.n_sample;
-    const int64_t n = a.n_sample, g = f_ti * 512 - (PK ? 0 : a.hb) + 8 * lane;
+    // ROW 2 (AC_WIN): the tile's first output o0 = 512 f_ti of the output row belongs to frame fr0 and reads the input row from in0 on; the outputs
+    // from the next frame's first one (tile-relative index bnd) read TAPS - 1 samples further on -- the image is the contiguous input
+    int64_t in0 = f_ti * 512 - (PK ? 0 : a.hb);
+    if constexpr (ROW == 2) {
+      const int64_t o0 = f_ti * 512;
+      const uint32_t fr0 = (uint32_t)o0 / (uint32_t)a.row_opf;
+      in0 = (int64_t)fr0 * a.row_n + (o0 - (int64_t)fr0 * a.row_opf);
+      T.bnd = (int)((int64_t)(fr0 + 1) * a.row_opf - o0);
+    }
+    const int64_t n = a.n_sample, g = in0 + 8 * lane;
     T.ti = f_ti; T.fr = f_fr; T.obj = f_obj;
     // every load is unconditional (addresses clamped into the frame; what the clamped lanes fetch is never used), so
     // the loop body has no load under a branch and the waits stay counted
     const int64_t gc = g < 0 ? 0 : (g < n ? g : n - 8);
     { const v4u_t t_ = *reinterpret_cast<const v4u_t *>(row + gc); T.mv = make_uint4(t_.x, t_.y, t_.z, t_.w); }
-    const int64_t g2 = f_ti * 512 - (PK ? 0 : a.hb) + 512 + 8 * (lane < a.nxg ? lane : 0);
+    const int64_t g2 = in0 + 512 + 8 * (lane < a.nxg ? lane : 0);
     T.ev = *reinterpret_cast<const uint4 *>(row + (g2 < n ? g2 : n - 8));
 #ifndef ACDSP_MV_LDS_EDGE
-    if constexpr (EDGE) {   // frame-edge patches of AC_CLIP / AC_MIRROR: the source samples of positions -1 - lane and n + lane
+    if constexpr (ROW == 1) {
+      // the one frame edge (a multiple of the frame length, 0 and the row's end included) that can lie inside the image (P0 - hb, P0 + 512 + hb):
+      // frames are at least 512 + 2 hb samples long.  Its two halos take the mirrored / clipped samples of the frame they belong to.
+      const int64_t P0 = f_ti * 512, c = P0 - a.hb + 1;
+      const int64_t B = c <= 0 ? 0 : (int64_t)(((uint32_t)c + (uint32_t)a.row_n - 1u) / (uint32_t)a.row_n) * a.row_n;
+      T.bnd = B < P0 + 512 + a.hb ? (int)(B - (P0 - a.hb)) : (1 << 20);
+      const int l = lane < a.h ? lane : 0;
+      int64_t sl = a.mode == 2 ? B : B + 1 + l, sr = a.mode == 2 ? B - 1 : B - 2 - l;
+      sl = sl > n - 1 ? n - 1 : sl;                  // (the row's end: no frame behind it; the row's start: none in front)
+      sr = sr < 0 ? 0 : (sr > n - 1 ? n - 1 : sr);
+      T.fxl = row[sl];
+      T.fxr = row[sr];
+    } else if constexpr (EDGE) {   // frame-edge patches of AC_CLIP / AC_MIRROR: the source samples of positions -1 - lane and n + lane
       const int l = lane < a.h ? lane : 0;
       T.fxl = row[a.mode == 2 ? 0 : 1 + l];
       T.fxr = row[a.mode == 2 ? n - 1 : n - 2 - l];
@@ -195,11 +218,19 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
   };
   auto process = [&](Tile &T) {
     const int64_t ti = T.ti, fr = T.fr, obj = T.obj, p0 = ti * 512 - a.hb;
+    const int bnd = ROW != 0 ? T.bnd : 0;
     // image position of this lane's eight samples: 8 lane, or -- packed short frames -- frame f' = 8 lane / n of the tile at hb + f' (n + 2 hb)
-    const int lb = PK ? a.hb + ((8 * lane) >> a.pk_sh) * a.pk_pitch + ((8 * lane) & (a.pk_n - 1)) : 8 * lane;
+    // (ROW: the samples behind the frame edge sit 2 hb further on -- the gap holds the right halo of the frame that ends and the left halo of the one that begins)
+    const int gap = 2 * a.hb;
+    const int lb = PK ? a.hb + ((8 * lane) >> a.pk_sh) * a.pk_pitch + ((8 * lane) & (a.pk_n - 1)) : (ROW == 1 ? 8 * lane + (8 * lane >= bnd ? gap : 0) : 8 * lane);
     *reinterpret_cast<uint4 *>(img + lb) = T.mv;
-    if (lane < a.nxg) { *reinterpret_cast<uint4 *>(img + 512 + 8 * lane) = T.ev; }
-    if constexpr (EDGE) {   // positions outside [0, n) take the clipped / mirrored source sample
+    if (lane < a.nxg) { *reinterpret_cast<uint4 *>(img + 512 + 8 * lane + (ROW == 1 && 512 + 8 * lane >= bnd ? gap : 0)) = T.ev; }
+    if constexpr (ROW == 1) {
+      if (lane < a.h && bnd < (1 << 20)) {
+        img[bnd + lane] = T.fxr;
+        img[bnd + gap - 1 - lane] = T.fxl;
+      }
+    } else if constexpr (EDGE) {   // positions outside [0, n) take the clipped / mirrored source sample
       if constexpr (PK) {
         // every frame of the tile has both its halos inside the image: filled from the staged samples themselves
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -278,7 +309,7 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     } else {
     uint32_t R[4 * NR + 1];
     {
-      const unsigned char *wb = reinterpret_cast<const unsigned char *>(img + (PK ? lb - a.hb : lb)) + 2 * a.off;
+      const unsigned char *wb = reinterpret_cast<const unsigned char *>(img + (PK ? lb - a.hb : (ROW == 1 ? 8 * lane + (8 * lane + a.hb >= bnd ? gap : 0) : (ROW == 2 ? 8 * lane + (8 * lane >= bnd ? 2 * a.h : 0) : lb)))) + 2 * a.off;
       const int bo = 2 * a.off;
       if ((bo & 15) == 0) {
 #pragma unroll
@@ -677,6 +708,40 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s, bool *mfma) {
     a.n_tiles = (int64_t)p.n_obj * a.tpf;
     a.run_ok = 0;   // (packed tiles keep element stores when the output row is off the boundary)
   }
+  // Frames that are no multiple of the 512-output tile (round 6: frames of 1000 samples at 0.57 where 1024 run 0.68).  Frame-relative tiles start wherever
+  // their frame starts: every 1 KB store run and load straddles cache lines, and the frame's last tile is partly empty.  With AC_CLIP / AC_MIRROR input
+  // and output positions of a row coincide, so the tiles can walk the ROW in aligned 512-output steps and take the frame edges where they fall: at most
+  // one edge per tile image (frames of at least 512 + 2 hb samples), the samples behind it shifted by a gap of 2 hb that holds both halos (ROW instantiations).
+  a.row_n = 0;
+  static const bool no_row = getenv("ACDSP_NO_MVAVG_ROW") != nullptr;   // A/B knob
+  const bool mf_wanted = [&] {
+    ACDSP_TUNE_ENV(mf_env0, "ACDSP_MVAVG_MFMA_MIN");
+    const int mn = mf_env0 ? atoi(mf_env0) : (p.win_mode == 0 ? 9 : 11);
+    return p.frag && p.frag_nb > 0 && a.linear && mn > 0 && p.taps >= mn;
+  }();
+  if (!no_row && !a.pk_n && !mf_wanted && p.win_mode != 0 && p.n_sample % 512 != 0 && p.n_sample >= 512 + 2 * a.hb && a.vec_ok &&
+      p.n_sample * p.n_frames < (int64_t(1) << 31) - 1024) {
+    a.row_n = (int32_t)p.n_sample;
+    a.n_sample = p.n_sample * p.n_frames; a.n_frames = 1; a.opf = a.n_sample; a.tpf = (a.opf + 511) / 512;
+    a.n_tiles = (int64_t)p.n_obj * a.tpf;
+  }
+  // ... and AC_WIN (ROW 2): N - TAPS + 1 outputs per frame lie back to back in the output row while their windows jump TAPS - 1 samples at every frame
+  // edge.  Where both are multiples of 8 (TAPS = 9, 17, 25 ...: the windows stay aligned) the tiles walk the OUTPUT row; the image is the contiguous input
+  // and the lanes behind the edge start TAPS - 1 samples further on.
+  a.row_opf = 0;
+  {
+    ACDSP_TUNE_ENV(roww_env, "ACDSP_MVAVG_ROWW_MAX");   // A/B knob: the longest window that walks the output row (longer ones: matrix cores, frame-relative)
+    // (same box, 512 objects x 2^20 in frames of 1024: 9 taps 0.54 frame-relative v_dot2 / 0.59 matrix cores / 0.69 row walk; 17 taps 0.62 / 0.61 / 0.62; 25 taps
+    // 0.55 / 0.59 / 0.55; 33 taps 0.50 / 0.61 / 0.49 -- the v_dot2 form is VALU-bound from 17 taps on, where the walk buys nothing)
+    const int roww_max = roww_env ? atoi(roww_env) : 9;
+    if (!no_row && p.win_mode == 0 && p.taps <= roww_max && p.taps > 1 && (p.taps - 1) % 8 == 0 && p.out_per_frame >= 512 && p.out_per_frame % 512 != 0 && a.vec_ok &&
+        p.n_sample * p.n_frames < (int64_t(1) << 31) - 1024) {
+      a.row_n = (int32_t)p.n_sample; a.row_opf = (int32_t)p.out_per_frame;
+      a.n_sample = p.n_sample * p.n_frames; a.n_frames = 1; a.opf = p.out_per_frame * p.n_frames; a.tpf = (a.opf + 511) / 512;
+      a.n_tiles = (int64_t)p.n_obj * a.tpf;
+      a.nxg += (p.taps - 1) / 8;
+    }
+  }
   a.tiles_per_wave = 16;   // 16 KB spans (8 / 16 tiles alike, 32: -5 %, 64: -9 %: profiles/r3_span_sweep.txt)
   while (a.tiles_per_wave > 1 && a.n_tiles / a.tiles_per_wave < 16384) { a.tiles_per_wave /= 2; }
   ACDSP_TUNE_ENV(tpw_env, "ACDSP_MVAVG_TPW");   // tuning knob: tiles per wave
@@ -692,7 +757,7 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s, bool *mfma) {
   // (same box, 512 objects x 2^20, frames of 1024: v_dot2 0.68 / MFMA 0.62 of the roofline at 9 taps, 0.57 / 0.62 at 11, 0.46 / 0.61 at 33, 0.29 / 0.53 at
   // 65; AC_WIN 0.54 / 0.58 at 9 taps -- profiles/r6_mvavg_mfma.txt)
   const int mf_min = mf_env ? atoi(mf_env) : (p.win_mode == 0 ? 9 : 11);
-  if (p.frag && p.frag_nb > 0 && a.linear && !a.pk_n && mf_min > 0 && p.taps >= mf_min) {
+  if (p.frag && p.frag_nb > 0 && a.linear && !a.pk_n && !a.row_n && mf_min > 0 && p.taps >= mf_min) {
     a.frag = p.frag;
     a.kbias = (int32_t)(128 * p.frag_csum);
 // (NR = 9: only REGION -- how far the right-edge patches reach into the image -- depends on it here)
@@ -715,6 +780,8 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s, bool *mfma) {
   const int nr = p.taps <= 9 ? 2 : (p.taps <= 17 ? 3 : (p.taps <= 25 ? 4 : (p.taps <= 33 ? 5 : (p.taps <= 49 ? 7 : 9))));   // taps <= 8 NR - 7
 #define ACDSP_MV_LAUNCH2(NR_, LIN_, CV_)                                                                                           \
   if (a.pk_n) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true, true>), grid, dim3(256), 0, s, a); }               \
+  else if (a.row_n && a.row_opf) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, false, false, 0, false, 2>), grid, dim3(256), 0, s, a); } \
+  else if (a.row_n) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true, false, 0, false, 1>), grid, dim3(256), 0, s, a); } \
   else if (a.run_ok) {                                                                                                             \
     if (a.mode != 0) { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, true, false, 0, true>), grid, dim3(256), 0, s, a); } \
     else { hipLaunchKernelGGL((mv_avg_stream_kernel<NR_, LIN_, CV_, false, false, 0, true>), grid, dim3(256), 0, s, a); }          \

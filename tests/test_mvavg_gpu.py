@@ -104,7 +104,8 @@ def test_stream_kernel_classes(mode, taps):
     for k, (fa, _) in enumerate(STREAM_ACC):
         for fo in (A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(24, 10, True, "TRN", "WRAP"), A.Fmt(40, 18), A.Fmt(12, 6, False, "RND", "SAT")):
             # windows of 11 taps and more (9 with AC_WIN) in the linear class: the same kernel with its sums on the matrix cores (round 6)
-            want = "stream_mfma" if (taps >= (9 if mode == "WIN" else 11) and k < 2) else "stream_dot2"
+            # (AC_WIN at 9 taps and 1016 outputs per frame: the output-row walk of the v_dot2 form)
+            want = "stream_mfma" if (taps >= 11 and k < 2) else "stream_dot2"
             check(taps, mode, fin, fc, fa, fo, 1024, 3, n_obj=2, seed=200 + k, coeffs=small_coeffs(rng, taps), path=want)
 
 
@@ -166,6 +167,39 @@ def test_output_frames_off_a_16_byte_boundary_leave_as_aligned_runs(taps):
         full = buf.cpu().numpy()
         assert (full[:, :shift] == -7).all() and (full[:, shift + opf * nf:] == -7).all(), "stores outside the output row"
         assert eng.path in ("stream", "stream_mfma")
+
+
+@pytest.mark.parametrize("mode", ["MIRROR", "CLIP"])
+@pytest.mark.parametrize("taps", [1, 3, 5, 9])
+def test_frames_that_are_no_multiple_of_the_tile_walk_the_row(mode, taps):
+    """Round 6: with AC_CLIP / AC_MIRROR and frames of at least 512 + 2 hb samples that are no multiple of 512, the tiles walk the row in aligned
+    512-output steps and the frame edges fall anywhere inside them (both halos of an edge in a gap of the wave's image).  Frame lengths that put
+    the edge at every kind of place -- just behind a tile start, just in front of a tile end, inside the left / right margin of the image --
+    single-frame rows, rows whose length is no multiple of 512, many objects."""
+    rng = np.random.default_rng(taps)
+    fin, fc, fa = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18)
+    for fo in (A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(32, 12)):
+        for n, nf in ((1000, 9), (528, 7), (536, 33), (600, 5), (1016, 4), (1032, 4), (1040, 3), (2056, 3), (4104, 2), (1000, 1), (520, 6), (7 * 512 + 8, 5), (768, 10)):
+            check(taps, mode, fin, fc, fa, fo, n, nf, n_obj=3, seed=n + nf, coeffs=small_coeffs(rng, taps), path="stream", max_sample=8192)
+    # edges at every residue of 8 inside a tile: frames of 512 + 8 j samples
+    for j in (3, 9, 17, 31, 47, 63):
+        check(taps, mode, fin, fc, fa, A.Fmt(16, 8, True, "RND", "SAT"), 512 + 8 * j, 13, n_obj=2, seed=j, coeffs=small_coeffs(rng, taps), path="stream", max_sample=8192)
+    check(taps, mode, fin, fc, fa, A.Fmt(16, 8, True, "RND", "SAT"), 1000, 70, n_obj=40, seed=99, coeffs=small_coeffs(rng, taps), path="stream", max_sample=8192)
+
+
+@pytest.mark.parametrize("taps", [9, 17, 25, 33])
+def test_ac_win_frames_walk_the_output_row(taps):
+    """Round 6: AC_WIN with TAPS - 1 a multiple of 8 and at least 512 outputs per frame -- the tiles walk the OUTPUT row in aligned 512-output steps,
+    the windows behind a frame edge start TAPS - 1 samples further on in the contiguous input image (ROW 2; by default for 9 taps, longer windows
+    with ACDSP_MVAVG_ROWW_MAX -- the matrix-core form otherwise: either way the oracle's outputs).  Edges at every kind of place inside a tile."""
+    rng = np.random.default_rng(taps)
+    fin, fc, fa = A.Fmt(16, 8), A.Fmt(16, 2), A.Fmt(40, 18)
+    for fo in (A.Fmt(16, 8, True, "RND", "SAT"), A.Fmt(32, 12), A.Fmt(40, 18)):
+        for n, nf in ((1024, 9), (1000, 7), (520 + taps - 1, 6), (528 + taps - 1, 33), (600, 5), (1536, 4), (2056, 3), (4096, 3), (1024, 1), (768, 10)):
+            check(taps, "WIN", fin, fc, fa, fo, n, nf, n_obj=3, seed=n + nf, coeffs=small_coeffs(rng, taps), path="stream", max_sample=8192)
+    for j in (1, 9, 17, 31, 47, 63):
+        check(taps, "WIN", fin, fc, fa, A.Fmt(16, 8, True, "RND", "SAT"), 512 + 8 * j + taps - 1, 13, n_obj=2, seed=j, coeffs=small_coeffs(rng, taps), path="stream", max_sample=8192)
+    check(taps, "WIN", fin, fc, fa, A.Fmt(16, 8, True, "RND", "SAT"), 1024, 70, n_obj=40, seed=98, coeffs=small_coeffs(rng, taps), path="stream", max_sample=8192)
 
 
 def test_matrix_core_window_sums_many_frames_and_objects():
