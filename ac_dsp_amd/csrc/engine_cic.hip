@@ -73,10 +73,27 @@ int32_t acdsp_cic_create(const acdsp_cic_desc_t *desc, acdsp_cic_t *out) {
   {
     // two-stage decimator (cic2.hip) where R = R1 R2 with a compiled stage-1 rate: its chunk 0 starts `wu` steps of 256 R1 inputs early,
     // so the handle keeps that much input history (the samples beyond the filter memory only ever feed warm-up values the combs cancel)
+    // (below R = 32 the one-stage FIR identity serves the rates it has a plan for; where it has none -- R M N too many taps, e.g. R 24 M 2 N 4 -- the
+    // two-stage kernel takes over there as well instead of the recurrence kernel)
+    bool one_stage = false;
+    if (!desc->interp && !h->wide && desc->R < 32 && (desc->in.W + (desc->in.S ? 0 : 1) + 7) / 8 <= h->in_eb && getenv("ACDSP_NO_GEN") == nullptr) {
+      const int L = desc->R * h->me;
+      std::vector<uint64_t> c(1, 1);
+      for (int st = 0; st < desc->N; st++) {
+        std::vector<uint64_t> nx(c.size() + L - 1, 0);
+        for (size_t i = 0; i < c.size(); i++) { for (int j = 0; j < L; j++) { nx[i + j] += c[i]; } }
+        c.swap(nx);
+      }
+      std::vector<int64_t> t((size_t)desc->N - 1, 0);
+      for (uint64_t v : c) { t.push_back((int64_t)v); }
+      FirGenPlan probe;
+      std::vector<uint32_t> fr;
+      one_stage = fir_gen_plan(t.data(), (int)t.size(), desc->R, 15, &probe, &fr) && fir_gen_plan(t.data(), (int)t.size(), desc->R, 0, &probe, &fr);
+    }
     static const bool no_c2 = getenv("ACDSP_NO_CIC2") != nullptr;         // A/B knob: recurrence kernel as before
     static const bool c2_all = getenv("ACDSP_CIC2_ALL") != nullptr;       // A/B knob: also where the one-stage FIR identity fits (R < 32)
     const int in_bits = desc->in.W + (desc->in.S ? 0 : 1);
-    if (!desc->interp && !h->wide && !no_c2 && (desc->R >= 32 || c2_all) && (in_bits + 7) / 8 <= h->in_eb && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) &&
+    if (!desc->interp && !h->wide && !no_c2 && (desc->R >= 32 || c2_all || !one_stage) && (in_bits + 7) / 8 <= h->in_eb && !(desc->flags & ACDSP_FLAG_FORCE_GENERIC) &&
         cic2_factor(h->in_eb, desc->R, h->me, desc->N, &h->c2_R1, &h->c2_R2, &h->c2_wu)) {
       cic2_stage1_taps(h->c2_R1, desc->N, &h->c2_taps);
       FirGenPlan probe;

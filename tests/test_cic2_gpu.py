@@ -58,6 +58,9 @@ CASES = [
     # second set of stage-1 rates (12 / 6 / 7 / 4 / 3 on 16-bit samples, 6 / 7 on 32-bit samples)
     (16, 1, 36, 1, 4), (16, 1, 42, 1, 3), (16, 1, 49, 2, 3), (16, 1, 44, 1, 4), (16, 1, 33, 1, 5), (16, 1, 252, 1, 3), (12, 4, 84, 2, 3), (16, 1, 63, 1, 4),
     (16, 1, 39, 2, 2), (32, 16, 42, 1, 4), (32, 16, 49, 1, 3), (32, 16, 66, 2, 3), (24, 8, 77, 1, 3),
+    # rates below 32 whose R M N is too many taps for the one-stage FIR identity (they ran the recurrence kernel)
+    (16, 1, 24, 2, 4), (32, 16, 24, 2, 5), (16, 1, 30, 1, 6), (32, 16, 27, 2, 3), (16, 1, 28, 2, 5), (16, 1, 14, 2, 6), (32, 16, 16, 2, 6), (16, 1, 25, 2, 3),
+    (32, 16, 21, 2, 5), (16, 1, 15, 2, 6),
 ]
 
 
