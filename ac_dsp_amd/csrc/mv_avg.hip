@@ -527,7 +527,8 @@ __global__ void __launch_bounds__(256) mv_avg_w32_kernel(MvAvgParams p, MvW32Arg
     for (int j = tid; j < nwin; j += 256) {
       int64_t pos = m0 - h + j;
       if (p.win_mode != 0) { pos = fold_pos(pos, p.n_sample, p.win_mode); }
-      win[j] = (pos >= 0 && pos < p.n_sample) ? xrow[pos] : 0;
+      // (round 6: 16-bit containers as well -- frames that are no multiple of 8 samples, weights beyond the int32 class of the streaming kernel: 0.03 on the int64 kernel)
+      win[j] = (pos >= 0 && pos < p.n_sample) ? (p.in_eb == 4 ? xrow[pos] : (int32_t)load_raw(p.x, obj * p.in_stride + fr * p.n_sample + pos, 2, p.in.S)) : 0;
     }
     __syncthreads();
     const int64_t k0 = (int64_t)blockIdx.x * 1024 + 4 * tid;    // first of this thread's four outputs within the frame
@@ -588,7 +589,7 @@ __global__ void __launch_bounds__(256) mv_avg_w32_kernel(MvAvgParams p, MvW32Arg
 // true: launched (mv_avg_w32_kernel's class and shape conditions)
 static bool try_w32(const MvAvgParams &p, hipStream_t s) {
   static const bool off = getenv("ACDSP_NO_MVAVG_W32") != nullptr;   // A/B knob
-  if (off || p.force_generic || !p.h_coeffs || p.in_eb != 4 || !(p.in.S || p.in.W <= 31) || p.taps > 1025) { return false; }
+  if (off || p.force_generic || !p.h_coeffs || (p.in_eb != 4 && p.in_eb != 2) || !(p.in.S || p.in.W <= 31) || p.taps > 1025) { return false; }
   if (p.acc.O != ACDSP_WRAP || (p.acc.Q != ACDSP_TRN && p.acc.Q != ACDSP_RND) || p.cf.F >= 62) { return false; }   // order-free class
   const int d = p.acc.F - p.in.F, sh = p.cf.F;
   const int i_in = p.in.W - p.in.F, i_acc = p.acc.W - p.acc.F;

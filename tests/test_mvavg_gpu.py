@@ -30,7 +30,8 @@ def check(taps, mode, fin, fc, fa, fo, n_sample, n_frames, n_obj=3, seed=0, forc
     if path is not None:
         # "stream": the streaming kernel in either form (v_dot2 / matrix cores -- the split is by window length, tested in
         # test_stream_kernel_classes); "stream_dot2" / "stream_mfma": that form
-        allowed = {"stream": ("stream", "stream_mfma"), "stream_dot2": ("stream",)}.get(path, (path,))
+        # "int64_sums": the general order-free kernels -- since round 6 the sliding-window kernel takes 16-bit samples too where its class conditions hold
+        allowed = {"stream": ("stream", "stream_mfma"), "stream_dot2": ("stream",), "int64_sums": ("int64_sums", "stream32")}.get(path, (path,))
         assert eng.path in allowed, (eng.path, path)
 
 

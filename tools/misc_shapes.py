@@ -63,6 +63,7 @@ if which in ("both", "mvavg"):
                                         (9, "CLIP", 1024, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")), (3, "MIRROR", 1024, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")),
                                         (33, "MIRROR", 1024, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")), (65, "MIRROR", 1024, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")),
                                         (13, "WIN", 1024, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")), (29, "WIN", 1024, F(16, 8), F(40, 18), F(32, 12)),   # output frames off a 16-byte boundary
+                                        (9, "MIRROR", 1004, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")),   # frames that are no multiple of 8 samples: the sliding-window kernel
                                         (9, "MIRROR", 128, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")), (9, "MIRROR", 4096, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")),
                                         (9, "MIRROR", 1000, F(16, 8), F(40, 18), F(16, 8, True, "RND", "SAT")), (9, "MIRROR", 1024, F(16, 8), F(40, 18), F(32, 12)),
                                         (9, "MIRROR", 1024, F(16, 8), F(40, 18), F(40, 18)), (9, "MIRROR", 1024, F(12, 4), F(30, 10), F(12, 4, True, "RND", "SAT")),
