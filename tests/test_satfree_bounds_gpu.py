@@ -85,6 +85,6 @@ def test_mv_avg_at_the_bound(sum_abs, expect):
     eng = A.MvAvg(4096, taps, "MIRROR", fin, fc, fa, fo, n_objects=4)
     eng.set_coeffs(c)
     y = eng.run(torch.from_numpy(x).to(torch.int16).cuda(), n_sample).cpu().numpy().astype(np.int64)
-    assert (eng.path in ("stream", "int64_sums")) if expect == "wrapping" else (eng.path == expect), (eng.path, expect)
+    assert (eng.path in ("stream", "int64_sums", "stream32")) if expect == "wrapping" else (eng.path == expect), (eng.path, expect)
     yo = OracleMvAvg(taps, "MIRROR", ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_obj=4).run(c, x, n_sample)
     assert np.array_equal(y, yo)
