@@ -98,6 +98,7 @@ struct MvStreamArgs {
   int16_t c16o[66];           // the same behind one zero: pairs (c[2q-1], c[2q]) for odd outputs, whose windows start in a high half
   int32_t taps, h, hb, off, mode, nxg;
   int32_t linear, ls, e, rnd_e;
+  int32_t pk16;               // 32-bit epilogue into a signed 16-bit AC_SAT output at aligned frames: saturating packs
   int32_t cv32, s32, r32, lo32, hi32, ko32;   // 32-bit epilogue: q = (S + r32) >> s32, clamp, wrap (ko32 = 32 - W_out or 0)
   int32_t ka, rs, ls2, ko;    // 64-bit epilogue (see IdConv in intg_dump.hip)
   uint64_t am, om;
@@ -360,7 +361,24 @@ __global__ void __launch_bounds__(256) mv_avg_stream_kernel(MvStreamArgs a) {
     }
     __builtin_amdgcn_wave_barrier();   // every lane has its window: the image may be overwritten
     const int64_t k0 = ti * 512 + 8 * vlane;
-    if (k0 < a.opf) {
+    bool done16 = false;
+    if constexpr (CV32 && !RUN) {
+      // signed 16-bit AC_SAT outputs (the bench row's OUT_TYPE): shift, then v_cvt_pk_i16_i32 saturates and packs two outputs per instruction --
+      // 12 instead of 28 VALU instructions per lane and tile on a kernel that is bound by VALU issue
+      if (a.pk16) {
+        if (k0 < a.opf) {
+          typedef short v2s16_ __attribute__((ext_vector_type(2)));
+          uint4 v;
+          v.x = __builtin_bit_cast(uint32_t, (v2s16_)__builtin_amdgcn_cvt_pk_i16(S[0] >> a.s32, S[1] >> a.s32));
+          v.y = __builtin_bit_cast(uint32_t, (v2s16_)__builtin_amdgcn_cvt_pk_i16(S[2] >> a.s32, S[3] >> a.s32));
+          v.z = __builtin_bit_cast(uint32_t, (v2s16_)__builtin_amdgcn_cvt_pk_i16(S[4] >> a.s32, S[5] >> a.s32));
+          v.w = __builtin_bit_cast(uint32_t, (v2s16_)__builtin_amdgcn_cvt_pk_i16(S[6] >> a.s32, S[7] >> a.s32));
+          ACDSP_MV_ST(v, reinterpret_cast<uint4 *>((int16_t *)a.y + (obj * a.out_stride + fr * a.opf + k0)));
+        }
+        done16 = true;
+      }
+    }
+    if (!done16 && k0 < a.opf) {
       const int64_t yb = obj * a.out_stride + fr * a.opf + k0;
       int64_t ov[8];                                  // OUT raw words (the low out_eb bytes are what leaves)
       if constexpr (CV32) {
@@ -692,6 +710,8 @@ static bool try_stream(const MvAvgParams &p, hipStream_t s, bool *mfma) {
   }
   a.out_eb = p.out_eb;
   a.vec_ok = p.out_per_frame % 8 == 0 && p.out_stride % 8 == 0 && ((uintptr_t)p.y % 16) == 0;
+  static const bool no_pk16 = getenv("ACDSP_NO_MVAVG_PK16") != nullptr;   // A/B knob
+  a.pk16 = !no_pk16 && a.cv32 && a.vec_ok && p.out_eb == 2 && a.lo32 == -32768 && a.hi32 == 32767 && a.ko32 == 0 && a.om == ~uint64_t(0);
   static const bool no_run = getenv("ACDSP_NO_MVAVG_RUN") != nullptr;   // A/B knob: element stores for unaligned output frames
   a.run_ok = !a.vec_ok && !no_run && ((uintptr_t)p.y % p.out_eb) == 0 && p.out_eb <= 4;   // (8-byte outputs: 4 KB + the offset would not fit the image; they keep element stores, 64 contiguous bytes per lane)
   a.n_sample = p.n_sample; a.n_frames = p.n_frames; a.opf = p.out_per_frame; a.in_stride = p.in_stride; a.out_stride = p.out_stride;

@@ -203,6 +203,31 @@ def test_ac_win_frames_walk_the_output_row(taps):
     check(taps, "WIN", fin, fc, fa, A.Fmt(16, 8, True, "RND", "SAT"), 1024, 70, n_obj=40, seed=98, coeffs=small_coeffs(rng, taps), path="stream", max_sample=8192)
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("taps", [3, 9, 17, 33, 65])
+def test_signed_16_bit_saturating_outputs_take_the_packed_epilogue(mode, taps):
+    """Round 6: OUT_TYPEs of 16 signed bits with AC_SAT leave the 32-bit epilogue through v_cvt_pk_i16_i32 (shift, then a saturating pack of two outputs).
+    Sums that exceed both ends of the output range by far and by one LSB, AC_TRN and AC_RND, every shift the class admits, v_dot2 and matrix-core forms."""
+    fin, fc = A.Fmt(16, 8), A.Fmt(16, 2)
+    rng = np.random.default_rng(taps)
+    c_big = np.full(taps, 32767 // taps, dtype=np.int64)                 # gain ~2: full-scale inputs saturate the output both ways
+    c_edge = np.zeros(taps, dtype=np.int64)
+    c_edge[taps // 2] = 16384                                              # gain exactly 1: outputs AT the ends of the range
+    for fa, fo in ((A.Fmt(40, 18), A.Fmt(16, 8, True, "RND", "SAT")), (A.Fmt(40, 18), A.Fmt(16, 8, True, "TRN", "SAT")), (A.Fmt(40, 18), A.Fmt(16, 2, True, "RND", "SAT")),
+                   (A.Fmt(48, 20), A.Fmt(16, 12, True, "RND", "SAT")), (A.Fmt(40, 18), A.Fmt(16, 9, True, "TRN", "SAT"))):
+        for c in (c_big, c_edge, -c_big, small_coeffs(rng, taps)):
+            n_sample, n_frames = 1024, 3
+            x = rng.choice(np.array([-32768, 32767, -32767, 32766, 0, 1, -1, 12345, -23456], dtype=np.int64), size=(2, n_sample * n_frames))
+            x[0, :700] = 32767
+            x[0, 700:1500] = -32768
+            eng = A.MvAvg(n_sample, taps, mode, fin, fc, fa, fo, n_objects=2)
+            eng.set_coeffs(c)
+            y = eng.run(torch.from_numpy(x).to(torch.int16).cuda(), n_sample).cpu().numpy().astype(np.int64)
+            yo = OracleMvAvg(taps, mode, ofmt(fin), ofmt(fc), ofmt(fa), ofmt(fo), n_obj=2).run(c, x, n_sample)
+            assert np.array_equal(y, yo), (fa, fo, np.argwhere(y != yo)[:4])
+            assert eng.path in ("stream", "stream_mfma")
+
+
 def test_matrix_core_window_sums_many_frames_and_objects():
     """Runs of tiles that cross frames and objects, a partial last run, unsigned 15-bit samples."""
     rng = np.random.default_rng(77)
